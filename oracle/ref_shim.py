@@ -1,0 +1,118 @@
+"""Import the *real* reference (zju3dv/LoFTR at /root/reference) on a box without kornia/yacs.
+
+TEST INFRASTRUCTURE ONLY, and only usable in the authoring container: /root/reference does not
+exist on the GPU box.  Used by tests/golden/make_golden.py (to generate the committed golden
+vectors) and by tests/test_oracle_vs_reference.py (skipped when the reference is absent).
+
+The reference imports three things that are not installed here:
+  * yacs.config.CfgNode                       (src/loftr/utils/cvpr_ds_config.py:1)
+  * kornia.geometry.subpix.dsnt.spatial_expectation2d, kornia.utils.grid.create_meshgrid
+                                               (src/loftr/utils/fine_matching.py:5-6,49-50)
+  * src.loftr.utils.superglue.log_optimal_transport (git-ignored third-party file,
+                                               src/loftr/utils/coarse_matching.py:75-79)
+They are replaced by in-memory stub modules that restate the published semantics
+(kornia 0.4.1; SuperGlue master).  No reference source is copied.
+"""
+import os
+import sys
+import types
+
+import torch
+
+REFERENCE_ROOT = os.environ.get("LOFTR_REFERENCE_ROOT", "/root/reference")
+
+
+def reference_available() -> bool:
+    return os.path.isfile(os.path.join(REFERENCE_ROOT, "src", "loftr", "loftr.py"))
+
+
+class _CfgNode(dict):
+    """Enough of yacs.config.CfgNode for cvpr_ds_config.py: attribute access on a dict."""
+
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError as e:  # pragma: no cover
+            raise AttributeError(k) from e
+
+    def __setattr__(self, k, v):
+        self[k] = v
+
+
+def _create_meshgrid(height, width, normalized_coordinates=True, device=None):
+    xs = torch.linspace(0, width - 1, width, device=device)
+    ys = torch.linspace(0, height - 1, height, device=device)
+    if normalized_coordinates:
+        xs = (xs / (width - 1) - 0.5) * 2
+        ys = (ys / (height - 1) - 0.5) * 2
+    gy, gx = torch.meshgrid(ys, xs, indexing="ij")
+    return torch.stack([gx, gy], -1)[None]          # [1,H,W,2], (x,y)
+
+
+def _spatial_expectation2d(inp, normalized_coordinates=True):
+    b, c, h, w = inp.shape
+    grid = _create_meshgrid(h, w, normalized_coordinates, inp.device).to(inp.dtype)
+    px = grid[..., 0].reshape(1, 1, -1)
+    py = grid[..., 1].reshape(1, 1, -1)
+    flat = inp.reshape(b, c, -1)
+    return torch.stack([(flat * px).sum(-1), (flat * py).sum(-1)], -1)
+
+
+def _log_optimal_transport(scores, alpha, iters):
+    """SuperGlue's log_optimal_transport, restated (see oracle/loftr_oracle.py)."""
+    import math
+    b, m, n = scores.shape
+    one = scores.new_tensor(1)
+    ms, ns = (m * one).to(scores), (n * one).to(scores)
+    bins0 = alpha.expand(b, m, 1)
+    bins1 = alpha.expand(b, 1, n)
+    alpha_ = alpha.expand(b, 1, 1)
+    couplings = torch.cat([torch.cat([scores, bins0], -1), torch.cat([bins1, alpha_], -1)], 1)
+    norm = -(ms + ns).log()
+    log_mu = torch.cat([norm.expand(m), ns.log()[None] + norm])[None].expand(b, -1)
+    log_nu = torch.cat([norm.expand(n), ms.log()[None] + norm])[None].expand(b, -1)
+    u, v = torch.zeros_like(log_mu), torch.zeros_like(log_nu)
+    for _ in range(iters):
+        u = log_mu - torch.logsumexp(couplings + v.unsqueeze(1), dim=2)
+        v = log_nu - torch.logsumexp(couplings + u.unsqueeze(2), dim=1)
+    return couplings + u.unsqueeze(2) + v.unsqueeze(1) - norm
+
+
+def _install_stubs():
+    def mod(name, **attrs):
+        m = sys.modules.get(name)
+        if m is None:
+            m = types.ModuleType(name)
+            sys.modules[name] = m
+        for k, v in attrs.items():
+            setattr(m, k, v)
+        return m
+
+    mod("yacs")
+    mod("yacs.config", CfgNode=_CfgNode)
+    dsnt = mod("kornia.geometry.subpix.dsnt", spatial_expectation2d=_spatial_expectation2d)
+    mod("kornia")
+    mod("kornia.geometry")
+    mod("kornia.geometry.subpix", dsnt=dsnt)
+    mod("kornia.utils")
+    mod("kornia.utils.grid", create_meshgrid=_create_meshgrid)
+    # The installed `transformers` package carries a line-equivalent log_optimal_transport;
+    # prefer it when importable so the OT oracle is pinned against independent code.
+    lot = _log_optimal_transport
+    try:
+        from transformers.models.superglue.modeling_superglue import log_optimal_transport as _hf
+        lot = _hf
+    except Exception:
+        pass
+    mod("src.loftr.utils.superglue", log_optimal_transport=lot)
+
+
+def import_reference():
+    """Returns (LoFTR class, default_cfg) of the real reference."""
+    if not reference_available():
+        raise RuntimeError(f"reference not found at {REFERENCE_ROOT}")
+    _install_stubs()
+    if REFERENCE_ROOT not in sys.path:
+        sys.path.insert(0, REFERENCE_ROOT)
+    from src.loftr import LoFTR, default_cfg  # noqa
+    return LoFTR, default_cfg

@@ -1,0 +1,217 @@
+"""Generate the golden vectors in tests/golden/*.npz by running the REAL reference.
+
+Run in the authoring container only (needs /root/reference):
+
+    python tests/golden/make_golden.py            # all cases
+    python tests/golden/make_golden.py small_ds   # one case
+
+For each case in ``CASES`` the script
+  1. regenerates the synthetic weights / backbone-output feature maps from their seeds
+     (``loftr_amd.synth``),
+  2. instantiates the reference ``src.loftr.LoFTR`` (through ``oracle/ref_shim.py``), loads the
+     weights, replaces *only* its backbone by a stub that returns the synthetic feature maps,
+  3. calls the reference's own ``forward(data)`` on CPU / fp32 / eval / no_grad,
+  4. stores the outputs (small cases: every batch-dict tensor; large cases: matches, key
+     points and digests of ``conf_matrix``) together with the recipe and input checksums.
+
+The reference has no golden vectors of its own; these files are what pins
+``oracle/loftr_oracle.py`` and, on the GPU box, the HIP path.
+"""
+import copy
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+
+from loftr_amd.config import get_cfg                      # noqa: E402
+from loftr_amd.synth import make_weights, make_features, checksum   # noqa: E402
+from oracle.ref_shim import import_reference              # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+# name -> recipe.  'full' = store every tensor; otherwise digests of the big ones.
+CASES = {
+    # different coarse sizes for image0 / image1 (loftr.py:48-49 branch), tiny, everything stored
+    "small_ds": dict(n=2, hw0_c=(8, 12), hw1_c=(10, 8), wseed=0, fseed=11, corr=0.0,
+                     mc=dict(thr=0.0, border_rm=1), temp_bug_fix=True, full=True),
+    # correlated pair, stock threshold, border 2
+    "small_ds_corr": dict(n=2, hw0_c=(12, 16), hw1_c=(12, 16), wseed=1, fseed=12, corr=0.7,
+                          mc=dict(thr=0.2, border_rm=2), temp_bug_fix=False, full=True),
+    # MegaDepth-style padding masks + scale0/scale1 (coarse_matching.py:28-43,115-118,243-244)
+    "small_mask": dict(n=2, hw0_c=(12, 12), hw1_c=(12, 12), wseed=2, fseed=13, corr=0.6,
+                       mc=dict(thr=0.0, border_rm=2), temp_bug_fix=False, full=True,
+                       valid0=[(9, 12), (12, 10)], valid1=[(12, 8), (10, 12)],
+                       scale0=[[1.9, 1.9], [1.25, 1.5]], scale1=[[1.0, 2.0], [1.6, 1.6]]),
+    # Sinkhorn / optimal transport (coarse_matching.py:121-143), both prefilter settings
+    "small_ot": dict(n=2, hw0_c=(12, 16), hw1_c=(12, 16), wseed=3, fseed=14, corr=0.6,
+                     mc=dict(thr=0.0, border_rm=2, match_type="sinkhorn", skh_prefilter=False,
+                             sparse_spvs=True), temp_bug_fix=True, full=True),
+    "small_ot_prefilter": dict(n=2, hw0_c=(10, 12), hw1_c=(12, 10), wseed=4, fseed=15, corr=0.0,
+                               mc=dict(thr=0.0, border_rm=1, match_type="sinkhorn",
+                                       skh_prefilter=True, sparse_spvs=False),
+                               temp_bug_fix=True, full=True),
+    "small_ot_mask": dict(n=2, hw0_c=(12, 12), hw1_c=(12, 12), wseed=5, fseed=16, corr=0.6,
+                          mc=dict(thr=0.0, border_rm=2, match_type="sinkhorn", skh_prefilter=False,
+                                  sparse_spvs=True), temp_bug_fix=False, full=True,
+                          valid0=[(9, 12), (12, 10)], valid1=[(12, 8), (10, 12)],
+                          scale0=[[1.9, 1.9], [1.25, 1.5]], scale1=[[1.0, 2.0], [1.6, 1.6]]),
+    # no match survives: the M == 0 path (fine_preprocess.py:34-37, fine_matching.py:33-41)
+    "small_empty": dict(n=2, hw0_c=(8, 12), hw1_c=(8, 12), wseed=0, fseed=17, corr=0.0,
+                        mc=dict(thr=0.999, border_rm=2), temp_bug_fix=True, full=True),
+    # medium: oracle still runs in seconds
+    "mid_ds": dict(n=2, hw0_c=(30, 40), hw1_c=(30, 40), wseed=6, fseed=18, corr=0.5,
+                   mc=dict(thr=0.2, border_rm=2), temp_bug_fix=True, full=False),
+    # BASELINE configs[0]/[1] geometry: 640x480 -> 60x80 coarse (L=S=4800)
+    "full_ds_thr0": dict(n=1, hw0_c=(60, 80), hw1_c=(60, 80), wseed=0, fseed=1, corr=0.3,
+                         mc=dict(thr=0.0, border_rm=2), temp_bug_fix=True, full=False),
+    "full_ds_thr02": dict(n=2, hw0_c=(60, 80), hw1_c=(60, 80), wseed=0, fseed=2, corr=0.5,
+                          mc=dict(thr=0.2, border_rm=2), temp_bug_fix=True, full=False),
+    "full_ot": dict(n=1, hw0_c=(60, 80), hw1_c=(60, 80), wseed=0, fseed=3, corr=0.5,
+                    mc=dict(thr=0.0, border_rm=2, match_type="sinkhorn", skh_prefilter=False,
+                            sparse_spvs=True), temp_bug_fix=True, full=False),
+    # BASELINE configs[3]: 840x840 outdoor -> 105x105 coarse (L=S=11025), padded to 840x560
+    "outdoor_mask": dict(n=1, hw0_c=(105, 105), hw1_c=(105, 105), wseed=0, fseed=4, corr=0.5,
+                         mc=dict(thr=0.2, border_rm=2), temp_bug_fix=False, full=False,
+                         valid0=[(70, 105)], valid1=[(70, 105)],
+                         scale0=[[1.9, 1.9]], scale1=[[1.9, 1.9]]),
+}
+
+
+def build_case_inputs(rc):
+    """Inputs of a case as numpy arrays (shared by make_golden and the tests)."""
+    mc = dict(rc["mc"])
+    cfg = get_cfg(**mc)
+    cfg["coarse"]["temp_bug_fix"] = rc["temp_bug_fix"]
+    w = make_weights(rc["wseed"], cfg)
+    c0, c1, f0, f1 = make_features(rc["fseed"], rc["n"], tuple(rc["hw0_c"]), tuple(rc["hw1_c"]),
+                                   corr=rc["corr"])
+    inp = dict(cfg=cfg, w=w, feat_c0=c0, feat_c1=c1, feat_f0=f0, feat_f1=f1,
+               hw0_i=(rc["hw0_c"][0] * 8, rc["hw0_c"][1] * 8),
+               hw1_i=(rc["hw1_c"][0] * 8, rc["hw1_c"][1] * 8),
+               mask0=None, mask1=None, scale0=None, scale1=None)
+    if "valid0" in rc:
+        n = rc["n"]
+        m0 = np.zeros((n,) + tuple(rc["hw0_c"]), bool)
+        m1 = np.zeros((n,) + tuple(rc["hw1_c"]), bool)
+        for b in range(n):
+            m0[b, :rc["valid0"][b][0], :rc["valid0"][b][1]] = True
+            m1[b, :rc["valid1"][b][0], :rc["valid1"][b][1]] = True
+        inp.update(mask0=m0, mask1=m1, scale0=np.asarray(rc["scale0"], np.float32),
+                   scale1=np.asarray(rc["scale1"], np.float32))
+    return inp
+
+
+def input_checksums(inp):
+    cs = {k: checksum(inp[k]) for k in ("feat_c0", "feat_c1", "feat_f0", "feat_f1")}
+    cs["weights"] = float(sum(checksum(v) for _, v in sorted(inp["w"].items())))
+    return cs
+
+
+class _BackboneStub(torch.nn.Module):
+    """Stands in for ResNetFPN: returns the synthetic (feat_c, feat_f) (loftr.py:45-49)."""
+
+    def __init__(self, inp):
+        super().__init__()
+        self.inp = inp
+        self.calls = 0
+
+    def forward(self, x):
+        i = self.inp
+        t = torch.from_numpy
+        if x.shape[0] == 2 * i["feat_c0"].shape[0] and i["hw0_i"] == i["hw1_i"]:
+            return [torch.cat([t(i["feat_c0"]), t(i["feat_c1"])], 0),
+                    torch.cat([t(i["feat_f0"]), t(i["feat_f1"])], 0)]
+        self.calls += 1
+        if self.calls == 1:
+            return [t(i["feat_c0"]), t(i["feat_f0"])]
+        return [t(i["feat_c1"]), t(i["feat_f1"])]
+
+
+def run_reference(inp):
+    """The reference's own LoFTR.forward on the synthetic backbone outputs.  Returns the dict."""
+    RefLoFTR, _ = import_reference()
+    cfg = copy.deepcopy(inp["cfg"])
+    model = RefLoFTR(cfg).eval()
+    sd = model.state_dict()
+    for k, v in inp["w"].items():
+        assert k in sd and tuple(sd[k].shape) == tuple(np.shape(v)), k
+        sd[k] = torch.from_numpy(np.asarray(v))
+    model.load_state_dict(sd, strict=True)
+    model.backbone = _BackboneStub(inp)
+    n = inp["feat_c0"].shape[0]
+    data = {"image0": torch.zeros(n, 1, *inp["hw0_i"]), "image1": torch.zeros(n, 1, *inp["hw1_i"])}
+    if inp["mask0"] is not None:
+        data.update(mask0=torch.from_numpy(inp["mask0"]), mask1=torch.from_numpy(inp["mask1"]),
+                    scale0=torch.from_numpy(inp["scale0"]), scale1=torch.from_numpy(inp["scale1"]))
+    # also capture the coarse / fine transformer outputs (stage boundaries of SURVEY §8a)
+    grabbed = {}
+    model.loftr_coarse.register_forward_hook(
+        lambda m, a, out: grabbed.update(feat_c0=out[0].numpy().copy(), feat_c1=out[1].numpy().copy()))
+    model.fine_preprocess.register_forward_hook(
+        lambda m, a, out: grabbed.update(feat_f0_unfold_pre=out[0].numpy().copy(),
+                                         feat_f1_unfold_pre=out[1].numpy().copy()))
+    model.loftr_fine.register_forward_hook(
+        lambda m, a, out: grabbed.update(feat_f0_unfold=out[0].numpy().copy(),
+                                         feat_f1_unfold=out[1].numpy().copy()))
+    with torch.no_grad():
+        model(data)
+    out = {k: (v.numpy() if torch.is_tensor(v) else v) for k, v in data.items()
+           if k not in ("image0", "image1")}
+    out.update(grabbed)
+    return out
+
+
+def conf_digest(conf):
+    """Size-independent digests of an [N,L,S] confidence volume."""
+    conf = np.asarray(conf, np.float64)
+    n, L, S = conf.shape
+    rng = np.random.default_rng(12345)
+    idx = np.stack([rng.integers(0, n, 4096), rng.integers(0, L, 4096), rng.integers(0, S, 4096)], 1)
+    return dict(conf_row_sum=conf.sum(2).astype(np.float32), conf_col_sum=conf.sum(1).astype(np.float32),
+                conf_row_max=conf.max(2).astype(np.float32), conf_col_max=conf.max(1).astype(np.float32),
+                conf_sample_idx=idx.astype(np.int64),
+                conf_sample_val=conf[idx[:, 0], idx[:, 1], idx[:, 2]].astype(np.float32))
+
+
+KEEP_ALWAYS = ("b_ids", "i_ids", "j_ids", "gt_mask", "m_bids", "mkpts0_c", "mkpts1_c", "mconf",
+               "expec_f", "mkpts0_f", "mkpts1_f")
+KEEP_FULL = ("conf_matrix", "conf_matrix_with_bin", "feat_c0", "feat_c1")
+KEEP_FULL_HEAD = ("feat_f0_unfold_pre", "feat_f1_unfold_pre", "feat_f0_unfold", "feat_f1_unfold")
+HEAD = 12   # per-match window tensors are 12.8 kB each: keep the first HEAD matches only
+
+
+def make(name):
+    rc = CASES[name]
+    inp = build_case_inputs(rc)
+    out = run_reference(inp)
+    store = {k: np.asarray(out[k]) for k in KEEP_ALWAYS}
+    store.update(conf_digest(out["conf_matrix"]))
+    if "conf_matrix_with_bin" in out:
+        a = np.asarray(out["conf_matrix_with_bin"], np.float64)
+        store["assign_bin_col"] = a[:, :, -1].astype(np.float32)     # dustbin column  [N,L+1]
+        store["assign_bin_row"] = a[:, -1, :].astype(np.float32)     # dustbin row     [N,S+1]
+    if rc["full"]:
+        for k in KEEP_FULL:
+            if k in out:
+                store[k] = np.asarray(out[k])
+        for k in KEEP_FULL_HEAD:
+            if k in out:
+                store[k] = np.asarray(out[k])[:HEAD]
+    store["recipe"] = np.array(json.dumps(rc))
+    store["checksums"] = np.array(json.dumps(input_checksums(inp)))
+    store["hw"] = np.array([out["hw0_c"], out["hw1_c"], out["hw0_f"], out["hw1_f"]], np.int64)
+    path = os.path.join(HERE, f"{name}.npz")
+    np.savez_compressed(path, **store)
+    print(f"{name}: M={len(store['mconf'])}  conf.max={store['conf_row_max'].max():.4f}  "
+          f"-> {os.path.getsize(path) / 1e3:.1f} kB")
+
+
+if __name__ == "__main__":
+    names = sys.argv[1:] or list(CASES)
+    for nm in names:
+        make(nm)
