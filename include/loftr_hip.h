@@ -1,0 +1,177 @@
+/* libloftr_hip -- C-ABI of the MI355X-native LoFTR matching path (gfx950 / CDNA4).
+ *
+ * Drop-in boundary.  The reference (zju3dv/LoFTR) is pure Python: it has no FFI / plugin
+ * registry; the seam is nn.Module composition in src/loftr/loftr.py:20-27,56-75.  Each entry
+ * point below replaces the ATen op sequence of one of those sub-modules and is what a ctypes
+ * binding inside the reference's modules would call (INTEGRATION.md shows the stub).  The
+ * Python mirror of the reference interface lives in loftr_amd/ and calls exactly these symbols.
+ *
+ * Conventions
+ *   - every function is asynchronous on the caller-supplied hipStream_t (passed as void*);
+ *   - all device buffers are caller-allocated (PyTorch owns memory); the library never
+ *     allocates or frees device memory; `*_workspace_bytes` tells how much scratch to pass;
+ *   - all floating point is fp32, ids are int64, masks are uint8 (0 = padded), as in the
+ *     reference;
+ *   - return value: 0 = ok, negative = loftr_status below (no exceptions, no global state).
+ */
+#ifndef LOFTR_HIP_H_
+#define LOFTR_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+  LOFTR_OK = 0,
+  LOFTR_ERR_BAD_ARG = -1,       /* null pointer / non-positive or unsupported shape            */
+  LOFTR_ERR_UNSUPPORTED = -2,   /* shape outside what the kernels are built for (C, H, D, W)   */
+  LOFTR_ERR_WORKSPACE = -3,     /* workspace smaller than *_workspace_bytes()                  */
+  LOFTR_ERR_LAUNCH = -4,        /* HIP reported a launch error                                 */
+  LOFTR_ERR_NO_DEVICE = -5      /* no gfx950 device visible                                    */
+} loftr_status;
+
+#define LOFTR_HIP_ABI_VERSION 1
+
+int loftr_hip_abi_version(void);
+const char* loftr_hip_status_string(int status);
+/* 0 if the current HIP device is a gfx950 part, LOFTR_ERR_NO_DEVICE otherwise. */
+int loftr_hip_device_check(void);
+
+/* ---- position encoding + flatten ---------------------------------------------------------
+ * Replaces: PositionEncodingSine.forward (src/loftr/utils/position_encoding.py:37-42) followed
+ * by rearrange 'n c h w -> n (h w) c' (src/loftr/loftr.py:58-59).
+ *   feat [N,C,H,W] (contiguous NCHW), pe [C,pe_h,pe_w] (the module's constant table, H<=pe_h,
+ *   W<=pe_w), out [N,H*W,C]. */
+int loftr_pos_encode_flatten(const float* feat, const float* pe, int pe_h, int pe_w,
+                             float* out, int N, int C, int H, int W, void* stream);
+
+/* ---- LoFTREncoderLayer / LocalFeatureTransformer ------------------------------------------
+ * Weights of one LoFTREncoderLayer (src/loftr/loftr_module/transformer.py:7-33); every matrix
+ * is the nn.Linear weight as stored in the state_dict: [out_features, in_features] row-major. */
+typedef struct {
+  const float* q_proj;   /* [C, C]   */
+  const float* k_proj;   /* [C, C]   */
+  const float* v_proj;   /* [C, C]   */
+  const float* merge;    /* [C, C]   */
+  const float* mlp0;     /* [2C, 2C] */
+  const float* mlp2;     /* [C, 2C]  */
+  const float* norm1_w;  /* [C] */
+  const float* norm1_b;  /* [C] */
+  const float* norm2_w;  /* [C] */
+  const float* norm2_b;  /* [C] */
+} loftr_layer_weights;
+
+/* Scratch needed by loftr_encoder_layer_fwd / loftr_transformer_fwd for `nb` sequences of
+ * length L attending to sequences of length S (transformer: pass nb = 2*N). */
+size_t loftr_encoder_workspace_bytes(int nb, int L, int S, int C);
+
+/* Replaces: LoFTREncoderLayer.forward (transformer.py:35-58) incl. LinearAttention.forward
+ * (src/loftr/loftr_module/linear_attention.py:20-47).
+ *   x [nb,L,C], source [nb,S,C], x_mask [nb,L] / source_mask [nb,S] uint8 or NULL,
+ *   out [nb,L,C] (may alias x).  C in {128, 256}, H = 8. */
+int loftr_encoder_layer_fwd(const float* x, const float* source, const uint8_t* x_mask,
+                            const uint8_t* source_mask, const loftr_layer_weights* w, float* out,
+                            int nb, int L, int S, int C, int H, void* ws, size_t ws_bytes,
+                            void* stream);
+
+/* Replaces: LocalFeatureTransformer.forward (transformer.py:80-101), in place on feat0/feat1.
+ *   feat0 [N,L,C], feat1 [N,S,C]; layer_is_cross[i] = 0 for 'self', 1 for 'cross';
+ *   cross layers keep the reference's sequential dependency (feat1 attends to the UPDATED
+ *   feat0, :96-97).  When L == S and feat1 == feat0 + N*L*C the two self-attention calls of a
+ *   layer run as one batch of 2N sequences. */
+int loftr_transformer_fwd(float* feat0, float* feat1, const uint8_t* mask0, const uint8_t* mask1,
+                          const loftr_layer_weights* layers, const int* layer_is_cross,
+                          int n_layers, int N, int L, int S, int C, int H, void* ws,
+                          size_t ws_bytes, void* stream);
+
+/* ---- CoarseMatching ------------------------------------------------------------------------
+ * Geometry + selection parameters shared by the two match types. */
+typedef struct {
+  int N, h0c, w0c, h1c, w1c;     /* L = h0c*w0c, S = h1c*w1c                                    */
+  int C;                         /* descriptor width (256)                                      */
+  float thr;                     /* config['thr']            (strict >)                         */
+  int border_rm;                 /* config['border_rm']                                          */
+  float scale;                   /* hw0_i[0] / hw0_c[0]      (coarse_matching.py:242)           */
+  const uint8_t* mask0;          /* [N,L] or NULL (MegaDepth padding masks)                     */
+  const uint8_t* mask1;          /* [N,S] or NULL                                               */
+  const float* scale0;           /* [N,2] or NULL                                               */
+  const float* scale1;           /* [N,2] or NULL                                               */
+} loftr_coarse_params;
+
+/* Match outputs; capacity must be N*L rows (at most one match per row of conf_matrix).
+ * counts[0] = M (total), counts[1+b] = matches of pair b.  Rows are in ascending (b, i). */
+typedef struct {
+  int64_t* b_ids;     /* [N*L] */
+  int64_t* i_ids;     /* [N*L] */
+  int64_t* j_ids;     /* [N*L] */
+  float* mconf;       /* [N*L] */
+  float* mkpts0_c;    /* [N*L,2] */
+  float* mkpts1_c;    /* [N*L,2] */
+  int32_t* counts;    /* [1+N]   */
+} loftr_match_out;
+
+size_t loftr_coarse_match_workspace_bytes(int N, int L, int S);
+
+/* Replaces: CoarseMatching.forward, match_type='dual_softmax' + get_coarse_match, eval branch
+ * (src/loftr/utils/coarse_matching.py:105-119,150-196,238-261).
+ *   feat_c0 [N,L,C], feat_c1 [N,S,C]; conf_out [N,L,S] or NULL (data['conf_matrix'] elided). */
+int loftr_coarse_match_dual_softmax(const float* feat_c0, const float* feat_c1,
+                                    const loftr_coarse_params* p, float temperature,
+                                    float* conf_out, const loftr_match_out* out, void* ws,
+                                    size_t ws_bytes, void* stream);
+
+/* Replaces: CoarseMatching.forward, match_type='sinkhorn' (coarse_matching.py:121-143, calling
+ * SuperGlue's log_optimal_transport) + get_coarse_match.
+ *   conf_out [N,L,S] REQUIRED (used as the score store); assign_out [N,L+1,S+1] or NULL
+ *   (data['conf_matrix_with_bin'] when config['sparse_spvs']). */
+int loftr_coarse_match_sinkhorn(const float* feat_c0, const float* feat_c1,
+                                const loftr_coarse_params* p, float bin_score, int iters,
+                                int prefilter, float* conf_out, float* assign_out,
+                                const loftr_match_out* out, void* ws, size_t ws_bytes,
+                                void* stream);
+
+/* ---- FinePreprocess ------------------------------------------------------------------------
+ * Replaces: FinePreprocess.forward (src/loftr/loftr_module/fine_preprocess.py:29-59): 5x5
+ * windows (stride = hf/hc, zero padded) of the fine maps at the matched cells, fused with the
+ * down-projected coarse features.  No unfold volume is materialised.
+ *   feat_f0/1: fine maps addressed through element strides (sn,sc,sh,sw) so both NCHW and
+ *   channels-last storage work; feat_c0 [N,L,Cc], feat_c1 [N,S,Cc] (transformer outputs);
+ *   out0/out1 [M,W*W,Cf].  down_w [Cf,Cc], down_b [Cf], merge_w [Cf,2Cf], merge_b [Cf];
+ *   pass down_w = NULL for fine_concat_coarse_feat = False. */
+typedef struct {
+  const float* data;
+  long sn, sc, sh, sw;    /* element strides */
+  int H, W;               /* fine map size   */
+} loftr_fmap;
+
+size_t loftr_fine_preprocess_workspace_bytes(int M, int W, int Cf);
+
+int loftr_fine_preprocess(const loftr_fmap* feat_f0, const loftr_fmap* feat_f1,
+                          const float* feat_c0, const float* feat_c1, int L, int S, int Cc,
+                          const int64_t* b_ids, const int64_t* i_ids, const int64_t* j_ids, int M,
+                          int w0c, int w1c, int stride, int W, int Cf,
+                          const float* down_w, const float* down_b, const float* merge_w,
+                          const float* merge_b, float* out0, float* out1, void* ws,
+                          size_t ws_bytes, void* stream);
+
+/* ---- FineMatching ---------------------------------------------------------------------------
+ * Replaces: FineMatching.forward + get_fine_match (src/loftr/utils/fine_matching.py:15-74).
+ *   feat_f0/1 [M,WW,C]; mkpts1_c [M,2]; b_ids [M]; scale = hw0_i[0]/hw0_f[0];
+ *   scale1 [N,2] or NULL (applied iff the batch has 'scale0', fine_matching.py:68);
+ *   expec_f [M,3] (x, y, std), mkpts1_f [M,2].  (mkpts0_f is mkpts0_c, :66.) */
+int loftr_fine_match(const float* feat_f0, const float* feat_f1, int M, int WW, int C,
+                     const float* mkpts1_c, const int64_t* b_ids, float scale,
+                     const float* scale1, float* expec_f, float* mkpts1_f, void* stream);
+
+/* ---- building block exposed for tests / profiling ------------------------------------------
+ * out[M,N] = A[M,K] @ Wt[N,K]^T  (the fp32-MFMA GEMM every linear layer above is built on). */
+int loftr_linear_fwd(const float* a, const float* w, float* out, int M, int N, int K,
+                     void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LOFTR_HIP_H_ */

@@ -1,0 +1,712 @@
+// CoarseMatching (src/loftr/utils/coarse_matching.py) without ever running the reference's ~14
+// elementwise passes over the [N, L, S] score volume.
+//
+// dual-softmax  (coarse_matching.py:105-119 + get_coarse_match :150-196,238-261)
+//   pass A  score_stats : sim tile = <f0,f1>/(C*T) on the fp32 matrix cores; per-wave online
+//                         (max, sum exp) of every row and column of the tile -> partials
+//   merge   stats       : partials -> (max, 1/sum) per row and per column
+//   pass B  score_conf  : recompute the tile (bitwise the same sim), conf = softmax_row * softmax_col,
+//                         write conf_matrix ONCE (optional), per-wave row (max, first argmax) and
+//                         column max partials of conf
+//   merge   colmax      : column maxima of conf
+//   select              : per row: global (max, first argmax), threshold / border / mutual-NN test,
+//                         block-local exclusive scan of the survivors
+//   scan + scatter      : ordered compaction -> b_ids, i_ids, j_ids, mconf, mkpts*_c (ascending (b,i))
+//
+// sinkhorn  (coarse_matching.py:121-143 + SuperGlue log_optimal_transport)
+//   score_store         : Z = <f0,f1>/C written once into conf_out (it is the returned buffer anyway)
+//   3 x (row LSE, col LSE) in the log domain with the dustbin row / column handled analytically
+//   ot_finalize         : conf = exp(Z + u + v - norm) in place, optional [L+1, S+1] assignment
+//                         matrix, dustbin prefilter, the same row/col max partials as pass B
+//   then the same select / scan / scatter.
+#include "gemm.h"
+
+namespace {
+
+using Cfg = GemmCfg<128, 128, 16, 2, 2>;
+constexpr float SENTINEL = -3.0e38f;          // marks out-of-range tile entries (never a real score)
+
+struct Geometry {
+  int N, L, S, C;
+  int h0c, w0c, h1c, w1c;
+  int PJ, PI;                                   // partials per row (col tiles * WN) / per col
+};
+
+__device__ __forceinline__ bool in_range(float v) { return v > -1.0e38f; }
+
+// acc -> sim in place: scale, padding mask (-1e9), out-of-range -> SENTINEL.
+template <bool HAS_MASK>
+__device__ __forceinline__ void acc_to_sim(f32x16 (&acc)[Cfg::TM][Cfg::TN], int m0, int n0, int L, int S,
+                                           float scale, const uint8_t* __restrict__ mask0,
+                                           const uint8_t* __restrict__ mask1) {
+#pragma unroll
+  for (int j = 0; j < Cfg::TN; ++j) {
+    const int col = acc_col<Cfg>(n0, j);
+    const bool cok = col < S;
+    bool cm = true;
+    if (HAS_MASK) cm = cok ? mask1[col] != 0 : false;
+#pragma unroll
+    for (int i = 0; i < Cfg::TM; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = acc_row<Cfg>(m0, i, r);
+        float v = acc[i][j][r] * scale;
+        if (HAS_MASK) {
+          const bool rm = row < L ? mask0[row] != 0 : false;
+          if (!(rm && cm)) v = LOFTR_NEG_INF;            // masked_fill_(~(m0 x m1), -INF)  :115-118
+        }
+        if (!(cok && row < L)) v = SENTINEL;
+        acc[i][j][r] = v;
+      }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// pass A
+template <bool HAS_MASK>
+__global__ __launch_bounds__(Cfg::THREADS) void score_stats_kernel(
+    const float* __restrict__ f0, const float* __restrict__ f1, Geometry g, float scale,
+    const uint8_t* __restrict__ mask0, const uint8_t* __restrict__ mask1,
+    float2* __restrict__ rowpart, float2* __restrict__ colpart) {
+  __shared__ __attribute__((aligned(16))) float lds[Cfg::LDS_FLOATS];
+  const int n = blockIdx.z, m0 = blockIdx.y * Cfg::BM, n0 = blockIdx.x * Cfg::BN;
+  const float* a = f0 + (long)n * g.L * g.C;
+  const float* b = f1 + (long)n * g.S * g.C;
+  f32x16 acc[Cfg::TM][Cfg::TN];
+  gemm_mainloop<Cfg>(asrc_plain(a, g.C), b, g.C, g.L, g.S, g.C, m0, n0, lds, acc);
+  acc_to_sim<HAS_MASK>(acc, m0, n0, g.L, g.S, scale, HAS_MASK ? mask0 + (long)n * g.L : nullptr,
+                       HAS_MASK ? mask1 + (long)n * g.S : nullptr);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave / Cfg::WN, wn = wave % Cfg::WN;
+  // rows: reduce over the TN tiles of the lane and the 32 lanes of the half-wave
+  const int pj = blockIdx.x * Cfg::WN + wn;
+#pragma unroll
+  for (int i = 0; i < Cfg::TM; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float m = SENTINEL;
+#pragma unroll
+      for (int j = 0; j < Cfg::TN; ++j) m = fmaxf(m, acc[i][j][r]);
+      m = half_max(m);
+      float s = 0.f;
+#pragma unroll
+      for (int j = 0; j < Cfg::TN; ++j) s += in_range(acc[i][j][r]) ? expf(acc[i][j][r] - m) : 0.f;
+      s = half_sum(s);
+      const int row = acc_row<Cfg>(m0, i, r);
+      if ((lane & 31) == 0 && row < g.L) rowpart[((long)n * g.L + row) * g.PJ + pj] = make_float2(m, s);
+    }
+  // columns: reduce over the TM*16 rows of the lane and the other half-wave
+  const int pi = blockIdx.y * Cfg::WM + wm;
+#pragma unroll
+  for (int j = 0; j < Cfg::TN; ++j) {
+    float m = SENTINEL;
+#pragma unroll
+    for (int i = 0; i < Cfg::TM; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) m = fmaxf(m, acc[i][j][r]);
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < Cfg::TM; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s += in_range(acc[i][j][r]) ? expf(acc[i][j][r] - m) : 0.f;
+    s += __shfl_xor(s, 32, 64);
+    const int col = acc_col<Cfg>(n0, j);
+    if (lane < 32 && col < g.S) colpart[((long)n * g.S + col) * g.PI + pi] = make_float2(m, s);
+  }
+}
+
+// (max, sum) partials -> (max, 1/sum).   one thread per row (or column)
+__global__ void merge_stats_kernel(const float2* __restrict__ part, float2* __restrict__ stat, long rows, int P) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows) return;
+  const float2* p = part + i * P;
+  float m = SENTINEL;
+  for (int k = 0; k < P; ++k) m = fmaxf(m, p[k].x);
+  float s = 0.f;
+  for (int k = 0; k < P; ++k) s += in_range(p[k].x) ? p[k].y * expf(p[k].x - m) : 0.f;
+  stat[i] = make_float2(m, 1.f / s);
+}
+
+// Row (max, first argmax) and column max partials of a tile of conf held in acc.
+__device__ __forceinline__ void conf_partials(f32x16 (&acc)[Cfg::TM][Cfg::TN], int m0, int n0, int n,
+                                              const Geometry& g, int bx, int by,
+                                              float2* __restrict__ rowmax_part,
+                                              float* __restrict__ colmax_part) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave / Cfg::WN, wn = wave % Cfg::WN;
+  const int pj = bx * Cfg::WN + wn, pi = by * Cfg::WM + wm;
+#pragma unroll
+  for (int i = 0; i < Cfg::TM; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float bv = -1.f; int bc = 0x7fffffff;
+#pragma unroll
+      for (int j = 0; j < Cfg::TN; ++j) {            // ascending columns: strict > keeps the first
+        const float v = acc[i][j][r];
+        if (v > bv) { bv = v; bc = acc_col<Cfg>(n0, j); }
+      }
+#pragma unroll
+      for (int o = 16; o >= 1; o >>= 1) {
+        const float ov = __shfl_xor(bv, o, 64);
+        const int oc = __shfl_xor(bc, o, 64);
+        if (ov > bv || (ov == bv && oc < bc)) { bv = ov; bc = oc; }
+      }
+      const int row = acc_row<Cfg>(m0, i, r);
+      if ((lane & 31) == 0 && row < g.L)
+        rowmax_part[((long)n * g.L + row) * g.PJ + pj] = make_float2(bv, __int_as_float(bc));
+    }
+#pragma unroll
+  for (int j = 0; j < Cfg::TN; ++j) {
+    float m = -1.f;
+#pragma unroll
+    for (int i = 0; i < Cfg::TM; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) m = fmaxf(m, acc[i][j][r]);
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    const int col = acc_col<Cfg>(n0, j);
+    if (lane < 32 && col < g.S) colmax_part[((long)n * g.S + col) * g.PI + pi] = m;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// pass B
+template <bool HAS_MASK>
+__global__ __launch_bounds__(Cfg::THREADS) void score_conf_kernel(
+    const float* __restrict__ f0, const float* __restrict__ f1, Geometry g, float scale,
+    const uint8_t* __restrict__ mask0, const uint8_t* __restrict__ mask1,
+    const float2* __restrict__ rowstat, const float2* __restrict__ colstat,
+    float* __restrict__ conf_out, float2* __restrict__ rowmax_part, float* __restrict__ colmax_part) {
+  __shared__ __attribute__((aligned(16))) float lds[Cfg::LDS_FLOATS];
+  const int n = blockIdx.z, m0 = blockIdx.y * Cfg::BM, n0 = blockIdx.x * Cfg::BN;
+  const float* a = f0 + (long)n * g.L * g.C;
+  const float* b = f1 + (long)n * g.S * g.C;
+  f32x16 acc[Cfg::TM][Cfg::TN];
+  gemm_mainloop<Cfg>(asrc_plain(a, g.C), b, g.C, g.L, g.S, g.C, m0, n0, lds, acc);
+  acc_to_sim<HAS_MASK>(acc, m0, n0, g.L, g.S, scale, HAS_MASK ? mask0 + (long)n * g.L : nullptr,
+                       HAS_MASK ? mask1 + (long)n * g.S : nullptr);
+  float2 cs[Cfg::TN];
+#pragma unroll
+  for (int j = 0; j < Cfg::TN; ++j) {
+    const int col = min(acc_col<Cfg>(n0, j), g.S - 1);
+    cs[j] = colstat[(long)n * g.S + col];
+  }
+#pragma unroll
+  for (int i = 0; i < Cfg::TM; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = acc_row<Cfg>(m0, i, r);
+      const float2 rs = rowstat[(long)n * g.L + min(row, g.L - 1)];
+#pragma unroll
+      for (int j = 0; j < Cfg::TN; ++j) {
+        const float v = acc[i][j][r];
+        float c = -1.f;                                        // out of range: below any confidence
+        if (in_range(v)) {
+          // softmax(sim, dim=1) * softmax(sim, dim=2)          coarse_matching.py:119
+          c = (expf(v - cs[j].x) * cs[j].y) * (expf(v - rs.x) * rs.y);
+          if (conf_out) conf_out[((long)n * g.L + row) * g.S + acc_col<Cfg>(n0, j)] = c;
+        }
+        acc[i][j][r] = c;
+      }
+    }
+  conf_partials(acc, m0, n0, n, g, blockIdx.x, blockIdx.y, rowmax_part, colmax_part);
+}
+
+__global__ void merge_colmax_kernel(const float* __restrict__ part, float* __restrict__ colmax, long cols, int P) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= cols) return;
+  float m = -1.f;
+  for (int k = 0; k < P; ++k) m = fmaxf(m, part[i * P + k]);
+  colmax[i] = m;
+}
+
+// ------------------------------------------------------------------------------------------
+// valid[n] = (h0, w0, h1, w1) of the top-left-anchored valid rectangles of the padding masks,
+// recovered like coarse_matching.py:37-38: p_m.sum(1).max(-1), p_m.sum(-1).max(-1).
+__global__ void valid_hw_kernel(const uint8_t* __restrict__ mask0, const uint8_t* __restrict__ mask1,
+                                int h0c, int w0c, int h1c, int w1c, int* __restrict__ valid) {
+  const int n = blockIdx.x;
+  __shared__ int res[4];
+  if (threadIdx.x < 4) res[threadIdx.x] = 0;
+  __syncthreads();
+  for (int which = 0; which < 2; ++which) {
+    const uint8_t* m = which ? mask1 + (long)n * h1c * w1c : mask0 + (long)n * h0c * w0c;
+    const int h = which ? h1c : h0c, w = which ? w1c : w0c;
+    for (int x = threadIdx.x; x < w; x += blockDim.x) {        // column sums -> valid height
+      int s = 0;
+      for (int y = 0; y < h; ++y) s += m[y * w + x] != 0;
+      atomicMax(&res[which * 2 + 0], s);
+    }
+    for (int y = threadIdx.x; y < h; y += blockDim.x) {        // row sums -> valid width
+      int s = 0;
+      for (int x = 0; x < w; ++x) s += m[y * w + x] != 0;
+      atomicMax(&res[which * 2 + 1], s);
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < 4) valid[n * 4 + threadIdx.x] = res[threadIdx.x];
+}
+
+struct SelectParams {
+  Geometry g;
+  float thr; int border;
+  const int* valid;                 // [N,4] or null
+};
+
+// python slice semantics of `m[b, lim:] = False` with lim = hv - bd possibly negative
+__device__ __forceinline__ int upper_limit(int hv, int bd, int hc) {
+  int lim = hv - bd;
+  if (lim < 0) lim = max(lim + hc, 0);
+  return lim;
+}
+
+// one thread per row of the flattened [N*L] rows; 256 rows per block
+__global__ __launch_bounds__(256) void select_kernel(SelectParams sp, const float2* __restrict__ rowmax_part,
+                                                     const float* __restrict__ colmax,
+                                                     int* __restrict__ cand_j, float* __restrict__ cand_conf,
+                                                     int* __restrict__ cand_rank, int* __restrict__ block_count,
+                                                     int* __restrict__ counts) {
+  const Geometry& g = sp.g;
+  const long row = (long)blockIdx.x * 256 + threadIdx.x;
+  const long rows = (long)g.N * g.L;
+  bool flag = false;
+  int bj = 0; float bv = 0.f; int n = 0;
+  if (row < rows) {
+    n = (int)(row / g.L);
+    const int i = (int)(row - (long)n * g.L);
+    const float2* p = rowmax_part + row * g.PJ;
+    bv = -1.f; bj = 0;
+    for (int k = 0; k < g.PJ; ++k) {                 // ascending column chunks: > keeps the first
+      const float2 e = p[k];
+      if (e.x > bv) { bv = e.x; bj = __float_as_int(e.y); }
+    }
+    // 1. confidence threshold (:172)  2. borders (:176-183)  3. mutual nearest (:187-189)
+    flag = bv > sp.thr;
+    if (flag && sp.border > 0) {
+      const int y0 = i / g.w0c, x0 = i % g.w0c, y1 = bj / g.w1c, x1 = bj % g.w1c;
+      int l_h0, l_w0, l_h1, l_w1;
+      if (sp.valid) {
+        const int* v = sp.valid + n * 4;
+        l_h0 = upper_limit(v[0], sp.border, g.h0c); l_w0 = upper_limit(v[1], sp.border, g.w0c);
+        l_h1 = upper_limit(v[2], sp.border, g.h1c); l_w1 = upper_limit(v[3], sp.border, g.w1c);
+      } else {
+        l_h0 = g.h0c - sp.border; l_w0 = g.w0c - sp.border; l_h1 = g.h1c - sp.border; l_w1 = g.w1c - sp.border;
+      }
+      const int b = sp.border;
+      flag = y0 >= b && x0 >= b && y1 >= b && x1 >= b && y0 < l_h0 && x0 < l_w0 && y1 < l_h1 && x1 < l_w1;
+    }
+    if (flag) flag = bv == colmax[(long)n * g.S + bj];
+  }
+  // block-local exclusive scan of the flags (ballot per wave + wave offsets through LDS)
+  __shared__ int wave_tot[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const unsigned long long bal = __ballot(flag);
+  const int within = __popcll(bal & ((1ull << lane) - 1ull));
+  if (lane == 0) wave_tot[wave] = __popcll(bal);
+  __syncthreads();
+  int off = 0;
+  for (int w = 0; w < wave; ++w) off += wave_tot[w];
+  if (row < rows) {
+    cand_j[row] = bj;
+    cand_conf[row] = bv;
+    cand_rank[row] = flag ? off + within : -1;
+    if (flag) atomicAdd(&counts[1 + n], 1);
+  }
+  if (threadIdx.x == 0) block_count[blockIdx.x] = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
+}
+
+// exclusive scan of the per-block counts (single block) + total
+__global__ __launch_bounds__(1024) void scan_blocks_kernel(const int* __restrict__ block_count,
+                                                           int* __restrict__ block_off, int nblk,
+                                                           int* __restrict__ counts) {
+  __shared__ int buf[1024];
+  __shared__ int carry;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (int base = 0; base < nblk; base += 1024) {
+    const int i = base + threadIdx.x;
+    const int v = i < nblk ? block_count[i] : 0;
+    buf[threadIdx.x] = v;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {              // Hillis-Steele inclusive scan
+      int t = threadIdx.x >= o ? buf[threadIdx.x - o] : 0;
+      __syncthreads();
+      buf[threadIdx.x] += t;
+      __syncthreads();
+    }
+    if (i < nblk) block_off[i] = carry + buf[threadIdx.x] - v;
+    __syncthreads();
+    if (threadIdx.x == 1023) carry += buf[1023];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) counts[0] = carry;
+}
+
+struct ScatterParams {
+  Geometry g;
+  float scale; const float* scale0; const float* scale1;
+  loftr_match_out out;
+};
+
+__global__ __launch_bounds__(256) void scatter_kernel(ScatterParams sp, const int* __restrict__ cand_j,
+                                                      const float* __restrict__ cand_conf,
+                                                      const int* __restrict__ cand_rank,
+                                                      const int* __restrict__ block_off) {
+  const Geometry& g = sp.g;
+  const long row = (long)blockIdx.x * 256 + threadIdx.x;
+  if (row >= (long)g.N * g.L) return;
+  const int rk = cand_rank[row];
+  if (rk < 0) return;
+  const long dst = block_off[blockIdx.x] + rk;
+  const int n = (int)(row / g.L);
+  const int i = (int)(row - (long)n * g.L);
+  const int j = cand_j[row];
+  sp.out.b_ids[dst] = n;
+  sp.out.i_ids[dst] = i;
+  sp.out.j_ids[dst] = j;
+  sp.out.mconf[dst] = cand_conf[row];
+  // mkpts = stack([id % w, id // w]) * (scale * scale{0,1}[b])       coarse_matching.py:242-250
+  float s0x = sp.scale, s0y = sp.scale, s1x = sp.scale, s1y = sp.scale;
+  if (sp.scale0) { s0x = sp.scale * sp.scale0[n * 2]; s0y = sp.scale * sp.scale0[n * 2 + 1]; }
+  if (sp.scale1) { s1x = sp.scale * sp.scale1[n * 2]; s1y = sp.scale * sp.scale1[n * 2 + 1]; }
+  sp.out.mkpts0_c[dst * 2 + 0] = (float)(i % g.w0c) * s0x;
+  sp.out.mkpts0_c[dst * 2 + 1] = (float)(i / g.w0c) * s0y;
+  sp.out.mkpts1_c[dst * 2 + 0] = (float)(j % g.w1c) * s1x;
+  sp.out.mkpts1_c[dst * 2 + 1] = (float)(j / g.w1c) * s1y;
+}
+
+// ------------------------------------------------------------------------------------------
+// Sinkhorn pieces
+__global__ __launch_bounds__(Cfg::THREADS) void score_store_kernel(const float* __restrict__ f0,
+                                                                   const float* __restrict__ f1, Geometry g,
+                                                                   float scale, const uint8_t* __restrict__ mask0,
+                                                                   const uint8_t* __restrict__ mask1,
+                                                                   float* __restrict__ z) {
+  __shared__ __attribute__((aligned(16))) float lds[Cfg::LDS_FLOATS];
+  const int n = blockIdx.z, m0 = blockIdx.y * Cfg::BM, n0 = blockIdx.x * Cfg::BN;
+  f32x16 acc[Cfg::TM][Cfg::TN];
+  gemm_mainloop<Cfg>(asrc_plain(f0 + (long)n * g.L * g.C, g.C), f1 + (long)n * g.S * g.C, g.C, g.L, g.S, g.C,
+                     m0, n0, lds, acc);
+  if (mask0) acc_to_sim<true>(acc, m0, n0, g.L, g.S, scale, mask0 + (long)n * g.L, mask1 + (long)n * g.S);
+  else acc_to_sim<false>(acc, m0, n0, g.L, g.S, scale, nullptr, nullptr);
+#pragma unroll
+  for (int i = 0; i < Cfg::TM; ++i)
+#pragma unroll
+    for (int j = 0; j < Cfg::TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float v = acc[i][j][r];
+        if (in_range(v)) z[((long)n * g.L + acc_row<Cfg>(m0, i, r)) * g.S + acc_col<Cfg>(n0, j)] = v;
+      }
+}
+
+// u[n][i] = log_mu[i] - logsumexp_j(Zfull[i][j] + v[j]),  i in [0, L]  (row L = dustbin row),
+// j over the S real columns plus the dustbin column (value alpha).  One wave per row.
+//   grid (ceil((L+1)/4), N), 256 threads.
+__global__ __launch_bounds__(256) void ot_row_lse_kernel(const float* __restrict__ z, Geometry g, float alpha,
+                                                         float norm, const float* __restrict__ v,
+                                                         float* __restrict__ u) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n = blockIdx.y, i = blockIdx.x * 4 + wave;
+  if (i > g.L) return;
+  const float* vn = v + (long)n * (g.S + 1);
+  const float* zr = z + ((long)n * g.L + min(i, g.L - 1)) * g.S;
+  const bool bin_row = i == g.L;
+  float m = SENTINEL;
+  for (int j = lane; j <= g.S; j += 64) {
+    const float x = ((bin_row || j == g.S) ? alpha : zr[j]) + vn[j];
+    m = fmaxf(m, x);
+  }
+  m = wave_max(m);
+  float s = 0.f;
+  for (int j = lane; j <= g.S; j += 64) {
+    const float x = ((bin_row || j == g.S) ? alpha : zr[j]) + vn[j];
+    s += expf(x - m);
+  }
+  s = wave_sum(s);
+  const float log_mu = bin_row ? logf((float)g.S) + norm : norm;
+  if (lane == 0) u[(long)n * (g.L + 1) + i] = log_mu - (m + logf(s));
+}
+
+// column partial (max, sum exp) of Zfull[i][j] + u[i] over a chunk of rows.
+//   grid (ceil((S+1)/64), RCH, N), 256 threads = 64 columns x 4 row lanes
+constexpr int OT_RCH = 32;
+__global__ __launch_bounds__(256) void ot_col_part_kernel(const float* __restrict__ z, Geometry g, float alpha,
+                                                          const float* __restrict__ u,
+                                                          float2* __restrict__ part) {
+  __shared__ float2 red[4][64];
+  const int n = blockIdx.z, j = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+  const int rows = g.L + 1;
+  const int per = ceil_div(rows, OT_RCH);
+  const int r0 = blockIdx.y * per, r1 = min(r0 + per, rows);
+  const float* un = u + (long)n * rows;
+  float m = SENTINEL, s = 0.f;
+  if (j <= g.S) {
+    const bool bin_col = j == g.S;
+    for (int i = r0 + rl; i < r1; i += 4) {
+      const float x = ((bin_col || i == g.L) ? alpha : z[((long)n * g.L + i) * g.S + j]) + un[i];
+      if (x > m) { s = s * expf(m - x) + 1.f; m = x; } else { s += expf(x - m); }
+    }
+  }
+  red[rl][threadIdx.x & 63] = make_float2(m, s);
+  __syncthreads();
+  if (rl == 0 && j <= g.S) {
+    float M = SENTINEL;
+    for (int k = 0; k < 4; ++k) M = fmaxf(M, red[k][threadIdx.x].x);
+    float Ssum = 0.f;
+    for (int k = 0; k < 4; ++k) Ssum += in_range(red[k][threadIdx.x].x) ? red[k][threadIdx.x].y * expf(red[k][threadIdx.x].x - M) : 0.f;
+    part[((long)n * (g.S + 1) + j) * OT_RCH + blockIdx.y] = make_float2(M, Ssum);
+  }
+}
+
+__global__ void ot_col_merge_kernel(const float2* __restrict__ part, Geometry g, float norm,
+                                    float* __restrict__ v) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long cols = (long)g.N * (g.S + 1);
+  if (idx >= cols) return;
+  const int j = (int)(idx % (g.S + 1));
+  const float2* p = part + idx * OT_RCH;
+  float m = SENTINEL;
+  for (int k = 0; k < OT_RCH; ++k) m = fmaxf(m, p[k].x);
+  float s = 0.f;
+  for (int k = 0; k < OT_RCH; ++k) s += in_range(p[k].x) ? p[k].y * expf(p[k].x - m) : 0.f;
+  const float log_nu = j == g.S ? logf((float)g.L) + norm : norm;
+  v[idx] = log_nu - (m + logf(s));
+}
+
+// dustbin prefilter (coarse_matching.py:136-140): row i is dropped when the argmax of its
+// assignment row (dustbin column included) is the dustbin; same for columns.
+//   rowkill[n][i], colkill[n][j].  Ties resolve to the first index like torch.max.
+__global__ __launch_bounds__(256) void ot_rowkill_kernel(const float* __restrict__ z, Geometry g, float alpha,
+                                                         const float* __restrict__ u, const float* __restrict__ v,
+                                                         uint8_t* __restrict__ rowkill) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n = blockIdx.y, i = blockIdx.x * 4 + wave;
+  if (i >= g.L) return;
+  const float* vn = v + (long)n * (g.S + 1);
+  const float* zr = z + ((long)n * g.L + i) * g.S;
+  float m = SENTINEL;
+  for (int j = lane; j < g.S; j += 64) m = fmaxf(m, zr[j] + vn[j]);
+  m = wave_max(m);
+  // assignment = exp(z + u + v - norm): monotone in (z + v) along a row; bin wins only if strictly larger
+  if (lane == 0) rowkill[(long)n * g.L + i] = (alpha + vn[g.S]) > m;
+}
+__global__ __launch_bounds__(256) void ot_colkill_kernel(const float* __restrict__ z, Geometry g, float alpha,
+                                                         const float* __restrict__ u, const float* __restrict__ v,
+                                                         uint8_t* __restrict__ colkill) {
+  const int n = blockIdx.y, j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= g.S) return;
+  const float* un = u + (long)n * (g.L + 1);
+  float m = SENTINEL;
+  for (int i = 0; i < g.L; ++i) m = fmaxf(m, z[((long)n * g.L + i) * g.S + j] + un[i]);
+  colkill[(long)n * g.S + j] = (alpha + un[g.L]) > m;
+}
+
+// conf = exp(z + u + v - norm) in place (+ full assignment matrix, + prefilter) and the row/col
+// max partials of conf.  Tile = 128 x 128 like the GEMM kernels so that conf_partials applies.
+__global__ __launch_bounds__(Cfg::THREADS) void ot_finalize_kernel(float* __restrict__ z, Geometry g, float norm,
+                                                                   const float* __restrict__ u,
+                                                                   const float* __restrict__ v,
+                                                                   const uint8_t* __restrict__ rowkill,
+                                                                   const uint8_t* __restrict__ colkill,
+                                                                   float* __restrict__ assign,
+                                                                   float2* __restrict__ rowmax_part,
+                                                                   float* __restrict__ colmax_part) {
+  const int n = blockIdx.z, m0 = blockIdx.y * Cfg::BM, n0 = blockIdx.x * Cfg::BN;
+  const float* un = u + (long)n * (g.L + 1);
+  const float* vn = v + (long)n * (g.S + 1);
+  f32x16 acc[Cfg::TM][Cfg::TN];
+#pragma unroll
+  for (int i = 0; i < Cfg::TM; ++i)
+#pragma unroll
+    for (int j = 0; j < Cfg::TN; ++j) {
+      const int col = acc_col<Cfg>(n0, j);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = acc_row<Cfg>(m0, i, r);
+        float c = -1.f;
+        if (row < g.L && col < g.S) {
+          const long o = ((long)n * g.L + row) * g.S + col;
+          c = expf(z[o] + un[row] + vn[col] - norm);
+          if (rowkill && (rowkill[(long)n * g.L + row] || colkill[(long)n * g.S + col])) c = 0.f;
+          // conf_matrix is a VIEW of assign_matrix in the reference (:133), so the prefilter
+          // zeroing (:139-140) is visible in conf_matrix_with_bin (:143) as well
+          if (assign) assign[((long)n * (g.L + 1) + row) * (g.S + 1) + col] = c;
+          z[o] = c;
+        }
+        acc[i][j][r] = c;
+      }
+    }
+  conf_partials(acc, m0, n0, n, g, blockIdx.x, blockIdx.y, rowmax_part, colmax_part);
+}
+
+// dustbin column / row / corner of the assignment matrix
+__global__ void ot_assign_bins_kernel(Geometry g, float alpha, float norm, const float* __restrict__ u,
+                                      const float* __restrict__ v, float* __restrict__ assign) {
+  const int n = blockIdx.y;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const float* un = u + (long)n * (g.L + 1);
+  const float* vn = v + (long)n * (g.S + 1);
+  float* an = assign + (long)n * (g.L + 1) * (g.S + 1);
+  if (t < g.L) an[(long)t * (g.S + 1) + g.S] = expf(alpha + un[t] + vn[g.S] - norm);
+  if (t <= g.S) an[(long)g.L * (g.S + 1) + t] = expf(alpha + un[g.L] + vn[t] - norm);
+}
+
+// ------------------------------------------------------------------------------------------
+struct MatchWs {
+  float2 *rowpart, *colpart, *rowstat, *colstat, *rowmax_part;
+  float *colmax_part, *colmax, *cand_conf;
+  int *cand_j, *cand_rank, *block_count, *block_off, *valid;
+  float *ot_u, *ot_v; float2* ot_part; uint8_t *rowkill, *colkill;
+  bool ok;
+};
+
+Geometry make_geometry(const loftr_coarse_params& p) {
+  Geometry g;
+  g.N = p.N; g.C = p.C; g.h0c = p.h0c; g.w0c = p.w0c; g.h1c = p.h1c; g.w1c = p.w1c;
+  g.L = p.h0c * p.w0c; g.S = p.h1c * p.w1c;
+  g.PJ = ceil_div(g.S, Cfg::BN) * Cfg::WN;
+  g.PI = ceil_div(g.L, Cfg::BM) * Cfg::WM;
+  return g;
+}
+
+MatchWs carve(void* ws, size_t bytes, const Geometry& g) {
+  WsAlloc wa(ws, bytes);
+  MatchWs m;
+  const size_t NL = (size_t)g.N * g.L, NS = (size_t)g.N * g.S;
+  m.rowpart = wa.take<float2>(NL * g.PJ);
+  m.colpart = wa.take<float2>(NS * g.PI);
+  m.rowstat = wa.take<float2>(NL);
+  m.colstat = wa.take<float2>(NS);
+  m.rowmax_part = wa.take<float2>(NL * g.PJ);
+  m.colmax_part = wa.take<float>(NS * g.PI);
+  m.colmax = wa.take<float>(NS);
+  m.cand_conf = wa.take<float>(NL);
+  m.cand_j = wa.take<int>(NL);
+  m.cand_rank = wa.take<int>(NL);
+  const size_t nblk = (NL + 255) / 256;
+  m.block_count = wa.take<int>(nblk);
+  m.block_off = wa.take<int>(nblk);
+  m.valid = wa.take<int>((size_t)g.N * 4);
+  m.ot_u = wa.take<float>((size_t)g.N * (g.L + 1));
+  m.ot_v = wa.take<float>((size_t)g.N * (g.S + 1));
+  m.ot_part = wa.take<float2>((size_t)g.N * (g.S + 1) * OT_RCH);
+  m.rowkill = wa.take<uint8_t>(NL);
+  m.colkill = wa.take<uint8_t>(NS);
+  m.ok = wa.ok();
+  return m;
+}
+
+size_t match_ws_bytes(int N, int L, int S) {
+  const size_t PJ = (size_t)ceil_div(S, Cfg::BN) * Cfg::WN, PI = (size_t)ceil_div(L, Cfg::BM) * Cfg::WM;
+  const size_t NL = (size_t)N * L, NS = (size_t)N * S;
+  size_t b = 0;
+  b += NL * PJ * 8 * 2 + NS * PI * 8 + NS * PI * 4;
+  b += NL * 8 + NS * 8 + NS * 4 + NL * 4 * 3 + ((NL + 255) / 256) * 8 + (size_t)N * 16;
+  b += (size_t)N * (L + 1) * 4 + (size_t)N * (S + 1) * 4 + (size_t)N * (S + 1) * OT_RCH * 8 + NL + NS;
+  return b + 32 * 256;     // alignment slack of the bump allocator
+}
+
+bool params_ok(const loftr_coarse_params* p, const loftr_match_out* o) {
+  if (!p || !o) return false;
+  if (p->N < 0 || p->h0c <= 0 || p->w0c <= 0 || p->h1c <= 0 || p->w1c <= 0) return false;
+  if ((p->mask0 == nullptr) != (p->mask1 == nullptr)) return false;
+  return o->b_ids && o->i_ids && o->j_ids && o->mconf && o->mkpts0_c && o->mkpts1_c && o->counts;
+}
+
+// select -> scan -> scatter on the row/col max partials of conf
+int select_and_compact(const Geometry& g, const loftr_coarse_params& p, const loftr_match_out& out,
+                       const MatchWs& w, hipStream_t st) {
+  const long NL = (long)g.N * g.L, NS = (long)g.N * g.S;
+  hipLaunchKernelGGL(merge_colmax_kernel, dim3(ceil_div((int)NS, 256)), dim3(256), 0, st, w.colmax_part, w.colmax, NS, g.PI);
+  const int* valid = nullptr;
+  if (p.mask0) {
+    hipLaunchKernelGGL(valid_hw_kernel, dim3(g.N), dim3(128), 0, st, p.mask0, p.mask1, g.h0c, g.w0c, g.h1c, g.w1c, w.valid);
+    valid = w.valid;
+  }
+  (void)hipMemsetAsync(out.counts, 0, sizeof(int32_t) * (1 + g.N), st);
+  const int nblk = (int)((NL + 255) / 256);
+  SelectParams sp{g, p.thr, p.border_rm, valid};
+  hipLaunchKernelGGL(select_kernel, dim3(nblk), dim3(256), 0, st, sp, w.rowmax_part, w.colmax, w.cand_j, w.cand_conf,
+                     w.cand_rank, w.block_count, out.counts);
+  hipLaunchKernelGGL(scan_blocks_kernel, dim3(1), dim3(1024), 0, st, w.block_count, w.block_off, nblk, out.counts);
+  ScatterParams sc{g, p.scale, p.scale0, p.scale1, out};
+  hipLaunchKernelGGL(scatter_kernel, dim3(nblk), dim3(256), 0, st, sc, w.cand_j, w.cand_conf, w.cand_rank, w.block_off);
+  LOFTR_CHECK_LAUNCH();
+  return LOFTR_OK;
+}
+
+}  // namespace
+
+extern "C" size_t loftr_coarse_match_workspace_bytes(int N, int L, int S) {
+  if (N <= 0 || L <= 0 || S <= 0) return 0;
+  return match_ws_bytes(N, L, S);
+}
+
+extern "C" int loftr_coarse_match_dual_softmax(const float* feat_c0, const float* feat_c1,
+                                               const loftr_coarse_params* p, float temperature,
+                                               float* conf_out, const loftr_match_out* out, void* ws,
+                                               size_t ws_bytes, void* stream) {
+  LOFTR_CHECK_ARG(feat_c0 && feat_c1 && params_ok(p, out) && temperature > 0.f);
+  if (p->C % Cfg::BK != 0) return LOFTR_ERR_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  if (p->N == 0) { (void)hipMemsetAsync(out->counts, 0, sizeof(int32_t), st); return LOFTR_OK; }
+  LOFTR_CHECK_ARG(ws != nullptr);
+  const Geometry g = make_geometry(*p);
+  MatchWs w = carve(ws, ws_bytes, g);
+  if (!w.ok) return LOFTR_ERR_WORKSPACE;
+  // feat / sqrt(C) on both sides, then / temperature                 coarse_matching.py:108-114
+  const float scale = 1.f / ((float)g.C * temperature);
+  const dim3 grid(ceil_div(g.S, Cfg::BN), ceil_div(g.L, Cfg::BM), g.N), block(Cfg::THREADS);
+  const long NL = (long)g.N * g.L, NS = (long)g.N * g.S;
+  if (p->mask0)
+    hipLaunchKernelGGL((score_stats_kernel<true>), grid, block, 0, st, feat_c0, feat_c1, g, scale, p->mask0, p->mask1, w.rowpart, w.colpart);
+  else
+    hipLaunchKernelGGL((score_stats_kernel<false>), grid, block, 0, st, feat_c0, feat_c1, g, scale, p->mask0, p->mask1, w.rowpart, w.colpart);
+  hipLaunchKernelGGL(merge_stats_kernel, dim3(ceil_div((int)NL, 256)), dim3(256), 0, st, w.rowpart, w.rowstat, NL, g.PJ);
+  hipLaunchKernelGGL(merge_stats_kernel, dim3(ceil_div((int)NS, 256)), dim3(256), 0, st, w.colpart, w.colstat, NS, g.PI);
+  if (p->mask0)
+    hipLaunchKernelGGL((score_conf_kernel<true>), grid, block, 0, st, feat_c0, feat_c1, g, scale, p->mask0, p->mask1, w.rowstat, w.colstat, conf_out, w.rowmax_part, w.colmax_part);
+  else
+    hipLaunchKernelGGL((score_conf_kernel<false>), grid, block, 0, st, feat_c0, feat_c1, g, scale, p->mask0, p->mask1, w.rowstat, w.colstat, conf_out, w.rowmax_part, w.colmax_part);
+  LOFTR_CHECK_LAUNCH();
+  return select_and_compact(g, *p, *out, w, st);
+}
+
+extern "C" int loftr_coarse_match_sinkhorn(const float* feat_c0, const float* feat_c1,
+                                           const loftr_coarse_params* p, float bin_score, int iters,
+                                           int prefilter, float* conf_out, float* assign_out,
+                                           const loftr_match_out* out, void* ws, size_t ws_bytes,
+                                           void* stream) {
+  LOFTR_CHECK_ARG(feat_c0 && feat_c1 && params_ok(p, out) && conf_out && iters >= 0);
+  if (p->C % Cfg::BK != 0) return LOFTR_ERR_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  if (p->N == 0) { (void)hipMemsetAsync(out->counts, 0, sizeof(int32_t), st); return LOFTR_OK; }
+  LOFTR_CHECK_ARG(ws != nullptr);
+  const Geometry g = make_geometry(*p);
+  MatchWs w = carve(ws, ws_bytes, g);
+  if (!w.ok) return LOFTR_ERR_WORKSPACE;
+  const float scale = 1.f / (float)g.C;                    // no temperature   coarse_matching.py:123
+  const float norm = -logf((float)(g.L + g.S));            // SuperGlue: norm = -log(m + n)
+  const dim3 grid(ceil_div(g.S, Cfg::BN), ceil_div(g.L, Cfg::BM), g.N), block(Cfg::THREADS);
+  hipLaunchKernelGGL(score_store_kernel, grid, block, 0, st, feat_c0, feat_c1, g, scale, p->mask0, p->mask1, conf_out);
+  (void)hipMemsetAsync(w.ot_u, 0, sizeof(float) * g.N * (g.L + 1), st);
+  (void)hipMemsetAsync(w.ot_v, 0, sizeof(float) * g.N * (g.S + 1), st);
+  const long cols = (long)g.N * (g.S + 1);
+  for (int it = 0; it < iters; ++it) {
+    hipLaunchKernelGGL(ot_row_lse_kernel, dim3(ceil_div(g.L + 1, 4), g.N), dim3(256), 0, st, conf_out, g, bin_score, norm, w.ot_v, w.ot_u);
+    hipLaunchKernelGGL(ot_col_part_kernel, dim3(ceil_div(g.S + 1, 64), OT_RCH, g.N), dim3(256), 0, st, conf_out, g, bin_score, w.ot_u, w.ot_part);
+    hipLaunchKernelGGL(ot_col_merge_kernel, dim3(ceil_div((int)cols, 256)), dim3(256), 0, st, w.ot_part, g, norm, w.ot_v);
+  }
+  const uint8_t *rk = nullptr, *ck = nullptr;
+  if (prefilter) {
+    hipLaunchKernelGGL(ot_rowkill_kernel, dim3(ceil_div(g.L, 4), g.N), dim3(256), 0, st, conf_out, g, bin_score, w.ot_u, w.ot_v, w.rowkill);
+    hipLaunchKernelGGL(ot_colkill_kernel, dim3(ceil_div(g.S, 256), g.N), dim3(256), 0, st, conf_out, g, bin_score, w.ot_u, w.ot_v, w.colkill);
+    rk = w.rowkill; ck = w.colkill;
+  }
+  if (assign_out)
+    hipLaunchKernelGGL(ot_assign_bins_kernel, dim3(ceil_div((g.L > g.S ? g.L : g.S) + 1, 256), g.N), dim3(256), 0, st, g, bin_score, norm, w.ot_u, w.ot_v, assign_out);
+  hipLaunchKernelGGL(ot_finalize_kernel, grid, block, 0, st, conf_out, g, norm, w.ot_u, w.ot_v, rk, ck, assign_out, w.rowmax_part, w.colmax_part);
+  LOFTR_CHECK_LAUNCH();
+  return select_and_compact(g, *p, *out, w, st);
+}

@@ -1,0 +1,63 @@
+// Position encoding + NCHW -> N(HW)C flatten, library entry points that are not kernels.
+//   reference: src/loftr/utils/position_encoding.py:37-42, src/loftr/loftr.py:58-59
+#include "common.h"
+#include <string.h>
+
+namespace {
+// 32 x 32 tile transpose through LDS: read rows of [C][HW] (coalesced along HW), write rows of
+// [HW][C] (coalesced along C).  The constant sine table is added on the way.
+//   grid (ceil(HW/32), ceil(C/32), N), block (32, 8)
+__global__ void pos_encode_flatten_kernel(const float* __restrict__ feat, const float* __restrict__ pe,
+                                          int pe_h, int pe_w, float* __restrict__ out, int C, int H, int W) {
+  __shared__ float tile[32][33];
+  const int HW = H * W;
+  const int n = blockIdx.z, hw0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+  const float* in = feat + (long)n * C * HW;
+  for (int k = threadIdx.y; k < 32; k += 8) {
+    const int c = c0 + k, hw = hw0 + threadIdx.x;
+    float v = 0.f;
+    if (c < C && hw < HW) {
+      const int y = hw / W, x = hw - y * W;
+      v = in[(long)c * HW + hw] + pe[((long)c * pe_h + y) * pe_w + x];
+    }
+    tile[k][threadIdx.x] = v;
+  }
+  __syncthreads();
+  for (int k = threadIdx.y; k < 32; k += 8) {
+    const int hw = hw0 + k, c = c0 + threadIdx.x;
+    if (hw < HW && c < C) out[((long)n * HW + hw) * C + c] = tile[threadIdx.x][k];
+  }
+}
+}  // namespace
+
+extern "C" int loftr_pos_encode_flatten(const float* feat, const float* pe, int pe_h, int pe_w, float* out,
+                                        int N, int C, int H, int W, void* stream) {
+  LOFTR_CHECK_ARG(feat && pe && out && N >= 0 && C > 0 && H > 0 && W > 0 && H <= pe_h && W <= pe_w);
+  if (N == 0) return LOFTR_OK;
+  hipLaunchKernelGGL(pos_encode_flatten_kernel, dim3(ceil_div(H * W, 32), ceil_div(C, 32), N), dim3(32, 8), 0,
+                     (hipStream_t)stream, feat, pe, pe_h, pe_w, out, C, H, W);
+  LOFTR_CHECK_LAUNCH();
+  return LOFTR_OK;
+}
+
+extern "C" int loftr_hip_abi_version(void) { return LOFTR_HIP_ABI_VERSION; }
+
+extern "C" const char* loftr_hip_status_string(int status) {
+  switch (status) {
+    case LOFTR_OK: return "ok";
+    case LOFTR_ERR_BAD_ARG: return "bad argument (null pointer or invalid shape)";
+    case LOFTR_ERR_UNSUPPORTED: return "shape not supported by the gfx950 kernels";
+    case LOFTR_ERR_WORKSPACE: return "workspace too small";
+    case LOFTR_ERR_LAUNCH: return "HIP kernel launch failed";
+    case LOFTR_ERR_NO_DEVICE: return "no gfx950 (MI355X) device";
+    default: return "unknown status";
+  }
+}
+
+extern "C" int loftr_hip_device_check(void) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return LOFTR_ERR_NO_DEVICE;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return LOFTR_ERR_NO_DEVICE;
+  return strncmp(prop.gcnArchName, "gfx950", 6) == 0 ? LOFTR_OK : LOFTR_ERR_NO_DEVICE;
+}
