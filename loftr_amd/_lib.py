@@ -1,0 +1,90 @@
+"""ctypes binding of libloftr_hip.so (include/loftr_hip.h).
+
+The product path has NO fallback: if the shared object is missing or a call fails, this module
+raises.  Build it with ``python -m loftr_amd.build`` (hipcc, gfx950).
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libloftr_hip.so")
+
+_p = C.c_void_p
+_i = C.c_int
+_f = C.c_float
+_sz = C.c_size_t
+_l = C.c_long
+
+
+class LayerWeights(C.Structure):
+    _fields_ = [(n, _p) for n in ("q_proj", "k_proj", "v_proj", "merge", "mlp0", "mlp2",
+                                  "norm1_w", "norm1_b", "norm2_w", "norm2_b")]
+
+
+class CoarseParams(C.Structure):
+    _fields_ = [("N", _i), ("h0c", _i), ("w0c", _i), ("h1c", _i), ("w1c", _i), ("C", _i),
+                ("thr", _f), ("border_rm", _i), ("scale", _f),
+                ("mask0", _p), ("mask1", _p), ("scale0", _p), ("scale1", _p)]
+
+
+class MatchOut(C.Structure):
+    _fields_ = [(n, _p) for n in ("b_ids", "i_ids", "j_ids", "mconf", "mkpts0_c", "mkpts1_c", "counts")]
+
+
+class FMap(C.Structure):
+    _fields_ = [("data", _p), ("sn", _l), ("sc", _l), ("sh", _l), ("sw", _l), ("H", _i), ("W", _i)]
+
+
+# symbol -> (restype, argtypes); must list every function declared in include/loftr_hip.h
+SIGNATURES = {
+    "loftr_hip_abi_version": (_i, []),
+    "loftr_hip_status_string": (C.c_char_p, [_i]),
+    "loftr_hip_device_check": (_i, []),
+    "loftr_pos_encode_flatten": (_i, [_p, _p, _i, _i, _p, _i, _i, _i, _i, _p]),
+    "loftr_encoder_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    "loftr_encoder_layer_fwd": (_i, [_p, _p, _p, _p, C.POINTER(LayerWeights), _p, _i, _i, _i, _i, _i, _p, _sz, _p]),
+    "loftr_transformer_fwd": (_i, [_p, _p, _p, _p, C.POINTER(LayerWeights), C.POINTER(_i), _i, _i, _i, _i, _i, _i,
+                                   _p, _sz, _p]),
+    "loftr_coarse_match_workspace_bytes": (_sz, [_i, _i, _i]),
+    "loftr_coarse_match_dual_softmax": (_i, [_p, _p, C.POINTER(CoarseParams), _f, _p, C.POINTER(MatchOut), _p, _sz, _p]),
+    "loftr_coarse_match_sinkhorn": (_i, [_p, _p, C.POINTER(CoarseParams), _f, _i, _i, _p, _p, C.POINTER(MatchOut),
+                                         _p, _sz, _p]),
+    "loftr_fine_preprocess_workspace_bytes": (_sz, [_i, _i, _i]),
+    "loftr_fine_preprocess": (_i, [C.POINTER(FMap), C.POINTER(FMap), _p, _p, _i, _i, _i, _p, _p, _p, _i, _i, _i, _i,
+                                   _i, _i, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
+    "loftr_fine_match": (_i, [_p, _p, _i, _i, _i, _p, _p, _f, _p, _p, _p, _p]),
+    "loftr_linear_fwd": (_i, [_p, _p, _p, _i, _i, _i, _p]),
+}
+
+ABI_VERSION = 1
+_lib = None
+
+
+class LoftrHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load (once) and type the shared library.  Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise LoftrHipError(
+            f"{LIB_PATH} not found: the HIP extension is not built. Run `python -m loftr_amd.build` "
+            "(needs hipcc). There is no CPU / PyTorch fallback for the matching path.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if a declared symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    if lib.loftr_hip_abi_version() != ABI_VERSION:
+        raise LoftrHipError(f"ABI mismatch: library {lib.loftr_hip_abi_version()} != binding {ABI_VERSION}; rebuild")
+    _lib = lib
+    return lib
+
+
+def check(status, what=""):
+    if status != 0:
+        msg = load().loftr_hip_status_string(status).decode()
+        raise LoftrHipError(f"{what or 'libloftr_hip'} failed: {msg} (status {status})")

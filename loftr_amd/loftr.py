@@ -1,0 +1,281 @@
+"""Drop-in ``LoFTR`` matcher whose matching path runs on hand-written HIP kernels (gfx950).
+
+Host-side mirror of the reference interface (zju3dv/LoFTR ``src/loftr/loftr.py``): same
+constructor, same ``forward(data)`` that *mutates* the batch dict with the same keys / dtypes,
+same sub-module and parameter names (so reference checkpoints load with ``strict=True``), same
+exceptions.  Every sub-module after the backbone holds parameters only; its arithmetic is one
+call into ``libloftr_hip.so`` (``loftr_amd/ops.py``).  There is no PyTorch fallback: on a box
+without the built extension or without a GPU the forward raises.
+
+Scope: inference (``.eval()``).  The training-only branches of the reference (GT padding /
+random sampling in ``coarse_matching.py:200-236``) are outside the hot path and raise.
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .backbone import build_backbone
+
+
+class PositionEncodingSine(nn.Module):
+    """2-D sinusoidal encoding; constant table identical to position_encoding.py:22-35."""
+
+    def __init__(self, d_model, max_shape=(256, 256), temp_bug_fix=True):
+        super().__init__()
+        ys = torch.arange(1, max_shape[0] + 1, dtype=torch.float32).view(1, -1, 1).expand(1, *max_shape)
+        xs = torch.arange(1, max_shape[1] + 1, dtype=torch.float32).view(1, 1, -1).expand(1, *max_shape)
+        idx = torch.arange(0, d_model // 2, 2).float()
+        if temp_bug_fix:
+            freq = torch.exp(idx * (-math.log(10000.0) / (d_model // 2)))
+        else:   # the reference's legacy variant: `-log(1e4) / d_model // 2` floors to -1.0 (:28)
+            freq = torch.exp(idx * (-math.log(10000.0) / d_model // 2))
+        freq = freq[:, None, None]
+        pe = torch.zeros((d_model, *max_shape))
+        pe[0::4] = torch.sin(xs * freq)
+        pe[1::4] = torch.cos(xs * freq)
+        pe[2::4] = torch.sin(ys * freq)
+        pe[3::4] = torch.cos(ys * freq)
+        self.register_buffer("pe", pe.unsqueeze(0), persistent=False)     # [1, C, H, W]
+
+    def forward(self, x):
+        """x [N,C,H,W] -> (x + pe) flattened to [N, H*W, C] (fuses loftr.py:58-59's rearrange)."""
+        return ops.pos_encode_flatten(x.contiguous(), self.pe[0])
+
+
+class LoFTREncoderLayer(nn.Module):
+    """Parameter container + single-layer forward.  transformer.py:7-58."""
+
+    def __init__(self, d_model, nhead, attention="linear"):
+        super().__init__()
+        if attention != "linear":
+            raise NotImplementedError("only attention='linear' is on the HIP path (no shipped config uses 'full')")
+        self.dim = d_model // nhead
+        self.nhead = nhead
+        self.q_proj = nn.Linear(d_model, d_model, bias=False)
+        self.k_proj = nn.Linear(d_model, d_model, bias=False)
+        self.v_proj = nn.Linear(d_model, d_model, bias=False)
+        self.merge = nn.Linear(d_model, d_model, bias=False)
+        self.mlp = nn.Sequential(
+            nn.Linear(d_model * 2, d_model * 2, bias=False),
+            nn.ReLU(True),
+            nn.Linear(d_model * 2, d_model, bias=False),
+        )
+        self.norm1 = nn.LayerNorm(d_model)
+        self.norm2 = nn.LayerNorm(d_model)
+
+    def weight_struct(self):
+        sd = {"q_proj": self.q_proj.weight, "k_proj": self.k_proj.weight, "v_proj": self.v_proj.weight,
+              "merge": self.merge.weight, "mlp0": self.mlp[0].weight, "mlp2": self.mlp[2].weight,
+              "norm1_w": self.norm1.weight, "norm1_b": self.norm1.bias,
+              "norm2_w": self.norm2.weight, "norm2_b": self.norm2.bias}
+        for k, v in sd.items():
+            if not v.is_contiguous():
+                raise RuntimeError(f"{k}: parameter must be contiguous")
+        return ops.layer_weights_struct(sd)
+
+    def forward(self, x, source, x_mask=None, source_mask=None):
+        return ops.encoder_layer(x.contiguous(), source.contiguous(), self.weight_struct(), self.nhead,
+                                 x_mask, source_mask)
+
+
+class LocalFeatureTransformer(nn.Module):
+    """transformer.py:61-101.  The layer loop runs inside the C-ABI (one call per transformer)."""
+
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        self.d_model = config["d_model"]
+        self.nhead = config["nhead"]
+        self.layer_names = config["layer_names"]
+        self.layers = nn.ModuleList([LoFTREncoderLayer(config["d_model"], config["nhead"], config["attention"])
+                                     for _ in range(len(self.layer_names))])
+        self._reset_parameters()
+
+    def _reset_parameters(self):
+        first = self.layers[0].state_dict() if len(self.layers) else {}
+        for p in self.layers[0].parameters() if len(self.layers) else []:
+            if p.dim() > 1:
+                nn.init.xavier_uniform_(p)
+        # the reference deep-copies ONE initialised layer (transformer.py:71-72) and then re-inits
+        # every matrix (:75-78); only the second step matters for the resulting distribution
+        for layer in self.layers[1:]:
+            for p in layer.parameters():
+                if p.dim() > 1:
+                    nn.init.xavier_uniform_(p)
+        del first
+
+    def forward(self, feat0, feat1, mask0=None, mask1=None):
+        assert self.d_model == feat0.size(2), "the feature number of src and transformer must be equal"
+        for name in self.layer_names:
+            if name not in ("self", "cross"):
+                raise KeyError
+        structs = [layer.weight_struct() for layer in self.layers]
+        return ops.transformer(feat0.contiguous(), feat1.contiguous(), structs, self.layer_names, self.nhead,
+                               mask0, mask1)
+
+
+class CoarseMatching(nn.Module):
+    """coarse_matching.py:61-261 (inference branch)."""
+
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        self.thr = config["thr"]
+        self.border_rm = config["border_rm"]
+        self.train_coarse_percent = config["train_coarse_percent"]
+        self.train_pad_num_gt_min = config["train_pad_num_gt_min"]
+        self.match_type = config["match_type"]
+        # data['conf_matrix'] is a public output of the reference (:145); writing it costs one
+        # L*S*4-byte store per pair.  Set False to elide it (data['conf_matrix'] = None).
+        self.materialize_conf = True
+        if self.match_type == "dual_softmax":
+            self.temperature = config["dsmax_temperature"]
+        elif self.match_type == "sinkhorn":
+            self.bin_score = nn.Parameter(torch.tensor(config["skh_init_bin_score"], requires_grad=True))
+            self.skh_iters = config["skh_iters"]
+            self.skh_prefilter = config["skh_prefilter"]
+        else:
+            raise NotImplementedError()
+
+    def forward(self, feat_c0, feat_c1, data, mask_c0=None, mask_c1=None):
+        if self.training:
+            raise NotImplementedError("CoarseMatching: the training branch (GT padding / sampling, "
+                                      "coarse_matching.py:200-236) is outside the HIP hot path; call .eval()")
+        scale = data["hw0_i"][0] / data["hw0_c"][0]
+        kw = dict(thr=self.thr, border_rm=self.border_rm, scale=scale, match_type=self.match_type,
+                  mask0=mask_c0, mask1=mask_c1, scale0=data.get("scale0"), scale1=data.get("scale1"))
+        if self.match_type == "dual_softmax":
+            kw.update(temperature=self.temperature, want_conf=self.materialize_conf)
+        else:
+            sparse = self.config["sparse_spvs"]          # KeyError with cvpr default_cfg, like the reference (:142)
+            kw.update(bin_score=float(self.bin_score.detach()), skh_iters=self.skh_iters,
+                      skh_prefilter=self.skh_prefilter, want_assign=bool(sparse))
+        r = ops.coarse_match(feat_c0, feat_c1, tuple(data["hw0_c"]), tuple(data["hw1_c"]), **kw)
+        if "conf_matrix_with_bin" in r:
+            data.update({"conf_matrix_with_bin": r["conf_matrix_with_bin"]})
+        data.update({"conf_matrix": r["conf_matrix"]})
+        mconf = r["mconf"]
+        out = {"b_ids": r["b_ids"], "i_ids": r["i_ids"], "j_ids": r["j_ids"]}
+        if self.thr >= 0:
+            # conf > thr >= 0  =>  mconf != 0 everywhere: the `mconf != 0` filter of :254-258 is a no-op
+            out.update({"gt_mask": torch.zeros_like(mconf, dtype=torch.bool), "m_bids": r["b_ids"],
+                        "mkpts0_c": r["mkpts0_c"], "mkpts1_c": r["mkpts1_c"], "mconf": mconf})
+        else:
+            keep = mconf != 0
+            out.update({"gt_mask": mconf == 0, "m_bids": r["b_ids"][keep], "mkpts0_c": r["mkpts0_c"][keep],
+                        "mkpts1_c": r["mkpts1_c"][keep], "mconf": mconf[keep]})
+        data.update(**out)
+        data["_match_counts"] = r["counts"]               # [1+N] int32: total, per pair (extra key)
+
+
+class FinePreprocess(nn.Module):
+    """fine_preprocess.py:7-59."""
+
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        self.cat_c_feat = config["fine_concat_coarse_feat"]
+        self.W = self.config["fine_window_size"]
+        d_model_c = self.config["coarse"]["d_model"]
+        d_model_f = self.config["fine"]["d_model"]
+        self.d_model_f = d_model_f
+        if self.cat_c_feat:
+            self.down_proj = nn.Linear(d_model_c, d_model_f, bias=True)
+            self.merge_feat = nn.Linear(2 * d_model_f, d_model_f, bias=True)
+        for p in self.parameters():
+            if p.dim() > 1:
+                nn.init.kaiming_normal_(p, mode="fan_out", nonlinearity="relu")
+
+    def forward(self, feat_f0, feat_f1, feat_c0, feat_c1, data):
+        W = self.W
+        stride = data["hw0_f"][0] // data["hw0_c"][0]
+        data.update({"W": W})
+        if data["b_ids"].shape[0] == 0:
+            feat0 = torch.empty(0, self.W ** 2, self.d_model_f, device=feat_f0.device)
+            feat1 = torch.empty(0, self.W ** 2, self.d_model_f, device=feat_f0.device)
+            return feat0, feat1
+        kw = {}
+        if self.cat_c_feat:
+            kw = dict(down_w=self.down_proj.weight, down_b=self.down_proj.bias,
+                      merge_w=self.merge_feat.weight, merge_b=self.merge_feat.bias)
+        return ops.fine_preprocess(feat_f0, feat_f1, feat_c0, feat_c1, data["b_ids"], data["i_ids"], data["j_ids"],
+                                   tuple(data["hw0_c"]), tuple(data["hw1_c"]), W, stride, **kw)
+
+
+class FineMatching(nn.Module):
+    """fine_matching.py:9-74."""
+
+    def forward(self, feat_f0, feat_f1, data):
+        M, WW, C = feat_f0.shape
+        scale = data["hw0_i"][0] / data["hw0_f"][0]
+        if M == 0:
+            assert self.training is False, "M is always >0, when training, see coarse_matching.py"
+            data.update({"expec_f": torch.empty(0, 3, device=feat_f0.device),
+                         "mkpts0_f": data["mkpts0_c"], "mkpts1_f": data["mkpts1_c"]})
+            return
+        # reference quirk kept: scale1 is applied iff 'scale0' is in the batch (fine_matching.py:68)
+        scale1 = data["scale1"] if "scale0" in data else None
+        n = len(data["mconf"])
+        expec, mk1f = ops.fine_match(feat_f0, feat_f1, data["mkpts1_c"], data["b_ids"], scale, scale1)
+        data.update({"expec_f": expec, "mkpts0_f": data["mkpts0_c"], "mkpts1_f": mk1f[:n]})
+
+
+class LoFTR(nn.Module):
+    """loftr.py:12-81."""
+
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        self.backbone = build_backbone(config)
+        self.pos_encoding = PositionEncodingSine(config["coarse"]["d_model"],
+                                                 temp_bug_fix=config["coarse"]["temp_bug_fix"])
+        self.loftr_coarse = LocalFeatureTransformer(config["coarse"])
+        self.coarse_matching = CoarseMatching(config["match_coarse"])
+        self.fine_preprocess = FinePreprocess(config)
+        self.loftr_fine = LocalFeatureTransformer(config["fine"])
+        self.fine_matching = FineMatching()
+
+    def run_backbone(self, data):
+        """Step 1 of forward (loftr.py:39-54): returns (feat_c0, feat_c1, feat_f0, feat_f1)."""
+        data.update({"bs": data["image0"].size(0),
+                     "hw0_i": data["image0"].shape[2:], "hw1_i": data["image1"].shape[2:]})
+        if data["hw0_i"] == data["hw1_i"]:
+            feats_c, feats_f = self.backbone(torch.cat([data["image0"], data["image1"]], dim=0))
+            (feat_c0, feat_c1), (feat_f0, feat_f1) = feats_c.split(data["bs"]), feats_f.split(data["bs"])
+        else:
+            (feat_c0, feat_f0), (feat_c1, feat_f1) = self.backbone(data["image0"]), self.backbone(data["image1"])
+        return feat_c0, feat_c1, feat_f0, feat_f1
+
+    def match_from_features(self, feat_c0, feat_c1, feat_f0, feat_f1, data):
+        """Steps 2-5 of forward (loftr.py:51-75): THE hot path.  `data` needs bs, hw0_i, hw1_i."""
+        data.update({"hw0_c": feat_c0.shape[2:], "hw1_c": feat_c1.shape[2:],
+                     "hw0_f": feat_f0.shape[2:], "hw1_f": feat_f1.shape[2:]})
+        feat_c0 = self.pos_encoding(feat_c0)
+        feat_c1 = self.pos_encoding(feat_c1)
+        mask_c0 = mask_c1 = None
+        if "mask0" in data:
+            mask_c0, mask_c1 = data["mask0"].flatten(-2), data["mask1"].flatten(-2)
+        feat_c0, feat_c1 = self.loftr_coarse(feat_c0, feat_c1, mask_c0, mask_c1)
+        self.coarse_matching(feat_c0, feat_c1, data, mask_c0=mask_c0, mask_c1=mask_c1)
+        feat_f0_unfold, feat_f1_unfold = self.fine_preprocess(feat_f0, feat_f1, feat_c0, feat_c1, data)
+        if feat_f0_unfold.size(0) != 0:
+            feat_f0_unfold, feat_f1_unfold = self.loftr_fine(feat_f0_unfold, feat_f1_unfold)
+        self.fine_matching(feat_f0_unfold, feat_f1_unfold, data)
+
+    @torch.no_grad()
+    def forward(self, data):
+        """Updates `data` in place exactly like the reference (loftr.py:29-75).
+
+        data: image0, image1 [N,1,H,W] float; optional mask0/mask1 [N,H/8,W/8] ('0' = padded),
+        scale0/scale1 [N,2].
+        """
+        feat_c0, feat_c1, feat_f0, feat_f1 = self.run_backbone(data)
+        self.match_from_features(feat_c0, feat_c1, feat_f0, feat_f1, data)
+
+    def load_state_dict(self, state_dict, *args, **kwargs):
+        for k in list(state_dict.keys()):
+            if k.startswith("matcher."):
+                state_dict[k.replace("matcher.", "", 1)] = state_dict.pop(k)
+        return super().load_state_dict(state_dict, *args, **kwargs)

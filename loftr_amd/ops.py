@@ -1,0 +1,226 @@
+"""Tensor-level wrappers over the C-ABI (one function per entry point of include/loftr_hip.h).
+
+PyTorch is plumbing here: it owns device memory and the stream; all arithmetic of the matching
+path happens in the HIP kernels.  Every wrapper requires CUDA(ROCm) float32 contiguous tensors
+and raises otherwise -- there is no CPU fallback.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import CoarseParams, FMap, LayerWeights, MatchOut, check
+
+_WS = {}          # device index -> cached workspace tensor (grown on demand, never shrunk)
+
+LAYER_FIELDS = (("q_proj", "q_proj.weight"), ("k_proj", "k_proj.weight"), ("v_proj", "v_proj.weight"),
+                ("merge", "merge.weight"), ("mlp0", "mlp.0.weight"), ("mlp2", "mlp.2.weight"),
+                ("norm1_w", "norm1.weight"), ("norm1_b", "norm1.bias"),
+                ("norm2_w", "norm2.weight"), ("norm2_b", "norm2.bias"))
+
+
+def _need(t, name, dtype=torch.float32):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise _lib.LoftrHipError(f"{name}: expected a GPU tensor (the HIP matching path has no CPU fallback)")
+    if t.dtype != dtype:
+        raise _lib.LoftrHipError(f"{name}: expected {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise _lib.LoftrHipError(f"{name}: expected a contiguous tensor")
+    return t
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def workspace(nbytes, device):
+    """Cached scratch buffer of at least nbytes on `device` (safe to share: stream ordered)."""
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    buf = _WS.get(idx)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(int(nbytes * 1.25) + 4096, dtype=torch.uint8, device=device)
+        _WS[idx] = buf
+    return buf
+
+
+def _mask_u8(m, name):
+    if m is None:
+        return None
+    if m.dtype == torch.bool:
+        m = m.to(torch.uint8)
+    return _need(m.contiguous(), name, torch.uint8)
+
+
+# ---------------------------------------------------------------------------------------------
+def linear(a, w):
+    """a [M,K] @ w[N,K]^T on the fp32 matrix cores (building block, exposed for tests)."""
+    _need(a, "a"); _need(w, "w")
+    M, K = a.shape
+    N = w.shape[0]
+    out = torch.empty(M, N, device=a.device, dtype=torch.float32)
+    check(_lib.load().loftr_linear_fwd(_ptr(a), _ptr(w), _ptr(out), M, N, K, _stream()), "loftr_linear_fwd")
+    return out
+
+
+def pos_encode_flatten(feat, pe):
+    """feat [N,C,H,W] + pe[:, :H, :W], flattened to [N, H*W, C].  pe: [C, pe_h, pe_w]."""
+    _need(feat, "feat"); _need(pe, "pe")
+    N, Cc, H, W = feat.shape
+    out = torch.empty(N, H * W, Cc, device=feat.device, dtype=torch.float32)
+    check(_lib.load().loftr_pos_encode_flatten(_ptr(feat), _ptr(pe), pe.shape[-2], pe.shape[-1], _ptr(out),
+                                               N, Cc, H, W, _stream()), "loftr_pos_encode_flatten")
+    return out
+
+
+def layer_weights_struct(tensors):
+    """dict(field -> tensor) -> LayerWeights (keeps nothing alive: caller holds the tensors)."""
+    lw = LayerWeights()
+    for field, _ in LAYER_FIELDS:
+        setattr(lw, field, tensors[field].data_ptr())
+    return lw
+
+
+def encoder_layer(x, source, w_struct, nhead, x_mask=None, source_mask=None, out=None):
+    """One LoFTREncoderLayer.  x [nb,L,C], source [nb,S,C] -> [nb,L,C]."""
+    _need(x, "x"); _need(source, "source")
+    nb, L, Cc = x.shape
+    S = source.shape[1]
+    xm, sm = _mask_u8(x_mask, "x_mask"), _mask_u8(source_mask, "source_mask")
+    if x_mask is not None and x_mask is source_mask:
+        sm = xm
+    out = torch.empty_like(x) if out is None else out
+    lib = _lib.load()
+    nbytes = lib.loftr_encoder_workspace_bytes(nb, L, S, Cc)
+    ws = workspace(nbytes, x.device)
+    check(lib.loftr_encoder_layer_fwd(_ptr(x), _ptr(source), _ptr(xm), _ptr(sm), C.byref(w_struct), _ptr(out),
+                                      nb, L, S, Cc, nhead, _ptr(ws), ws.numel(), _stream()),
+          "loftr_encoder_layer_fwd")
+    return out
+
+
+def transformer(feat0, feat1, layer_structs, layer_names, nhead, mask0=None, mask1=None):
+    """LocalFeatureTransformer.forward.  Returns new (feat0, feat1); inputs are not modified."""
+    _need(feat0, "feat0"); _need(feat1, "feat1")
+    N, L, Cc = feat0.shape
+    S = feat1.shape[1]
+    m0, m1 = _mask_u8(mask0, "mask0"), _mask_u8(mask1, "mask1")
+    if L == S:          # stack -> the two self-attention calls of a layer run as one batch of 2N
+        both = torch.cat([feat0, feat1], 0)
+        f0, f1 = both[:N], both[N:]
+        if m0 is not None:
+            mb = torch.cat([m0, m1], 0)
+            m0, m1 = mb[:N], mb[N:]
+    else:
+        f0, f1 = feat0.clone(), feat1.clone()
+    n_layers = len(layer_names)
+    arr = (LayerWeights * n_layers)(*layer_structs)
+    kinds = (C.c_int * n_layers)(*[{"self": 0, "cross": 1}[n] for n in layer_names])   # KeyError like the reference
+    lib = _lib.load()
+    nbytes = lib.loftr_encoder_workspace_bytes(2 * N, L, S, Cc)
+    ws = workspace(nbytes, feat0.device)
+    check(lib.loftr_transformer_fwd(_ptr(f0), _ptr(f1), _ptr(m0), _ptr(m1), arr, kinds, n_layers, N, L, S, Cc, nhead,
+                                    _ptr(ws), ws.numel(), _stream()), "loftr_transformer_fwd")
+    return f0, f1
+
+
+def coarse_match(feat_c0, feat_c1, hw0_c, hw1_c, thr, border_rm, scale, match_type="dual_softmax",
+                 temperature=0.1, bin_score=None, skh_iters=3, skh_prefilter=False, mask0=None, mask1=None,
+                 scale0=None, scale1=None, want_conf=True, want_assign=False):
+    """CoarseMatching.forward (eval).  Returns dict(conf_matrix, [conf_matrix_with_bin], b_ids, i_ids,
+    j_ids, mconf, mkpts0_c, mkpts1_c, counts).  One host sync (the match count), like torch.where
+    in the reference (coarse_matching.py:194)."""
+    _need(feat_c0, "feat_c0"); _need(feat_c1, "feat_c1")
+    N, L, Cc = feat_c0.shape
+    S = feat_c1.shape[1]
+    dev = feat_c0.device
+    assert L == hw0_c[0] * hw0_c[1] and S == hw1_c[0] * hw1_c[1]
+    m0, m1 = _mask_u8(mask0, "mask0"), _mask_u8(mask1, "mask1")
+    s0 = None if scale0 is None else _need(scale0.to(torch.float32).contiguous(), "scale0")
+    s1 = None if scale1 is None else _need(scale1.to(torch.float32).contiguous(), "scale1")
+    cap = max(N * L, 1)
+    b_ids = torch.empty(cap, dtype=torch.int64, device=dev)
+    i_ids = torch.empty(cap, dtype=torch.int64, device=dev)
+    j_ids = torch.empty(cap, dtype=torch.int64, device=dev)
+    mconf = torch.empty(cap, dtype=torch.float32, device=dev)
+    mk0 = torch.empty(cap, 2, dtype=torch.float32, device=dev)
+    mk1 = torch.empty(cap, 2, dtype=torch.float32, device=dev)
+    counts = torch.zeros(1 + N, dtype=torch.int32, device=dev)
+    p = CoarseParams(N, hw0_c[0], hw0_c[1], hw1_c[0], hw1_c[1], Cc, float(thr), int(border_rm), float(scale),
+                     m0.data_ptr() if m0 is not None else None, m1.data_ptr() if m1 is not None else None,
+                     s0.data_ptr() if s0 is not None else None, s1.data_ptr() if s1 is not None else None)
+    mo = MatchOut(b_ids.data_ptr(), i_ids.data_ptr(), j_ids.data_ptr(), mconf.data_ptr(), mk0.data_ptr(),
+                  mk1.data_ptr(), counts.data_ptr())
+    lib = _lib.load()
+    ws = workspace(lib.loftr_coarse_match_workspace_bytes(N, L, S), dev)
+    out = {}
+    if match_type == "dual_softmax":
+        conf = torch.empty(N, L, S, device=dev, dtype=torch.float32) if want_conf else None
+        check(lib.loftr_coarse_match_dual_softmax(_ptr(feat_c0), _ptr(feat_c1), C.byref(p), float(temperature),
+                                                  _ptr(conf), C.byref(mo), _ptr(ws), ws.numel(), _stream()),
+              "loftr_coarse_match_dual_softmax")
+    elif match_type == "sinkhorn":
+        conf = torch.empty(N, L, S, device=dev, dtype=torch.float32)
+        assign = torch.empty(N, L + 1, S + 1, device=dev, dtype=torch.float32) if want_assign else None
+        check(lib.loftr_coarse_match_sinkhorn(_ptr(feat_c0), _ptr(feat_c1), C.byref(p), float(bin_score),
+                                              int(skh_iters), int(bool(skh_prefilter)), _ptr(conf), _ptr(assign),
+                                              C.byref(mo), _ptr(ws), ws.numel(), _stream()),
+              "loftr_coarse_match_sinkhorn")
+        if want_assign:
+            out["conf_matrix_with_bin"] = assign
+    else:
+        raise NotImplementedError(match_type)
+    M = int(counts[0].item()) if N > 0 else 0            # the one D2H sync of the path
+    out.update(conf_matrix=conf, b_ids=b_ids[:M], i_ids=i_ids[:M], j_ids=j_ids[:M], mconf=mconf[:M],
+               mkpts0_c=mk0[:M], mkpts1_c=mk1[:M], counts=counts)
+    return out
+
+
+def _fmap(t):
+    """[N,C,H,W] tensor with arbitrary (e.g. channels-last) strides -> FMap."""
+    sn, sc, sh, sw = t.stride()
+    return FMap(t.data_ptr(), sn, sc, sh, sw, t.shape[2], t.shape[3])
+
+
+def fine_preprocess(feat_f0, feat_f1, feat_c0, feat_c1, b_ids, i_ids, j_ids, hw0_c, hw1_c, W, stride,
+                    down_w=None, down_b=None, merge_w=None, merge_b=None):
+    """FinePreprocess.forward for M > 0.  Returns (feat_f0_unfold, feat_f1_unfold) [M, W*W, Cf]."""
+    for t, n in ((feat_f0, "feat_f0"), (feat_f1, "feat_f1")):
+        if not t.is_cuda or t.dtype != torch.float32:
+            raise _lib.LoftrHipError(f"{n}: expected a float32 GPU tensor")
+    _need(feat_c0, "feat_c0"); _need(feat_c1, "feat_c1")
+    M = b_ids.shape[0]
+    Cf = feat_f0.shape[1]
+    dev = feat_f0.device
+    out0 = torch.empty(M, W * W, Cf, device=dev, dtype=torch.float32)
+    out1 = torch.empty(M, W * W, Cf, device=dev, dtype=torch.float32)
+    if M == 0:
+        return out0, out1
+    lib = _lib.load()
+    ws = workspace(lib.loftr_fine_preprocess_workspace_bytes(M, W, Cf), dev)
+    f0, f1 = _fmap(feat_f0), _fmap(feat_f1)
+    check(lib.loftr_fine_preprocess(C.byref(f0), C.byref(f1), _ptr(feat_c0), _ptr(feat_c1), feat_c0.shape[1],
+                                    feat_c1.shape[1], feat_c0.shape[2], _ptr(_need(b_ids, "b_ids", torch.int64)),
+                                    _ptr(_need(i_ids, "i_ids", torch.int64)), _ptr(_need(j_ids, "j_ids", torch.int64)),
+                                    M, hw0_c[1], hw1_c[1], int(stride), int(W), Cf, _ptr(down_w), _ptr(down_b),
+                                    _ptr(merge_w), _ptr(merge_b), _ptr(out0), _ptr(out1), _ptr(ws), ws.numel(),
+                                    _stream()), "loftr_fine_preprocess")
+    return out0, out1
+
+
+def fine_match(feat_f0, feat_f1, mkpts1_c, b_ids, scale, scale1=None):
+    """FineMatching for M > 0.  Returns (expec_f [M,3], mkpts1_f [M,2])."""
+    _need(feat_f0, "feat_f0"); _need(feat_f1, "feat_f1")
+    M, WW, Cf = feat_f0.shape
+    dev = feat_f0.device
+    expec = torch.empty(M, 3, device=dev, dtype=torch.float32)
+    mk1f = torch.empty(M, 2, device=dev, dtype=torch.float32)
+    s1 = None if scale1 is None else _need(scale1.to(torch.float32).contiguous(), "scale1")
+    check(_lib.load().loftr_fine_match(_ptr(feat_f0), _ptr(feat_f1), M, WW, Cf,
+                                       _ptr(_need(mkpts1_c.contiguous(), "mkpts1_c")),
+                                       _ptr(_need(b_ids, "b_ids", torch.int64)), float(scale), _ptr(s1), _ptr(expec),
+                                       _ptr(mk1f), _stream()), "loftr_fine_match")
+    return expec, mk1f
