@@ -166,6 +166,17 @@ int loftr_fine_match(const float* feat_f0, const float* feat_f1, int M, int WW, 
                      const float* mkpts1_c, const int64_t* b_ids, float scale,
                      const float* scale1, float* expec_f, float* mkpts1_f, void* stream);
 
+/* ---- per-kernel timing (profiling aid; the only process-global state of the library) ---------
+ * When bit `id` of the mask is set, every launch of that kernel is bracketed by hipEvents
+ * recorded on the launch stream (up to 4096 launches between reads).  Replaces the reference's
+ * InferenceProfiler (src/utils/profiler.py:7-28: cuda.synchronize()-bracketed wall clocks).
+ * loftr_hip_timing_read synchronises the recorded events and returns the accumulated GPU time
+ * (ms) and launch count of kernel `id`; reset != 0 clears the accumulators. */
+int loftr_hip_timing_enable(unsigned mask);
+int loftr_hip_timing_kernel_count(void);
+const char* loftr_hip_timing_kernel_name(int id);
+int loftr_hip_timing_read(int id, double* total_ms, long long* launches, int reset);
+
 /* ---- building block exposed for tests / profiling ------------------------------------------
  * out[M,N] = A[M,K] @ Wt[N,K]^T  (the fp32-MFMA GEMM every linear layer above is built on). */
 int loftr_linear_fwd(const float* a, const float* w, float* out, int M, int N, int K,

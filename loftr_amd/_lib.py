@@ -53,6 +53,10 @@ SIGNATURES = {
     "loftr_fine_preprocess": (_i, [C.POINTER(FMap), C.POINTER(FMap), _p, _p, _i, _i, _i, _p, _p, _p, _i, _i, _i, _i,
                                    _i, _i, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
     "loftr_fine_match": (_i, [_p, _p, _i, _i, _i, _p, _p, _f, _p, _p, _p, _p]),
+    "loftr_hip_timing_enable": (_i, [C.c_uint]),
+    "loftr_hip_timing_kernel_count": (_i, []),
+    "loftr_hip_timing_kernel_name": (C.c_char_p, [_i]),
+    "loftr_hip_timing_read": (_i, [_i, C.POINTER(C.c_double), C.POINTER(C.c_longlong), _i]),
     "loftr_linear_fwd": (_i, [_p, _p, _p, _i, _i, _i, _p]),
 }
 

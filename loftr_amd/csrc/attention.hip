@@ -179,17 +179,20 @@ int launch_linear_attention(const float* Qf, const float* Kf, const float* Vf, f
     float* part = wa.take<float>((size_t)nb * 8 * splits * 33 * 32);
     float* kv = wa.take<float>((size_t)nb * 8 * 33 * 32);
     if (!wa.ok()) return LOFTR_ERR_WORKSPACE;
-    hipLaunchKernelGGL(kv_partial_kernel, dim3(splits, 8, nb), dim3(256), 0, st, Kf, Vf, part, S, C, splits);
+    { TimedLaunch tl(LOFTR_T_KV, st);
+      hipLaunchKernelGGL(kv_partial_kernel, dim3(splits, 8, nb), dim3(256), 0, st, Kf, Vf, part, S, C, splits); }
     hipLaunchKernelGGL(kv_finalize_kernel, dim3(8, nb), dim3(256), 0, st, part, kv, splits);
-    hipLaunchKernelGGL(attn_apply_kernel, dim3(ceil_div(L, 64), nb), dim3(256), 0, st, Qf, kv, msg, L, C,
-                       (float)S, eps);
+    { TimedLaunch tl(LOFTR_T_ATTN_APPLY, st);
+      hipLaunchKernelGGL(attn_apply_kernel, dim3(ceil_div(L, 64), nb), dim3(256), 0, st, Qf, kv, msg, L, C,
+                         (float)S, eps); }
     LOFTR_CHECK_LAUNCH();
     return LOFTR_OK;
   }
   if (C == 128 && H == 8 && (size_t)(L + S) * C * sizeof(float) <= 64 * 1024) {
     const size_t lds = (size_t)(L + S) * C * sizeof(float);
-    hipLaunchKernelGGL((attn_small_kernel<16>), dim3(nb), dim3(128), lds, st, Qf, Kf, Vf, msg, L, S, C,
-                       (float)S, eps);
+    { TimedLaunch tl(LOFTR_T_ATTN_SMALL, st);
+      hipLaunchKernelGGL((attn_small_kernel<16>), dim3(nb), dim3(128), lds, st, Qf, Kf, Vf, msg, L, S, C,
+                         (float)S, eps); }
     LOFTR_CHECK_LAUNCH();
     return LOFTR_OK;
   }

@@ -659,16 +659,22 @@ extern "C" int loftr_coarse_match_dual_softmax(const float* feat_c0, const float
   const float scale = 1.f / ((float)g.C * temperature);
   const dim3 grid(ceil_div(g.S, Cfg::BN), ceil_div(g.L, Cfg::BM), g.N), block(Cfg::THREADS);
   const long NL = (long)g.N * g.L, NS = (long)g.N * g.S;
-  if (p->mask0)
-    hipLaunchKernelGGL((score_stats_kernel<true>), grid, block, 0, st, feat_c0, feat_c1, g, scale, p->mask0, p->mask1, w.rowpart, w.colpart);
-  else
-    hipLaunchKernelGGL((score_stats_kernel<false>), grid, block, 0, st, feat_c0, feat_c1, g, scale, p->mask0, p->mask1, w.rowpart, w.colpart);
+  {
+    TimedLaunch tl(LOFTR_T_SCORE_STATS, st);
+    if (p->mask0)
+      hipLaunchKernelGGL((score_stats_kernel<true>), grid, block, 0, st, feat_c0, feat_c1, g, scale, p->mask0, p->mask1, w.rowpart, w.colpart);
+    else
+      hipLaunchKernelGGL((score_stats_kernel<false>), grid, block, 0, st, feat_c0, feat_c1, g, scale, p->mask0, p->mask1, w.rowpart, w.colpart);
+  }
   hipLaunchKernelGGL(merge_stats_kernel, dim3(ceil_div((int)NL, 256)), dim3(256), 0, st, w.rowpart, w.rowstat, NL, g.PJ);
   hipLaunchKernelGGL(merge_stats_kernel, dim3(ceil_div((int)NS, 256)), dim3(256), 0, st, w.colpart, w.colstat, NS, g.PI);
-  if (p->mask0)
-    hipLaunchKernelGGL((score_conf_kernel<true>), grid, block, 0, st, feat_c0, feat_c1, g, scale, p->mask0, p->mask1, w.rowstat, w.colstat, conf_out, w.rowmax_part, w.colmax_part);
-  else
-    hipLaunchKernelGGL((score_conf_kernel<false>), grid, block, 0, st, feat_c0, feat_c1, g, scale, p->mask0, p->mask1, w.rowstat, w.colstat, conf_out, w.rowmax_part, w.colmax_part);
+  {
+    TimedLaunch tl(LOFTR_T_SCORE_CONF, st);
+    if (p->mask0)
+      hipLaunchKernelGGL((score_conf_kernel<true>), grid, block, 0, st, feat_c0, feat_c1, g, scale, p->mask0, p->mask1, w.rowstat, w.colstat, conf_out, w.rowmax_part, w.colmax_part);
+    else
+      hipLaunchKernelGGL((score_conf_kernel<false>), grid, block, 0, st, feat_c0, feat_c1, g, scale, p->mask0, p->mask1, w.rowstat, w.colstat, conf_out, w.rowmax_part, w.colmax_part);
+  }
   LOFTR_CHECK_LAUNCH();
   return select_and_compact(g, *p, *out, w, st);
 }
@@ -689,7 +695,8 @@ extern "C" int loftr_coarse_match_sinkhorn(const float* feat_c0, const float* fe
   const float scale = 1.f / (float)g.C;                    // no temperature   coarse_matching.py:123
   const float norm = -logf((float)(g.L + g.S));            // SuperGlue: norm = -log(m + n)
   const dim3 grid(ceil_div(g.S, Cfg::BN), ceil_div(g.L, Cfg::BM), g.N), block(Cfg::THREADS);
-  hipLaunchKernelGGL(score_store_kernel, grid, block, 0, st, feat_c0, feat_c1, g, scale, p->mask0, p->mask1, conf_out);
+  { TimedLaunch tl(LOFTR_T_OT_STORE, st);
+    hipLaunchKernelGGL(score_store_kernel, grid, block, 0, st, feat_c0, feat_c1, g, scale, p->mask0, p->mask1, conf_out); }
   (void)hipMemsetAsync(w.ot_u, 0, sizeof(float) * g.N * (g.L + 1), st);
   (void)hipMemsetAsync(w.ot_v, 0, sizeof(float) * g.N * (g.S + 1), st);
   const long cols = (long)g.N * (g.S + 1);

@@ -130,8 +130,9 @@ extern "C" int loftr_fine_preprocess(const loftr_fmap* feat_f0, const loftr_fmap
   int64_t* idx0 = wa.take<int64_t>(M);
   int64_t* idx1 = wa.take<int64_t>(M);
   if (!wa.ok()) return LOFTR_ERR_WORKSPACE;
-  hipLaunchKernelGGL(gather_windows_kernel, dim3(M, 2), dim3(Cf < 64 ? 64 : Cf), 0, st, *feat_f0, *feat_f1, b_ids,
-                     i_ids, j_ids, M, w0c, w1c, stride, W, Cf, win0, win1);
+  { TimedLaunch tl(LOFTR_T_GATHER, st);
+    hipLaunchKernelGGL(gather_windows_kernel, dim3(M, 2), dim3(Cf < 64 ? 64 : Cf), 0, st, *feat_f0, *feat_f1, b_ids,
+                       i_ids, j_ids, M, w0c, w1c, stride, W, Cf, win0, win1); }
   hipLaunchKernelGGL(coarse_index_kernel, dim3(ceil_div(M, 256)), dim3(256), 0, st, b_ids, i_ids, j_ids, M, L, S, idx0, idx1);
   LOFTR_CHECK_LAUNCH();
   int rc;

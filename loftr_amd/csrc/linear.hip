@@ -39,6 +39,7 @@ int launch_linear(const LinearArgs& p, LinearEpi epi, hipStream_t st) {
   if (p.K % CfgGen::BK != 0 || p.N <= 0) return LOFTR_ERR_UNSUPPORTED;
   dim3 grid(ceil_div(p.N, CfgGen::BN), ceil_div(p.M, CfgGen::BM));
   dim3 block(CfgGen::THREADS);
+  TimedLaunch tl(LOFTR_T_LINEAR, st);
   switch (epi) {
     case EPI_STORE: hipLaunchKernelGGL((linear_kernel<CfgGen, EPI_STORE>), grid, block, 0, st, p); break;
     case EPI_RELU: hipLaunchKernelGGL((linear_kernel<CfgGen, EPI_RELU>), grid, block, 0, st, p); break;
@@ -84,6 +85,7 @@ int launch_proj(const ProjArgs& p, hipStream_t st) {
   if (p.M <= 0) return LOFTR_OK;
   if (p.C % CfgGen::BN != 0 || p.nseg < 1 || p.nseg > 3) return LOFTR_ERR_UNSUPPORTED;
   dim3 grid(p.nseg * p.C / CfgGen::BN, ceil_div(p.M, CfgGen::BM));
+  TimedLaunch tl(LOFTR_T_PROJ, st);
   hipLaunchKernelGGL((proj_kernel<CfgGen>), grid, dim3(CfgGen::THREADS), 0, st, p);
   LOFTR_CHECK_LAUNCH();
   return LOFTR_OK;
@@ -171,6 +173,7 @@ __global__ __launch_bounds__(Cfg::THREADS) void linear_ln_kernel(LinearLNArgs p)
 int launch_linear_ln(const LinearLNArgs& p, hipStream_t st) {
   if (p.M <= 0) return LOFTR_OK;
   if (p.K % 16 != 0) return LOFTR_ERR_UNSUPPORTED;
+  TimedLaunch tl(LOFTR_T_LINEAR_LN, st);
   if (p.C == 256) {
     hipLaunchKernelGGL((linear_ln_kernel<CfgLN256>), dim3(ceil_div(p.M, CfgLN256::BM)),
                        dim3(CfgLN256::THREADS), 0, st, p);

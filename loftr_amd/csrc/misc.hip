@@ -40,6 +40,68 @@ extern "C" int loftr_pos_encode_flatten(const float* feat, const float* pe, int 
   return LOFTR_OK;
 }
 
+// ---- per-kernel timing ---------------------------------------------------------------------
+unsigned g_loftr_timing_mask = 0;
+namespace {
+constexpr int T_POOL = 4096;                 // event pairs per kernel id; recording stops when full
+struct TimingSlot {
+  hipEvent_t ev[T_POOL][2];
+  int created, used;
+  double total_ms; long long launches;
+};
+TimingSlot g_slots[LOFTR_T_COUNT];
+const char* const T_NAMES[LOFTR_T_COUNT] = {"score_stats_kernel", "score_conf_kernel", "proj_kernel", "linear_kernel",
+                                            "linear_ln_kernel", "kv_partial_kernel", "attn_apply_kernel",
+                                            "attn_small_kernel", "gather_windows_kernel", "score_store_kernel"};
+void timing_drain(TimingSlot& s) {
+  for (int i = 0; i < s.used; ++i) {
+    float ms = 0.f;
+    if (hipEventSynchronize(s.ev[i][1]) == hipSuccess && hipEventElapsedTime(&ms, s.ev[i][0], s.ev[i][1]) == hipSuccess) {
+      s.total_ms += ms;
+      s.launches += 1;
+    }
+  }
+  s.used = 0;
+}
+}  // namespace
+
+void loftr_timing_mark(int id, hipStream_t st, bool end) {
+  TimingSlot& s = g_slots[id];
+  if (!end) {
+    if (s.used >= T_POOL) return;
+    if (s.used >= s.created) {
+      if (hipEventCreate(&s.ev[s.created][0]) != hipSuccess || hipEventCreate(&s.ev[s.created][1]) != hipSuccess) return;
+      s.created++;
+    }
+    (void)hipEventRecord(s.ev[s.used][0], st);
+  } else {
+    if (s.used >= s.created) return;
+    (void)hipEventRecord(s.ev[s.used][1], st);
+    s.used++;
+  }
+}
+
+extern "C" int loftr_hip_timing_enable(unsigned mask) {
+  g_loftr_timing_mask = mask & ((1u << LOFTR_T_COUNT) - 1u);
+  return LOFTR_OK;
+}
+
+extern "C" int loftr_hip_timing_kernel_count(void) { return LOFTR_T_COUNT; }
+
+extern "C" const char* loftr_hip_timing_kernel_name(int id) {
+  return (id >= 0 && id < LOFTR_T_COUNT) ? T_NAMES[id] : "";
+}
+
+extern "C" int loftr_hip_timing_read(int id, double* total_ms, long long* launches, int reset) {
+  LOFTR_CHECK_ARG(id >= 0 && id < LOFTR_T_COUNT && total_ms && launches);
+  TimingSlot& s = g_slots[id];
+  timing_drain(s);
+  *total_ms = s.total_ms;
+  *launches = s.launches;
+  if (reset) { s.total_ms = 0.0; s.launches = 0; }
+  return LOFTR_OK;
+}
+
 extern "C" int loftr_hip_abi_version(void) { return LOFTR_HIP_ABI_VERSION; }
 
 extern "C" const char* loftr_hip_status_string(int status) {

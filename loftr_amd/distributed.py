@@ -1,0 +1,74 @@
+"""Multi-GPU data-parallel matching: one process per GPU, image pairs sharded by rank.
+
+The reference does exactly this with Lightning DDP + DistributedSampler (src/lightning/data.py:315,
+test.py:65) and merges results afterwards by a pickled gloo ``gather`` (src/utils/comm.py:179-219).
+Here the only exchange on the data path is an all-gather of the per-pair match counts
+(``int32[N_local]`` per rank -> ``int32[N_global]``): a few hundred bytes, latency bound, RCCL over
+xGMI on GPUs (backend "nccl") and gloo on CPU for the tests.  With the counts every rank can rebase
+its local ``b_ids`` into the global batch and knows the global offset of its matches; the optional
+``all_gather_matches`` pads to the maximum count like comm.py:113-138 pads its byte tensors.
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(n_items, rank, world):
+    """Contiguous [lo, hi) slice of `n_items` pairs owned by `rank` (first ranks take the remainder)."""
+    base, rem = divmod(n_items, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def all_gather_match_counts(local_counts, n_global, group=None):
+    """local_counts int32 [N_local] (data['_match_counts'][1:]) -> int32 [n_global] in rank order.
+
+    Ranks may own different numbers of pairs (shard_bounds); shorter shards are padded for the
+    collective and the padding removed afterwards."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    n_max = -(-n_global // world)
+    buf = torch.zeros(n_max, dtype=torch.int32, device=local_counts.device)
+    buf[: local_counts.numel()] = local_counts.to(torch.int32)
+    out = torch.empty(world * n_max, dtype=torch.int32, device=local_counts.device)
+    dist.all_gather_into_tensor(out, buf, group=group)
+    parts = []
+    for r in range(world):
+        lo, hi = shard_bounds(n_global, r, world)
+        parts.append(out[r * n_max: r * n_max + (hi - lo)])
+    del rank
+    return torch.cat(parts)
+
+
+def globalize(data, n_global, group=None):
+    """Adds the global view to a rank-local batch dict after forward():
+    ``match_counts_global`` [n_global], ``b_ids_global`` (local b_ids rebased by the shard offset)
+    and ``match_offset`` (index of this rank's first match in the concatenated global match list)."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    counts = all_gather_match_counts(data["_match_counts"][1:], n_global, group)
+    lo, _ = shard_bounds(n_global, rank, world)
+    data["match_counts_global"] = counts
+    data["b_ids_global"] = data["b_ids"] + lo
+    data["match_offset"] = int(counts[:lo].sum().item()) if lo else 0
+    return data
+
+
+def all_gather_matches(data, group=None):
+    """[M_global, 5] float32 rows (mkpts0_f, mkpts1_f, mconf) + global b_ids, in ascending global
+    (b, i) order.  Padded all-gather (20 B per match); optional -- not on the bench's timed path."""
+    world = dist.get_world_size(group)
+    counts = data["match_counts_global"]
+    rows = torch.cat([data["mkpts0_f"], data["mkpts1_f"], data["mconf"][:, None],
+                      data["b_ids_global"].to(torch.float32)[:, None]], 1)
+    m_local = torch.tensor([rows.shape[0]], dtype=torch.int64, device=rows.device)
+    m_all = [torch.zeros_like(m_local) for _ in range(world)]
+    dist.all_gather(m_all, m_local, group=group)
+    m_all = [int(m.item()) for m in m_all]
+    m_max = max(max(m_all), 1)
+    pad = torch.zeros(m_max, 6, dtype=torch.float32, device=rows.device)
+    pad[: rows.shape[0]] = rows
+    out = torch.empty(world * m_max, 6, dtype=torch.float32, device=rows.device)
+    dist.all_gather_into_tensor(out, pad, group=group)
+    parts = [out[r * m_max: r * m_max + m_all[r]] for r in range(world)]
+    allrows = torch.cat(parts)
+    assert int(counts.sum().item()) == allrows.shape[0]
+    return allrows[:, :5], allrows[:, 5].to(torch.int64)

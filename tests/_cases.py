@@ -105,3 +105,40 @@ def check_conf_digest(conf_or_digest, g, tol=TOL_CONF):
     for k in ("conf_row_sum", "conf_col_sum"):
         err = np.abs(np.asarray(d[k], np.float64) - np.asarray(g[k], np.float64)).max()
         assert err <= 20 * tol, (k, err)
+
+
+# ---------------------------------------------------------------------------------------------
+# HIP path runner (GPU tests, smoke, bench share it through this module or their own copy)
+def build_hip_matcher(cfg, w, device="cuda:0"):
+    """loftr_amd.LoFTR with the synthetic hot-path weights loaded (backbone left random)."""
+    import copy
+    import torch
+    from loftr_amd import LoFTR
+    model = LoFTR(copy.deepcopy(cfg)).eval()
+    sd = {k: torch.from_numpy(np.ascontiguousarray(np.asarray(v))) for k, v in w.items()}
+    missing, unexpected = model.load_state_dict(sd, strict=False)
+    assert not unexpected, unexpected
+    assert all(k.startswith("backbone.") for k in missing), [k for k in missing if not k.startswith("backbone.")]
+    return model.to(device)
+
+
+def run_hip(inp, device="cuda:0", model=None, materialize_conf=True):
+    """The HIP hot path on a case's inputs -> dict of numpy arrays with the reference's keys."""
+    import torch
+    model = model or build_hip_matcher(inp["cfg"], inp["w"], device)
+    model.coarse_matching.materialize_conf = materialize_conf
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
+    n = inp["feat_c0"].shape[0]
+    data = {"bs": n, "hw0_i": torch.Size(inp["hw0_i"]), "hw1_i": torch.Size(inp["hw1_i"])}
+    if inp["mask0"] is not None:
+        data.update(mask0=t(inp["mask0"]), mask1=t(inp["mask1"]), scale0=t(inp["scale0"]), scale1=t(inp["scale1"]))
+    with torch.no_grad():
+        model.match_from_features(t(inp["feat_c0"]), t(inp["feat_c1"]), t(inp["feat_f0"]), t(inp["feat_f1"]), data)
+    torch.cuda.synchronize()
+    out = {}
+    for k, v in data.items():
+        if torch.is_tensor(v):
+            out[k] = v.detach().cpu().numpy()
+        elif v is not None:
+            out[k] = v
+    return out

@@ -1,0 +1,105 @@
+"""CPU-side checks of the C-ABI boundary: the shared library builds/loads and exports every
+symbol include/loftr_hip.h declares; argument validation that needs no GPU returns the
+documented status codes; the product path fails loudly without a GPU."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from loftr_amd import _lib, build as build_mod
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    build_mod.build(verbose=False)
+    return _lib.load()
+
+
+def _declared_symbols():
+    src = open(os.path.join(ROOT, "include", "loftr_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(loftr_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_symbols_exported(lib):
+    names = _declared_symbols()
+    assert len(names) >= 14
+    raw = ctypes.CDLL(_lib.LIB_PATH)
+    for n in names:
+        assert hasattr(raw, n), f"{n} declared in include/loftr_hip.h but not exported"
+    assert sorted(_lib.SIGNATURES) == names, "ctypes binding out of sync with the header"
+
+
+def test_abi_version_and_status_strings(lib):
+    assert lib.loftr_hip_abi_version() == _lib.ABI_VERSION
+    assert lib.loftr_hip_status_string(0) == b"ok"
+    for code in (-1, -2, -3, -4, -5):
+        assert lib.loftr_hip_status_string(code) not in (b"ok", b"unknown status")
+    assert lib.loftr_hip_status_string(-99) == b"unknown status"
+
+
+def test_workspace_queries(lib):
+    assert lib.loftr_encoder_workspace_bytes(0, 10, 10, 256) == 0
+    a = lib.loftr_encoder_workspace_bytes(2, 4800, 4800, 256)
+    assert a >= 2 * 4800 * 256 * 4 * 7
+    assert lib.loftr_encoder_workspace_bytes(4, 4800, 4800, 256) > a
+    assert lib.loftr_coarse_match_workspace_bytes(1, 4800, 4800) > 0
+    assert lib.loftr_coarse_match_workspace_bytes(0, 4800, 4800) == 0
+    assert lib.loftr_fine_preprocess_workspace_bytes(0, 5, 128) == 0
+    assert lib.loftr_fine_preprocess_workspace_bytes(100, 5, 128) >= 2 * 100 * 25 * 128 * 4
+
+
+def test_bad_arguments_return_status(lib):
+    # null pointers -> LOFTR_ERR_BAD_ARG before any device work
+    assert lib.loftr_linear_fwd(None, None, None, 4, 4, 16, None) == -1
+    assert lib.loftr_pos_encode_flatten(None, None, 256, 256, None, 1, 256, 8, 8, None) == -1
+    assert lib.loftr_fine_match(None, None, 3, 25, 128, None, None, 2.0, None, None, None, None) == -1
+    # M == 0 is a no-op success on every fine entry point
+    assert lib.loftr_fine_match(None, None, 0, 25, 128, None, None, 2.0, None, None, None, None) == 0
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU failure mode")
+def test_no_cpu_fallback():
+    """The product path raises on CPU tensors instead of silently computing elsewhere."""
+    from loftr_amd import ops
+    with pytest.raises(_lib.LoftrHipError):
+        ops.linear(torch.zeros(4, 16), torch.zeros(4, 16))
+    with pytest.raises(_lib.LoftrHipError):
+        ops.pos_encode_flatten(torch.zeros(1, 256, 4, 4), torch.zeros(256, 8, 8))
+
+
+def test_state_dict_names_match_reference_contract():
+    """Parameter names / shapes the reference checkpoints carry (SURVEY.md §5 checkpoint row)."""
+    from loftr_amd import LoFTR, default_cfg, get_cfg
+    m = LoFTR(default_cfg)
+    sd = m.state_dict()
+    assert len(sd) == 211
+    assert sum(p.numel() for p in m.parameters()) == 11_561_456
+    assert tuple(sd["loftr_coarse.layers.7.mlp.0.weight"].shape) == (512, 512)
+    assert tuple(sd["loftr_coarse.layers.0.mlp.2.weight"].shape) == (256, 512)
+    assert tuple(sd["loftr_fine.layers.1.q_proj.weight"].shape) == (128, 128)
+    assert tuple(sd["fine_preprocess.down_proj.weight"].shape) == (128, 256)
+    assert tuple(sd["fine_preprocess.merge_feat.weight"].shape) == (128, 256)
+    assert "pos_encoding.pe" not in sd                       # persistent=False, position_encoding.py:35
+    assert "backbone.layer1.0.conv1.weight" in sd
+    # 'matcher.' prefix stripping of loftr.py:77-81
+    m.load_state_dict({"matcher." + k: v for k, v in sd.items()}, strict=True)
+    ot = LoFTR(get_cfg(match_type="sinkhorn", sparse_spvs=True))
+    assert "coarse_matching.bin_score" in ot.state_dict()
+    with pytest.raises(NotImplementedError):
+        LoFTR(get_cfg(match_type="nope"))
+    with pytest.raises(ValueError):
+        cfg = get_cfg(); cfg["backbone_type"] = "VGG"; LoFTR(cfg)
+
+
+def test_position_table_matches_oracle():
+    from loftr_amd.loftr import PositionEncodingSine
+    from oracle import loftr_oracle as O
+    for fix in (True, False):
+        pe = PositionEncodingSine(256, (64, 64), temp_bug_fix=fix).pe[0].numpy()
+        assert np.abs(pe[:, :30, :40] - O.position_encoding_table(256, 30, 40, fix)).max() <= 1e-5

