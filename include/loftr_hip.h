@@ -10,7 +10,8 @@
  *   - every function is asynchronous on the caller-supplied hipStream_t (passed as void*);
  *   - all device buffers are caller-allocated (PyTorch owns memory); the library never
  *     allocates or frees device memory; `*_workspace_bytes` tells how much scratch to pass;
- *   - all floating point is fp32, ids are int64, masks are uint8 (0 = padded), as in the
+ *   - all floating point data is fp32 (GEMMs evaluate fp32 products as 3 fp16 MFMAs with fp32
+ *     accumulation, csrc/gemm.h), ids are int64, masks are uint8 (0 = padded), as in the
  *     reference;
  *   - return value: 0 = ok, negative = loftr_status below (no exceptions, no global state).
  */
@@ -33,20 +34,28 @@ typedef enum {
   LOFTR_ERR_NO_DEVICE = -5      /* no gfx950 device visible                                    */
 } loftr_status;
 
-#define LOFTR_HIP_ABI_VERSION 1
+#define LOFTR_HIP_ABI_VERSION 2
 
 int loftr_hip_abi_version(void);
 const char* loftr_hip_status_string(int status);
 /* 0 if the current HIP device is a gfx950 part, LOFTR_ERR_NO_DEVICE otherwise. */
 int loftr_hip_device_check(void);
 
+/* A 4-D feature map [N,C,H,W] addressed through element strides (sn,sc,sh,sw), so that both NCHW
+ * and channels-last (what the MIOpen backbone produces fastest) storage work without a copy. */
+typedef struct {
+  const float* data;
+  long sn, sc, sh, sw;    /* element strides */
+  int H, W;               /* spatial size    */
+} loftr_fmap;
+
 /* ---- position encoding + flatten ---------------------------------------------------------
  * Replaces: PositionEncodingSine.forward (src/loftr/utils/position_encoding.py:37-42) followed
  * by rearrange 'n c h w -> n (h w) c' (src/loftr/loftr.py:58-59).
- *   feat [N,C,H,W] (contiguous NCHW), pe [C,pe_h,pe_w] (the module's constant table, H<=pe_h,
- *   W<=pe_w), out [N,H*W,C]. */
-int loftr_pos_encode_flatten(const float* feat, const float* pe, int pe_h, int pe_w,
-                             float* out, int N, int C, int H, int W, void* stream);
+ *   feat: [N,C,H,W] map (any strides), pe [C,pe_h,pe_w] (the module's constant table, H<=pe_h,
+ *   W<=pe_w), out [N,H*W,C] contiguous. */
+int loftr_pos_encode_flatten(const loftr_fmap* feat, const float* pe, int pe_h, int pe_w,
+                             float* out, int N, int C, void* stream);
 
 /* ---- LoFTREncoderLayer / LocalFeatureTransformer ------------------------------------------
  * Weights of one LoFTREncoderLayer (src/loftr/loftr_module/transformer.py:7-33); every matrix
@@ -137,15 +146,10 @@ int loftr_coarse_match_sinkhorn(const float* feat_c0, const float* feat_c1,
  * Replaces: FinePreprocess.forward (src/loftr/loftr_module/fine_preprocess.py:29-59): 5x5
  * windows (stride = hf/hc, zero padded) of the fine maps at the matched cells, fused with the
  * down-projected coarse features.  No unfold volume is materialised.
- *   feat_f0/1: fine maps addressed through element strides (sn,sc,sh,sw) so both NCHW and
- *   channels-last storage work; feat_c0 [N,L,Cc], feat_c1 [N,S,Cc] (transformer outputs);
+ *   feat_f0/1: fine maps (loftr_fmap, any strides; channels-last reads are fully coalesced);
+ *   feat_c0 [N,L,Cc], feat_c1 [N,S,Cc] (transformer outputs);
  *   out0/out1 [M,W*W,Cf].  down_w [Cf,Cc], down_b [Cf], merge_w [Cf,2Cf], merge_b [Cf];
  *   pass down_w = NULL for fine_concat_coarse_feat = False. */
-typedef struct {
-  const float* data;
-  long sn, sc, sh, sw;    /* element strides */
-  int H, W;               /* fine map size   */
-} loftr_fmap;
 
 size_t loftr_fine_preprocess_workspace_bytes(int M, int W, int Cf);
 
@@ -178,7 +182,8 @@ const char* loftr_hip_timing_kernel_name(int id);
 int loftr_hip_timing_read(int id, double* total_ms, long long* launches, int reset);
 
 /* ---- building block exposed for tests / profiling ------------------------------------------
- * out[M,N] = A[M,K] @ Wt[N,K]^T  (the fp32-MFMA GEMM every linear layer above is built on). */
+ * out[M,N] = A[M,K] @ Wt[N,K]^T  (the fp32-accurate split-fp16 MFMA GEMM every linear layer above
+ * is built on; K % 4 == 0). */
 int loftr_linear_fwd(const float* a, const float* w, float* out, int M, int N, int K,
                      void* stream);
 

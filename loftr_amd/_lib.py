@@ -40,7 +40,7 @@ SIGNATURES = {
     "loftr_hip_abi_version": (_i, []),
     "loftr_hip_status_string": (C.c_char_p, [_i]),
     "loftr_hip_device_check": (_i, []),
-    "loftr_pos_encode_flatten": (_i, [_p, _p, _i, _i, _p, _i, _i, _i, _i, _p]),
+    "loftr_pos_encode_flatten": (_i, [C.POINTER(FMap), _p, _i, _i, _p, _i, _i, _p]),
     "loftr_encoder_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "loftr_encoder_layer_fwd": (_i, [_p, _p, _p, _p, C.POINTER(LayerWeights), _p, _i, _i, _i, _i, _i, _p, _sz, _p]),
     "loftr_transformer_fwd": (_i, [_p, _p, _p, _p, C.POINTER(LayerWeights), C.POINTER(_i), _i, _i, _i, _i, _i, _i,
@@ -60,7 +60,7 @@ SIGNATURES = {
     "loftr_linear_fwd": (_i, [_p, _p, _p, _i, _i, _i, _p]),
 }
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 _lib = None
 
 

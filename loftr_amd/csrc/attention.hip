@@ -50,66 +50,45 @@ __global__ __launch_bounds__(256) void kv_partial_kernel(const float* __restrict
 }
 
 // kv [nb,H,33,32]: rows 0..31 = KV[d][v], row 32 = Ksum[d].   grid (H, nb), 256 threads.
+// Also folds KV into the merge projection (transformer.py:51): pm[n][j][h*32+d] =
+// sum_v KV[n,h,d,v] * Wm[j][h*32+v]  -- the per-batch-element B operand of the fused
+// attention + merge GEMM (gemm.h: AttnXform).  Thread j owns output row j (C == 256 == blockDim).
 __global__ __launch_bounds__(256) void kv_finalize_kernel(const float* __restrict__ part,
-                                                          float* __restrict__ kv, int splits) {
-  const long base = ((long)blockIdx.y * gridDim.x + blockIdx.x);
+                                                          float* __restrict__ kv, int splits,
+                                                          const float* __restrict__ wm,
+                                                          float* __restrict__ pm) {
+  __shared__ __attribute__((aligned(16))) float skv[33 * 32];
+  const int h = blockIdx.x, n = blockIdx.y, H = gridDim.x;
+  const long base = (long)n * H + h;
   const float* p = part + base * splits * (33 * 32);
   float* o = kv + base * (33 * 32);
   for (int e = threadIdx.x; e < 33 * 32; e += 256) {
     float s = 0.f;
     for (int k = 0; k < splits; ++k) s += p[(long)k * (33 * 32) + e];
     o[e] = s;
+    skv[e] = s;
   }
-}
-
-// out[n,l,h,:] for 64 tokens x 8 heads per block: one thread per (token, head), the 32x32 KV of
-// its head broadcast from LDS.   grid (ceil(L/64), nb), 256 threads; wave w handles heads w, w+4.
-__global__ __launch_bounds__(256) void attn_apply_kernel(const float* __restrict__ Qf,
-                                                         const float* __restrict__ kv,
-                                                         float* __restrict__ msg, int L, int C,
-                                                         float v_length, float eps) {
-  __shared__ __attribute__((aligned(16))) float skv[8][33][32];
-  const int n = blockIdx.y;
-  const float* kvn = kv + (long)n * 8 * 33 * 32;
-  for (int e = threadIdx.x; e < 8 * 33 * 32 / 4; e += 256)
-    reinterpret_cast<f32x4*>(&skv[0][0][0])[e] = reinterpret_cast<const f32x4*>(kvn)[e];
   __syncthreads();
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int l = blockIdx.x * 64 + lane;
-  if (l >= L) return;
-#pragma unroll 1
-  for (int hh = 0; hh < 2; ++hh) {
-    const int h = wave + 4 * hh;
-    const float* qp = Qf + ((long)n * L + l) * C + h * 32;
-    f32x4 q[8];
+  const int C = H * 32, j = threadIdx.x;
+  f32x4 w4[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) q[i] = reinterpret_cast<const f32x4*>(qp)[i];
-    float z = 0.f;
+  for (int i = 0; i < 8; ++i) w4[i] = reinterpret_cast<const f32x4*>(wm + (long)j * C + h * 32)[i];
+  float* dst = pm + ((long)n * C + j) * C + h * 32;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const f32x4 ks = *reinterpret_cast<const f32x4*>(&skv[h][32][i * 4]);
-      z += q[i].x * ks.x + q[i].y * ks.y + q[i].z * ks.z + q[i].w * ks.w;
-    }
-    z = v_length / (z + eps);
-    f32x4 o[8];
+  for (int d4 = 0; d4 < 8; ++d4) {
+    f32x4 r;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) o[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int dd = 0; dd < 4; ++dd) {
+      const float* kvrow = &skv[(d4 * 4 + dd) * 32];
+      float s = 0.f;
 #pragma unroll
-    for (int dq = 0; dq < 8; ++dq) {
-#pragma unroll
-      for (int dd = 0; dd < 4; ++dd) {
-        const float qv = q[dq][dd];
-        const int dI = dq * 4 + dd;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const f32x4 kvv = *reinterpret_cast<const f32x4*>(&skv[h][dI][i * 4]);
-          o[i] += qv * kvv;
-        }
+      for (int i = 0; i < 8; ++i) {
+        const f32x4 k4 = *reinterpret_cast<const f32x4*>(kvrow + i * 4);      // LDS broadcast
+        s += k4.x * w4[i].x + k4.y * w4[i].y + k4.z * w4[i].z + k4.w * w4[i].w;
       }
+      r[dd] = s;
     }
-    float* op = msg + ((long)n * L + l) * C + h * 32;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) reinterpret_cast<f32x4*>(op)[i] = o[i] * z;
+    reinterpret_cast<f32x4*>(dst)[d4] = r;
   }
 }
 
@@ -166,28 +145,34 @@ size_t attention_workspace_bytes(int nb, int S, int C) {
   if (C != 256) return 0;
   const int splits = ceil_div(S, KV_CHUNK);
   return align_up((size_t)nb * 8 * splits * 33 * 32 * sizeof(float), 256) +
-         align_up((size_t)nb * 8 * 33 * 32 * sizeof(float), 256) + 512;
+         align_up((size_t)nb * 8 * 33 * 32 * sizeof(float), 256) +
+         align_up((size_t)nb * C * C * sizeof(float), 256) + 1024;
+}
+
+// Coarse level (C = 256, H = 8): KV / Ksum reduction + the merged projection P.  The apply step
+// runs inside the merge GEMM (linear.hip: linear_ln_kernel<.., true>).
+int launch_attention_kv(const float* Kf, const float* Vf, const float* merge_w, int nb, int S, int C, int H,
+                        void* ws, size_t ws_bytes, const float** kv_out, const float** pm_out, hipStream_t st) {
+  if (!(C == 256 && H == 8)) return LOFTR_ERR_UNSUPPORTED;
+  const int splits = ceil_div(S, KV_CHUNK);
+  WsAlloc wa(ws, ws_bytes);
+  float* part = wa.take<float>((size_t)nb * 8 * splits * 33 * 32);
+  float* kv = wa.take<float>((size_t)nb * 8 * 33 * 32);
+  float* pm = wa.take<float>((size_t)nb * C * C);
+  if (!wa.ok()) return LOFTR_ERR_WORKSPACE;
+  { TimedLaunch tl(LOFTR_T_KV, st);
+    hipLaunchKernelGGL(kv_partial_kernel, dim3(splits, 8, nb), dim3(256), 0, st, Kf, Vf, part, S, C, splits); }
+  hipLaunchKernelGGL(kv_finalize_kernel, dim3(8, nb), dim3(256), 0, st, part, kv, splits, merge_w, pm);
+  LOFTR_CHECK_LAUNCH();
+  *kv_out = kv;
+  *pm_out = pm;
+  return LOFTR_OK;
 }
 
 int launch_linear_attention(const float* Qf, const float* Kf, const float* Vf, float* msg, int nb,
                             int L, int S, int C, int H, void* ws, size_t ws_bytes, hipStream_t st) {
   if (nb <= 0) return LOFTR_OK;
   const float eps = 1e-6f;                         // LinearAttention(eps=1e-6), linear_attention.py:15
-  if (C == 256 && H == 8) {
-    const int splits = ceil_div(S, KV_CHUNK);
-    WsAlloc wa(ws, ws_bytes);
-    float* part = wa.take<float>((size_t)nb * 8 * splits * 33 * 32);
-    float* kv = wa.take<float>((size_t)nb * 8 * 33 * 32);
-    if (!wa.ok()) return LOFTR_ERR_WORKSPACE;
-    { TimedLaunch tl(LOFTR_T_KV, st);
-      hipLaunchKernelGGL(kv_partial_kernel, dim3(splits, 8, nb), dim3(256), 0, st, Kf, Vf, part, S, C, splits); }
-    hipLaunchKernelGGL(kv_finalize_kernel, dim3(8, nb), dim3(256), 0, st, part, kv, splits);
-    { TimedLaunch tl(LOFTR_T_ATTN_APPLY, st);
-      hipLaunchKernelGGL(attn_apply_kernel, dim3(ceil_div(L, 64), nb), dim3(256), 0, st, Qf, kv, msg, L, C,
-                         (float)S, eps); }
-    LOFTR_CHECK_LAUNCH();
-    return LOFTR_OK;
-  }
   if (C == 128 && H == 8 && (size_t)(L + S) * C * sizeof(float) <= 64 * 1024) {
     const size_t lds = (size_t)(L + S) * C * sizeof(float);
     { TimedLaunch tl(LOFTR_T_ATTN_SMALL, st);

@@ -23,7 +23,7 @@
 
 namespace {
 
-using Cfg = GemmCfg<128, 128, 16, 2, 2>;
+using Cfg = GemmCfg<128, 128, 2, 2>;
 constexpr float SENTINEL = -3.0e38f;          // marks out-of-range tile entries (never a real score)
 
 struct Geometry {
@@ -64,7 +64,7 @@ __device__ __forceinline__ void acc_to_sim(f32x16 (&acc)[Cfg::TM][Cfg::TN], int 
 // ------------------------------------------------------------------------------------------
 // pass A
 template <bool HAS_MASK>
-__global__ __launch_bounds__(Cfg::THREADS) void score_stats_kernel(
+__global__ __launch_bounds__(Cfg::THREADS, 2) void score_stats_kernel(
     const float* __restrict__ f0, const float* __restrict__ f1, Geometry g, float scale,
     const uint8_t* __restrict__ mask0, const uint8_t* __restrict__ mask1,
     float2* __restrict__ rowpart, float2* __restrict__ colpart) {
@@ -172,7 +172,7 @@ __device__ __forceinline__ void conf_partials(f32x16 (&acc)[Cfg::TM][Cfg::TN], i
 // ------------------------------------------------------------------------------------------
 // pass B
 template <bool HAS_MASK>
-__global__ __launch_bounds__(Cfg::THREADS) void score_conf_kernel(
+__global__ __launch_bounds__(Cfg::THREADS, 2) void score_conf_kernel(
     const float* __restrict__ f0, const float* __restrict__ f1, Geometry g, float scale,
     const uint8_t* __restrict__ mask0, const uint8_t* __restrict__ mask1,
     const float2* __restrict__ rowstat, const float2* __restrict__ colstat,
@@ -377,7 +377,7 @@ __global__ __launch_bounds__(256) void scatter_kernel(ScatterParams sp, const in
 
 // ------------------------------------------------------------------------------------------
 // Sinkhorn pieces
-__global__ __launch_bounds__(Cfg::THREADS) void score_store_kernel(const float* __restrict__ f0,
+__global__ __launch_bounds__(Cfg::THREADS, 2) void score_store_kernel(const float* __restrict__ f0,
                                                                    const float* __restrict__ f1, Geometry g,
                                                                    float scale, const uint8_t* __restrict__ mask0,
                                                                    const uint8_t* __restrict__ mask1,
@@ -504,7 +504,7 @@ __global__ __launch_bounds__(256) void ot_colkill_kernel(const float* __restrict
 
 // conf = exp(z + u + v - norm) in place (+ full assignment matrix, + prefilter) and the row/col
 // max partials of conf.  Tile = 128 x 128 like the GEMM kernels so that conf_partials applies.
-__global__ __launch_bounds__(Cfg::THREADS) void ot_finalize_kernel(float* __restrict__ z, Geometry g, float norm,
+__global__ __launch_bounds__(Cfg::THREADS, 2) void ot_finalize_kernel(float* __restrict__ z, Geometry g, float norm,
                                                                    const float* __restrict__ u,
                                                                    const float* __restrict__ v,
                                                                    const uint8_t* __restrict__ rowkill,
@@ -648,7 +648,7 @@ extern "C" int loftr_coarse_match_dual_softmax(const float* feat_c0, const float
                                                float* conf_out, const loftr_match_out* out, void* ws,
                                                size_t ws_bytes, void* stream) {
   LOFTR_CHECK_ARG(feat_c0 && feat_c1 && params_ok(p, out) && temperature > 0.f);
-  if (p->C % Cfg::BK != 0) return LOFTR_ERR_UNSUPPORTED;
+  if (p->C % 4 != 0) return LOFTR_ERR_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
   if (p->N == 0) { (void)hipMemsetAsync(out->counts, 0, sizeof(int32_t), st); return LOFTR_OK; }
   LOFTR_CHECK_ARG(ws != nullptr);
@@ -685,7 +685,7 @@ extern "C" int loftr_coarse_match_sinkhorn(const float* feat_c0, const float* fe
                                            const loftr_match_out* out, void* ws, size_t ws_bytes,
                                            void* stream) {
   LOFTR_CHECK_ARG(feat_c0 && feat_c1 && params_ok(p, out) && conf_out && iters >= 0);
-  if (p->C % Cfg::BK != 0) return LOFTR_ERR_UNSUPPORTED;
+  if (p->C % 4 != 0) return LOFTR_ERR_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
   if (p->N == 0) { (void)hipMemsetAsync(out->counts, 0, sizeof(int32_t), st); return LOFTR_OK; }
   LOFTR_CHECK_ARG(ws != nullptr);

@@ -119,7 +119,7 @@ extern "C" int loftr_fine_preprocess(const loftr_fmap* feat_f0, const loftr_fmap
     return LOFTR_OK;
   }
   LOFTR_CHECK_ARG(feat_c0 && feat_c1 && down_b && merge_w && merge_b && ws);
-  if (Cf % 16 != 0 || Cc % 16 != 0) return LOFTR_ERR_UNSUPPORTED;
+  if (Cf % 4 != 0 || Cc % 4 != 0) return LOFTR_ERR_UNSUPPORTED;
   WsAlloc wa(ws, ws_bytes);
   float* win0 = wa.take<float>((size_t)M * WW * Cf);
   float* win1 = wa.take<float>((size_t)M * WW * Cf);

@@ -37,6 +37,10 @@ int launch_proj(const ProjArgs& p, hipStream_t st);
 
 // out = [residual +] LayerNorm(A @ W^T) * gamma + beta     (N == C, one block spans the row)
 //   merge + norm1 (transformer.py:51-52) and mlp.2 + norm2 + residual (:55-58).
+//   Batched-attention mode (attn_kv != null, C == 256): A is the feature-mapped Q [nb, L, C], the B
+//   operand of batch element n is w + n*C*C (= P_n, attention.hip) and the linear-attention
+//   normaliser is applied to A on the fly (gemm.h: AttnXform); M = L rows per batch element,
+//   grid.y = nb so no tile straddles two batch elements.
 struct LinearLNArgs {
   ASrc a;
   const float* w; int ldw;
@@ -45,5 +49,7 @@ struct LinearLNArgs {
   float* out;                   // [M, C]
   int M, C, K;
   float eps;
+  const float* attn_kv;         // [nb, 8, 33, 32] or null
+  int nb; float v_length; float attn_eps;
 };
 int launch_linear_ln(const LinearLNArgs& p, hipStream_t st);

@@ -1,14 +1,14 @@
-// Linear layers of the LoFTR encoder on the fp32 matrix cores, with the surrounding elementwise
+// Linear layers of the LoFTR encoder on the matrix cores (fp16x3 split GEMM, gemm.h), with the surrounding elementwise
 // work fused into the epilogue (feature map, ReLU, bias, LayerNorm, residual).
 #include "linear.h"
 
-using CfgGen = GemmCfg<128, 128, 16, 2, 2>;     // generic tile: 4 waves, 64x64 per wave
-using CfgLN256 = GemmCfg<64, 256, 16, 1, 4>;    // full 256-wide rows in one block (LayerNorm)
-using CfgLN128 = GemmCfg<128, 128, 16, 2, 2>;   // full 128-wide rows in one block
+using CfgGen = GemmCfg<128, 128, 2, 2>;     // generic tile: 4 waves, 64x64 per wave
+using CfgLN256 = GemmCfg<64, 256, 1, 4>;    // full 256-wide rows in one block (LayerNorm)
+using CfgLN128 = GemmCfg<128, 128, 2, 2>;   // full 128-wide rows in one block
 
 // ------------------------------------------------------------------------------------------
 template <typename Cfg, int EPI>
-__global__ __launch_bounds__(Cfg::THREADS) void linear_kernel(LinearArgs p) {
+__global__ __launch_bounds__(Cfg::THREADS, 2) void linear_kernel(LinearArgs p) {
   __shared__ __attribute__((aligned(16))) float lds[Cfg::LDS_FLOATS];
   const int m0 = blockIdx.y * Cfg::BM, n0 = blockIdx.x * Cfg::BN;
   f32x16 acc[Cfg::TM][Cfg::TN];
@@ -36,7 +36,7 @@ __global__ __launch_bounds__(Cfg::THREADS) void linear_kernel(LinearArgs p) {
 
 int launch_linear(const LinearArgs& p, LinearEpi epi, hipStream_t st) {
   if (p.M <= 0) return LOFTR_OK;
-  if (p.K % CfgGen::BK != 0 || p.N <= 0) return LOFTR_ERR_UNSUPPORTED;
+  if (p.K % 4 != 0 || p.N <= 0) return LOFTR_ERR_UNSUPPORTED;
   dim3 grid(ceil_div(p.N, CfgGen::BN), ceil_div(p.M, CfgGen::BM));
   dim3 block(CfgGen::THREADS);
   TimedLaunch tl(LOFTR_T_LINEAR, st);
@@ -52,7 +52,7 @@ int launch_linear(const LinearArgs& p, LinearEpi epi, hipStream_t st) {
 
 // ------------------------------------------------------------------------------------------
 template <typename Cfg>
-__global__ __launch_bounds__(Cfg::THREADS) void proj_kernel(ProjArgs p) {
+__global__ __launch_bounds__(Cfg::THREADS, 2) void proj_kernel(ProjArgs p) {
   __shared__ __attribute__((aligned(16))) float lds[Cfg::LDS_FLOATS];
   const int m0 = blockIdx.y * Cfg::BM;
   const int nglob = blockIdx.x * Cfg::BN;          // column in the concatenated [nseg*C] output
@@ -94,12 +94,20 @@ int launch_proj(const ProjArgs& p, hipStream_t st) {
 // ------------------------------------------------------------------------------------------
 // GEMM + LayerNorm (+ residual).  One block spans the whole row (BN == C), so the row statistics
 // are a reduction over the TN tiles of a lane, the 32 lanes of a half-wave and the WN waves.
-template <typename Cfg>
-__global__ __launch_bounds__(Cfg::THREADS) void linear_ln_kernel(LinearLNArgs p) {
+template <typename Cfg, bool ATTN>
+__global__ __launch_bounds__(Cfg::THREADS, 2) void linear_ln_kernel(LinearLNArgs p) {
   __shared__ __attribute__((aligned(16))) float lds[Cfg::LDS_FLOATS];
   const int m0 = blockIdx.x * Cfg::BM;
   f32x16 acc[Cfg::TM][Cfg::TN];
-  gemm_mainloop<Cfg>(p.a, p.w, p.ldw, p.M, p.C, p.K, m0, 0, lds, acc);
+  if (ATTN) {
+    const long n = blockIdx.y;
+    p.a.p0 += n * p.M * (long)p.a.ld0;
+    p.out += n * p.M * (long)p.C;
+    AttnXform ax{p.attn_kv + n * (8 * 33 * 32), p.v_length, p.attn_eps, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    gemm_mainloop<Cfg, AttnXform>(p.a, p.w + n * (long)p.C * p.C, p.ldw, p.M, p.C, p.K, m0, 0, lds, acc, ax);
+  } else {
+    gemm_mainloop<Cfg>(p.a, p.w, p.ldw, p.M, p.C, p.K, m0, 0, lds, acc);
+  }
   __syncthreads();                                  // all waves done with the staging buffers
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wm = wave / Cfg::WN, wn = wave % Cfg::WN;
@@ -172,13 +180,17 @@ __global__ __launch_bounds__(Cfg::THREADS) void linear_ln_kernel(LinearLNArgs p)
 
 int launch_linear_ln(const LinearLNArgs& p, hipStream_t st) {
   if (p.M <= 0) return LOFTR_OK;
-  if (p.K % 16 != 0) return LOFTR_ERR_UNSUPPORTED;
+  if (p.K % 4 != 0) return LOFTR_ERR_UNSUPPORTED;
   TimedLaunch tl(LOFTR_T_LINEAR_LN, st);
-  if (p.C == 256) {
-    hipLaunchKernelGGL((linear_ln_kernel<CfgLN256>), dim3(ceil_div(p.M, CfgLN256::BM)),
+  if (p.attn_kv) {
+    if (p.C != 256 || p.K != 256 || p.residual || p.nb <= 0) return LOFTR_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL((linear_ln_kernel<CfgLN256, true>), dim3(ceil_div(p.M, CfgLN256::BM), p.nb),
+                       dim3(CfgLN256::THREADS), 0, st, p);
+  } else if (p.C == 256) {
+    hipLaunchKernelGGL((linear_ln_kernel<CfgLN256, false>), dim3(ceil_div(p.M, CfgLN256::BM)),
                        dim3(CfgLN256::THREADS), 0, st, p);
   } else if (p.C == 128) {
-    hipLaunchKernelGGL((linear_ln_kernel<CfgLN128>), dim3(ceil_div(p.M, CfgLN128::BM)),
+    hipLaunchKernelGGL((linear_ln_kernel<CfgLN128, false>), dim3(ceil_div(p.M, CfgLN128::BM)),
                        dim3(CfgLN128::THREADS), 0, st, p);
   } else {
     return LOFTR_ERR_UNSUPPORTED;

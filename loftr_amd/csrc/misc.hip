@@ -7,35 +7,47 @@ namespace {
 // 32 x 32 tile transpose through LDS: read rows of [C][HW] (coalesced along HW), write rows of
 // [HW][C] (coalesced along C).  The constant sine table is added on the way.
 //   grid (ceil(HW/32), ceil(C/32), N), block (32, 8)
-__global__ void pos_encode_flatten_kernel(const float* __restrict__ feat, const float* __restrict__ pe,
-                                          int pe_h, int pe_w, float* __restrict__ out, int C, int H, int W) {
+//   CL = channels-last input (sc == 1): only the sine table goes through the transpose, the
+//   feature value is read in the output's own (coalesced along C) order.
+template <bool CL>
+__global__ void pos_encode_flatten_kernel(loftr_fmap f, const float* __restrict__ pe,
+                                          int pe_h, int pe_w, float* __restrict__ out, int C) {
   __shared__ float tile[32][33];
-  const int HW = H * W;
+  const int H = f.H, W = f.W, HW = H * W;
   const int n = blockIdx.z, hw0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
-  const float* in = feat + (long)n * C * HW;
+  const float* in = f.data + (long)n * f.sn;
   for (int k = threadIdx.y; k < 32; k += 8) {
     const int c = c0 + k, hw = hw0 + threadIdx.x;
     float v = 0.f;
     if (c < C && hw < HW) {
       const int y = hw / W, x = hw - y * W;
-      v = in[(long)c * HW + hw] + pe[((long)c * pe_h + y) * pe_w + x];
+      v = pe[((long)c * pe_h + y) * pe_w + x];
+      if (!CL) v += in[(long)c * f.sc + (long)y * f.sh + (long)x * f.sw];
     }
     tile[k][threadIdx.x] = v;
   }
   __syncthreads();
   for (int k = threadIdx.y; k < 32; k += 8) {
     const int hw = hw0 + k, c = c0 + threadIdx.x;
-    if (hw < HW && c < C) out[((long)n * HW + hw) * C + c] = tile[threadIdx.x][k];
+    if (hw < HW && c < C) {
+      float v = tile[threadIdx.x][k];
+      if (CL) { const int y = hw / W, x = hw - y * W; v += in[(long)y * f.sh + (long)x * f.sw + c]; }
+      out[((long)n * HW + hw) * C + c] = v;
+    }
   }
 }
 }  // namespace
 
-extern "C" int loftr_pos_encode_flatten(const float* feat, const float* pe, int pe_h, int pe_w, float* out,
-                                        int N, int C, int H, int W, void* stream) {
-  LOFTR_CHECK_ARG(feat && pe && out && N >= 0 && C > 0 && H > 0 && W > 0 && H <= pe_h && W <= pe_w);
+extern "C" int loftr_pos_encode_flatten(const loftr_fmap* feat, const float* pe, int pe_h, int pe_w, float* out,
+                                        int N, int C, void* stream) {
+  LOFTR_CHECK_ARG(feat && feat->data && pe && out && N >= 0 && C > 0 && feat->H > 0 && feat->W > 0 &&
+                  feat->H <= pe_h && feat->W <= pe_w);
   if (N == 0) return LOFTR_OK;
-  hipLaunchKernelGGL(pos_encode_flatten_kernel, dim3(ceil_div(H * W, 32), ceil_div(C, 32), N), dim3(32, 8), 0,
-                     (hipStream_t)stream, feat, pe, pe_h, pe_w, out, C, H, W);
+  const dim3 grid(ceil_div(feat->H * feat->W, 32), ceil_div(C, 32), N), block(32, 8);
+  if (feat->sc == 1)
+    hipLaunchKernelGGL((pos_encode_flatten_kernel<true>), grid, block, 0, (hipStream_t)stream, *feat, pe, pe_h, pe_w, out, C);
+  else
+    hipLaunchKernelGGL((pos_encode_flatten_kernel<false>), grid, block, 0, (hipStream_t)stream, *feat, pe, pe_h, pe_w, out, C);
   LOFTR_CHECK_LAUNCH();
   return LOFTR_OK;
 }

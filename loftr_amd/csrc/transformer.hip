@@ -56,15 +56,26 @@ int encoder_layer(const float* x, const float* src, const uint8_t* x_mask, const
     ProjArgs pkv{src, Ms, C, 2, {w.k_proj, w.v_proj, nullptr}, {e.k, e.v, nullptr}, {1, 2, 0}, src_mask, inv_s};
     if ((rc = launch_proj(pkv, st))) return rc;
   }
-  if ((rc = launch_linear_attention(e.q, e.k, e.v, e.msg, nb, L, S, C, H, e.attn, e.attn_bytes, st))) return rc;
-  // message = norm1(merge(message))                                   transformer.py:51-52
-  LinearLNArgs m{asrc_plain(e.msg, C), w.merge, C, w.norm1_w, w.norm1_b, nullptr, e.msgn, Ml, C, C, 1e-5f};
-  if ((rc = launch_linear_ln(m, st))) return rc;
+  if (C == 256) {
+    // coarse level: KV reduction, then attention-apply + merge + norm1 as ONE GEMM   transformer.py:50-52
+    const float *kv = nullptr, *pm = nullptr;
+    if ((rc = launch_attention_kv(e.k, e.v, w.merge, nb, S, C, H, e.attn, e.attn_bytes, &kv, &pm, st))) return rc;
+    LinearLNArgs m{asrc_plain(e.q, C), pm, C, w.norm1_w, w.norm1_b, nullptr, e.msgn, L, C, C, 1e-5f,
+                   kv, nb, (float)S, 1e-6f};             // LinearAttention(eps=1e-6), linear_attention.py:15
+    if ((rc = launch_linear_ln(m, st))) return rc;
+  } else {
+    if ((rc = launch_linear_attention(e.q, e.k, e.v, e.msg, nb, L, S, C, H, e.attn, e.attn_bytes, st))) return rc;
+    // message = norm1(merge(message))                                   transformer.py:51-52
+    LinearLNArgs m{asrc_plain(e.msg, C), w.merge, C, w.norm1_w, w.norm1_b, nullptr, e.msgn, Ml, C, C, 1e-5f,
+                   nullptr, 0, 0.f, 0.f};
+    if ((rc = launch_linear_ln(m, st))) return rc;
+  }
   // hidden = relu(mlp.0(cat[x, message]))                             transformer.py:55
   LinearArgs h{asrc_cat(x, C, e.msgn, C, C), w.mlp0, 2 * C, e.hid, 2 * C, Ml, 2 * C, 2 * C, nullptr, 1};
   if ((rc = launch_linear(h, EPI_RELU, st))) return rc;
   // out = x + norm2(mlp.2(hidden))                                    transformer.py:55-58
-  LinearLNArgs o{asrc_plain(e.hid, 2 * C), w.mlp2, 2 * C, w.norm2_w, w.norm2_b, x, out, Ml, C, 2 * C, 1e-5f};
+  LinearLNArgs o{asrc_plain(e.hid, 2 * C), w.mlp2, 2 * C, w.norm2_w, w.norm2_b, x, out, Ml, C, 2 * C, 1e-5f,
+                 nullptr, 0, 0.f, 0.f};
   return launch_linear_ln(o, st);
 }
 

@@ -41,7 +41,7 @@ class PositionEncodingSine(nn.Module):
 
     def forward(self, x):
         """x [N,C,H,W] -> (x + pe) flattened to [N, H*W, C] (fuses loftr.py:58-59's rearrange)."""
-        return ops.pos_encode_flatten(x.contiguous(), self.pe[0])
+        return ops.pos_encode_flatten(x, self.pe[0])
 
 
 class LoFTREncoderLayer(nn.Module):
@@ -228,7 +228,10 @@ class LoFTR(nn.Module):
     def __init__(self, config):
         super().__init__()
         self.config = config
-        self.backbone = build_backbone(config)
+        # channels-last is MIOpen's fastest fp32 layout on MI355X (-16 % backbone time) and hands the
+        # HIP path [.., H, W, C]-ordered maps: the flatten and the fine-window gather then read
+        # fully coalesced.  Pure storage-order choice: parameter names / shapes are unchanged.
+        self.backbone = build_backbone(config).to(memory_format=torch.channels_last)
         self.pos_encoding = PositionEncodingSine(config["coarse"]["d_model"],
                                                  temp_bug_fix=config["coarse"]["temp_bug_fix"])
         self.loftr_coarse = LocalFeatureTransformer(config["coarse"])
@@ -241,11 +244,12 @@ class LoFTR(nn.Module):
         """Step 1 of forward (loftr.py:39-54): returns (feat_c0, feat_c1, feat_f0, feat_f1)."""
         data.update({"bs": data["image0"].size(0),
                      "hw0_i": data["image0"].shape[2:], "hw1_i": data["image1"].shape[2:]})
+        cl = lambda img: img.contiguous(memory_format=torch.channels_last)   # C == 1: a restride, no copy
         if data["hw0_i"] == data["hw1_i"]:
-            feats_c, feats_f = self.backbone(torch.cat([data["image0"], data["image1"]], dim=0))
+            feats_c, feats_f = self.backbone(cl(torch.cat([data["image0"], data["image1"]], dim=0)))
             (feat_c0, feat_c1), (feat_f0, feat_f1) = feats_c.split(data["bs"]), feats_f.split(data["bs"])
         else:
-            (feat_c0, feat_f0), (feat_c1, feat_f1) = self.backbone(data["image0"]), self.backbone(data["image1"])
+            (feat_c0, feat_f0), (feat_c1, feat_f1) = self.backbone(cl(data["image0"])), self.backbone(cl(data["image1"]))
         return feat_c0, feat_c1, feat_f0, feat_f1
 
     def match_from_features(self, feat_c0, feat_c1, feat_f0, feat_f1, data):

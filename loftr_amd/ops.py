@@ -67,12 +67,15 @@ def linear(a, w):
 
 
 def pos_encode_flatten(feat, pe):
-    """feat [N,C,H,W] + pe[:, :H, :W], flattened to [N, H*W, C].  pe: [C, pe_h, pe_w]."""
-    _need(feat, "feat"); _need(pe, "pe")
+    """feat [N,C,H,W] (any strides, e.g. channels-last) + pe[:, :H, :W], flattened to [N, H*W, C]."""
+    if not feat.is_cuda or feat.dtype != torch.float32:
+        raise _lib.LoftrHipError("feat: expected a float32 GPU tensor (the HIP matching path has no CPU fallback)")
+    _need(pe, "pe")
     N, Cc, H, W = feat.shape
     out = torch.empty(N, H * W, Cc, device=feat.device, dtype=torch.float32)
-    check(_lib.load().loftr_pos_encode_flatten(_ptr(feat), _ptr(pe), pe.shape[-2], pe.shape[-1], _ptr(out),
-                                               N, Cc, H, W, _stream()), "loftr_pos_encode_flatten")
+    fm = _fmap(feat)
+    check(_lib.load().loftr_pos_encode_flatten(C.byref(fm), _ptr(pe), pe.shape[-2], pe.shape[-1], _ptr(out),
+                                               N, Cc, _stream()), "loftr_pos_encode_flatten")
     return out
 
 

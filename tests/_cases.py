@@ -122,18 +122,19 @@ def build_hip_matcher(cfg, w, device="cuda:0"):
     return model.to(device)
 
 
-def run_hip(inp, device="cuda:0", model=None, materialize_conf=True):
+def run_hip(inp, device="cuda:0", model=None, materialize_conf=True, channels_last=False):
     """The HIP hot path on a case's inputs -> dict of numpy arrays with the reference's keys."""
     import torch
     model = model or build_hip_matcher(inp["cfg"], inp["w"], device)
     model.coarse_matching.materialize_conf = materialize_conf
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
+    tf = (lambda a: t(a).contiguous(memory_format=torch.channels_last)) if channels_last else t
     n = inp["feat_c0"].shape[0]
     data = {"bs": n, "hw0_i": torch.Size(inp["hw0_i"]), "hw1_i": torch.Size(inp["hw1_i"])}
     if inp["mask0"] is not None:
         data.update(mask0=t(inp["mask0"]), mask1=t(inp["mask1"]), scale0=t(inp["scale0"]), scale1=t(inp["scale1"]))
     with torch.no_grad():
-        model.match_from_features(t(inp["feat_c0"]), t(inp["feat_c1"]), t(inp["feat_f0"]), t(inp["feat_f1"]), data)
+        model.match_from_features(tf(inp["feat_c0"]), tf(inp["feat_c1"]), tf(inp["feat_f0"]), tf(inp["feat_f1"]), data)
     torch.cuda.synchronize()
     out = {}
     for k, v in data.items():

@@ -57,7 +57,7 @@ def test_workspace_queries(lib):
 def test_bad_arguments_return_status(lib):
     # null pointers -> LOFTR_ERR_BAD_ARG before any device work
     assert lib.loftr_linear_fwd(None, None, None, 4, 4, 16, None) == -1
-    assert lib.loftr_pos_encode_flatten(None, None, 256, 256, None, 1, 256, 8, 8, None) == -1
+    assert lib.loftr_pos_encode_flatten(None, None, 256, 256, None, 1, 256, None) == -1
     assert lib.loftr_fine_match(None, None, 3, 25, 128, None, None, 2.0, None, None, None, None) == -1
     # M == 0 is a no-op success on every fine entry point
     assert lib.loftr_fine_match(None, None, 0, 25, 128, None, None, 2.0, None, None, None, None) == 0

@@ -74,6 +74,9 @@ def test_hip_vs_oracle_stages(name):
     fc1 = model.pos_encoding(t(inp["feat_c1"]))
     tbf = inp["cfg"]["coarse"]["temp_bug_fix"]
     assert np.abs(fc0.cpu().numpy() - O.add_pos_flatten(inp["feat_c0"], tbf)).max() <= 1e-5
+    # channels-last storage (what the backbone hands over) must give the same bytes
+    fc0_cl = model.pos_encoding(t(inp["feat_c0"]).contiguous(memory_format=torch.channels_last))
+    assert torch.equal(fc0_cl, fc0)
     m0 = m1 = None
     if inp["mask0"] is not None:
         m0, m1 = t(inp["mask0"]).flatten(-2), t(inp["mask1"]).flatten(-2)
@@ -95,6 +98,17 @@ def test_conf_matrix_elided_same_matches():
     b = run_hip(inp, materialize_conf=False)
     assert "conf_matrix" not in b
     for k in ("b_ids", "i_ids", "j_ids", "mconf", "mkpts1_f"):
+        assert np.array_equal(a[k], b[k]), k
+
+
+@pytest.mark.parametrize("name", ["small_ds", "mid_ds"])
+def test_channels_last_features_identical(name):
+    """NCHW and channels-last backbone outputs go through different load paths (transposing
+    flatten / strided gather vs coalesced) and must produce bitwise identical results."""
+    rc, inp, g = load_case(name)
+    a = run_hip(inp, channels_last=False)
+    b = run_hip(inp, channels_last=True)
+    for k in ("conf_matrix", "b_ids", "i_ids", "j_ids", "mconf", "mkpts1_f", "expec_f"):
         assert np.array_equal(a[k], b[k]), k
 
 

@@ -1,0 +1,51 @@
+#!/usr/bin/env python
+"""Per-kernel HBM traffic from two rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE, rocpd sqlite).
+
+    python tools/rocpd_pmc.py <fetch.db> <write.db> [--json profiles/pmc_traffic.json]
+
+FETCH_SIZE / WRITE_SIZE are reported by rocprofv3 in KiB.  gfx950 correction (MI355X_MICROARCH.md
+§HBM): FETCH_SIZE counts the 128-B requests of a wide coalesced streaming read at 64 B, i.e. it
+reports HALF the bytes -> doubled here ("fetch_x2").  WRITE_SIZE is uncalibrated in the guide; it
+is calibrated below against a kernel with a known write volume (score_conf_kernel writes exactly
+N*L*S*4 bytes of conf_matrix) and the factor printed.
+"""
+import json
+import re
+import sqlite3
+import sys
+
+
+def per_kernel(path, counter):
+    db = sqlite3.connect(path)
+    rows = db.execute("select kernel_name, count(*), avg(value), min(value), max(value) from counters_collection "
+                      "where counter_name=? group by kernel_name", (counter,)).fetchall()
+    return {r[0]: dict(n=r[1], avg_kib=r[2], min_kib=r[3], max_kib=r[4]) for r in rows}
+
+
+def short(name):
+    name = re.sub(r"\(anonymous namespace\)::", "", name)
+    name = re.sub(r"^void ", "", name)
+    return re.split(r"[<(]", name)[0]
+
+
+def main():
+    fetch, write = per_kernel(sys.argv[1], "FETCH_SIZE"), per_kernel(sys.argv[2], "WRITE_SIZE")
+    out = {}
+    print(f"{'kernel':44s} {'calls':>6} {'fetch_x2 MB':>12} {'write MB':>10} {'hbm MB/launch':>14}")
+    for k in sorted(set(fetch) | set(write), key=lambda k: -(fetch.get(k, {}).get('avg_kib', 0) * fetch.get(k, {}).get('n', 0))):
+        if not ("kernel" in k and ("loftr" in k or "Geometry" in k or "Args" in k or "anonymous" in k or "attn" in k or "kv_" in k
+                                  or "gather" in k or "fine_match" in k or "pos_encode" in k)):
+            continue
+        f = fetch.get(k, {}).get("avg_kib", 0.0) * 1024 * 2
+        w = write.get(k, {}).get("avg_kib", 0.0) * 1024
+        n = fetch.get(k, write.get(k))["n"]
+        key = short(k)
+        tag = key if key not in out else key + "#" + str(sum(1 for x in out if x.startswith(key)))
+        out[tag] = dict(full_name=k[:160], launches=n, fetch_bytes_x2=f, write_bytes=w, hbm_bytes_per_launch=f + w)
+        print(f"{tag:44s} {n:6d} {f / 1e6:12.2f} {w / 1e6:10.2f} {(f + w) / 1e6:14.2f}")
+    if "--json" in sys.argv:
+        json.dump(out, open(sys.argv[sys.argv.index("--json") + 1], "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()
