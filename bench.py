@@ -85,7 +85,6 @@ def algorithmic_work(B, L, S, M, C_=256, Cf=128, WW=25):
     w["linear_kernel"] = (w["linear_kernel"][0] + fp_f, w["linear_kernel"][1] + fp_b)
     nl = n_self + n_cross
     w["kv_partial_kernel"] = (nl * 2 * rows_c * C_ * 32 + nl * rows_c * C_, nl * 4 * 2 * rows_c * C_)
-    w["attn_apply_kernel"] = (nl * (2 * rows_c * C_ * 32 + 2 * rows_c * C_), nl * 4 * 2 * rows_c * C_)
     w["attn_small_kernel"] = (2 * 2 * (2 * 2 * M * WW * Cf * 16), 2 * 4 * 4 * 2 * M * WW * Cf)
     w["score_stats_kernel"] = (2 * B * L * S * C_, 4 * B * (L + S) * C_)
     w["score_conf_kernel"] = (2 * B * L * S * C_, 4 * B * ((L + S) * C_ + L * S))
@@ -168,6 +167,9 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
 
+    # MIOpen picks its fastest fp32 channels-last kernels only through the find step (47.8 vs 73 ms for
+    # the 16-image backbone batch, tools/micro/backbone_variants.py); the search runs during warm-up.
+    torch.backends.cudnn.benchmark = True
     lib = _lib.load()
     _lib.check(lib.loftr_hip_device_check(), "device check")
     ids = kernel_ids(lib)

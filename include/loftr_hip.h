@@ -34,7 +34,7 @@ typedef enum {
   LOFTR_ERR_NO_DEVICE = -5      /* no gfx950 device visible                                    */
 } loftr_status;
 
-#define LOFTR_HIP_ABI_VERSION 2
+#define LOFTR_HIP_ABI_VERSION 3
 
 int loftr_hip_abi_version(void);
 const char* loftr_hip_status_string(int status);
@@ -122,7 +122,7 @@ typedef struct {
   int32_t* counts;    /* [1+N]   */
 } loftr_match_out;
 
-size_t loftr_coarse_match_workspace_bytes(int N, int L, int S);
+size_t loftr_coarse_match_workspace_bytes(int N, int L, int S, int C);
 
 /* Replaces: CoarseMatching.forward, match_type='dual_softmax' + get_coarse_match, eval branch
  * (src/loftr/utils/coarse_matching.py:105-119,150-196,238-261).
@@ -149,7 +149,7 @@ int loftr_coarse_match_sinkhorn(const float* feat_c0, const float* feat_c1,
  *   feat_f0/1: fine maps (loftr_fmap, any strides; channels-last reads are fully coalesced);
  *   feat_c0 [N,L,Cc], feat_c1 [N,S,Cc] (transformer outputs);
  *   out0/out1 [M,W*W,Cf].  down_w [Cf,Cc], down_b [Cf], merge_w [Cf,2Cf], merge_b [Cf];
- *   pass down_w = NULL for fine_concat_coarse_feat = False. */
+ *   (fine_concat_coarse_feat = False -- down_w NULL -- is not supported: no shipped config uses it.) */
 
 size_t loftr_fine_preprocess_workspace_bytes(int M, int W, int Cf);
 
@@ -183,9 +183,10 @@ int loftr_hip_timing_read(int id, double* total_ms, long long* launches, int res
 
 /* ---- building block exposed for tests / profiling ------------------------------------------
  * out[M,N] = A[M,K] @ Wt[N,K]^T  (the fp32-accurate split-fp16 MFMA GEMM every linear layer above
- * is built on; K % 4 == 0). */
+ * is built on). */
+size_t loftr_linear_workspace_bytes(int M, int N, int K);
 int loftr_linear_fwd(const float* a, const float* w, float* out, int M, int N, int K,
-                     void* stream);
+                     void* ws, size_t ws_bytes, void* stream);
 
 #ifdef __cplusplus
 }

@@ -45,7 +45,7 @@ SIGNATURES = {
     "loftr_encoder_layer_fwd": (_i, [_p, _p, _p, _p, C.POINTER(LayerWeights), _p, _i, _i, _i, _i, _i, _p, _sz, _p]),
     "loftr_transformer_fwd": (_i, [_p, _p, _p, _p, C.POINTER(LayerWeights), C.POINTER(_i), _i, _i, _i, _i, _i, _i,
                                    _p, _sz, _p]),
-    "loftr_coarse_match_workspace_bytes": (_sz, [_i, _i, _i]),
+    "loftr_coarse_match_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "loftr_coarse_match_dual_softmax": (_i, [_p, _p, C.POINTER(CoarseParams), _f, _p, C.POINTER(MatchOut), _p, _sz, _p]),
     "loftr_coarse_match_sinkhorn": (_i, [_p, _p, C.POINTER(CoarseParams), _f, _i, _i, _p, _p, C.POINTER(MatchOut),
                                          _p, _sz, _p]),
@@ -57,10 +57,11 @@ SIGNATURES = {
     "loftr_hip_timing_kernel_count": (_i, []),
     "loftr_hip_timing_kernel_name": (C.c_char_p, [_i]),
     "loftr_hip_timing_read": (_i, [_i, C.POINTER(C.c_double), C.POINTER(C.c_longlong), _i]),
-    "loftr_linear_fwd": (_i, [_p, _p, _p, _i, _i, _i, _p]),
+    "loftr_linear_workspace_bytes": (_sz, [_i, _i, _i]),
+    "loftr_linear_fwd": (_i, [_p, _p, _p, _i, _i, _i, _p, _sz, _p]),
 }
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 _lib = None
 
 

@@ -1,15 +1,17 @@
 // Linear-attention core launchers (defined in attention.hip).
 #pragma once
-#include "common.h"
+#include "gemm.h"
 
 size_t attention_workspace_bytes(int nb, int S, int C);
 
-// Coarse level: Kf/Vf [nb,S,C] -> kv [nb,8,33,32] (KV + Ksum) and pm [nb,C,C] (KV folded into the
-// merge weight); both live in `ws`.
+// Coarse level (C = 256, 8 heads of 32): Kf/Vf [nb,S,C] fp32 (feature-mapped, masked, V / S) ->
+//   kv [nb,8,33,32] fp32 (rows 0..31 = KV[d][v], row 32 = Ksum[d]) and
+//   pm [nb,C,C] SP      (KV folded into the merge weight: the per-pair B operand of the fused
+//                        attention + merge GEMM);   both live in `ws`.
 int launch_attention_kv(const float* Kf, const float* Vf, const float* merge_w, int nb, int S, int C, int H,
-                        void* ws, size_t ws_bytes, const float** kv_out, const float** pm_out, hipStream_t st);
+                        void* ws, size_t ws_bytes, const float** kv_out, const sp_t** pm_out, hipStream_t st);
 
-// Qf [nb,L,C], Kf/Vf [nb,S,C]: outputs of the projection kernel (feature map, masks and the
-// 1/S scaling already applied).  msg [nb,L,C].
-int launch_linear_attention(const float* Qf, const float* Kf, const float* Vf, float* msg, int nb,
-                            int L, int S, int C, int H, void* ws, size_t ws_bytes, hipStream_t st);
+// Fine level (per-match windows, C = 128, 8 heads of 16): whole attention of one window per block.
+//   Qf [nb,L,C], Kf/Vf [nb,S,C] fp32 -> msg [nb,L,C] SP.
+int launch_attention_small(const float* Qf, const float* Kf, const float* Vf, sp_t* msg, int nb, int L, int S,
+                           int C, int H, hipStream_t st);

@@ -4,6 +4,11 @@
 //     KV[n,h,d,v] = sum_s K[n,s,h,d] V[n,s,h,v]          (:43)
 //     Ksum[n,h,d] = sum_s K[n,s,h,d]                     (:44, K.sum(dim=1))
 //     out[n,l,h,v] = (sum_d Q[n,l,h,d] KV[n,h,d,v]) * S / (sum_d Q[n,l,h,d] Ksum[n,h,d] + eps)   (:44-45)
+// At the coarse level the last line never runs as such: with z[l,h] = S / (Q[l,h,:].Ksum[h,:] + eps)
+//     merge(out)[l,:] = sum_h z[l,h] (Q[l,h,:] @ KV_h) @ Wm[:, h-block]^T = (z (.) Q)[l,:] @ P,
+//     P[(h,d), j] = sum_v KV[h,d,v] Wm[j, h*32+v]
+// so the Q projection's epilogue applies z (the KV reduction runs before it) and the merge GEMM
+// takes the per-pair P as its B operand: no message tensor, no separate apply kernel.
 #include "attention.h"
 
 // ------------------------------------------------------------------------------------------
@@ -50,13 +55,13 @@ __global__ __launch_bounds__(256) void kv_partial_kernel(const float* __restrict
 }
 
 // kv [nb,H,33,32]: rows 0..31 = KV[d][v], row 32 = Ksum[d].   grid (H, nb), 256 threads.
-// Also folds KV into the merge projection (transformer.py:51): pm[n][j][h*32+d] =
-// sum_v KV[n,h,d,v] * Wm[j][h*32+v]  -- the per-batch-element B operand of the fused
-// attention + merge GEMM (gemm.h: AttnXform).  Thread j owns output row j (C == 256 == blockDim).
+// Also folds KV into the merge projection: pm[n][j][h*32+d] = sum_v KV[n,h,d,v] * Wm[j][h*32+v],
+// written as SP (one whole 128-B group per thread: row j, group h).  Thread j owns output row j
+// (C == 256 == blockDim).
 __global__ __launch_bounds__(256) void kv_finalize_kernel(const float* __restrict__ part,
                                                           float* __restrict__ kv, int splits,
                                                           const float* __restrict__ wm,
-                                                          float* __restrict__ pm) {
+                                                          sp_t* __restrict__ pm) {
   __shared__ __attribute__((aligned(16))) float skv[33 * 32];
   const int h = blockIdx.x, n = blockIdx.y, H = gridDim.x;
   const long base = (long)n * H + h;
@@ -73,22 +78,30 @@ __global__ __launch_bounds__(256) void kv_finalize_kernel(const float* __restric
   f32x4 w4[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) w4[i] = reinterpret_cast<const f32x4*>(wm + (long)j * C + h * 32)[i];
-  float* dst = pm + ((long)n * C + j) * C + h * 32;
+  uint32_t packed[32];                                   // hi | lo << 16 of P[j][h*32 + d]
 #pragma unroll
-  for (int d4 = 0; d4 < 8; ++d4) {
-    f32x4 r;
+  for (int d = 0; d < 32; ++d) {
+    const float* kvrow = &skv[d * 32];
+    float s = 0.f;
 #pragma unroll
-    for (int dd = 0; dd < 4; ++dd) {
-      const float* kvrow = &skv[(d4 * 4 + dd) * 32];
-      float s = 0.f;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const f32x4 k4 = *reinterpret_cast<const f32x4*>(kvrow + i * 4);      // LDS broadcast
-        s += k4.x * w4[i].x + k4.y * w4[i].y + k4.z * w4[i].z + k4.w * w4[i].w;
-      }
-      r[dd] = s;
+    for (int i = 0; i < 8; ++i) {
+      const f32x4 k4 = *reinterpret_cast<const f32x4*>(kvrow + i * 4);      // LDS broadcast
+      s += k4.x * w4[i].x + k4.y * w4[i].y + k4.z * w4[i].z + k4.w * w4[i].w;
     }
-    reinterpret_cast<f32x4*>(dst)[d4] = r;
+    packed[d] = sp_pack(s);
+  }
+  u32x4* dst = reinterpret_cast<u32x4*>(pm + ((long)n * C + j) * C + h * 32);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {                          // hi halfs of d = 8q .. 8q+7
+    u32x4 hi, lo;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const uint32_t a = packed[q * 8 + 2 * e], b2 = packed[q * 8 + 2 * e + 1];
+      hi[e] = (a & 0xffffu) | (b2 << 16);
+      lo[e] = (a >> 16) | (b2 & 0xffff0000u);
+    }
+    dst[q] = hi;
+    dst[4 + q] = lo;
   }
 }
 
@@ -100,7 +113,7 @@ template <int D>
 __global__ __launch_bounds__(128) void attn_small_kernel(const float* __restrict__ Qf,
                                                          const float* __restrict__ Kf,
                                                          const float* __restrict__ Vf,
-                                                         float* __restrict__ msg, int L, int S,
+                                                         sp_t* __restrict__ msg, int L, int S,
                                                          int C, float v_length, float eps) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   float* sq = sm;               // [L][C]
@@ -136,7 +149,7 @@ __global__ __launch_bounds__(128) void attn_small_kernel(const float* __restrict
       num += q * kvr[d];
       den += q * ks[d];
     }
-    msg[(n * L + l) * C + c] = num * (v_length / (den + eps));
+    sp_store(msg + (n * L + l) * C, c, num * (v_length / (den + eps)), true);
   }
 }
 
@@ -146,19 +159,17 @@ size_t attention_workspace_bytes(int nb, int S, int C) {
   const int splits = ceil_div(S, KV_CHUNK);
   return align_up((size_t)nb * 8 * splits * 33 * 32 * sizeof(float), 256) +
          align_up((size_t)nb * 8 * 33 * 32 * sizeof(float), 256) +
-         align_up((size_t)nb * C * C * sizeof(float), 256) + 1024;
+         align_up((size_t)nb * C * C * sizeof(sp_t), 256) + 1024;
 }
 
-// Coarse level (C = 256, H = 8): KV / Ksum reduction + the merged projection P.  The apply step
-// runs inside the merge GEMM (linear.hip: linear_ln_kernel<.., true>).
 int launch_attention_kv(const float* Kf, const float* Vf, const float* merge_w, int nb, int S, int C, int H,
-                        void* ws, size_t ws_bytes, const float** kv_out, const float** pm_out, hipStream_t st) {
+                        void* ws, size_t ws_bytes, const float** kv_out, const sp_t** pm_out, hipStream_t st) {
   if (!(C == 256 && H == 8)) return LOFTR_ERR_UNSUPPORTED;
   const int splits = ceil_div(S, KV_CHUNK);
   WsAlloc wa(ws, ws_bytes);
   float* part = wa.take<float>((size_t)nb * 8 * splits * 33 * 32);
   float* kv = wa.take<float>((size_t)nb * 8 * 33 * 32);
-  float* pm = wa.take<float>((size_t)nb * C * C);
+  sp_t* pm = wa.take<sp_t>((size_t)nb * C * C);
   if (!wa.ok()) return LOFTR_ERR_WORKSPACE;
   { TimedLaunch tl(LOFTR_T_KV, st);
     hipLaunchKernelGGL(kv_partial_kernel, dim3(splits, 8, nb), dim3(256), 0, st, Kf, Vf, part, S, C, splits); }
@@ -169,15 +180,15 @@ int launch_attention_kv(const float* Kf, const float* Vf, const float* merge_w, 
   return LOFTR_OK;
 }
 
-int launch_linear_attention(const float* Qf, const float* Kf, const float* Vf, float* msg, int nb,
-                            int L, int S, int C, int H, void* ws, size_t ws_bytes, hipStream_t st) {
+int launch_attention_small(const float* Qf, const float* Kf, const float* Vf, sp_t* msg, int nb, int L, int S,
+                           int C, int H, hipStream_t st) {
   if (nb <= 0) return LOFTR_OK;
   const float eps = 1e-6f;                         // LinearAttention(eps=1e-6), linear_attention.py:15
   if (C == 128 && H == 8 && (size_t)(L + S) * C * sizeof(float) <= 64 * 1024) {
     const size_t lds = (size_t)(L + S) * C * sizeof(float);
-    { TimedLaunch tl(LOFTR_T_ATTN_SMALL, st);
-      hipLaunchKernelGGL((attn_small_kernel<16>), dim3(nb), dim3(128), lds, st, Qf, Kf, Vf, msg, L, S, C,
-                         (float)S, eps); }
+    TimedLaunch tl(LOFTR_T_ATTN_SMALL, st);
+    hipLaunchKernelGGL((attn_small_kernel<16>), dim3(nb), dim3(128), lds, st, Qf, Kf, Vf, msg, L, S, C,
+                       (float)S, eps);
     LOFTR_CHECK_LAUNCH();
     return LOFTR_OK;
   }

@@ -2,7 +2,7 @@
 // elementwise passes over the [N, L, S] score volume.
 //
 // dual-softmax  (coarse_matching.py:105-119 + get_coarse_match :150-196,238-261)
-//   pass A  score_stats : sim tile = <f0,f1>/(C*T) on the fp32 matrix cores; per-wave online
+//   pass A  score_stats : sim tile = <f0,f1>/(C*T) on the matrix cores (split-fp16 core, gemm.h); per-wave online
 //                         (max, sum exp) of every row and column of the tile -> partials
 //   merge   stats       : partials -> (max, 1/sum) per row and per column
 //   pass B  score_conf  : recompute the tile (bitwise the same sim), conf = softmax_row * softmax_col,
@@ -33,6 +33,29 @@ struct Geometry {
 };
 
 __device__ __forceinline__ bool in_range(float v) { return v > -1.0e38f; }
+
+// XCD-aware order of the (pair, row tile, col tile) space of the score GEMMs.  The unit of locality
+// is an 8 x 8 super-tile of 128 x 128 tiles of one pair: its 64 workgroups are exactly what one XCD
+// (32 CUs x 2) holds at a time and they share 8 + 8 descriptor panels (2 MB < the XCD's 4 MB L2).
+// Units are dealt round-robin to the XCDs with the pair index fastest, so with N = 8 pairs every
+// XCD works on its own pair.   launch: 1-D grid of score_grid(g) workgroups.
+constexpr int ST = 8;
+__host__ __device__ inline int score_units(const Geometry& g) {
+  return g.N * ceil_div(ceil_div(g.L, Cfg::BM), ST) * ceil_div(ceil_div(g.S, Cfg::BN), ST);
+}
+inline unsigned score_grid(const Geometry& g) { return (unsigned)(NUM_XCD * ceil_div(score_units(g), NUM_XCD) * ST * ST); }
+__device__ __forceinline__ bool score_tile(const Geometry& g, int& n, int& ti, int& tj) {
+  const int id = blockIdx.x, xcd = id % NUM_XCD, slot = id / NUM_XCD;
+  const int u = (slot / (ST * ST)) * NUM_XCD + xcd, within = slot % (ST * ST);
+  if (u >= score_units(g)) return false;
+  const int tiles_m = ceil_div(g.L, Cfg::BM), tiles_n = ceil_div(g.S, Cfg::BN);
+  const int nst_j = ceil_div(tiles_n, ST);
+  n = u % g.N;
+  const int st = u / g.N;
+  ti = (st / nst_j) * ST + within / ST;
+  tj = (st % nst_j) * ST + within % ST;
+  return ti < tiles_m && tj < tiles_n;
+}
 
 // acc -> sim in place: scale, padding mask (-1e9), out-of-range -> SENTINEL.
 template <bool HAS_MASK>
@@ -65,13 +88,15 @@ __device__ __forceinline__ void acc_to_sim(f32x16 (&acc)[Cfg::TM][Cfg::TN], int 
 // pass A
 template <bool HAS_MASK>
 __global__ __launch_bounds__(Cfg::THREADS, 2) void score_stats_kernel(
-    const float* __restrict__ f0, const float* __restrict__ f1, Geometry g, float scale,
+    const sp_t* __restrict__ f0, const sp_t* __restrict__ f1, Geometry g, float scale,
     const uint8_t* __restrict__ mask0, const uint8_t* __restrict__ mask1,
     float2* __restrict__ rowpart, float2* __restrict__ colpart) {
   __shared__ __attribute__((aligned(16))) float lds[Cfg::LDS_FLOATS];
-  const int n = blockIdx.z, m0 = blockIdx.y * Cfg::BM, n0 = blockIdx.x * Cfg::BN;
-  const float* a = f0 + (long)n * g.L * g.C;
-  const float* b = f1 + (long)n * g.S * g.C;
+  int n, ti, tj;
+  if (!score_tile(g, n, ti, tj)) return;
+  const int m0 = ti * Cfg::BM, n0 = tj * Cfg::BN;
+  const sp_t* a = f0 + (long)n * g.L * g.C;
+  const sp_t* b = f1 + (long)n * g.S * g.C;
   f32x16 acc[Cfg::TM][Cfg::TN];
   gemm_mainloop<Cfg>(asrc_plain(a, g.C), b, g.C, g.L, g.S, g.C, m0, n0, lds, acc);
   acc_to_sim<HAS_MASK>(acc, m0, n0, g.L, g.S, scale, HAS_MASK ? mask0 + (long)n * g.L : nullptr,
@@ -79,7 +104,7 @@ __global__ __launch_bounds__(Cfg::THREADS, 2) void score_stats_kernel(
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wm = wave / Cfg::WN, wn = wave % Cfg::WN;
   // rows: reduce over the TN tiles of the lane and the 32 lanes of the half-wave
-  const int pj = blockIdx.x * Cfg::WN + wn;
+  const int pj = tj * Cfg::WN + wn;
 #pragma unroll
   for (int i = 0; i < Cfg::TM; ++i)
 #pragma unroll
@@ -96,7 +121,7 @@ __global__ __launch_bounds__(Cfg::THREADS, 2) void score_stats_kernel(
       if ((lane & 31) == 0 && row < g.L) rowpart[((long)n * g.L + row) * g.PJ + pj] = make_float2(m, s);
     }
   // columns: reduce over the TM*16 rows of the lane and the other half-wave
-  const int pi = blockIdx.y * Cfg::WM + wm;
+  const int pi = ti * Cfg::WM + wm;
 #pragma unroll
   for (int j = 0; j < Cfg::TN; ++j) {
     float m = SENTINEL;
@@ -104,13 +129,13 @@ __global__ __launch_bounds__(Cfg::THREADS, 2) void score_stats_kernel(
     for (int i = 0; i < Cfg::TM; ++i)
 #pragma unroll
       for (int r = 0; r < 16; ++r) m = fmaxf(m, acc[i][j][r]);
-    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    m = fmaxf(m, LOFTR_DPP_SWAP32(m));
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < Cfg::TM; ++i)
 #pragma unroll
       for (int r = 0; r < 16; ++r) s += in_range(acc[i][j][r]) ? expf(acc[i][j][r] - m) : 0.f;
-    s += __shfl_xor(s, 32, 64);
+    s += LOFTR_DPP_SWAP32(s);
     const int col = acc_col<Cfg>(n0, j);
     if (lane < 32 && col < g.S) colpart[((long)n * g.S + col) * g.PI + pi] = make_float2(m, s);
   }
@@ -140,18 +165,15 @@ __device__ __forceinline__ void conf_partials(f32x16 (&acc)[Cfg::TM][Cfg::TN], i
   for (int i = 0; i < Cfg::TM; ++i)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      float bv = -1.f; int bc = 0x7fffffff;
+      float bv = -1.f;
 #pragma unroll
-      for (int j = 0; j < Cfg::TN; ++j) {            // ascending columns: strict > keeps the first
-        const float v = acc[i][j][r];
-        if (v > bv) { bv = v; bc = acc_col<Cfg>(n0, j); }
-      }
+      for (int j = 0; j < Cfg::TN; ++j) bv = fmaxf(bv, acc[i][j][r]);
+      bv = half_max(bv);                             // maximum over the wave's 64-column strip
+      int bc = 0x7fffffff;                           // first column that attains it
 #pragma unroll
-      for (int o = 16; o >= 1; o >>= 1) {
-        const float ov = __shfl_xor(bv, o, 64);
-        const int oc = __shfl_xor(bc, o, 64);
-        if (ov > bv || (ov == bv && oc < bc)) { bv = ov; bc = oc; }
-      }
+      for (int j = Cfg::TN - 1; j >= 0; --j)
+        if (acc[i][j][r] == bv) bc = acc_col<Cfg>(n0, j);
+      bc = half_min_i32(bc);
       const int row = acc_row<Cfg>(m0, i, r);
       if ((lane & 31) == 0 && row < g.L)
         rowmax_part[((long)n * g.L + row) * g.PJ + pj] = make_float2(bv, __int_as_float(bc));
@@ -163,7 +185,7 @@ __device__ __forceinline__ void conf_partials(f32x16 (&acc)[Cfg::TM][Cfg::TN], i
     for (int i = 0; i < Cfg::TM; ++i)
 #pragma unroll
       for (int r = 0; r < 16; ++r) m = fmaxf(m, acc[i][j][r]);
-    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    m = fmaxf(m, LOFTR_DPP_SWAP32(m));
     const int col = acc_col<Cfg>(n0, j);
     if (lane < 32 && col < g.S) colmax_part[((long)n * g.S + col) * g.PI + pi] = m;
   }
@@ -173,14 +195,16 @@ __device__ __forceinline__ void conf_partials(f32x16 (&acc)[Cfg::TM][Cfg::TN], i
 // pass B
 template <bool HAS_MASK>
 __global__ __launch_bounds__(Cfg::THREADS, 2) void score_conf_kernel(
-    const float* __restrict__ f0, const float* __restrict__ f1, Geometry g, float scale,
+    const sp_t* __restrict__ f0, const sp_t* __restrict__ f1, Geometry g, float scale,
     const uint8_t* __restrict__ mask0, const uint8_t* __restrict__ mask1,
     const float2* __restrict__ rowstat, const float2* __restrict__ colstat,
     float* __restrict__ conf_out, float2* __restrict__ rowmax_part, float* __restrict__ colmax_part) {
   __shared__ __attribute__((aligned(16))) float lds[Cfg::LDS_FLOATS];
-  const int n = blockIdx.z, m0 = blockIdx.y * Cfg::BM, n0 = blockIdx.x * Cfg::BN;
-  const float* a = f0 + (long)n * g.L * g.C;
-  const float* b = f1 + (long)n * g.S * g.C;
+  int n, ti, tj;
+  if (!score_tile(g, n, ti, tj)) return;
+  const int m0 = ti * Cfg::BM, n0 = tj * Cfg::BN;
+  const sp_t* a = f0 + (long)n * g.L * g.C;
+  const sp_t* b = f1 + (long)n * g.S * g.C;
   f32x16 acc[Cfg::TM][Cfg::TN];
   gemm_mainloop<Cfg>(asrc_plain(a, g.C), b, g.C, g.L, g.S, g.C, m0, n0, lds, acc);
   acc_to_sim<HAS_MASK>(acc, m0, n0, g.L, g.S, scale, HAS_MASK ? mask0 + (long)n * g.L : nullptr,
@@ -209,7 +233,7 @@ __global__ __launch_bounds__(Cfg::THREADS, 2) void score_conf_kernel(
         acc[i][j][r] = c;
       }
     }
-  conf_partials(acc, m0, n0, n, g, blockIdx.x, blockIdx.y, rowmax_part, colmax_part);
+  conf_partials(acc, m0, n0, n, g, tj, ti, rowmax_part, colmax_part);
 }
 
 __global__ void merge_colmax_kernel(const float* __restrict__ part, float* __restrict__ colmax, long cols, int P) {
@@ -377,13 +401,15 @@ __global__ __launch_bounds__(256) void scatter_kernel(ScatterParams sp, const in
 
 // ------------------------------------------------------------------------------------------
 // Sinkhorn pieces
-__global__ __launch_bounds__(Cfg::THREADS, 2) void score_store_kernel(const float* __restrict__ f0,
-                                                                   const float* __restrict__ f1, Geometry g,
+__global__ __launch_bounds__(Cfg::THREADS, 2) void score_store_kernel(const sp_t* __restrict__ f0,
+                                                                   const sp_t* __restrict__ f1, Geometry g,
                                                                    float scale, const uint8_t* __restrict__ mask0,
                                                                    const uint8_t* __restrict__ mask1,
                                                                    float* __restrict__ z) {
   __shared__ __attribute__((aligned(16))) float lds[Cfg::LDS_FLOATS];
-  const int n = blockIdx.z, m0 = blockIdx.y * Cfg::BM, n0 = blockIdx.x * Cfg::BN;
+  int n, ti, tj;
+  if (!score_tile(g, n, ti, tj)) return;
+  const int m0 = ti * Cfg::BM, n0 = tj * Cfg::BN;
   f32x16 acc[Cfg::TM][Cfg::TN];
   gemm_mainloop<Cfg>(asrc_plain(f0 + (long)n * g.L * g.C, g.C), f1 + (long)n * g.S * g.C, g.C, g.L, g.S, g.C,
                      m0, n0, lds, acc);
@@ -558,6 +584,7 @@ struct MatchWs {
   float *colmax_part, *colmax, *cand_conf;
   int *cand_j, *cand_rank, *block_count, *block_off, *valid;
   float *ot_u, *ot_v; float2* ot_part; uint8_t *rowkill, *colkill;
+  sp_t *f0sp, *f1sp;             // SP copies of the descriptors (GEMM operands, gemm.h)
   bool ok;
 };
 
@@ -593,18 +620,21 @@ MatchWs carve(void* ws, size_t bytes, const Geometry& g) {
   m.ot_part = wa.take<float2>((size_t)g.N * (g.S + 1) * OT_RCH);
   m.rowkill = wa.take<uint8_t>(NL);
   m.colkill = wa.take<uint8_t>(NS);
+  m.f0sp = wa.take<sp_t>(NL * g.C);
+  m.f1sp = wa.take<sp_t>(NS * g.C);
   m.ok = wa.ok();
   return m;
 }
 
-size_t match_ws_bytes(int N, int L, int S) {
+size_t match_ws_bytes(int N, int L, int S, int C) {
   const size_t PJ = (size_t)ceil_div(S, Cfg::BN) * Cfg::WN, PI = (size_t)ceil_div(L, Cfg::BM) * Cfg::WM;
   const size_t NL = (size_t)N * L, NS = (size_t)N * S;
   size_t b = 0;
   b += NL * PJ * 8 * 2 + NS * PI * 8 + NS * PI * 4;
   b += NL * 8 + NS * 8 + NS * 4 + NL * 4 * 3 + ((NL + 255) / 256) * 8 + (size_t)N * 16;
   b += (size_t)N * (L + 1) * 4 + (size_t)N * (S + 1) * 4 + (size_t)N * (S + 1) * OT_RCH * 8 + NL + NS;
-  return b + 32 * 256;     // alignment slack of the bump allocator
+  b += (NL + NS) * (size_t)C * 4;
+  return b + 34 * 256;     // alignment slack of the bump allocator
 }
 
 bool params_ok(const loftr_coarse_params* p, const loftr_match_out* o) {
@@ -638,42 +668,53 @@ int select_and_compact(const Geometry& g, const loftr_coarse_params& p, const lo
 
 }  // namespace
 
-extern "C" size_t loftr_coarse_match_workspace_bytes(int N, int L, int S) {
-  if (N <= 0 || L <= 0 || S <= 0) return 0;
-  return match_ws_bytes(N, L, S);
+extern "C" size_t loftr_coarse_match_workspace_bytes(int N, int L, int S, int C) {
+  if (N <= 0 || L <= 0 || S <= 0 || C <= 0) return 0;
+  return match_ws_bytes(N, L, S, C);
 }
+
+namespace {
+// descriptors -> SP (both images in one launch)
+int stage_descriptors(const float* f0, const float* f1, const Geometry& g, const MatchWs& w, hipStream_t st) {
+  SpJobs j; j.n = 2;
+  j.src[0] = f0; j.dst[0] = w.f0sp; j.rows[0] = g.N * g.L; j.K[0] = g.C; j.ld[0] = g.C;
+  j.src[1] = f1; j.dst[1] = w.f1sp; j.rows[1] = g.N * g.S; j.K[1] = g.C; j.ld[1] = g.C;
+  return launch_sp_convert(j, st);
+}
+}  // namespace
 
 extern "C" int loftr_coarse_match_dual_softmax(const float* feat_c0, const float* feat_c1,
                                                const loftr_coarse_params* p, float temperature,
                                                float* conf_out, const loftr_match_out* out, void* ws,
                                                size_t ws_bytes, void* stream) {
   LOFTR_CHECK_ARG(feat_c0 && feat_c1 && params_ok(p, out) && temperature > 0.f);
-  if (p->C % 4 != 0) return LOFTR_ERR_UNSUPPORTED;
+  if (p->C % 32 != 0) return LOFTR_ERR_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
   if (p->N == 0) { (void)hipMemsetAsync(out->counts, 0, sizeof(int32_t), st); return LOFTR_OK; }
   LOFTR_CHECK_ARG(ws != nullptr);
   const Geometry g = make_geometry(*p);
   MatchWs w = carve(ws, ws_bytes, g);
   if (!w.ok) return LOFTR_ERR_WORKSPACE;
+  { int rc = stage_descriptors(feat_c0, feat_c1, g, w, st); if (rc) return rc; }
   // feat / sqrt(C) on both sides, then / temperature                 coarse_matching.py:108-114
   const float scale = 1.f / ((float)g.C * temperature);
-  const dim3 grid(ceil_div(g.S, Cfg::BN), ceil_div(g.L, Cfg::BM), g.N), block(Cfg::THREADS);
+  const dim3 sgrid(score_grid(g)), block(Cfg::THREADS);
   const long NL = (long)g.N * g.L, NS = (long)g.N * g.S;
   {
     TimedLaunch tl(LOFTR_T_SCORE_STATS, st);
     if (p->mask0)
-      hipLaunchKernelGGL((score_stats_kernel<true>), grid, block, 0, st, feat_c0, feat_c1, g, scale, p->mask0, p->mask1, w.rowpart, w.colpart);
+      hipLaunchKernelGGL((score_stats_kernel<true>), sgrid, block, 0, st, w.f0sp, w.f1sp, g, scale, p->mask0, p->mask1, w.rowpart, w.colpart);
     else
-      hipLaunchKernelGGL((score_stats_kernel<false>), grid, block, 0, st, feat_c0, feat_c1, g, scale, p->mask0, p->mask1, w.rowpart, w.colpart);
+      hipLaunchKernelGGL((score_stats_kernel<false>), sgrid, block, 0, st, w.f0sp, w.f1sp, g, scale, p->mask0, p->mask1, w.rowpart, w.colpart);
   }
   hipLaunchKernelGGL(merge_stats_kernel, dim3(ceil_div((int)NL, 256)), dim3(256), 0, st, w.rowpart, w.rowstat, NL, g.PJ);
   hipLaunchKernelGGL(merge_stats_kernel, dim3(ceil_div((int)NS, 256)), dim3(256), 0, st, w.colpart, w.colstat, NS, g.PI);
   {
     TimedLaunch tl(LOFTR_T_SCORE_CONF, st);
     if (p->mask0)
-      hipLaunchKernelGGL((score_conf_kernel<true>), grid, block, 0, st, feat_c0, feat_c1, g, scale, p->mask0, p->mask1, w.rowstat, w.colstat, conf_out, w.rowmax_part, w.colmax_part);
+      hipLaunchKernelGGL((score_conf_kernel<true>), sgrid, block, 0, st, w.f0sp, w.f1sp, g, scale, p->mask0, p->mask1, w.rowstat, w.colstat, conf_out, w.rowmax_part, w.colmax_part);
     else
-      hipLaunchKernelGGL((score_conf_kernel<false>), grid, block, 0, st, feat_c0, feat_c1, g, scale, p->mask0, p->mask1, w.rowstat, w.colstat, conf_out, w.rowmax_part, w.colmax_part);
+      hipLaunchKernelGGL((score_conf_kernel<false>), sgrid, block, 0, st, w.f0sp, w.f1sp, g, scale, p->mask0, p->mask1, w.rowstat, w.colstat, conf_out, w.rowmax_part, w.colmax_part);
   }
   LOFTR_CHECK_LAUNCH();
   return select_and_compact(g, *p, *out, w, st);
@@ -685,18 +726,19 @@ extern "C" int loftr_coarse_match_sinkhorn(const float* feat_c0, const float* fe
                                            const loftr_match_out* out, void* ws, size_t ws_bytes,
                                            void* stream) {
   LOFTR_CHECK_ARG(feat_c0 && feat_c1 && params_ok(p, out) && conf_out && iters >= 0);
-  if (p->C % 4 != 0) return LOFTR_ERR_UNSUPPORTED;
+  if (p->C % 32 != 0) return LOFTR_ERR_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
   if (p->N == 0) { (void)hipMemsetAsync(out->counts, 0, sizeof(int32_t), st); return LOFTR_OK; }
   LOFTR_CHECK_ARG(ws != nullptr);
   const Geometry g = make_geometry(*p);
   MatchWs w = carve(ws, ws_bytes, g);
   if (!w.ok) return LOFTR_ERR_WORKSPACE;
+  { int rc = stage_descriptors(feat_c0, feat_c1, g, w, st); if (rc) return rc; }
   const float scale = 1.f / (float)g.C;                    // no temperature   coarse_matching.py:123
   const float norm = -logf((float)(g.L + g.S));            // SuperGlue: norm = -log(m + n)
-  const dim3 grid(ceil_div(g.S, Cfg::BN), ceil_div(g.L, Cfg::BM), g.N), block(Cfg::THREADS);
+  const dim3 grid(ceil_div(g.S, Cfg::BN), ceil_div(g.L, Cfg::BM), g.N), sgrid(score_grid(g)), block(Cfg::THREADS);
   { TimedLaunch tl(LOFTR_T_OT_STORE, st);
-    hipLaunchKernelGGL(score_store_kernel, grid, block, 0, st, feat_c0, feat_c1, g, scale, p->mask0, p->mask1, conf_out); }
+    hipLaunchKernelGGL(score_store_kernel, sgrid, block, 0, st, w.f0sp, w.f1sp, g, scale, p->mask0, p->mask1, conf_out); }
   (void)hipMemsetAsync(w.ot_u, 0, sizeof(float) * g.N * (g.L + 1), st);
   (void)hipMemsetAsync(w.ot_v, 0, sizeof(float) * g.N * (g.S + 1), st);
   const long cols = (long)g.N * (g.S + 1);

@@ -40,6 +40,22 @@ struct TimedLaunch {          // RAII: records an event pair around the launches
   ~TimedLaunch() { if (on) loftr_timing_mark(id, st, true); }
 };
 
+// ---- XCD-aware tile order --------------------------------------------------------------------
+// MI355X dispatches the workgroups of a launch round-robin over its 8 XCDs (linear id % 8) and every
+// XCD has a private 4 MB L2.  Column tiles that share the same A rows must therefore sit on the SAME
+// XCD at the same time or the A panel is fetched from HBM once per column tile (measured: 4-6x the
+// algorithmic read traffic).  1-D launches of xcd_grid(tiles_m, tiles_n) workgroups are mapped as
+//   xcd = id % 8, slot = id / 8  ->  tile_n = slot % tiles_n, tile_m = (slot / tiles_n) * 8 + xcd
+// so each XCD sweeps all column tiles of its own row tiles back to back.
+constexpr int NUM_XCD = 8;
+static inline unsigned xcd_grid(int tiles_m, int tiles_n) { return (unsigned)(NUM_XCD * ceil_div(tiles_m, NUM_XCD) * tiles_n); }
+__device__ __forceinline__ bool xcd_tile(int tiles_m, int tiles_n, int& tile_m, int& tile_n) {
+  const int id = blockIdx.x, xcd = id % NUM_XCD, slot = id / NUM_XCD;
+  tile_n = slot % tiles_n;
+  tile_m = (slot / tiles_n) * NUM_XCD + xcd;
+  return tile_m < tiles_m;
+}
+
 // Bump allocator over the caller-supplied workspace (the library never mallocs device memory).
 struct WsAlloc {
   char* base; size_t cap; size_t off;
@@ -64,16 +80,54 @@ __device__ __forceinline__ float wave_max(float v) {
   for (int o = 32; o >= 1; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
   return v;
 }
-// reduce across the 32 lanes of one half-wave (lanes that share lane>>5)
+// Reductions across the 32 lanes of one half-wave (lanes that share lane>>5), result in ALL of them.
+// DPP only (quad_perm, row_half_mirror, row_mirror, row_bcast15) + two v_readlane: no LDS-crossbar
+// ds_bpermute traffic (what __shfl_xor compiles to), which the GEMM epilogues would otherwise issue
+// five times per accumulator register.
+#define LOFTR_DPP(v_, ctrl_) __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v_), ctrl_, 0xF, 0xF, true))
+__device__ __forceinline__ float half_bcast(float v) {          // lanes 16-31 / 48-63 hold the result
+  const float lo = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 31));
+  const float hi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+  return (threadIdx.x & 32) ? hi : lo;
+}
 __device__ __forceinline__ float half_sum(float v) {
-#pragma unroll
-  for (int o = 16; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  v += LOFTR_DPP(v, 0xB1);        // quad_perm [1,0,3,2]
+  v += LOFTR_DPP(v, 0x4E);        // quad_perm [2,3,0,1]
+  v += LOFTR_DPP(v, 0x141);       // row_half_mirror
+  v += LOFTR_DPP(v, 0x140);       // row_mirror            -> every lane: sum of its row of 16
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x142, 0xA, 0xF, false));  // row_bcast15 into rows 1,3
+  return half_bcast(v);
+}
+// value held by lane ^ 32 (the other half-wave): one v_permlane32_swap, no LDS crossbar
+__device__ __forceinline__ float swap32(float v) {
+#if __has_builtin(__builtin_amdgcn_permlane32_swap)
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_int(v), __float_as_int(v), false, false);
+  return __int_as_float((threadIdx.x & 32) ? r[0] : r[1]);
+#else
+  return __shfl_xor(v, 32, 64);
+#endif
+}
+#define LOFTR_DPP_SWAP32(v_) swap32(v_)
+
+// first (smallest) index over the half-wave; INT_MAX lanes do not participate
+__device__ __forceinline__ int half_min_i32(int v) {
+#define LOFTR_DPPI(v_, ctrl_) __builtin_amdgcn_update_dpp(0x7fffffff, v_, ctrl_, 0xF, 0xF, false)
+  v = min(v, LOFTR_DPPI(v, 0xB1));
+  v = min(v, LOFTR_DPPI(v, 0x4E));
+  v = min(v, LOFTR_DPPI(v, 0x141));
+  v = min(v, LOFTR_DPPI(v, 0x140));
+  v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x142, 0xA, 0xF, false));
+#undef LOFTR_DPPI
+  const int lo = __builtin_amdgcn_readlane(v, 31), hi = __builtin_amdgcn_readlane(v, 63);
+  return (threadIdx.x & 32) ? hi : lo;
 }
 __device__ __forceinline__ float half_max(float v) {
-#pragma unroll
-  for (int o = 16; o >= 1; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return v;
+  v = fmaxf(v, LOFTR_DPP(v, 0xB1));
+  v = fmaxf(v, LOFTR_DPP(v, 0x4E));
+  v = fmaxf(v, LOFTR_DPP(v, 0x141));
+  v = fmaxf(v, LOFTR_DPP(v, 0x140));
+  v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x142, 0xA, 0xF, false)));
+  return half_bcast(v);
 }
 
 __device__ __forceinline__ float elu1(float x) {     // elu(x)+1, linear_attention.py:10-11

@@ -8,12 +8,13 @@ namespace {
 // One block per (match, side): copies the W x W window of the fine map centred on the matched
 // coarse cell into a dense [W*W, Cf] tile (zeros outside the map) -- the only rows of
 // F.unfold(kernel=W, stride, padding=W//2) the reference ever uses (fine_preprocess.py:40-47).
-// Thread <-> channel, so the write is coalesced and a channels-last map is read coalesced too.
-//   grid (M, 2), Cf threads.
+// Thread <-> channel, so a channels-last map is read coalesced; the tile is written in the SP
+// GEMM-operand format (gemm.h) because its only consumer is the merge_feat GEMM.
+//   grid (M, 2), Cf threads (Cf even, a multiple of 32).
 __global__ void gather_windows_kernel(loftr_fmap f0, loftr_fmap f1, const int64_t* __restrict__ b_ids,
                                       const int64_t* __restrict__ i_ids, const int64_t* __restrict__ j_ids,
                                       int M, int w0c, int w1c, int stride, int W, int Cf,
-                                      float* __restrict__ win0, float* __restrict__ win1) {
+                                      sp_t* __restrict__ win0, sp_t* __restrict__ win1) {
   const int m = blockIdx.x, side = blockIdx.y;
   const loftr_fmap f = side ? f1 : f0;
   const int wc = side ? w1c : w0c;
@@ -21,7 +22,7 @@ __global__ void gather_windows_kernel(loftr_fmap f0, loftr_fmap f1, const int64_
   const long b = b_ids[m];
   const int cy = (int)(cell / wc) * stride, cx = (int)(cell % wc) * stride;
   const int r = W / 2;
-  float* out = (side ? win1 : win0) + (long)m * W * W * Cf;
+  sp_t* out = (side ? win1 : win0) + (long)m * W * W * Cf;
   for (int c = threadIdx.x; c < Cf; c += blockDim.x) {
     const float* base = f.data + b * f.sn + (long)c * f.sc;
     for (int wy = 0; wy < W; ++wy) {
@@ -30,20 +31,24 @@ __global__ void gather_windows_kernel(loftr_fmap f0, loftr_fmap f1, const int64_
         const int x = cx + wx - r;
         float v = 0.f;
         if (y >= 0 && y < f.H && x >= 0 && x < f.W) v = base[(long)y * f.sh + (long)x * f.sw];
-        out[(wy * W + wx) * Cf + c] = v;
+        sp_store(out + (wy * W + wx) * Cf, c, v, true);
       }
     }
   }
 }
 
-// flat row indices of the matched coarse features: b*L + i and b*S + j
-__global__ void coarse_index_kernel(const int64_t* __restrict__ b_ids, const int64_t* __restrict__ i_ids,
-                                    const int64_t* __restrict__ j_ids, int M, int L, int S,
-                                    int64_t* __restrict__ idx0, int64_t* __restrict__ idx1) {
-  const int m = blockIdx.x * blockDim.x + threadIdx.x;
-  if (m >= M) return;
-  idx0[m] = b_ids[m] * L + i_ids[m];
-  idx1[m] = b_ids[m] * S + j_ids[m];
+// Matched coarse features feat_c0[b, i, :] / feat_c1[b, j, :] (fine_preprocess.py:51-52) gathered into
+// dense [M, Cc] SP tiles (A operand of down_proj).   grid (M, 2), Cc threads.
+__global__ void gather_coarse_kernel(const float* __restrict__ fc0, const float* __restrict__ fc1,
+                                     const int64_t* __restrict__ b_ids, const int64_t* __restrict__ i_ids,
+                                     const int64_t* __restrict__ j_ids, int L, int S, int Cc,
+                                     sp_t* __restrict__ cg0, sp_t* __restrict__ cg1) {
+  const long m = blockIdx.x;
+  const int side = blockIdx.y;
+  const long row = side ? b_ids[m] * S + j_ids[m] : b_ids[m] * L + i_ids[m];
+  const float* src = (side ? fc1 : fc0) + row * Cc;
+  sp_t* dst = (side ? cg1 : cg0) + m * Cc;
+  for (int c = threadIdx.x; c < Cc; c += blockDim.x) sp_store(dst, c, src[c], true);
 }
 
 // FineMatching: one wave per match.  Lane r < WW owns window position r.
@@ -92,11 +97,13 @@ __global__ __launch_bounds__(256) void fine_match_kernel(const float* __restrict
 
 extern "C" size_t loftr_fine_preprocess_workspace_bytes(int M, int W, int Cf) {
   if (M <= 0) return 0;
+  const size_t Cc = 2 * (size_t)Cf;                               // coarse width (d_model_c = 256 for Cf = 128)
   size_t b = 0;
-  b += 2 * align_up((size_t)M * W * W * Cf * sizeof(float), 256);   // windows
-  b += 4 * align_up((size_t)M * Cf * sizeof(float), 256);           // down-projected ctx, merged ctx (x2 sides)
-  b += 2 * align_up((size_t)M * sizeof(int64_t), 256);
-  return b + 4096;
+  b += 2 * align_up((size_t)M * W * W * Cf * 4, 256);             // windows (SP)
+  b += 2 * align_up((size_t)M * Cc * 4 * 2, 256);                 // gathered coarse features (SP), generous
+  b += 4 * align_up((size_t)M * Cf * 4, 256);                     // down-projected ctx (SP), merged ctx (fp32), x2 sides
+  b += align_up((size_t)Cf * Cc * 4 * 2, 256) + 2 * align_up((size_t)Cf * Cf * 4, 256);   // weights (SP)
+  return b + 8192;
 }
 
 extern "C" int loftr_fine_preprocess(const loftr_fmap* feat_f0, const loftr_fmap* feat_f1,
@@ -112,46 +119,53 @@ extern "C" int loftr_fine_preprocess(const loftr_fmap* feat_f0, const loftr_fmap
   LOFTR_CHECK_ARG(w0c > 0 && w1c > 0 && stride > 0 && W > 0 && (W & 1) && Cf > 0 && Cf <= 1024);
   hipStream_t st = (hipStream_t)stream;
   const int WW = W * W;
-  if (!down_w) {                                   // fine_concat_coarse_feat = False: windows only
-    hipLaunchKernelGGL(gather_windows_kernel, dim3(M, 2), dim3(Cf < 64 ? 64 : Cf), 0, st, *feat_f0, *feat_f1, b_ids,
-                       i_ids, j_ids, M, w0c, w1c, stride, W, Cf, out0, out1);
-    LOFTR_CHECK_LAUNCH();
-    return LOFTR_OK;
+  if (!down_w) {                                   // fine_concat_coarse_feat = False: windows only (fp32 out)
+    return LOFTR_ERR_UNSUPPORTED;                  // no shipped config uses it (cvpr_ds_config.py:13, default.py:13)
   }
   LOFTR_CHECK_ARG(feat_c0 && feat_c1 && down_b && merge_w && merge_b && ws);
-  if (Cf % 4 != 0 || Cc % 4 != 0) return LOFTR_ERR_UNSUPPORTED;
+  if (Cf % 32 != 0 || Cc % 32 != 0 || Cc > 2 * Cf * 2) return LOFTR_ERR_UNSUPPORTED;
   WsAlloc wa(ws, ws_bytes);
-  float* win0 = wa.take<float>((size_t)M * WW * Cf);
-  float* win1 = wa.take<float>((size_t)M * WW * Cf);
-  float* cdn0 = wa.take<float>((size_t)M * Cf);
-  float* cdn1 = wa.take<float>((size_t)M * Cf);
+  sp_t* win0 = wa.take<sp_t>((size_t)M * WW * Cf);
+  sp_t* win1 = wa.take<sp_t>((size_t)M * WW * Cf);
+  sp_t* cg0 = wa.take<sp_t>((size_t)M * Cc);
+  sp_t* cg1 = wa.take<sp_t>((size_t)M * Cc);
+  sp_t* cdn0 = wa.take<sp_t>((size_t)M * Cf);
+  sp_t* cdn1 = wa.take<sp_t>((size_t)M * Cf);
   float* ctx0 = wa.take<float>((size_t)M * Cf);
   float* ctx1 = wa.take<float>((size_t)M * Cf);
-  int64_t* idx0 = wa.take<int64_t>(M);
-  int64_t* idx1 = wa.take<int64_t>(M);
+  sp_t* down_sp = wa.take<sp_t>((size_t)Cf * Cc);
+  sp_t* mwin_sp = wa.take<sp_t>((size_t)Cf * Cf);   // merge_feat.weight[:, :Cf]  (window half)
+  sp_t* mctx_sp = wa.take<sp_t>((size_t)Cf * Cf);   // merge_feat.weight[:, Cf:]  (coarse-context half)
   if (!wa.ok()) return LOFTR_ERR_WORKSPACE;
+  int rc;
+  {
+    SpJobs j; j.n = 3;
+    j.src[0] = down_w; j.dst[0] = down_sp; j.rows[0] = Cf; j.K[0] = Cc; j.ld[0] = Cc;
+    j.src[1] = merge_w; j.dst[1] = mwin_sp; j.rows[1] = Cf; j.K[1] = Cf; j.ld[1] = 2 * Cf;
+    j.src[2] = merge_w + Cf; j.dst[2] = mctx_sp; j.rows[2] = Cf; j.K[2] = Cf; j.ld[2] = 2 * Cf;
+    if ((rc = launch_sp_convert(j, st))) return rc;
+  }
   { TimedLaunch tl(LOFTR_T_GATHER, st);
     hipLaunchKernelGGL(gather_windows_kernel, dim3(M, 2), dim3(Cf < 64 ? 64 : Cf), 0, st, *feat_f0, *feat_f1, b_ids,
                        i_ids, j_ids, M, w0c, w1c, stride, W, Cf, win0, win1); }
-  hipLaunchKernelGGL(coarse_index_kernel, dim3(ceil_div(M, 256)), dim3(256), 0, st, b_ids, i_ids, j_ids, M, L, S, idx0, idx1);
+  hipLaunchKernelGGL(gather_coarse_kernel, dim3(M, 2), dim3(Cc < 64 ? 64 : (Cc > 1024 ? 1024 : Cc)), 0, st, feat_c0,
+                     feat_c1, b_ids, i_ids, j_ids, L, S, Cc, cg0, cg1);
   LOFTR_CHECK_LAUNCH();
-  int rc;
   for (int side = 0; side < 2; ++side) {
-    const float* fc = side ? feat_c1 : feat_c0;
-    const int64_t* idx = side ? idx1 : idx0;
-    float* cdn = side ? cdn1 : cdn0;
+    sp_t* cg = side ? cg1 : cg0;
+    sp_t* cdn = side ? cdn1 : cdn0;
     float* ctx = side ? ctx1 : ctx0;
-    float* win = side ? win1 : win0;
+    sp_t* win = side ? win1 : win0;
     float* out = side ? out1 : out0;
     // feat_c_win = down_proj(feat_c[b_ids, ids])                       fine_preprocess.py:51-52
-    LinearArgs d{asrc_gather(fc, Cc, idx), down_w, Cc, cdn, Cf, M, Cf, Cc, down_b, 1};
-    if ((rc = launch_linear(d, EPI_BIAS, st))) return rc;
+    LinearArgs d{asrc_plain(cg, Cc), down_sp, Cc, nullptr, cdn, Cf, M, Cf, Cc, down_b, 1, 1, false};
+    if ((rc = launch_linear(d, st))) return rc;
     // merge_feat(cat[window, repeat(feat_c_win)]) = window @ Wm[:, :Cf]^T + (feat_c_win @ Wm[:, Cf:]^T + b):
     // the coarse half is constant over the window -> computed once per match      :53-56
-    LinearArgs c{asrc_plain(cdn, Cf), merge_w + Cf, 2 * Cf, ctx, Cf, M, Cf, Cf, merge_b, 1};
-    if ((rc = launch_linear(c, EPI_BIAS, st))) return rc;
-    LinearArgs w{asrc_plain(win, Cf), merge_w, 2 * Cf, out, Cf, M * WW, Cf, Cf, ctx, WW};
-    if ((rc = launch_linear(w, EPI_GROUP_BIAS, st))) return rc;
+    LinearArgs c{asrc_plain(cdn, Cf), mctx_sp, Cf, ctx, nullptr, Cf, M, Cf, Cf, merge_b, 1, 1, false};
+    if ((rc = launch_linear(c, st))) return rc;
+    LinearArgs w{asrc_plain(win, Cf), mwin_sp, Cf, out, nullptr, Cf, M * WW, Cf, Cf, ctx, 2, WW, false};
+    if ((rc = launch_linear(w, st))) return rc;
   }
   return LOFTR_OK;
 }

@@ -1,5 +1,6 @@
-// Linear layers of the LoFTR encoder on the matrix cores (fp16x3 split GEMM, gemm.h), with the surrounding elementwise
-// work fused into the epilogue (feature map, ReLU, bias, LayerNorm, residual).
+// Linear layers of the LoFTR encoder on the matrix cores (split-fp16 GEMM core, gemm.h), with the
+// surrounding elementwise work fused into the epilogue (feature map, attention normaliser, ReLU,
+// bias, LayerNorm, residual, SP re-encoding for the next GEMM).
 #include "linear.h"
 
 using CfgGen = GemmCfg<128, 128, 2, 2>;     // generic tile: 4 waves, 64x64 per wave
@@ -7,86 +8,165 @@ using CfgLN256 = GemmCfg<64, 256, 1, 4>;    // full 256-wide rows in one block (
 using CfgLN128 = GemmCfg<128, 128, 2, 2>;   // full 128-wide rows in one block
 
 // ------------------------------------------------------------------------------------------
-template <typename Cfg, int EPI>
-__global__ __launch_bounds__(Cfg::THREADS, 2) void linear_kernel(LinearArgs p) {
-  __shared__ __attribute__((aligned(16))) float lds[Cfg::LDS_FLOATS];
-  const int m0 = blockIdx.y * Cfg::BM, n0 = blockIdx.x * Cfg::BN;
-  f32x16 acc[Cfg::TM][Cfg::TN];
-  gemm_mainloop<Cfg>(p.a, p.w, p.ldw, p.M, p.N, p.K, m0, n0, lds, acc);
+// Epilogues come in a FULL flavour (whole tile inside the matrix: no predicates, the common case)
+// and a guarded one; 32-bit offsets from a block-uniform tile base pointer.
+template <typename Cfg, bool FULL, bool OUT_F32, bool OUT_SP, int BIAS, bool RELU>
+__device__ __forceinline__ void linear_epilogue(const LinearArgs& p, f32x16 (&acc)[Cfg::TM][Cfg::TN], int m0, int n0) {
+  const EpiLane<Cfg> e;
+  float* of = OUT_F32 ? p.out_f32 + (long)m0 * p.ldo + n0 : nullptr;
+  sp_t* os = OUT_SP ? p.out_sp + (long)m0 * p.ldo + n0 : nullptr;
 #pragma unroll
-  for (int i = 0; i < Cfg::TM; ++i)
+  for (int j = 0; j < Cfg::TN; ++j) {
+    const int col = n0 + e.lcol + j * 32;
+    const bool cok = FULL || col < p.N;
+    const float bcol = (BIAS == 1 && cok) ? p.bias[col] : 0.f;
 #pragma unroll
-    for (int j = 0; j < Cfg::TN; ++j) {
-      const int col = acc_col<Cfg>(n0, j);
-      float bcol = 0.f;
-      if (EPI == EPI_BIAS) bcol = col < p.N ? p.bias[col] : 0.f;
+    for (int i = 0; i < Cfg::TM; ++i) {
+      f32x16 v = acc[i][j];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int row = acc_row<Cfg>(m0, i, r);
-        if (row < p.M && col < p.N) {
-          float v = acc[i][j][r];
-          if (EPI == EPI_RELU) v = fmaxf(v, 0.f);
-          if (EPI == EPI_BIAS) v += bcol;
-          if (EPI == EPI_GROUP_BIAS) v += p.bias[(long)(row / p.group) * p.N + col];
-          p.out[(long)row * p.ldo + col] = v;
+        const int trow = e.lrow + e.rr(i, r);
+        if (BIAS == 1) v[r] += bcol;
+        if (BIAS == 2) { if (FULL || (m0 + trow < p.M && cok)) v[r] += p.bias[(unsigned)(((m0 + trow) / p.group) * p.N + col)]; }
+        if (RELU) v[r] = fmaxf(v[r], 0.f);
+      }
+      if (OUT_F32) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int trow = e.lrow + e.rr(i, r);
+          if (FULL || (m0 + trow < p.M && cok)) of[(unsigned)(trow * p.ldo + e.lcol + j * 32)] = v[r];
+        }
+      }
+      if (OUT_SP) {
+        uint32_t w[16];
+        sp_words16(v, e.odd, w);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int trow = e.lrow + e.rr(i, r);
+          if (FULL || (m0 + trow < p.M && cok)) os[(unsigned)(trow * p.ldo + e.spcol + j * 32)] = w[r];
         }
       }
     }
+  }
 }
 
-int launch_linear(const LinearArgs& p, LinearEpi epi, hipStream_t st) {
+template <typename Cfg, bool OUT_F32, bool OUT_SP, int BIAS, bool RELU>
+__global__ __launch_bounds__(Cfg::THREADS, 2) void linear_kernel(LinearArgs p) {
+  __shared__ __attribute__((aligned(16))) float lds[Cfg::LDS_FLOATS];
+  int tm, tn;
+  if (!xcd_tile(ceil_div(p.M, Cfg::BM), ceil_div(p.N, Cfg::BN), tm, tn)) return;
+  const int m0 = tm * Cfg::BM, n0 = tn * Cfg::BN;
+  f32x16 acc[Cfg::TM][Cfg::TN];
+  gemm_mainloop<Cfg>(p.a, p.w, p.ldw, p.M, p.N, p.K, m0, n0, lds, acc);
+  if (m0 + Cfg::BM <= p.M && n0 + Cfg::BN <= p.N) linear_epilogue<Cfg, true, OUT_F32, OUT_SP, BIAS, RELU>(p, acc, m0, n0);
+  else linear_epilogue<Cfg, false, OUT_F32, OUT_SP, BIAS, RELU>(p, acc, m0, n0);
+}
+
+int launch_linear(const LinearArgs& p, hipStream_t st) {
   if (p.M <= 0) return LOFTR_OK;
-  if (p.K % 4 != 0 || p.N <= 0) return LOFTR_ERR_UNSUPPORTED;
-  dim3 grid(ceil_div(p.N, CfgGen::BN), ceil_div(p.M, CfgGen::BM));
-  dim3 block(CfgGen::THREADS);
+  if (p.K % 32 != 0 || p.N <= 0 || (p.out_sp && p.N % 32 != 0)) return LOFTR_ERR_UNSUPPORTED;
+  dim3 grid(xcd_grid(ceil_div(p.M, CfgGen::BM), ceil_div(p.N, CfgGen::BN))), block(CfgGen::THREADS);
   TimedLaunch tl(LOFTR_T_LINEAR, st);
-  switch (epi) {
-    case EPI_STORE: hipLaunchKernelGGL((linear_kernel<CfgGen, EPI_STORE>), grid, block, 0, st, p); break;
-    case EPI_RELU: hipLaunchKernelGGL((linear_kernel<CfgGen, EPI_RELU>), grid, block, 0, st, p); break;
-    case EPI_BIAS: hipLaunchKernelGGL((linear_kernel<CfgGen, EPI_BIAS>), grid, block, 0, st, p); break;
-    case EPI_GROUP_BIAS: hipLaunchKernelGGL((linear_kernel<CfgGen, EPI_GROUP_BIAS>), grid, block, 0, st, p); break;
-  }
+  const bool f = p.out_f32 != nullptr, s = p.out_sp != nullptr;
+  // the combinations the matching path uses
+  if (f && !s && p.bias_mode == 0 && !p.relu)
+    hipLaunchKernelGGL((linear_kernel<CfgGen, true, false, 0, false>), grid, block, 0, st, p);       // loftr_linear_fwd
+  else if (!f && s && p.bias_mode == 0 && p.relu)
+    hipLaunchKernelGGL((linear_kernel<CfgGen, false, true, 0, true>), grid, block, 0, st, p);        // mlp.0 + ReLU
+  else if (!f && s && p.bias_mode == 1 && !p.relu)
+    hipLaunchKernelGGL((linear_kernel<CfgGen, false, true, 1, false>), grid, block, 0, st, p);       // down_proj
+  else if (f && !s && p.bias_mode == 1 && !p.relu)
+    hipLaunchKernelGGL((linear_kernel<CfgGen, true, false, 1, false>), grid, block, 0, st, p);       // coarse context
+  else if (f && !s && p.bias_mode == 2 && !p.relu)
+    hipLaunchKernelGGL((linear_kernel<CfgGen, true, false, 2, false>), grid, block, 0, st, p);       // merge_feat windows
+  else
+    return LOFTR_ERR_UNSUPPORTED;
   LOFTR_CHECK_LAUNCH();
   return LOFTR_OK;
 }
 
 // ------------------------------------------------------------------------------------------
-template <typename Cfg>
-__global__ __launch_bounds__(Cfg::THREADS, 2) void proj_kernel(ProjArgs p) {
-  __shared__ __attribute__((aligned(16))) float lds[Cfg::LDS_FLOATS];
-  const int m0 = blockIdx.y * Cfg::BM;
-  const int nglob = blockIdx.x * Cfg::BN;          // column in the concatenated [nseg*C] output
-  const int seg = nglob / p.C;                     // block-uniform (BN divides C)
-  const int n0 = nglob - seg * p.C;
-  f32x16 acc[Cfg::TM][Cfg::TN];
-  ASrc a = ASrc{p.a, p.C, nullptr, 0, 1 << 30, nullptr};
-  gemm_mainloop<Cfg>(a, p.w[seg], p.C, p.M, p.C, p.C, m0, n0, lds, acc);
+template <typename Cfg, bool FULL, bool ZSCALE>
+__device__ __forceinline__ void proj_epilogue(const ProjArgs& p, f32x16 (&acc)[Cfg::TM][Cfg::TN], int seg, long n,
+                                              int m0, int n0) {
   const int kind = p.kind[seg];
-  float* out = p.out[seg];
+  const long row_base = n * p.M;
+  const uint8_t* mask = p.mask ? p.mask + row_base + m0 : nullptr;
+  const EpiLane<Cfg> e;
+  float mk[Cfg::TM][16];
 #pragma unroll
   for (int i = 0; i < Cfg::TM; ++i)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int row = acc_row<Cfg>(m0, i, r);
-      if (row >= p.M) continue;
-      float mk = p.mask ? (p.mask[row] ? 1.f : 0.f) : 1.f;
-      if (kind == 2) mk *= p.inv_s;
+      const int trow = e.lrow + e.rr(i, r);
+      float m = 1.f;
+      if (mask) m = mask[FULL ? trow : min(trow, p.M - 1 - m0)] ? 1.f : 0.f;
+      mk[i][r] = kind == 2 ? m * p.inv_s : m;
+    }
 #pragma unroll
-      for (int j = 0; j < Cfg::TN; ++j) {
-        const int col = acc_col<Cfg>(n0, j);
-        float v = acc[i][j][r];
-        if (kind != 2) v = v > 0.f ? v + 1.f : expf(v);     // elu(v)+1
-        out[(long)row * p.C + col] = v * mk;
+  for (int j = 0; j < Cfg::TN; ++j) {
+    const int col = n0 + e.lcol + j * 32;                          // head = col / 32, d = col % 32 = lane & 31
+    const float ksum = ZSCALE ? p.kv[(n * 8 + (col >> 5)) * (33 * 32) + 32 * 32 + (col & 31)] : 0.f;
+#pragma unroll
+    for (int i = 0; i < Cfg::TM; ++i) {
+      f32x16 v = acc[i][j];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float x = v[r];
+        if (kind != 2) x = x > 0.f ? x + 1.f : __expf(x);          // elu(x)+1
+        v[r] = x * mk[i][r];
+      }
+      if (ZSCALE) {
+        // the 32 lanes of this half-wave hold the 32 channels of one head of each of these rows
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float den = half_sum(v[r] * ksum);
+          v[r] *= p.v_length / (den + p.eps);
+        }
+        uint32_t w[16];
+        sp_words16(v, e.odd, w);
+        sp_t* os = reinterpret_cast<sp_t*>(p.out[seg]) + (row_base + m0) * p.C + n0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int trow = e.lrow + e.rr(i, r);
+          if (FULL || m0 + trow < p.M) os[(unsigned)(trow * p.C + e.spcol + j * 32)] = w[r];
+        }
+      } else {
+        float* of = reinterpret_cast<float*>(p.out[seg]) + (row_base + m0) * p.C + n0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int trow = e.lrow + e.rr(i, r);
+          if (FULL || m0 + trow < p.M) of[(unsigned)(trow * p.C + e.lcol + j * 32)] = v[r];
+        }
       }
     }
+  }
+}
+
+template <typename Cfg, bool ZSCALE>
+__global__ __launch_bounds__(Cfg::THREADS, 2) void proj_kernel(ProjArgs p) {
+  __shared__ __attribute__((aligned(16))) float lds[Cfg::LDS_FLOATS];
+  int tm, tn;
+  if (!xcd_tile(ceil_div(p.M, Cfg::BM), p.nseg * p.C / Cfg::BN, tm, tn)) return;
+  const int m0 = tm * Cfg::BM;
+  const long n = blockIdx.y;                       // batch element
+  const int nglob = tn * Cfg::BN;                  // column in the concatenated [nseg*C] output
+  const int seg = nglob / p.C;                     // block-uniform (BN divides C)
+  const int n0 = nglob - seg * p.C;
+  f32x16 acc[Cfg::TM][Cfg::TN];
+  gemm_mainloop<Cfg>(asrc_plain(p.a + n * p.M * p.C, p.C), p.w[seg], p.C, p.M, p.C, p.C, m0, n0, lds, acc);
+  if (m0 + Cfg::BM <= p.M) proj_epilogue<Cfg, true, ZSCALE>(p, acc, seg, n, m0, n0);
+  else proj_epilogue<Cfg, false, ZSCALE>(p, acc, seg, n, m0, n0);
 }
 
 int launch_proj(const ProjArgs& p, hipStream_t st) {
-  if (p.M <= 0) return LOFTR_OK;
+  if (p.M <= 0 || p.nbatch <= 0) return LOFTR_OK;
   if (p.C % CfgGen::BN != 0 || p.nseg < 1 || p.nseg > 3) return LOFTR_ERR_UNSUPPORTED;
-  dim3 grid(p.nseg * p.C / CfgGen::BN, ceil_div(p.M, CfgGen::BM));
+  if (p.kv && (p.C != 256 || p.nseg != 1 || p.kind[0] != 0)) return LOFTR_ERR_UNSUPPORTED;
+  dim3 grid(xcd_grid(ceil_div(p.M, CfgGen::BM), p.nseg * p.C / CfgGen::BN), p.nbatch);
   TimedLaunch tl(LOFTR_T_PROJ, st);
-  hipLaunchKernelGGL((proj_kernel<CfgGen>), grid, dim3(CfgGen::THREADS), 0, st, p);
+  if (p.kv) hipLaunchKernelGGL((proj_kernel<CfgGen, true>), grid, dim3(CfgGen::THREADS), 0, st, p);
+  else hipLaunchKernelGGL((proj_kernel<CfgGen, false>), grid, dim3(CfgGen::THREADS), 0, st, p);
   LOFTR_CHECK_LAUNCH();
   return LOFTR_OK;
 }
@@ -94,31 +174,28 @@ int launch_proj(const ProjArgs& p, hipStream_t st) {
 // ------------------------------------------------------------------------------------------
 // GEMM + LayerNorm (+ residual).  One block spans the whole row (BN == C), so the row statistics
 // are a reduction over the TN tiles of a lane, the 32 lanes of a half-wave and the WN waves.
-template <typename Cfg, bool ATTN>
+template <typename Cfg, bool HAS_RES, bool OUT_F32, bool OUT_SP>
 __global__ __launch_bounds__(Cfg::THREADS, 2) void linear_ln_kernel(LinearLNArgs p) {
   __shared__ __attribute__((aligned(16))) float lds[Cfg::LDS_FLOATS];
   const int m0 = blockIdx.x * Cfg::BM;
+  const long n = blockIdx.y;
+  const long row_base = n * p.M;
   f32x16 acc[Cfg::TM][Cfg::TN];
-  if (ATTN) {
-    const long n = blockIdx.y;
-    p.a.p0 += n * p.M * (long)p.a.ld0;
-    p.out += n * p.M * (long)p.C;
-    AttnXform ax{p.attn_kv + n * (8 * 33 * 32), p.v_length, p.attn_eps, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-    gemm_mainloop<Cfg, AttnXform>(p.a, p.w + n * (long)p.C * p.C, p.ldw, p.M, p.C, p.K, m0, 0, lds, acc, ax);
-  } else {
-    gemm_mainloop<Cfg>(p.a, p.w, p.ldw, p.M, p.C, p.K, m0, 0, lds, acc);
+  {
+    ASrc a = p.a;
+    a.p0 += row_base * a.ld0;
+    gemm_mainloop<Cfg>(a, p.w + n * p.w_batch_stride, p.ldw, p.M, p.C, p.K, m0, 0, lds, acc);
   }
   __syncthreads();                                  // all waves done with the staging buffers
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int wm = wave / Cfg::WN, wn = wave % Cfg::WN;
+  const int wn = wave % Cfg::WN;
   const float inv_c = 1.f / (float)p.C;
+  const EpiLane<Cfg> e;
+  const bool full = m0 + Cfg::BM <= p.M;            // block-uniform
 
   float* red = lds;                                 // [BM][WN] partial sums
   float* mean_s = lds + Cfg::BM * Cfg::WN;          // [BM]
   float* rstd_s = mean_s + Cfg::BM;                 // [BM]
-  auto lrow_of = [&](int i, int r) {
-    return wm * Cfg::WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-  };
   // pass 1: mean
 #pragma unroll
   for (int i = 0; i < Cfg::TM; ++i)
@@ -128,7 +205,7 @@ __global__ __launch_bounds__(Cfg::THREADS, 2) void linear_ln_kernel(LinearLNArgs
 #pragma unroll
       for (int j = 0; j < Cfg::TN; ++j) s += acc[i][j][r];
       s = half_sum(s);
-      if ((lane & 31) == 0) red[lrow_of(i, r) * Cfg::WN + wn] = s;
+      if ((lane & 31) == 0) red[(e.lrow + e.rr(i, r)) * Cfg::WN + wn] = s;
     }
   __syncthreads();
   if (threadIdx.x < Cfg::BM) {
@@ -139,16 +216,17 @@ __global__ __launch_bounds__(Cfg::THREADS, 2) void linear_ln_kernel(LinearLNArgs
   }
   __syncthreads();
   // pass 2: variance of the deviations (two-pass, like a reference LayerNorm in fp32)
+  float mu[Cfg::TM][16];
 #pragma unroll
   for (int i = 0; i < Cfg::TM; ++i)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const float mu = mean_s[lrow_of(i, r)];
+      mu[i][r] = mean_s[e.lrow + e.rr(i, r)];
       float s = 0.f;
 #pragma unroll
-      for (int j = 0; j < Cfg::TN; ++j) { float d = acc[i][j][r] - mu; s += d * d; }
+      for (int j = 0; j < Cfg::TN; ++j) { float d = acc[i][j][r] - mu[i][r]; s += d * d; }
       s = half_sum(s);
-      if ((lane & 31) == 0) red[lrow_of(i, r) * Cfg::WN + wn] = s;
+      if ((lane & 31) == 0) red[(e.lrow + e.rr(i, r)) * Cfg::WN + wn] = s;
     }
   __syncthreads();
   if (threadIdx.x < Cfg::BM) {
@@ -158,51 +236,68 @@ __global__ __launch_bounds__(Cfg::THREADS, 2) void linear_ln_kernel(LinearLNArgs
     rstd_s[threadIdx.x] = 1.f / sqrtf(s * inv_c + p.eps);
   }
   __syncthreads();
+  const long tile_base = (row_base + m0) * p.C;
+  const float* res = HAS_RES ? p.residual + tile_base : nullptr;
+  float* of = OUT_F32 ? p.out_f32 + tile_base : nullptr;
+  sp_t* os = OUT_SP ? p.out_sp + tile_base : nullptr;
+  float rs[Cfg::TM][16];
+#pragma unroll
+  for (int i = 0; i < Cfg::TM; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) rs[i][r] = rstd_s[e.lrow + e.rr(i, r)];
 #pragma unroll
   for (int j = 0; j < Cfg::TN; ++j) {
-    const int col = acc_col<Cfg>(0, j);
-    const float g = p.gamma[col], b = p.beta[col];
+    const float gam = p.gamma[e.lcol + j * 32], bet = p.beta[e.lcol + j * 32];
 #pragma unroll
-    for (int i = 0; i < Cfg::TM; ++i)
+    for (int i = 0; i < Cfg::TM; ++i) {
+      f32x16 v;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int row = acc_row<Cfg>(m0, i, r);
-        if (row < p.M) {
-          const int lr = lrow_of(i, r);
-          float v = (acc[i][j][r] - mean_s[lr]) * rstd_s[lr] * g + b;
-          const long o = (long)row * p.C + col;
-          if (p.residual) v += p.residual[o];
-          p.out[o] = v;
+        const int trow = e.lrow + e.rr(i, r);
+        const unsigned ro = (unsigned)((full ? trow : min(trow, p.M - 1 - m0)) * p.C);
+        v[r] = (acc[i][j][r] - mu[i][r]) * rs[i][r] * gam + bet;
+        if (HAS_RES) v[r] += res[ro + e.lcol + j * 32];
+      }
+      if (OUT_F32) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int trow = e.lrow + e.rr(i, r);
+          if (full || m0 + trow < p.M) of[(unsigned)(trow * p.C) + e.lcol + j * 32] = v[r];
         }
       }
+      if (OUT_SP) {
+        uint32_t w[16];
+        sp_words16(v, e.odd, w);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int trow = e.lrow + e.rr(i, r);
+          if (full || m0 + trow < p.M) os[(unsigned)(trow * p.C) + e.spcol + j * 32] = w[r];
+        }
+      }
+    }
   }
+}
+
+template <typename Cfg>
+static void launch_ln_variant(const LinearLNArgs& p, hipStream_t st, int& rc) {
+  const dim3 grid(ceil_div(p.M, Cfg::BM), p.nbatch), block(Cfg::THREADS);
+  const bool r = p.residual != nullptr, f = p.out_f32 != nullptr, s = p.out_sp != nullptr;
+  rc = LOFTR_OK;
+  if (!r && !f && s) hipLaunchKernelGGL((linear_ln_kernel<Cfg, false, false, true>), grid, block, 0, st, p);      // merge + norm1
+  else if (r && f && s) hipLaunchKernelGGL((linear_ln_kernel<Cfg, true, true, true>), grid, block, 0, st, p);     // mlp.2 + norm2 + x
+  else if (r && f && !s) hipLaunchKernelGGL((linear_ln_kernel<Cfg, true, true, false>), grid, block, 0, st, p);   // same, single-layer API
+  else rc = LOFTR_ERR_UNSUPPORTED;
 }
 
 int launch_linear_ln(const LinearLNArgs& p, hipStream_t st) {
-  if (p.M <= 0) return LOFTR_OK;
-  if (p.K % 4 != 0) return LOFTR_ERR_UNSUPPORTED;
+  if (p.M <= 0 || p.nbatch <= 0) return LOFTR_OK;
+  if (p.K % 32 != 0) return LOFTR_ERR_UNSUPPORTED;
   TimedLaunch tl(LOFTR_T_LINEAR_LN, st);
-  if (p.attn_kv) {
-    if (p.C != 256 || p.K != 256 || p.residual || p.nb <= 0) return LOFTR_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL((linear_ln_kernel<CfgLN256, true>), dim3(ceil_div(p.M, CfgLN256::BM), p.nb),
-                       dim3(CfgLN256::THREADS), 0, st, p);
-  } else if (p.C == 256) {
-    hipLaunchKernelGGL((linear_ln_kernel<CfgLN256, false>), dim3(ceil_div(p.M, CfgLN256::BM)),
-                       dim3(CfgLN256::THREADS), 0, st, p);
-  } else if (p.C == 128) {
-    hipLaunchKernelGGL((linear_ln_kernel<CfgLN128, false>), dim3(ceil_div(p.M, CfgLN128::BM)),
-                       dim3(CfgLN128::THREADS), 0, st, p);
-  } else {
-    return LOFTR_ERR_UNSUPPORTED;
-  }
+  int rc;
+  if (p.C == 256) launch_ln_variant<CfgLN256>(p, st, rc);
+  else if (p.C == 128) launch_ln_variant<CfgLN128>(p, st, rc);
+  else return LOFTR_ERR_UNSUPPORTED;
+  if (rc) return rc;
   LOFTR_CHECK_LAUNCH();
   return LOFTR_OK;
-}
-
-// ------------------------------------------------------------------------------------------
-extern "C" int loftr_linear_fwd(const float* a, const float* w, float* out, int M, int N, int K,
-                                void* stream) {
-  LOFTR_CHECK_ARG(a && w && out && M >= 0 && N > 0 && K > 0);
-  LinearArgs p{asrc_plain(a, K), w, K, out, N, M, N, K, nullptr, 1};
-  return launch_linear(p, EPI_STORE, (hipStream_t)stream);
 }

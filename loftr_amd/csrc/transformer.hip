@@ -1,82 +1,57 @@
 // LoFTREncoderLayer / LocalFeatureTransformer orchestration (host side of the C-ABI).
 //   reference: src/loftr/loftr_module/transformer.py:35-58 (layer), :80-101 (layer schedule).
+//
+// Data flow of one coarse layer call (x attends to source; SP = split-fp16 GEMM operand format):
+//   source_sp --proj(k,v)--> K, V fp32 --kv_partial/finalize--> KV, Ksum, P (= KV folded into merge, SP)
+//   x_sp --proj(q) + normaliser z--> Q' SP --GEMM with P + LN(norm1)--> message SP
+//   cat[x_sp, message] --GEMM mlp.0 + ReLU--> hidden SP --GEMM mlp.2 + LN(norm2) + x--> x' (fp32 and SP)
+// The residual stream is kept in fp32 (in place in the caller's buffers); its SP mirror only feeds GEMMs.
 #include "linear.h"
 #include "attention.h"
 
 namespace {
 
+constexpr int MAX_LAYERS = 16;
+
+struct LayerSp {                 // SP copies of one layer's matrices (workspace) + the fp32 originals needed
+  const sp_t *q, *k, *v, *merge, *mlp0, *mlp2;
+  const float* merge_f32;
+  const float *n1w, *n1b, *n2w, *n2b;
+};
+
 struct EncoderWs {
-  float *q, *k, *v, *msg, *msgn, *hid;
+  sp_t* q;                       // [rows_l, C]  coarse: z-scaled Q as SP; fine: Q fp32 (same size)
+  float *k, *v;                  // [rows_s, C]  fp32
+  sp_t *msg, *msgn, *hid;        // [rows_l, C] (fine only), [rows_l, C], [rows_l, 2C]
   void* attn; size_t attn_bytes;
   bool ok;
 };
 
+size_t weights_sp_dwords(int C) { return (size_t)10 * C * C; }
+
 size_t encoder_ws_bytes(int nb, int L, int S, int C) {
   size_t rows_l = (size_t)nb * L, rows_s = (size_t)nb * S;
   size_t b = 0;
-  b += 3 * align_up(rows_l * C * sizeof(float), 256);        // q, msg, msgn
-  b += 2 * align_up(rows_s * C * sizeof(float), 256);        // k, v
-  b += align_up(rows_l * 2 * C * sizeof(float), 256);        // hidden
+  b += 3 * align_up(rows_l * C * 4, 256);          // q, msg, msgn
+  b += 2 * align_up(rows_s * C * 4, 256);          // k, v
+  b += align_up(rows_l * 2 * C * 4, 256);          // hidden
   b += attention_workspace_bytes(nb, S, C);
   return b + 2048;
 }
 
-EncoderWs carve(void* ws, size_t bytes, int nb, int L, int S, int C) {
-  WsAlloc wa(ws, bytes);
+EncoderWs carve(WsAlloc& wa, int nb, int L, int S, int C) {
   EncoderWs e;
   size_t rows_l = (size_t)nb * L, rows_s = (size_t)nb * S;
-  e.q = wa.take<float>(rows_l * C);
-  e.msg = wa.take<float>(rows_l * C);
-  e.msgn = wa.take<float>(rows_l * C);
+  e.q = wa.take<sp_t>(rows_l * C);
+  e.msg = wa.take<sp_t>(rows_l * C);
+  e.msgn = wa.take<sp_t>(rows_l * C);
   e.k = wa.take<float>(rows_s * C);
   e.v = wa.take<float>(rows_s * C);
-  e.hid = wa.take<float>(rows_l * 2 * C);
+  e.hid = wa.take<sp_t>(rows_l * 2 * C);
   e.attn_bytes = attention_workspace_bytes(nb, S, C);
   e.attn = wa.take<char>(e.attn_bytes);
   e.ok = wa.ok();
   return e;
-}
-
-int encoder_layer(const float* x, const float* src, const uint8_t* x_mask, const uint8_t* src_mask,
-                  const loftr_layer_weights& w, float* out, int nb, int L, int S, int C, int H,
-                  void* ws, size_t ws_bytes, hipStream_t st) {
-  if (nb <= 0) return LOFTR_OK;
-  EncoderWs e = carve(ws, ws_bytes, nb, L, S, C);
-  if (!e.ok) return LOFTR_ERR_WORKSPACE;
-  const int Ml = nb * L, Ms = nb * S;
-  const float inv_s = 1.f / (float)S;                 // values / v_length, linear_attention.py:41-42
-  int rc;
-  if (x == src && x_mask == src_mask) {
-    // self attention: q, k, v share the A operand -> one launch over 3C output columns
-    ProjArgs p{x, Ml, C, 3, {w.q_proj, w.k_proj, w.v_proj}, {e.q, e.k, e.v}, {0, 1, 2}, x_mask, inv_s};
-    if ((rc = launch_proj(p, st))) return rc;
-  } else {
-    ProjArgs pq{x, Ml, C, 1, {w.q_proj, nullptr, nullptr}, {e.q, nullptr, nullptr}, {0, 0, 0}, x_mask, inv_s};
-    if ((rc = launch_proj(pq, st))) return rc;
-    ProjArgs pkv{src, Ms, C, 2, {w.k_proj, w.v_proj, nullptr}, {e.k, e.v, nullptr}, {1, 2, 0}, src_mask, inv_s};
-    if ((rc = launch_proj(pkv, st))) return rc;
-  }
-  if (C == 256) {
-    // coarse level: KV reduction, then attention-apply + merge + norm1 as ONE GEMM   transformer.py:50-52
-    const float *kv = nullptr, *pm = nullptr;
-    if ((rc = launch_attention_kv(e.k, e.v, w.merge, nb, S, C, H, e.attn, e.attn_bytes, &kv, &pm, st))) return rc;
-    LinearLNArgs m{asrc_plain(e.q, C), pm, C, w.norm1_w, w.norm1_b, nullptr, e.msgn, L, C, C, 1e-5f,
-                   kv, nb, (float)S, 1e-6f};             // LinearAttention(eps=1e-6), linear_attention.py:15
-    if ((rc = launch_linear_ln(m, st))) return rc;
-  } else {
-    if ((rc = launch_linear_attention(e.q, e.k, e.v, e.msg, nb, L, S, C, H, e.attn, e.attn_bytes, st))) return rc;
-    // message = norm1(merge(message))                                   transformer.py:51-52
-    LinearLNArgs m{asrc_plain(e.msg, C), w.merge, C, w.norm1_w, w.norm1_b, nullptr, e.msgn, Ml, C, C, 1e-5f,
-                   nullptr, 0, 0.f, 0.f};
-    if ((rc = launch_linear_ln(m, st))) return rc;
-  }
-  // hidden = relu(mlp.0(cat[x, message]))                             transformer.py:55
-  LinearArgs h{asrc_cat(x, C, e.msgn, C, C), w.mlp0, 2 * C, e.hid, 2 * C, Ml, 2 * C, 2 * C, nullptr, 1};
-  if ((rc = launch_linear(h, EPI_RELU, st))) return rc;
-  // out = x + norm2(mlp.2(hidden))                                    transformer.py:55-58
-  LinearLNArgs o{asrc_plain(e.hid, 2 * C), w.mlp2, 2 * C, w.norm2_w, w.norm2_b, x, out, Ml, C, 2 * C, 1e-5f,
-                 nullptr, 0, 0.f, 0.f};
-  return launch_linear_ln(o, st);
 }
 
 bool weights_ok(const loftr_layer_weights& w) {
@@ -84,11 +59,84 @@ bool weights_ok(const loftr_layer_weights& w) {
          w.norm2_w && w.norm2_b;
 }
 
+// queue the fp32 -> SP conversion of one layer's six matrices; returns the SP view
+LayerSp stage_layer(const loftr_layer_weights& w, sp_t* dst, int C, SpJobs& jobs) {
+  LayerSp l;
+  auto add = [&](const float* src, int rows, int K) {
+    const int i = jobs.n++;
+    jobs.src[i] = src; jobs.dst[i] = dst; jobs.rows[i] = rows; jobs.K[i] = K; jobs.ld[i] = K;
+    sp_t* r = dst;
+    dst += (size_t)rows * K;
+    return r;
+  };
+  l.q = add(w.q_proj, C, C);
+  l.k = add(w.k_proj, C, C);
+  l.v = add(w.v_proj, C, C);
+  l.merge = add(w.merge, C, C);
+  l.mlp0 = add(w.mlp0, 2 * C, 2 * C);
+  l.mlp2 = add(w.mlp2, C, 2 * C);
+  l.merge_f32 = w.merge;
+  l.n1w = w.norm1_w; l.n1b = w.norm1_b; l.n2w = w.norm2_w; l.n2b = w.norm2_b;
+  return l;
+}
+
+int encoder_layer(const float* x_f32, const sp_t* x_sp, const sp_t* src_sp, bool self,
+                  const uint8_t* x_mask, const uint8_t* src_mask, const LayerSp& w,
+                  float* out_f32, sp_t* out_sp, int nb, int L, int S, int C, int H,
+                  const EncoderWs& e, hipStream_t st) {
+  if (nb <= 0) return LOFTR_OK;
+  const int Ml = nb * L, Ms = nb * S;
+  const float inv_s = 1.f / (float)S;                 // values / v_length, linear_attention.py:41-42
+  const float attn_eps = 1e-6f;                       // LinearAttention(eps=1e-6), linear_attention.py:15
+  int rc;
+  if (C == 256) {
+    // k, v projections of the source -> KV / Ksum reduction -> P (KV folded into merge)
+    ProjArgs pkv{src_sp, Ms, C, 1, 2, {w.k, w.v, nullptr}, {e.k, e.v, nullptr}, {1, 2, 0}, src_mask, inv_s,
+                 nullptr, 0.f, 0.f};
+    if ((rc = launch_proj(pkv, st))) return rc;
+    const float* kv = nullptr; const sp_t* pm = nullptr;
+    if ((rc = launch_attention_kv(e.k, e.v, w.merge_f32, nb, S, C, H, e.attn, e.attn_bytes, &kv, &pm, st))) return rc;
+    // q projection with the normaliser applied in its epilogue (per pair: grid.z = nb)
+    ProjArgs pq{x_sp, L, C, nb, 1, {w.q, nullptr, nullptr}, {e.q, nullptr, nullptr}, {0, 0, 0}, x_mask, inv_s,
+                kv, (float)S, attn_eps};
+    if ((rc = launch_proj(pq, st))) return rc;
+    // message = norm1(merge(attention))  as ONE GEMM against P                    transformer.py:50-52
+    LinearLNArgs m{asrc_plain(e.q, C), pm, C, w.n1w, w.n1b, nullptr, nullptr, e.msgn, L, C, C, 1e-5f,
+                   nb, (long)C * C};
+    if ((rc = launch_linear_ln(m, st))) return rc;
+  } else {
+    float* qf = reinterpret_cast<float*>(e.q);
+    if (self) {
+      ProjArgs p{x_sp, Ml, C, 1, 3, {w.q, w.k, w.v}, {qf, e.k, e.v}, {0, 1, 2}, x_mask, inv_s, nullptr, 0.f, 0.f};
+      if ((rc = launch_proj(p, st))) return rc;
+    } else {
+      ProjArgs pq{x_sp, Ml, C, 1, 1, {w.q, nullptr, nullptr}, {qf, nullptr, nullptr}, {0, 0, 0}, x_mask, inv_s,
+                  nullptr, 0.f, 0.f};
+      if ((rc = launch_proj(pq, st))) return rc;
+      ProjArgs pkv{src_sp, Ms, C, 1, 2, {w.k, w.v, nullptr}, {e.k, e.v, nullptr}, {1, 2, 0}, src_mask, inv_s,
+                   nullptr, 0.f, 0.f};
+      if ((rc = launch_proj(pkv, st))) return rc;
+    }
+    if ((rc = launch_attention_small(qf, e.k, e.v, e.msg, nb, L, S, C, H, st))) return rc;
+    // message = norm1(merge(message))                                   transformer.py:51-52
+    LinearLNArgs m{asrc_plain(e.msg, C), w.merge, C, w.n1w, w.n1b, nullptr, nullptr, e.msgn, Ml, C, C, 1e-5f, 1, 0};
+    if ((rc = launch_linear_ln(m, st))) return rc;
+  }
+  // hidden = relu(mlp.0(cat[x, message]))                             transformer.py:55
+  LinearArgs h{asrc_cat(x_sp, e.msgn, C, C), w.mlp0, 2 * C, nullptr, e.hid, 2 * C, Ml, 2 * C, 2 * C, nullptr, 0, 1, true};
+  if ((rc = launch_linear(h, st))) return rc;
+  // out = x + norm2(mlp.2(hidden))                                    transformer.py:55-58
+  LinearLNArgs o{asrc_plain(e.hid, 2 * C), w.mlp2, 2 * C, w.n2w, w.n2b, x_f32, out_f32, out_sp, Ml, C, 2 * C, 1e-5f, 1, 0};
+  return launch_linear_ln(o, st);
+}
+
 }  // namespace
 
 extern "C" size_t loftr_encoder_workspace_bytes(int nb, int L, int S, int C) {
   if (nb <= 0 || L <= 0 || S <= 0 || C <= 0) return 0;
-  return encoder_ws_bytes(nb, L > S ? L : S, L > S ? L : S, C);
+  const int m = L > S ? L : S;
+  return encoder_ws_bytes(nb, m, m, C) + 2 * align_up((size_t)nb * m * C * 4, 256) +
+         align_up(weights_sp_dwords(C) * 4 * MAX_LAYERS, 256) + 4096;
 }
 
 extern "C" int loftr_encoder_layer_fwd(const float* x, const float* source, const uint8_t* x_mask,
@@ -98,8 +146,26 @@ extern "C" int loftr_encoder_layer_fwd(const float* x, const float* source, cons
   LOFTR_CHECK_ARG(x && source && w && out && nb >= 0 && L > 0 && S > 0 && (ws || nb == 0));
   LOFTR_CHECK_ARG(weights_ok(*w));
   if (!((C == 256 || C == 128) && H == 8)) return LOFTR_ERR_UNSUPPORTED;
-  return encoder_layer(x, source, x_mask, source_mask, *w, out, nb, L, S, C, H, ws, ws_bytes,
-                       (hipStream_t)stream);
+  if (nb == 0) return LOFTR_OK;
+  hipStream_t st = (hipStream_t)stream;
+  WsAlloc wa(ws, ws_bytes);
+  sp_t* x_sp = wa.take<sp_t>((size_t)nb * L * C);
+  sp_t* s_sp = wa.take<sp_t>((size_t)nb * S * C);
+  sp_t* w_sp = wa.take<sp_t>(weights_sp_dwords(C));
+  EncoderWs e = carve(wa, nb, L, S, C);
+  if (!e.ok) return LOFTR_ERR_WORKSPACE;
+  const bool self = (x == source) && (x_mask == source_mask);
+  SpJobs jobs; jobs.n = 0;
+  auto add = [&](const float* src, sp_t* dst, long rows) {
+    const int i = jobs.n++;
+    jobs.src[i] = src; jobs.dst[i] = dst; jobs.rows[i] = (int)rows; jobs.K[i] = C; jobs.ld[i] = C;
+  };
+  add(x, x_sp, (long)nb * L);
+  if (!self) add(source, s_sp, (long)nb * S);
+  const LayerSp lw = stage_layer(*w, w_sp, C, jobs);
+  int rc;
+  if ((rc = launch_sp_convert(jobs, st))) return rc;
+  return encoder_layer(x, x_sp, self ? x_sp : s_sp, self, x_mask, source_mask, lw, out, nullptr, nb, L, S, C, H, e, st);
 }
 
 extern "C" int loftr_transformer_fwd(float* feat0, float* feat1, const uint8_t* mask0,
@@ -108,29 +174,80 @@ extern "C" int loftr_transformer_fwd(float* feat0, float* feat1, const uint8_t* 
                                      int C, int H, void* ws, size_t ws_bytes, void* stream) {
   LOFTR_CHECK_ARG(feat0 && feat1 && layers && layer_is_cross && n_layers >= 0 && N >= 0 && L > 0 && S > 0);
   LOFTR_CHECK_ARG((mask0 == nullptr) == (mask1 == nullptr));
-  if (!((C == 256 || C == 128) && H == 8)) return LOFTR_ERR_UNSUPPORTED;
-  if (N == 0) return LOFTR_OK;
+  if (!((C == 256 || C == 128) && H == 8) || n_layers > MAX_LAYERS) return LOFTR_ERR_UNSUPPORTED;
+  if (N == 0 || n_layers == 0) return LOFTR_OK;
   LOFTR_CHECK_ARG(ws != nullptr);
   hipStream_t st = (hipStream_t)stream;
+  for (int i = 0; i < n_layers; ++i) LOFTR_CHECK_ARG(weights_ok(layers[i]));
   // The two self-attention calls of a layer are independent (transformer.py:92-94): when the two
   // feature sets are one contiguous [2N, L, C] buffer they run as a single batch of 2N.
   const bool stacked = (L == S) && (feat1 == feat0 + (size_t)N * L * C) &&
                        (mask0 == nullptr || mask1 == mask0 + (size_t)N * L);
+  WsAlloc wa(ws, ws_bytes);
+  sp_t* sp0 = wa.take<sp_t>((size_t)N * (L + S) * C);        // SP mirror of [feat0 ; feat1], contiguous
+  sp_t* sp1 = sp0 + (size_t)N * L * C;
+  sp_t* w_sp = wa.take<sp_t>(weights_sp_dwords(C) * n_layers);
+  EncoderWs e = carve(wa, 2 * N, L > S ? L : S, L > S ? L : S, C);
+  if (!e.ok) return LOFTR_ERR_WORKSPACE;
+  int rc;
+  LayerSp lw[MAX_LAYERS];
+  {
+    // residual stream -> SP mirror, all layer matrices -> SP: batched in launches of <= SP_MAX_JOBS tensors
+    SpJobs jobs; jobs.n = 0;
+    auto add = [&](const float* src, sp_t* dst, long rows) {
+      const int i = jobs.n++;
+      jobs.src[i] = src; jobs.dst[i] = dst; jobs.rows[i] = (int)rows; jobs.K[i] = C; jobs.ld[i] = C;
+    };
+    add(feat0, sp0, (long)N * L);
+    add(feat1, sp1, (long)N * S);
+    for (int i = 0; i < n_layers; ++i) {
+      if (jobs.n + 6 > SP_MAX_JOBS) {
+        if ((rc = launch_sp_convert(jobs, st))) return rc;
+        jobs.n = 0;
+      }
+      lw[i] = stage_layer(layers[i], w_sp + weights_sp_dwords(C) * i, C, jobs);
+    }
+    if ((rc = launch_sp_convert(jobs, st))) return rc;
+  }
   for (int i = 0; i < n_layers; ++i) {
-    LOFTR_CHECK_ARG(weights_ok(layers[i]));
-    int rc;
     if (!layer_is_cross[i]) {
       if (stacked) {
-        if ((rc = encoder_layer(feat0, feat0, mask0, mask0, layers[i], feat0, 2 * N, L, L, C, H, ws, ws_bytes, st))) return rc;
+        if ((rc = encoder_layer(feat0, sp0, sp0, true, mask0, mask0, lw[i], feat0, sp0, 2 * N, L, L, C, H, e, st))) return rc;
       } else {
-        if ((rc = encoder_layer(feat0, feat0, mask0, mask0, layers[i], feat0, N, L, L, C, H, ws, ws_bytes, st))) return rc;
-        if ((rc = encoder_layer(feat1, feat1, mask1, mask1, layers[i], feat1, N, S, S, C, H, ws, ws_bytes, st))) return rc;
+        if ((rc = encoder_layer(feat0, sp0, sp0, true, mask0, mask0, lw[i], feat0, sp0, N, L, L, C, H, e, st))) return rc;
+        if ((rc = encoder_layer(feat1, sp1, sp1, true, mask1, mask1, lw[i], feat1, sp1, N, S, S, C, H, e, st))) return rc;
       }
     } else {
       // sequential dependency kept: feat1 attends to the UPDATED feat0 (transformer.py:96-97)
-      if ((rc = encoder_layer(feat0, feat1, mask0, mask1, layers[i], feat0, N, L, S, C, H, ws, ws_bytes, st))) return rc;
-      if ((rc = encoder_layer(feat1, feat0, mask1, mask0, layers[i], feat1, N, S, L, C, H, ws, ws_bytes, st))) return rc;
+      if ((rc = encoder_layer(feat0, sp0, sp1, false, mask0, mask1, lw[i], feat0, sp0, N, L, S, C, H, e, st))) return rc;
+      if ((rc = encoder_layer(feat1, sp1, sp0, false, mask1, mask0, lw[i], feat1, sp1, N, S, L, C, H, e, st))) return rc;
     }
   }
   return LOFTR_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+extern "C" size_t loftr_linear_workspace_bytes(int M, int N, int K) {
+  if (M <= 0 || N <= 0 || K <= 0) return 0;
+  return align_up((size_t)M * ceil32(K) * 4, 256) + align_up((size_t)N * ceil32(K) * 4, 256) + 1024;
+}
+
+extern "C" int loftr_linear_fwd(const float* a, const float* w, float* out, int M, int N, int K,
+                                void* ws, size_t ws_bytes, void* stream) {
+  LOFTR_CHECK_ARG(a && w && out && M >= 0 && N > 0 && K > 0);
+  if (M == 0) return LOFTR_OK;
+  LOFTR_CHECK_ARG(ws != nullptr);
+  hipStream_t st = (hipStream_t)stream;
+  const int Kp = ceil32(K);
+  WsAlloc wa(ws, ws_bytes);
+  sp_t* a_sp = wa.take<sp_t>((size_t)M * Kp);
+  sp_t* w_sp = wa.take<sp_t>((size_t)N * Kp);
+  if (!wa.ok()) return LOFTR_ERR_WORKSPACE;
+  SpJobs jobs; jobs.n = 2;
+  jobs.src[0] = a; jobs.dst[0] = a_sp; jobs.rows[0] = M; jobs.K[0] = K; jobs.ld[0] = K;
+  jobs.src[1] = w; jobs.dst[1] = w_sp; jobs.rows[1] = N; jobs.K[1] = K; jobs.ld[1] = K;
+  int rc;
+  if ((rc = launch_sp_convert(jobs, st))) return rc;
+  LinearArgs p{asrc_plain(a_sp, Kp), w_sp, Kp, out, nullptr, N, M, N, Kp, nullptr, 0, 1, false};
+  return launch_linear(p, st);
 }

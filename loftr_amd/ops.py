@@ -57,12 +57,14 @@ def _mask_u8(m, name):
 
 # ---------------------------------------------------------------------------------------------
 def linear(a, w):
-    """a [M,K] @ w[N,K]^T on the fp32 matrix cores (building block, exposed for tests)."""
+    """a [M,K] @ w[N,K]^T on the split-fp16 GEMM core (building block, exposed for tests)."""
     _need(a, "a"); _need(w, "w")
     M, K = a.shape
     N = w.shape[0]
     out = torch.empty(M, N, device=a.device, dtype=torch.float32)
-    check(_lib.load().loftr_linear_fwd(_ptr(a), _ptr(w), _ptr(out), M, N, K, _stream()), "loftr_linear_fwd")
+    lib = _lib.load()
+    ws = workspace(lib.loftr_linear_workspace_bytes(M, N, K), a.device)
+    check(lib.loftr_linear_fwd(_ptr(a), _ptr(w), _ptr(out), M, N, K, _ptr(ws), ws.numel(), _stream()), "loftr_linear_fwd")
     return out
 
 
@@ -158,7 +160,7 @@ def coarse_match(feat_c0, feat_c1, hw0_c, hw1_c, thr, border_rm, scale, match_ty
     mo = MatchOut(b_ids.data_ptr(), i_ids.data_ptr(), j_ids.data_ptr(), mconf.data_ptr(), mk0.data_ptr(),
                   mk1.data_ptr(), counts.data_ptr())
     lib = _lib.load()
-    ws = workspace(lib.loftr_coarse_match_workspace_bytes(N, L, S), dev)
+    ws = workspace(lib.loftr_coarse_match_workspace_bytes(N, L, S, Cc), dev)
     out = {}
     if match_type == "dual_softmax":
         conf = torch.empty(N, L, S, device=dev, dtype=torch.float32) if want_conf else None

@@ -48,15 +48,15 @@ def test_workspace_queries(lib):
     a = lib.loftr_encoder_workspace_bytes(2, 4800, 4800, 256)
     assert a >= 2 * 4800 * 256 * 4 * 7
     assert lib.loftr_encoder_workspace_bytes(4, 4800, 4800, 256) > a
-    assert lib.loftr_coarse_match_workspace_bytes(1, 4800, 4800) > 0
-    assert lib.loftr_coarse_match_workspace_bytes(0, 4800, 4800) == 0
+    assert lib.loftr_coarse_match_workspace_bytes(1, 4800, 4800, 256) > 0
+    assert lib.loftr_coarse_match_workspace_bytes(0, 4800, 4800, 256) == 0
     assert lib.loftr_fine_preprocess_workspace_bytes(0, 5, 128) == 0
     assert lib.loftr_fine_preprocess_workspace_bytes(100, 5, 128) >= 2 * 100 * 25 * 128 * 4
 
 
 def test_bad_arguments_return_status(lib):
     # null pointers -> LOFTR_ERR_BAD_ARG before any device work
-    assert lib.loftr_linear_fwd(None, None, None, 4, 4, 16, None) == -1
+    assert lib.loftr_linear_fwd(None, None, None, 4, 4, 16, None, 0, None) == -1
     assert lib.loftr_pos_encode_flatten(None, None, 256, 256, None, 1, 256, None) == -1
     assert lib.loftr_fine_match(None, None, 3, 25, 128, None, None, 2.0, None, None, None, None) == -1
     # M == 0 is a no-op success on every fine entry point
