@@ -57,35 +57,106 @@ __device__ __forceinline__ bool score_tile(const Geometry& g, int& n, int& ti, i
   return ti < tiles_m && tj < tiles_n;
 }
 
+// exp for the softmax terms: v_exp_f32 on x * log2(e).  Arguments are <= 0 and the terms that
+// matter have |x| small; worst-case relative error ~|x| * 1e-7, far inside the 1e-4 budget on conf.
+__device__ __forceinline__ float fexp(float x) { return __expf(x); }
+
 // acc -> sim in place: scale, padding mask (-1e9), out-of-range -> SENTINEL.
-template <bool HAS_MASK>
+//   FULL: the tile lies inside [L, S] (block-uniform) -> no range tests.
+template <bool HAS_MASK, bool FULL>
 __device__ __forceinline__ void acc_to_sim(f32x16 (&acc)[Cfg::TM][Cfg::TN], int m0, int n0, int L, int S,
                                            float scale, const uint8_t* __restrict__ mask0,
                                            const uint8_t* __restrict__ mask1) {
+  const EpiLane<Cfg> e;
+  bool rm[Cfg::TM][16];
+  if (HAS_MASK) {
+#pragma unroll
+    for (int i = 0; i < Cfg::TM; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + e.lrow + e.rr(i, r);
+        rm[i][r] = (FULL || row < L) ? mask0[row] != 0 : false;
+      }
+  }
 #pragma unroll
   for (int j = 0; j < Cfg::TN; ++j) {
-    const int col = acc_col<Cfg>(n0, j);
-    const bool cok = col < S;
+    const int col = n0 + e.lcol + j * 32;
+    const bool cok = FULL || col < S;
     bool cm = true;
     if (HAS_MASK) cm = cok ? mask1[col] != 0 : false;
 #pragma unroll
     for (int i = 0; i < Cfg::TM; ++i)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int row = acc_row<Cfg>(m0, i, r);
         float v = acc[i][j][r] * scale;
-        if (HAS_MASK) {
-          const bool rm = row < L ? mask0[row] != 0 : false;
-          if (!(rm && cm)) v = LOFTR_NEG_INF;            // masked_fill_(~(m0 x m1), -INF)  :115-118
-        }
-        if (!(cok && row < L)) v = SENTINEL;
+        if (HAS_MASK) { if (!(rm[i][r] && cm)) v = LOFTR_NEG_INF; }   // masked_fill_(~(m0 x m1), -INF)  :115-118
+        if (!FULL) { if (!(cok && m0 + e.lrow + e.rr(i, r) < L)) v = SENTINEL; }
         acc[i][j][r] = v;
       }
   }
 }
 
 // ------------------------------------------------------------------------------------------
-// pass A
+// pass A epilogue: per-wave online (max, sum exp) of every row and column of the tile
+template <bool FULL>
+__device__ __forceinline__ void stats_epilogue(f32x16 (&acc)[Cfg::TM][Cfg::TN], const Geometry& g, int n, int ti,
+                                               int tj, float2* __restrict__ rowpart, float2* __restrict__ colpart) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave / Cfg::WN, wn = wave % Cfg::WN;
+  const EpiLane<Cfg> e;
+  const int m0 = ti * Cfg::BM, n0 = tj * Cfg::BN;
+  // rows: reduce over the TN tiles of the lane and the 32 lanes of the half-wave
+  const int pj = tj * Cfg::WN + wn;
+  float2* rp = rowpart + ((long)n * g.L + m0) * g.PJ + pj;
+#pragma unroll
+  for (int i = 0; i < Cfg::TM; ++i) {
+    f32x16 m = acc[i][0];
+#pragma unroll
+    for (int j = 1; j < Cfg::TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) m[r] = fmaxf(m[r], acc[i][j][r]);
+    half_max16(m);
+    f32x16 s;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      s[r] = 0.f;
+#pragma unroll
+      for (int j = 0; j < Cfg::TN; ++j) {
+        const float t = fexp(acc[i][j][r] - m[r]);
+        s[r] += (FULL || in_range(acc[i][j][r])) ? t : 0.f;
+      }
+    }
+    half_sum16(s);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int trow = e.lrow + e.rr(i, r);
+      if ((lane & 31) == 0 && (FULL || m0 + trow < g.L)) rp[(unsigned)(trow * g.PJ)] = make_float2(m[r], s[r]);
+    }
+  }
+  // columns: reduce over the TM*16 rows of the lane and the other half-wave
+  const int pi = ti * Cfg::WM + wm;
+#pragma unroll
+  for (int j = 0; j < Cfg::TN; ++j) {
+    float m = SENTINEL;
+#pragma unroll
+    for (int i = 0; i < Cfg::TM; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) m = fmaxf(m, acc[i][j][r]);
+    m = fmaxf(m, swap32(m));
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < Cfg::TM; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float t = fexp(acc[i][j][r] - m);
+        s += (FULL || in_range(acc[i][j][r])) ? t : 0.f;
+      }
+    s += swap32(s);
+    const int col = n0 + e.lcol + j * 32;
+    if (lane < 32 && (FULL || col < g.S)) colpart[((long)n * g.S + col) * g.PI + pi] = make_float2(m, s);
+  }
+}
+
 template <bool HAS_MASK>
 __global__ __launch_bounds__(Cfg::THREADS, 2) void score_stats_kernel(
     const sp_t* __restrict__ f0, const sp_t* __restrict__ f1, Geometry g, float scale,
@@ -99,45 +170,14 @@ __global__ __launch_bounds__(Cfg::THREADS, 2) void score_stats_kernel(
   const sp_t* b = f1 + (long)n * g.S * g.C;
   f32x16 acc[Cfg::TM][Cfg::TN];
   gemm_mainloop<Cfg>(asrc_plain(a, g.C), b, g.C, g.L, g.S, g.C, m0, n0, lds, acc);
-  acc_to_sim<HAS_MASK>(acc, m0, n0, g.L, g.S, scale, HAS_MASK ? mask0 + (long)n * g.L : nullptr,
-                       HAS_MASK ? mask1 + (long)n * g.S : nullptr);
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int wm = wave / Cfg::WN, wn = wave % Cfg::WN;
-  // rows: reduce over the TN tiles of the lane and the 32 lanes of the half-wave
-  const int pj = tj * Cfg::WN + wn;
-#pragma unroll
-  for (int i = 0; i < Cfg::TM; ++i)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      float m = SENTINEL;
-#pragma unroll
-      for (int j = 0; j < Cfg::TN; ++j) m = fmaxf(m, acc[i][j][r]);
-      m = half_max(m);
-      float s = 0.f;
-#pragma unroll
-      for (int j = 0; j < Cfg::TN; ++j) s += in_range(acc[i][j][r]) ? expf(acc[i][j][r] - m) : 0.f;
-      s = half_sum(s);
-      const int row = acc_row<Cfg>(m0, i, r);
-      if ((lane & 31) == 0 && row < g.L) rowpart[((long)n * g.L + row) * g.PJ + pj] = make_float2(m, s);
-    }
-  // columns: reduce over the TM*16 rows of the lane and the other half-wave
-  const int pi = ti * Cfg::WM + wm;
-#pragma unroll
-  for (int j = 0; j < Cfg::TN; ++j) {
-    float m = SENTINEL;
-#pragma unroll
-    for (int i = 0; i < Cfg::TM; ++i)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) m = fmaxf(m, acc[i][j][r]);
-    m = fmaxf(m, LOFTR_DPP_SWAP32(m));
-    float s = 0.f;
-#pragma unroll
-    for (int i = 0; i < Cfg::TM; ++i)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) s += in_range(acc[i][j][r]) ? expf(acc[i][j][r] - m) : 0.f;
-    s += LOFTR_DPP_SWAP32(s);
-    const int col = acc_col<Cfg>(n0, j);
-    if (lane < 32 && col < g.S) colpart[((long)n * g.S + col) * g.PI + pi] = make_float2(m, s);
+  const uint8_t* mk0 = HAS_MASK ? mask0 + (long)n * g.L : nullptr;
+  const uint8_t* mk1 = HAS_MASK ? mask1 + (long)n * g.S : nullptr;
+  if (m0 + Cfg::BM <= g.L && n0 + Cfg::BN <= g.S) {
+    acc_to_sim<HAS_MASK, true>(acc, m0, n0, g.L, g.S, scale, mk0, mk1);
+    stats_epilogue<true>(acc, g, n, ti, tj, rowpart, colpart);
+  } else {
+    acc_to_sim<HAS_MASK, false>(acc, m0, n0, g.L, g.S, scale, mk0, mk1);
+    stats_epilogue<false>(acc, g, n, ti, tj, rowpart, colpart);
   }
 }
 
@@ -149,11 +189,12 @@ __global__ void merge_stats_kernel(const float2* __restrict__ part, float2* __re
   float m = SENTINEL;
   for (int k = 0; k < P; ++k) m = fmaxf(m, p[k].x);
   float s = 0.f;
-  for (int k = 0; k < P; ++k) s += in_range(p[k].x) ? p[k].y * expf(p[k].x - m) : 0.f;
+  for (int k = 0; k < P; ++k) s += in_range(p[k].x) ? p[k].y * fexp(p[k].x - m) : 0.f;
   stat[i] = make_float2(m, 1.f / s);
 }
 
 // Row (max, first argmax) and column max partials of a tile of conf held in acc.
+template <bool FULL>
 __device__ __forceinline__ void conf_partials(f32x16 (&acc)[Cfg::TM][Cfg::TN], int m0, int n0, int n,
                                               const Geometry& g, int bx, int by,
                                               float2* __restrict__ rowmax_part,
@@ -161,23 +202,28 @@ __device__ __forceinline__ void conf_partials(f32x16 (&acc)[Cfg::TM][Cfg::TN], i
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wm = wave / Cfg::WN, wn = wave % Cfg::WN;
   const int pj = bx * Cfg::WN + wn, pi = by * Cfg::WM + wm;
+  const EpiLane<Cfg> e;
+  float2* rp = rowmax_part + ((long)n * g.L + m0) * g.PJ + pj;
 #pragma unroll
-  for (int i = 0; i < Cfg::TM; ++i)
+  for (int i = 0; i < Cfg::TM; ++i) {
+    f32x16 bv = acc[i][0];
+#pragma unroll
+    for (int j = 1; j < Cfg::TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) bv[r] = fmaxf(bv[r], acc[i][j][r]);
+    half_max16(bv);                                  // maximum over the wave's 64-column strip
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      float bv = -1.f;
-#pragma unroll
-      for (int j = 0; j < Cfg::TN; ++j) bv = fmaxf(bv, acc[i][j][r]);
-      bv = half_max(bv);                             // maximum over the wave's 64-column strip
       int bc = 0x7fffffff;                           // first column that attains it
 #pragma unroll
       for (int j = Cfg::TN - 1; j >= 0; --j)
-        if (acc[i][j][r] == bv) bc = acc_col<Cfg>(n0, j);
+        if (acc[i][j][r] == bv[r]) bc = n0 + e.lcol + j * 32;
       bc = half_min_i32(bc);
-      const int row = acc_row<Cfg>(m0, i, r);
-      if ((lane & 31) == 0 && row < g.L)
-        rowmax_part[((long)n * g.L + row) * g.PJ + pj] = make_float2(bv, __int_as_float(bc));
+      const int trow = e.lrow + e.rr(i, r);
+      if ((lane & 31) == 0 && (FULL || m0 + trow < g.L))
+        rp[(unsigned)(trow * g.PJ)] = make_float2(bv[r], __int_as_float(bc));
     }
+  }
 #pragma unroll
   for (int j = 0; j < Cfg::TN; ++j) {
     float m = -1.f;
@@ -185,14 +231,44 @@ __device__ __forceinline__ void conf_partials(f32x16 (&acc)[Cfg::TM][Cfg::TN], i
     for (int i = 0; i < Cfg::TM; ++i)
 #pragma unroll
       for (int r = 0; r < 16; ++r) m = fmaxf(m, acc[i][j][r]);
-    m = fmaxf(m, LOFTR_DPP_SWAP32(m));
-    const int col = acc_col<Cfg>(n0, j);
-    if (lane < 32 && col < g.S) colmax_part[((long)n * g.S + col) * g.PI + pi] = m;
+    m = fmaxf(m, swap32(m));
+    const int col = n0 + e.lcol + j * 32;
+    if (lane < 32 && (FULL || col < g.S)) colmax_part[((long)n * g.S + col) * g.PI + pi] = m;
   }
 }
 
 // ------------------------------------------------------------------------------------------
-// pass B
+// pass B epilogue: conf = softmax_row * softmax_col, written once
+template <bool FULL>
+__device__ __forceinline__ void conf_epilogue(f32x16 (&acc)[Cfg::TM][Cfg::TN], const Geometry& g, int n, int m0, int n0,
+                                              const float2* __restrict__ rowstat, const float2* __restrict__ colstat,
+                                              float* __restrict__ conf_out) {
+  const EpiLane<Cfg> e;
+  float2 cs[Cfg::TN];
+#pragma unroll
+  for (int j = 0; j < Cfg::TN; ++j) {
+    const int col = n0 + e.lcol + j * 32;
+    cs[j] = colstat[(long)n * g.S + (FULL ? col : min(col, g.S - 1))];
+  }
+  float* co = conf_out ? conf_out + ((long)n * g.L + m0) * g.S + n0 : nullptr;
+#pragma unroll
+  for (int i = 0; i < Cfg::TM; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int trow = e.lrow + e.rr(i, r);
+      const float2 rs = rowstat[(long)n * g.L + (FULL ? m0 + trow : min(m0 + trow, g.L - 1))];
+#pragma unroll
+      for (int j = 0; j < Cfg::TN; ++j) {
+        const float v = acc[i][j][r];
+        // softmax(sim, dim=1) * softmax(sim, dim=2)          coarse_matching.py:119
+        float c = (fexp(v - cs[j].x) * cs[j].y) * (fexp(v - rs.x) * rs.y);
+        if (!FULL) { if (!in_range(v)) c = -1.f; }             // out of range: below any confidence
+        if (co && (FULL || c >= 0.f)) co[(unsigned)(trow * g.S + e.lcol + j * 32)] = c;
+        acc[i][j][r] = c;
+      }
+    }
+}
+
 template <bool HAS_MASK>
 __global__ __launch_bounds__(Cfg::THREADS, 2) void score_conf_kernel(
     const sp_t* __restrict__ f0, const sp_t* __restrict__ f1, Geometry g, float scale,
@@ -207,33 +283,17 @@ __global__ __launch_bounds__(Cfg::THREADS, 2) void score_conf_kernel(
   const sp_t* b = f1 + (long)n * g.S * g.C;
   f32x16 acc[Cfg::TM][Cfg::TN];
   gemm_mainloop<Cfg>(asrc_plain(a, g.C), b, g.C, g.L, g.S, g.C, m0, n0, lds, acc);
-  acc_to_sim<HAS_MASK>(acc, m0, n0, g.L, g.S, scale, HAS_MASK ? mask0 + (long)n * g.L : nullptr,
-                       HAS_MASK ? mask1 + (long)n * g.S : nullptr);
-  float2 cs[Cfg::TN];
-#pragma unroll
-  for (int j = 0; j < Cfg::TN; ++j) {
-    const int col = min(acc_col<Cfg>(n0, j), g.S - 1);
-    cs[j] = colstat[(long)n * g.S + col];
+  const uint8_t* mk0 = HAS_MASK ? mask0 + (long)n * g.L : nullptr;
+  const uint8_t* mk1 = HAS_MASK ? mask1 + (long)n * g.S : nullptr;
+  if (m0 + Cfg::BM <= g.L && n0 + Cfg::BN <= g.S) {
+    acc_to_sim<HAS_MASK, true>(acc, m0, n0, g.L, g.S, scale, mk0, mk1);
+    conf_epilogue<true>(acc, g, n, m0, n0, rowstat, colstat, conf_out);
+    conf_partials<true>(acc, m0, n0, n, g, tj, ti, rowmax_part, colmax_part);
+  } else {
+    acc_to_sim<HAS_MASK, false>(acc, m0, n0, g.L, g.S, scale, mk0, mk1);
+    conf_epilogue<false>(acc, g, n, m0, n0, rowstat, colstat, conf_out);
+    conf_partials<false>(acc, m0, n0, n, g, tj, ti, rowmax_part, colmax_part);
   }
-#pragma unroll
-  for (int i = 0; i < Cfg::TM; ++i)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = acc_row<Cfg>(m0, i, r);
-      const float2 rs = rowstat[(long)n * g.L + min(row, g.L - 1)];
-#pragma unroll
-      for (int j = 0; j < Cfg::TN; ++j) {
-        const float v = acc[i][j][r];
-        float c = -1.f;                                        // out of range: below any confidence
-        if (in_range(v)) {
-          // softmax(sim, dim=1) * softmax(sim, dim=2)          coarse_matching.py:119
-          c = (expf(v - cs[j].x) * cs[j].y) * (expf(v - rs.x) * rs.y);
-          if (conf_out) conf_out[((long)n * g.L + row) * g.S + acc_col<Cfg>(n0, j)] = c;
-        }
-        acc[i][j][r] = c;
-      }
-    }
-  conf_partials(acc, m0, n0, n, g, tj, ti, rowmax_part, colmax_part);
 }
 
 __global__ void merge_colmax_kernel(const float* __restrict__ part, float* __restrict__ colmax, long cols, int P) {
@@ -413,8 +473,8 @@ __global__ __launch_bounds__(Cfg::THREADS, 2) void score_store_kernel(const sp_t
   f32x16 acc[Cfg::TM][Cfg::TN];
   gemm_mainloop<Cfg>(asrc_plain(f0 + (long)n * g.L * g.C, g.C), f1 + (long)n * g.S * g.C, g.C, g.L, g.S, g.C,
                      m0, n0, lds, acc);
-  if (mask0) acc_to_sim<true>(acc, m0, n0, g.L, g.S, scale, mask0 + (long)n * g.L, mask1 + (long)n * g.S);
-  else acc_to_sim<false>(acc, m0, n0, g.L, g.S, scale, nullptr, nullptr);
+  if (mask0) acc_to_sim<true, false>(acc, m0, n0, g.L, g.S, scale, mask0 + (long)n * g.L, mask1 + (long)n * g.S);
+  else acc_to_sim<false, false>(acc, m0, n0, g.L, g.S, scale, nullptr, nullptr);
 #pragma unroll
   for (int i = 0; i < Cfg::TM; ++i)
 #pragma unroll
@@ -563,7 +623,7 @@ __global__ __launch_bounds__(Cfg::THREADS, 2) void ot_finalize_kernel(float* __r
         acc[i][j][r] = c;
       }
     }
-  conf_partials(acc, m0, n0, n, g, blockIdx.x, blockIdx.y, rowmax_part, colmax_part);
+  conf_partials<false>(acc, m0, n0, n, g, blockIdx.x, blockIdx.y, rowmax_part, colmax_part);
 }
 
 // dustbin column / row / corner of the assignment matrix

@@ -81,54 +81,74 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 // Reductions across the 32 lanes of one half-wave (lanes that share lane>>5), result in ALL of them.
-// DPP only (quad_perm, row_half_mirror, row_mirror, row_bcast15) + two v_readlane: no LDS-crossbar
-// ds_bpermute traffic (what __shfl_xor compiles to), which the GEMM epilogues would otherwise issue
-// five times per accumulator register.
+// Four DPP steps reduce inside each row of 16 lanes (quad_perm x2, row_half_mirror, row_mirror), one
+// v_permlane16_swap (gfx950) exchanges the two rows: no LDS-crossbar ds_bpermute traffic (what
+// __shfl_xor compiles to), which the GEMM epilogues would otherwise issue five times per register.
 #define LOFTR_DPP(v_, ctrl_) __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v_), ctrl_, 0xF, 0xF, true))
-__device__ __forceinline__ float half_bcast(float v) {          // lanes 16-31 / 48-63 hold the result
-  const float lo = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 31));
-  const float hi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
-  return (threadIdx.x & 32) ? hi : lo;
-}
+#define LOFTR_DPPI(v_, ctrl_) __builtin_amdgcn_update_dpp(0, v_, ctrl_, 0xF, 0xF, true)
 __device__ __forceinline__ float half_sum(float v) {
   v += LOFTR_DPP(v, 0xB1);        // quad_perm [1,0,3,2]
   v += LOFTR_DPP(v, 0x4E);        // quad_perm [2,3,0,1]
   v += LOFTR_DPP(v, 0x141);       // row_half_mirror
   v += LOFTR_DPP(v, 0x140);       // row_mirror            -> every lane: sum of its row of 16
-  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x142, 0xA, 0xF, false));  // row_bcast15 into rows 1,3
-  return half_bcast(v);
-}
-// value held by lane ^ 32 (the other half-wave): one v_permlane32_swap, no LDS crossbar
-__device__ __forceinline__ float swap32(float v) {
-#if __has_builtin(__builtin_amdgcn_permlane32_swap)
-  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_int(v), __float_as_int(v), false, false);
-  return __int_as_float((threadIdx.x & 32) ? r[0] : r[1]);
-#else
-  return __shfl_xor(v, 32, 64);
-#endif
-}
-#define LOFTR_DPP_SWAP32(v_) swap32(v_)
-
-// first (smallest) index over the half-wave; INT_MAX lanes do not participate
-__device__ __forceinline__ int half_min_i32(int v) {
-#define LOFTR_DPPI(v_, ctrl_) __builtin_amdgcn_update_dpp(0x7fffffff, v_, ctrl_, 0xF, 0xF, false)
-  v = min(v, LOFTR_DPPI(v, 0xB1));
-  v = min(v, LOFTR_DPPI(v, 0x4E));
-  v = min(v, LOFTR_DPPI(v, 0x141));
-  v = min(v, LOFTR_DPPI(v, 0x140));
-  v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x142, 0xA, 0xF, false));
-#undef LOFTR_DPPI
-  const int lo = __builtin_amdgcn_readlane(v, 31), hi = __builtin_amdgcn_readlane(v, 63);
-  return (threadIdx.x & 32) ? hi : lo;
+  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_int(v), __float_as_int(v), false, false);
+  return __int_as_float(r[0]) + __int_as_float(r[1]);      // rows (0,1) / (2,3) combined
 }
 __device__ __forceinline__ float half_max(float v) {
   v = fmaxf(v, LOFTR_DPP(v, 0xB1));
   v = fmaxf(v, LOFTR_DPP(v, 0x4E));
   v = fmaxf(v, LOFTR_DPP(v, 0x141));
   v = fmaxf(v, LOFTR_DPP(v, 0x140));
-  v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x142, 0xA, 0xF, false)));
-  return half_bcast(v);
+  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_int(v), __float_as_int(v), false, false);
+  return fmaxf(__int_as_float(r[0]), __int_as_float(r[1]));
 }
+// first (smallest) index over the half-wave; INT_MAX lanes do not participate
+__device__ __forceinline__ int half_min_i32(int v) {
+  v = min(v, LOFTR_DPPI(v, 0xB1));
+  v = min(v, LOFTR_DPPI(v, 0x4E));
+  v = min(v, LOFTR_DPPI(v, 0x141));
+  v = min(v, LOFTR_DPPI(v, 0x140));
+  const auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+  return min((int)r[0], (int)r[1]);
+}
+// The same for the 16 accumulator registers of an MFMA tile at once, stage by stage, so that the DPP
+// steps of different registers issue back to back instead of each waiting out its VALU->DPP hazard.
+__device__ __forceinline__ void half_sum16(f32x16& v) {
+#pragma unroll
+  for (int r = 0; r < 16; ++r) v[r] += LOFTR_DPP(v[r], 0xB1);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) v[r] += LOFTR_DPP(v[r], 0x4E);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) v[r] += LOFTR_DPP(v[r], 0x141);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) v[r] += LOFTR_DPP(v[r], 0x140);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const auto q = __builtin_amdgcn_permlane16_swap(__float_as_int(v[r]), __float_as_int(v[r]), false, false);
+    v[r] = __int_as_float(q[0]) + __int_as_float(q[1]);
+  }
+}
+__device__ __forceinline__ void half_max16(f32x16& v) {
+#pragma unroll
+  for (int r = 0; r < 16; ++r) v[r] = fmaxf(v[r], LOFTR_DPP(v[r], 0xB1));
+#pragma unroll
+  for (int r = 0; r < 16; ++r) v[r] = fmaxf(v[r], LOFTR_DPP(v[r], 0x4E));
+#pragma unroll
+  for (int r = 0; r < 16; ++r) v[r] = fmaxf(v[r], LOFTR_DPP(v[r], 0x141));
+#pragma unroll
+  for (int r = 0; r < 16; ++r) v[r] = fmaxf(v[r], LOFTR_DPP(v[r], 0x140));
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const auto q = __builtin_amdgcn_permlane16_swap(__float_as_int(v[r]), __float_as_int(v[r]), false, false);
+    v[r] = fmaxf(__int_as_float(q[0]), __int_as_float(q[1]));
+  }
+}
+// value held by lane ^ 32 (the other half-wave): one v_permlane32_swap, no LDS crossbar
+__device__ __forceinline__ float swap32(float v) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_int(v), __float_as_int(v), false, false);
+  return __int_as_float((threadIdx.x & 32) ? r[0] : r[1]);
+}
+#define LOFTR_DPP_SWAP32(v_) swap32(v_)
 
 __device__ __forceinline__ float elu1(float x) {     // elu(x)+1, linear_attention.py:10-11
   return x > 0.f ? x + 1.f : __expf(x);               // expm1(x)+1 == exp(x)

@@ -118,11 +118,10 @@ __device__ __forceinline__ void proj_epilogue(const ProjArgs& p, f32x16 (&acc)[C
       }
       if (ZSCALE) {
         // the 32 lanes of this half-wave hold the 32 channels of one head of each of these rows
+        f32x16 den = v * ksum;
+        half_sum16(den);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float den = half_sum(v[r] * ksum);
-          v[r] *= p.v_length / (den + p.eps);
-        }
+        for (int r = 0; r < 16; ++r) v[r] *= p.v_length / (den[r] + p.eps);
         uint32_t w[16];
         sp_words16(v, e.odd, w);
         sp_t* os = reinterpret_cast<sp_t*>(p.out[seg]) + (row_base + m0) * p.C + n0;
@@ -198,15 +197,15 @@ __global__ __launch_bounds__(Cfg::THREADS, 2) void linear_ln_kernel(LinearLNArgs
   float* rstd_s = mean_s + Cfg::BM;                 // [BM]
   // pass 1: mean
 #pragma unroll
-  for (int i = 0; i < Cfg::TM; ++i)
+  for (int i = 0; i < Cfg::TM; ++i) {
+    f32x16 s = acc[i][0];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      float s = 0.f;
+    for (int j = 1; j < Cfg::TN; ++j) s += acc[i][j];
+    half_sum16(s);
 #pragma unroll
-      for (int j = 0; j < Cfg::TN; ++j) s += acc[i][j][r];
-      s = half_sum(s);
-      if ((lane & 31) == 0) red[(e.lrow + e.rr(i, r)) * Cfg::WN + wn] = s;
-    }
+    for (int r = 0; r < 16; ++r)
+      if ((lane & 31) == 0) red[(e.lrow + e.rr(i, r)) * Cfg::WN + wn] = s[r];
+  }
   __syncthreads();
   if (threadIdx.x < Cfg::BM) {
     float s = 0.f;
@@ -218,16 +217,20 @@ __global__ __launch_bounds__(Cfg::THREADS, 2) void linear_ln_kernel(LinearLNArgs
   // pass 2: variance of the deviations (two-pass, like a reference LayerNorm in fp32)
   float mu[Cfg::TM][16];
 #pragma unroll
-  for (int i = 0; i < Cfg::TM; ++i)
+  for (int i = 0; i < Cfg::TM; ++i) {
+    f32x16 s;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       mu[i][r] = mean_s[e.lrow + e.rr(i, r)];
-      float s = 0.f;
+      s[r] = 0.f;
 #pragma unroll
-      for (int j = 0; j < Cfg::TN; ++j) { float d = acc[i][j][r] - mu[i][r]; s += d * d; }
-      s = half_sum(s);
-      if ((lane & 31) == 0) red[(e.lrow + e.rr(i, r)) * Cfg::WN + wn] = s;
+      for (int j = 0; j < Cfg::TN; ++j) { float d = acc[i][j][r] - mu[i][r]; s[r] += d * d; }
     }
+    half_sum16(s);
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      if ((lane & 31) == 0) red[(e.lrow + e.rr(i, r)) * Cfg::WN + wn] = s[r];
+  }
   __syncthreads();
   if (threadIdx.x < Cfg::BM) {
     float s = 0.f;

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Summarise a rocprofv3 (rocpd sqlite) kernel trace: per-kernel calls / total / avg / min / max / %.
 
-    python tools/rocpd_summary.py gpurun_out/prof/r01_results.db > profiles/r01_kernel_stats.txt
+    python tools/rocpd_summary.py gpurun_out/prof/r01_results.db [naive_conv] > profiles/r01_kernel_stats.txt
 """
 import re
 import sqlite3
@@ -14,14 +14,23 @@ def short(name):
     return name if len(name) <= 110 else name[:107] + "..."
 
 
-def main(path):
+def main(path, skip_until=None):
     db = sqlite3.connect(path)
     cols = [r[1] for r in db.execute("pragma table_info(kernels)")]
     namecol = "name" if "name" in cols else "kernel_name"
+    where = ""
+    note = ""
+    if skip_until:
+        # drop everything up to the last dispatch of a kernel whose name contains `skip_until`
+        # (MIOpen's find-mode trial kernels during warm-up would otherwise drown the summary)
+        t = db.execute(f"select max(end) from kernels where {namecol} like ?", (f"%{skip_until}%",)).fetchone()[0]
+        if t:
+            where = f"where start > {t}"
+            note = f"   [dispatches after the last '{skip_until}' kernel only]"
     rows = db.execute(f"select {namecol}, count(*), sum(end-start), avg(end-start), min(end-start), max(end-start) "
-                      f"from kernels group by {namecol} order by 3 desc").fetchall()
+                      f"from kernels {where} group by {namecol} order by 3 desc").fetchall()
     total = sum(r[2] for r in rows)
-    print(f"# source: {path}   (rocprofv3 --kernel-trace --stats; durations in microseconds)")
+    print(f"# source: {path}   (rocprofv3 --kernel-trace --stats; durations in microseconds){note}")
     print(f"# total GPU kernel time: {total / 1e6:.3f} ms over {sum(r[1] for r in rows)} dispatches")
     print(f"{'calls':>7} {'total_us':>12} {'avg_us':>10} {'min_us':>10} {'max_us':>10} {'pct':>6}  kernel")
     for n, c, t, a, mn, mx in rows:
@@ -29,4 +38,4 @@ def main(path):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1])
+    main(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else None)
