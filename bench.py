@@ -42,7 +42,11 @@ from loftr_amd.synth import make_images, make_weights   # noqa: E402
 
 H_IMG, W_IMG = 480, 640
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-MFMA_F32_PEAK_TF = 157.3       # MI355X_MICROARCH.md: fp32-input MFMA = fp32 vector peak
+MFMA_F16_PEAK_TF = 2500.0      # MI355X_MICROARCH.md: dense fp16/bf16 MFMA peak
+MFMA_F32_PEAK_TF = 157.3       # MI355X_MICROARCH.md: fp32-input MFMA = fp32 vector peak (for context only)
+SPLIT_FACTOR = 3               # every fp32 product = 3 fp16 MFMAs (hi*hi + hi*lo + lo*hi), csrc/gemm.h
+GEMM_KERNELS = ("proj_kernel", "linear_kernel", "linear_ln_kernel", "score_stats_kernel", "score_conf_kernel",
+                "conv_kernel")
 
 K_IDS = {}
 
@@ -89,22 +93,51 @@ def algorithmic_work(B, L, S, M, C_=256, Cf=128, WW=25):
     w["score_stats_kernel"] = (2 * B * L * S * C_, 4 * B * (L + S) * C_)
     w["score_conf_kernel"] = (2 * B * L * S * C_, 4 * B * ((L + S) * C_ + L * S))
     w["gather_windows_kernel"] = (0, 2 * 4 * 2 * M * WW * Cf)
+    # backbone convolutions on the same GEMM core (conv.hip): ResNetFPN_8_2 over 2B images of 480x640
+    flops = nbytes = 0
+    for (cin, cout, k, stride, hin, win) in backbone_convs(H_IMG, W_IMG):
+        ho, wo = hin // stride, win // stride
+        flops += 2 * 2 * B * ho * wo * cout * cin * k * k
+        nbytes += 4 * 2 * B * (hin * win * cin + ho * wo * cout) + 4 * cout * cin * k * k
+    w["conv_kernel"] = (flops, nbytes)
     return w
 
 
+def backbone_convs(h, w):
+    """(cin, cout, k, stride, h_in, w_in) of every convolution conv.hip runs (resnet_fpn.py:43-118 minus the stem)."""
+    h2, w2, h4, w4, h8, w8 = h // 2, w // 2, h // 4, w // 4, h // 8, w // 8
+    L = []
+    L += [(128, 128, 3, 1, h2, w2)] * 4                                                   # layer1
+    L += [(128, 196, 3, 2, h2, w2), (128, 196, 1, 2, h2, w2)] + [(196, 196, 3, 1, h4, w4)] * 3   # layer2
+    L += [(196, 256, 3, 2, h4, w4), (196, 256, 1, 2, h4, w4)] + [(256, 256, 3, 1, h8, w8)] * 3   # layer3
+    L += [(256, 256, 1, 1, h8, w8), (196, 256, 1, 1, h4, w4), (256, 256, 3, 1, h4, w4), (256, 196, 3, 1, h4, w4)]
+    L += [(128, 196, 1, 1, h2, w2), (196, 196, 3, 1, h2, w2), (196, 128, 3, 1, h2, w2)]
+    return L
+
+
 def roofline_entry(name, total_ms, launches, flops, nbytes, steps):
+    """Roofline of one kernel.  `flops` / `nbytes` are ALGORITHMIC per step.  For the GEMM
+    kernels the matrix-core figure is the EXECUTED fp16 MFMA rate (3 MFMAs per fp32 product) against the
+    dense fp16 peak; the algorithmic fp32-equivalent rate and its ratio to the fp32-MFMA peak (what a
+    plain fp32 implementation is bounded by) are reported next to it."""
     if launches == 0 or total_ms <= 0:
         return None
     per_launch_ms = total_ms / launches
     t = total_ms / steps * 1e-3                      # seconds per step spent in this kernel
     gbs, tf = nbytes / t / 1e9, flops / t / 1e12
-    f_h, f_m = gbs / HBM_PEAK_GBS, tf / MFMA_F32_PEAK_TF
+    exec_tf = tf * (SPLIT_FACTOR if name in GEMM_KERNELS else 1)
+    peak_tf = MFMA_F16_PEAK_TF if name in GEMM_KERNELS else MFMA_F32_PEAK_TF
+    f_h, f_m = gbs / HBM_PEAK_GBS, exec_tf / peak_tf
     bound = "hbm" if f_h >= f_m else "mfma"
-    e = {"kernel": name, "bound": bound, "achieved": round(gbs if bound == "hbm" else tf, 2),
-         "peak": HBM_PEAK_GBS if bound == "hbm" else MFMA_F32_PEAK_TF,
+    e = {"kernel": name, "bound": bound, "achieved": round(gbs if bound == "hbm" else exec_tf, 2),
+         "peak": HBM_PEAK_GBS if bound == "hbm" else peak_tf,
          "unit": "GB/s" if bound == "hbm" else "TFLOP/s", "frac": round(max(f_h, f_m), 4), "traffic": None,
          "avg_launch_us": round(per_launch_ms * 1e3, 2), "launches_per_step": round(launches / steps, 2),
-         "ms_per_step": round(total_ms / steps, 4), "alg_GB_s": round(gbs, 1), "alg_TFLOP_s": round(tf, 2)}
+         "ms_per_step": round(total_ms / steps, 4), "alg_GB_s": round(gbs, 1), "hbm_frac": round(f_h, 4),
+         "alg_TFLOP_s": round(tf, 2), "mfma_frac": round(f_m, 4)}
+    if name in GEMM_KERNELS:
+        e["executed_fp16_TFLOP_s"] = round(exec_tf, 1)
+        e["x_fp32_mfma_peak"] = round(tf / MFMA_F32_PEAK_TF, 3)
     return e
 
 
@@ -153,6 +186,8 @@ def main():
     ap.add_argument("--no-conf", action="store_true", help="elide data['conf_matrix'] (not the headline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--roofline-kernel", default="auto")
+    ap.add_argument("--backbone", default="hip", choices=["hip", "torch"],
+                    help="hip: implicit-GEMM convolutions of this library (default); torch: MIOpen fp32")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -182,6 +217,7 @@ def main():
     model.load_state_dict(sd, strict=False)
     model = model.to(dev)
     model.coarse_matching.materialize_conf = not args.no_conf
+    model.backbone_impl = args.backbone
     B = args.batch
     i0, i1 = make_images(1234 + rank, B, H_IMG, W_IMG)
     img0, img1 = torch.from_numpy(i0).to(dev), torch.from_numpy(i1).to(dev)
@@ -208,16 +244,20 @@ def main():
     lib.loftr_hip_timing_enable((1 << len(ids)) - 1)
     for kid in ids.values():
         read_timing(lib, kid)
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
-    with torch.no_grad():
-        data = {"image0": img0, "image1": img1}
-        ev[0].record()
-        feats = model.run_backbone(data)
-        ev[1].record()
-        model.match_from_features(*feats, data)
-        ev[2].record()
-    torch.cuda.synchronize()
-    backbone_ms, hot_ms = ev[0].elapsed_time(ev[1]), ev[1].elapsed_time(ev[2])
+    NB = 3                                                   # instrumented steps for the breakdown
+    backbone_ms = hot_ms = 0.0
+    for _ in range(NB):
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        with torch.no_grad():
+            data = {"image0": img0, "image1": img1}
+            ev[0].record()
+            feats = model.run_backbone(data)
+            ev[1].record()
+            model.match_from_features(*feats, data)
+            ev[2].record()
+        torch.cuda.synchronize()
+        backbone_ms += ev[0].elapsed_time(ev[1]) / NB
+        hot_ms += ev[1].elapsed_time(ev[2]) / NB
     M = int(data["mconf"].shape[0])
     L = (H_IMG // 8) * (W_IMG // 8)
     work = algorithmic_work(B, L, L, M)
@@ -225,7 +265,7 @@ def main():
     for name, kid in ids.items():
         ms, n = read_timing(lib, kid)
         if name in work and n:
-            kernels.append(roofline_entry(name, ms, n, work[name][0], work[name][1], 1))
+            kernels.append(roofline_entry(name, ms, n, work[name][0], work[name][1], NB))
     kernels = [k for k in kernels if k]
     kernels.sort(key=lambda k: -k["ms_per_step"])
     dom = args.roofline_kernel if args.roofline_kernel != "auto" else (kernels[0]["kernel"] if kernels else None)
@@ -264,14 +304,16 @@ def main():
             "metric": "image-pairs/sec @640x480 indoor-ds", "value": round(value, 3), "unit": "image-pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "dtype_note": "fp32 data everywhere; backbone = MIOpen fp32; HIP GEMMs evaluate every fp32 product as 3 fp16 "
+                          "MFMAs on a (hi, lo) fp16 split with fp32 accumulation (fp32-class accuracy, csrc/gemm.h)",
             "config": {"workload": f"batch={B} 640x480 synthetic grayscale pairs per GPU, indoor_ds dual-softmax "
-                                   f"(BASELINE configs[1]), full LoFTR.forward = PyTorch-ROCm backbone + HIP matching path",
+                                   f"(BASELINE configs[1]), full LoFTR.forward = ResNet-FPN backbone ({'HIP implicit-GEMM convs, 7x7 stem in MIOpen' if args.backbone == 'hip' else 'PyTorch-ROCm / MIOpen fp32'}) + HIP matching path",
                        "weights": "seeded random init (no checkpoint on the box)", "thr": args.thr,
                        "thr_note": "stock thr 0.2 gives 0 matches with random weights; thr 0.0 keeps the fine stage loaded",
                        "conf_matrix_materialised": not args.no_conf, "matches_per_pair": round(m_total / (world * B), 1),
                        "global_batch": world * B, "parallelism": f"dp{world} (pairs sharded; RCCL all-gather of match counts)"},
-            "stage_ms": {"backbone_pytorch": round(backbone_ms, 3), "hot_path_hip": round(hot_ms, 3),
-                         "note": "one instrumented step, torch.cuda events on the launch stream"},
+            "stage_ms": {"backbone": round(backbone_ms, 3), "backbone_impl": args.backbone, "hot_path_hip": round(hot_ms, 3),
+                         "note": "mean of 3 instrumented steps, torch.cuda events on the launch stream"},
             "hot_path_pairs_per_s": round(B / (hot_ms * 1e-3), 2),
             "roofline": roof, "kernels": kernels,
         }

@@ -34,7 +34,7 @@ typedef enum {
   LOFTR_ERR_NO_DEVICE = -5      /* no gfx950 device visible                                    */
 } loftr_status;
 
-#define LOFTR_HIP_ABI_VERSION 3
+#define LOFTR_HIP_ABI_VERSION 4
 
 int loftr_hip_abi_version(void);
 const char* loftr_hip_status_string(int status);
@@ -169,6 +169,30 @@ int loftr_fine_preprocess(const loftr_fmap* feat_f0, const loftr_fmap* feat_f1,
 int loftr_fine_match(const float* feat_f0, const float* feat_f1, int M, int WW, int C,
                      const float* mkpts1_c, const int64_t* b_ids, float scale,
                      const float* scale1, float* expec_f, float* mkpts1_f, void* stream);
+
+/* ---- ResNet-FPN building blocks (the caller side of the path) -----------------
+ * Activations are NHWC tensors in the library's SP GEMM-operand format: uint32 [B, H, W, Cp] with
+ * Cp = C rounded up to a multiple of 32; per 32-channel group 16 dwords of fp16 "hi" halves then 16 dwords
+ * of fp16 "lo" halves (x ~= hi + lo, csrc/gemm.h); pad channels are zero.  loftr_sp_from_f32 /
+ * loftr_sp_to_f32 convert from / to plain fp32 NHWC.
+ *
+ * loftr_conv_bn_act replaces nn.Conv2d (bias=False) [+ eval-mode nn.BatchNorm2d] [+ residual add]
+ * [+ ReLU / LeakyReLU] of src/loftr/backbone/resnet_fpn.py:5-40,100-118 as ONE implicit-GEMM kernel:
+ *   x_sp [B,H,W,ceil32(Cin)], weight [Cout,Cin,KH,KW] fp32 as in the state_dict, addressed through its four
+ *   element strides (contiguous or channels-last storage), bn_* [Cout] or all NULL,
+ *   act: 0 none, 1 ReLU, 2 LeakyReLU(0.01); residual_sp [B,Ho,Wo,ceil32(Cout)] or NULL (added before act);
+ *   outputs y_sp (SP) and / or y_f32 (fp32 [B,Ho,Wo,Cout]); Ho = (H + 2 pad - KH) / stride + 1.
+ * loftr_upsample2x_add replaces F.interpolate(scale_factor=2, bilinear, align_corners=True) + add (:111-116). */
+size_t loftr_conv_workspace_bytes(int Cin, int Cout, int KH, int KW);
+int loftr_conv_bn_act(const uint32_t* x_sp, int B, int H, int W, int Cin, const float* weight,
+                      const long* weight_strides, int Cout, int KH, int KW, int stride, int pad, const float* bn_weight, const float* bn_bias,
+                      const float* bn_mean, const float* bn_var, float bn_eps, int act,
+                      const uint32_t* residual_sp, uint32_t* y_sp, float* y_f32, void* ws, size_t ws_bytes,
+                      void* stream);
+int loftr_upsample2x_add(const uint32_t* low_sp, const uint32_t* lateral_sp, uint32_t* out_sp, int B, int Hl,
+                         int Wl, int C, void* stream);
+int loftr_sp_from_f32(const float* src, uint32_t* dst_sp, long rows, int C, void* stream);
+int loftr_sp_to_f32(const uint32_t* src_sp, float* dst, long rows, int C, void* stream);
 
 /* ---- per-kernel timing (profiling aid; the only process-global state of the library) ---------
  * When bit `id` of the mask is set, every launch of that kernel is bracketed by hipEvents

@@ -1,12 +1,24 @@
-"""ResNet-FPN local feature CNN -- stays in PyTorch-ROCm (MIOpen), per BASELINE.json north_star.
+"""ResNet-FPN local feature CNN.
 
 Architecture and parameter names follow src/loftr/backbone/resnet_fpn.py:43-199 of the reference
 so that its checkpoints load with strict=True (``backbone.conv1.weight``,
-``backbone.layer1.0.conv1.weight`` ...).  Out of the hand-written hot path; it only *feeds* it
-(feat_c at 1/8 or 1/16 resolution, feat_f at 1/2 or 1/4).
+``backbone.layer1.0.conv1.weight`` ...).  It *feeds* the matching path (feat_c at 1/8 or 1/16
+resolution, feat_f at 1/2 or 1/4).
+
+Two execution paths over the same parameters:
+  * ``forward``      -- plain PyTorch-ROCm / MIOpen fp32 (what BASELINE.json's north_star keeps in
+                        PyTorch; also the reference the HIP path is tested against);
+  * ``forward_hip``  -- SURVEY.md §8(f) rank 1, the caller side of the hot path: every conv3x3 / conv1x1
+                        (+ folded eval BatchNorm + residual + ReLU / LeakyReLU) is one implicit-GEMM
+                        launch of the library's split-fp16 MFMA core (csrc/conv.hip), the FPN
+                        upsample+add one more kernel; only the 1-channel 7x7 stem stays in MIOpen.
+``LoFTR`` uses ``forward_hip`` on the GPU in eval mode (``backbone_impl='hip'``).
 """
+import torch
 import torch.nn as nn
 import torch.nn.functional as F
+
+from . import ops
 
 
 def _c1(cin, cout, stride=1):
@@ -59,6 +71,42 @@ class _ResNetFPN(nn.Module):
     def _up(x):
         return F.interpolate(x, scale_factor=2., mode="bilinear", align_corners=True)
 
+    # ---- HIP path helpers: an activation is (SP int32 tensor [B,H,W,ceil32(C)], C) -----------------
+    def _stem_hip(self, x):
+        """conv1 (7x7, one input channel) + bn1 + relu stay in MIOpen; hand over as SP NHWC."""
+        x0 = self.relu(self.bn1(self.conv1(x)))                       # channels-last fp32
+        return ops.sp_from_nhwc(x0.permute(0, 2, 3, 1).contiguous()), x0.shape[1]
+
+    @staticmethod
+    def _block_hip(blk, a):
+        """BasicBlock.forward (resnet_fpn.py:33-40) on an SP activation."""
+        x, cin = a
+        planes = blk.conv1.out_channels
+        y, _ = ops.conv_bn_act(x, cin, blk.conv1, blk.bn1, act=1)
+        res = x
+        if blk.downsample is not None:
+            res, _ = ops.conv_bn_act(x, cin, blk.downsample[0], blk.downsample[1], act=0)
+        y, _ = ops.conv_bn_act(y, planes, blk.conv2, blk.bn2, act=1, residual=res)      # relu(x + y)
+        return y, planes
+
+    @classmethod
+    def _stage_hip(cls, stage, a):
+        for blk in stage:
+            a = cls._block_hip(blk, a)
+        return a
+
+    @staticmethod
+    def _head_hip(head, a, want_f32):
+        """_fuse_head: conv3x3 + BN + LeakyReLU + conv3x3 (resnet_fpn.py:66-77)."""
+        x, cin = a
+        y, _ = ops.conv_bn_act(x, cin, head[0], head[1], act=2)
+        return ops.conv_bn_act(y, head[0].out_channels, head[3], None, act=0, want_sp=not want_f32, want_f32=want_f32)
+
+    @staticmethod
+    def _nchw_view(y_nhwc):
+        """fp32 [B,H,W,C] -> logical [B,C,H,W] with channels-last strides (no copy)."""
+        return y_nhwc.permute(0, 3, 1, 2)
+
 
 class ResNetFPN_8_2(_ResNetFPN):
     """Outputs at 1/8 (coarse) and 1/2 (fine).  resnet_fpn.py:43-118."""
@@ -90,6 +138,24 @@ class ResNetFPN_8_2(_ResNetFPN):
         x2_out = self.layer2_outconv2(self.layer2_outconv(x2) + self._up(x3_out))
         x1_out = self.layer1_outconv2(self.layer1_outconv(x1) + self._up(x2_out))
         return [x3_out, x1_out]
+
+    @torch.no_grad()
+    def forward_hip(self, x):
+        """Same function as ``forward`` (resnet_fpn.py:100-118) on the HIP implicit-GEMM convolutions."""
+        a0 = self._stem_hip(x)
+        a1 = self._stage_hip(self.layer1, a0)       # 1/2
+        a2 = self._stage_hip(self.layer2, a1)       # 1/4
+        a3 = self._stage_hip(self.layer3, a2)       # 1/8
+        d3 = self.layer3_outconv.out_channels
+        x3_sp, x3_f32 = ops.conv_bn_act(a3[0], a3[1], self.layer3_outconv, want_f32=True)
+        x2_lat, _ = ops.conv_bn_act(a2[0], a2[1], self.layer2_outconv)
+        t2 = ops.upsample2x_add(x3_sp, x2_lat, d3)
+        x2_out, _ = self._head_hip(self.layer2_outconv2, (t2, d3), want_f32=False)
+        d2 = self.layer2_outconv2[3].out_channels
+        x1_lat, _ = ops.conv_bn_act(a1[0], a1[1], self.layer1_outconv)
+        t1 = ops.upsample2x_add(x2_out, x1_lat, d2)
+        _, x1_f32 = self._head_hip(self.layer1_outconv2, (t1, d2), want_f32=True)
+        return [self._nchw_view(x3_f32), self._nchw_view(x1_f32)]
 
 
 class ResNetFPN_16_4(_ResNetFPN):
@@ -124,6 +190,25 @@ class ResNetFPN_16_4(_ResNetFPN):
         x3_out = self.layer3_outconv2(self.layer3_outconv(x3) + self._up(x4_out))
         x2_out = self.layer2_outconv2(self.layer2_outconv(x2) + self._up(x3_out))
         return [x4_out, x2_out]
+
+    @torch.no_grad()
+    def forward_hip(self, x):
+        """Same function as ``forward`` (resnet_fpn.py:178-199) on the HIP implicit-GEMM convolutions."""
+        a0 = self._stem_hip(x)
+        a1 = self._stage_hip(self.layer1, a0)       # 1/2
+        a2 = self._stage_hip(self.layer2, a1)       # 1/4
+        a3 = self._stage_hip(self.layer3, a2)       # 1/8
+        a4 = self._stage_hip(self.layer4, a3)       # 1/16
+        d4 = self.layer4_outconv.out_channels
+        x4_sp, x4_f32 = ops.conv_bn_act(a4[0], a4[1], self.layer4_outconv, want_f32=True)
+        x3_lat, _ = ops.conv_bn_act(a3[0], a3[1], self.layer3_outconv)
+        t3 = ops.upsample2x_add(x4_sp, x3_lat, d4)
+        x3_out, _ = self._head_hip(self.layer3_outconv2, (t3, d4), want_f32=False)
+        d3 = self.layer3_outconv2[3].out_channels
+        x2_lat, _ = ops.conv_bn_act(a2[0], a2[1], self.layer2_outconv)
+        t2 = ops.upsample2x_add(x3_out, x2_lat, d3)
+        _, x2_f32 = self._head_hip(self.layer2_outconv2, (t2, d3), want_f32=True)
+        return [self._nchw_view(x4_f32), self._nchw_view(x2_f32)]
 
 
 def build_backbone(config):

@@ -28,7 +28,8 @@ enum LoftrTimedKernel {
   LOFTR_T_ATTN_SMALL = 7,    // attention.hip: attn_small_kernel       (fine level)
   LOFTR_T_GATHER = 8,        // fine.hip: gather_windows_kernel
   LOFTR_T_OT_STORE = 9,      // coarse_match.hip: score_store_kernel   (sinkhorn)
-  LOFTR_T_COUNT = 10
+  LOFTR_T_CONV = 10,         // conv.hip: conv_kernel               (backbone implicit GEMM)
+  LOFTR_T_COUNT = 11
 };
 extern unsigned g_loftr_timing_mask;
 void loftr_timing_mark(int id, hipStream_t st, bool end);

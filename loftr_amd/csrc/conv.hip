@@ -1,0 +1,228 @@
+// ResNet-FPN building blocks on the split-fp16 GEMM core (the backbone is
+// ~80 % of LoFTR.forward once the matching path is fast).
+//   reference: src/loftr/backbone/resnet_fpn.py:5-118 (conv3x3 / conv1x1 / BasicBlock / FPN head)
+//
+// A convolution is an implicit GEMM: rows = output pixels, k = (filter tap, input channel), columns =
+// output channels; the A operand is gathered on the fly from the NHWC activation tensor (gemm.h, CONV
+// mode).  Activations live in HBM in the SP format [B, H, W, Cp] (channels padded to a multiple of 32,
+// pad channels hold zeros).  Eval-mode BatchNorm is folded into the weights (scale) and a per-channel
+// bias while they are re-laid out [Cout, Cin, KH, KW] fp32 -> [Cout, KH*KW*Cp] SP; the epilogue adds
+// the bias and the residual branch and applies ReLU / LeakyReLU.
+#include "gemm.h"
+
+namespace {
+
+using Cfg = GemmCfg<128, 128, 2, 2>;
+
+struct ConvArgs {
+  ASrc a;                       // asrc_conv(x, geometry)
+  const sp_t* w; int K;         // [Cout, K] SP, K = KH*KW*Cp
+  const float* bias;            // [Cout] (folded BN shift) or null
+  const sp_t* residual;         // [M, Coutp] SP or null (added before the activation)
+  sp_t* y_sp;                   // [M, Coutp] SP or null
+  float* y_f32;                 // [M, Cout] fp32 (NHWC) or null
+  int M, Cout, Coutp;
+  int act;                      // 0 none, 1 ReLU, 2 LeakyReLU(0.01)
+};
+
+template <bool FULL>
+__device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[Cfg::TM][Cfg::TN], int m0, int n0) {
+  const EpiLane<Cfg> e;
+  const sp_t* rs = p.residual ? p.residual + (long)m0 * p.Coutp + n0 : nullptr;
+  sp_t* os = p.y_sp ? p.y_sp + (long)m0 * p.Coutp + n0 : nullptr;
+  float* of = p.y_f32 ? p.y_f32 + (long)m0 * p.Cout + n0 : nullptr;
+#pragma unroll
+  for (int j = 0; j < Cfg::TN; ++j) {
+    const int col = n0 + e.lcol + j * 32;
+    const bool creal = col < p.Cout;              // a real output channel
+    const bool cpad = col < p.Coutp;              // inside the padded SP row (pad channels are written as 0)
+    const float b = (p.bias && creal) ? p.bias[col] : 0.f;
+#pragma unroll
+    for (int i = 0; i < Cfg::TM; ++i) {
+      f32x16 v = acc[i][j];
+      if (rs) {
+        uint32_t w[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int trow = e.lrow + e.rr(i, r);
+          const bool ok = (FULL || m0 + trow < p.M) && cpad;
+          w[r] = ok ? rs[(unsigned)(trow * p.Coutp + e.spcol + j * 32)] : 0u;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] += sp_value(w[r], e.odd);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float x = v[r] + b;
+        if (p.act == 1) x = fmaxf(x, 0.f);
+        if (p.act == 2) x = x > 0.f ? x : 0.01f * x;
+        v[r] = creal ? x : 0.f;
+      }
+      if (of) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int trow = e.lrow + e.rr(i, r);
+          if ((FULL || m0 + trow < p.M) && creal) of[(unsigned)(trow * p.Cout + e.lcol + j * 32)] = v[r];
+        }
+      }
+      if (os) {
+        uint32_t w[16];
+        sp_words16(v, e.odd, w);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int trow = e.lrow + e.rr(i, r);
+          if ((FULL || m0 + trow < p.M) && cpad) os[(unsigned)(trow * p.Coutp + e.spcol + j * 32)] = w[r];
+        }
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(Cfg::THREADS, 2) void conv_kernel(ConvArgs p) {
+  __shared__ __attribute__((aligned(16))) float lds[Cfg::LDS_FLOATS];
+  int tm, tn;
+  if (!xcd_tile(ceil_div(p.M, Cfg::BM), ceil_div(p.Coutp, Cfg::BN), tm, tn)) return;
+  const int m0 = tm * Cfg::BM, n0 = tn * Cfg::BN;
+  f32x16 acc[Cfg::TM][Cfg::TN];
+  gemm_mainloop<Cfg, true>(p.a, p.w, p.K, p.M, p.Cout, p.K, m0, n0, lds, acc);
+  if (m0 + Cfg::BM <= p.M) conv_epilogue<true>(p, acc, m0, n0);
+  else conv_epilogue<false>(p, acc, m0, n0);
+}
+
+// Weight preparation: fold eval-mode BN, transpose to tap-major, pad channels, encode as SP.
+//   w [Cout, Cin, KH, KW] -> wsp [Cout, KH*KW*Cp];  bias[co] = beta - mean * scale,  scale = gamma / sqrt(var + eps)
+//   grid (ceil(groups_per_row / 8), Cout), 256 threads: one half-wave per 32-column SP group.
+__global__ __launch_bounds__(256) void conv_prep_kernel(const float* __restrict__ w, const float* __restrict__ bn_w,
+                                                        const float* __restrict__ bn_b, const float* __restrict__ bn_m,
+                                                        const float* __restrict__ bn_v, float eps, int Cin, int Cp,
+                                                        int KH, int KW, long s_co, long s_ci, long s_ky, long s_kx,
+                                                        sp_t* __restrict__ wsp, float* __restrict__ bias) {
+  const int co = blockIdx.y;
+  const int K = KH * KW * Cp;
+  float scale = 1.f, shift = 0.f;
+  if (bn_w) {
+    scale = bn_w[co] / sqrtf(bn_v[co] + eps);
+    shift = bn_b[co] - bn_m[co] * scale;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) bias[co] = shift;
+  const int grp = blockIdx.x * 8 + (threadIdx.x >> 5);
+  if (grp * 32 >= K) return;
+  const int col = grp * 32 + (threadIdx.x & 31);
+  const int tap = col / Cp, c = col - tap * Cp;
+  float v = 0.f;
+  if (c < Cin) v = w[co * s_co + c * s_ci + (tap / KW) * s_ky + (tap % KW) * s_kx] * scale;
+  sp_store(wsp + (long)co * K, col, v, true);
+}
+
+// out = lateral + bilinear_x2(low), align_corners=True       (resnet_fpn.py:111-116: F.interpolate + add)
+//   low [B, Hl, Wl, Cp], lateral / out [B, 2Hl, 2Wl, Cp], all SP.   grid (pixels), Cp threads
+__global__ void upsample_add_kernel(const sp_t* __restrict__ low, const sp_t* __restrict__ lat, sp_t* __restrict__ out,
+                                    int Hl, int Wl, int Cp) {
+  const int Ho = 2 * Hl, Wo = 2 * Wl;
+  const long pix = blockIdx.x;
+  const int x = (int)(pix % Wo), y = (int)((pix / Wo) % Ho);
+  const long b = pix / ((long)Wo * Ho);
+  // torch upsample_bilinear2d, align_corners=True: src = dst * (in - 1) / (out - 1)
+  const float sy = Ho > 1 ? (float)(Hl - 1) / (float)(Ho - 1) : 0.f, sx = Wo > 1 ? (float)(Wl - 1) / (float)(Wo - 1) : 0.f;
+  const float fy = sy * (float)y, fx = sx * (float)x;
+  const int y0 = (int)fy, x0 = (int)fx;
+  const int y1 = y0 + (y0 < Hl - 1 ? 1 : 0), x1 = x0 + (x0 < Wl - 1 ? 1 : 0);
+  const float ly = fy - (float)y0, lx = fx - (float)x0;
+  const float hy = 1.f - ly, hx = 1.f - lx;
+  const sp_t* l00 = low + ((b * Hl + y0) * Wl + x0) * Cp;
+  const sp_t* l01 = low + ((b * Hl + y0) * Wl + x1) * Cp;
+  const sp_t* l10 = low + ((b * Hl + y1) * Wl + x0) * Cp;
+  const sp_t* l11 = low + ((b * Hl + y1) * Wl + x1) * Cp;
+  const sp_t* la = lat + pix * Cp;
+  sp_t* o = out + pix * Cp;
+  for (int c = threadIdx.x; c < Cp; c += blockDim.x) {
+    const int idx = sp_index(c);
+    const bool odd = c & 1;
+    const float v00 = sp_value(l00[idx], odd), v01 = sp_value(l01[idx], odd);
+    const float v10 = sp_value(l10[idx], odd), v11 = sp_value(l11[idx], odd);
+    const float up = hy * (hx * v00 + lx * v01) + ly * (hx * v10 + lx * v11);
+    const float r = sp_value(la[idx], odd) + up;
+    o[idx] = sp_word(r, odd);
+  }
+}
+
+// SP [rows, Cp] -> fp32 [rows, C]   (debug / hand-over helper)
+__global__ void sp_to_f32_kernel(const sp_t* __restrict__ src, float* __restrict__ dst, long rows, int C, int Cp) {
+  const long row = blockIdx.x;
+  for (int c = threadIdx.x; c < Cp; c += blockDim.x) {
+    const float v = sp_value(src[row * Cp + sp_index(c)], c & 1);
+    if (c < C) dst[row * C + c] = v;
+  }
+}
+
+}  // namespace
+
+extern "C" size_t loftr_conv_workspace_bytes(int Cin, int Cout, int KH, int KW) {
+  if (Cin <= 0 || Cout <= 0 || KH <= 0 || KW <= 0) return 0;
+  return align_up((size_t)Cout * KH * KW * ceil32(Cin) * 4, 256) + align_up((size_t)Cout * 4, 256) + 1024;
+}
+
+extern "C" int loftr_conv_bn_act(const uint32_t* x_sp, int B, int H, int W, int Cin, const float* weight,
+                                 const long* weight_strides, int Cout, int KH, int KW, int stride, int pad, const float* bn_weight, const float* bn_bias,
+                                 const float* bn_mean, const float* bn_var, float bn_eps, int act,
+                                 const uint32_t* residual_sp, uint32_t* y_sp, float* y_f32, void* ws, size_t ws_bytes,
+                                 void* stream) {
+  LOFTR_CHECK_ARG(x_sp && weight && weight_strides && (y_sp || y_f32) && ws && B >= 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0);
+  LOFTR_CHECK_ARG(KH > 0 && KW > 0 && stride > 0 && pad >= 0 && act >= 0 && act <= 2);
+  LOFTR_CHECK_ARG((bn_weight == nullptr) == (bn_bias == nullptr) && (bn_weight == nullptr) == (bn_mean == nullptr) &&
+                  (bn_weight == nullptr) == (bn_var == nullptr));
+  if (B == 0) return LOFTR_OK;
+  hipStream_t st = (hipStream_t)stream;
+  ConvGeom g;
+  g.H = H; g.W = W; g.Cp = ceil32(Cin); g.KH = KH; g.KW = KW; g.stride = stride; g.pad = pad;
+  g.Ho = (H + 2 * pad - KH) / stride + 1;
+  g.Wo = (W + 2 * pad - KW) / stride + 1;
+  if (g.Ho <= 0 || g.Wo <= 0 || H >= 32768 || W >= 32768) return LOFTR_ERR_UNSUPPORTED;
+  const long M = (long)B * g.Ho * g.Wo;
+  if (M * (long)ceil32(Cout) >= (1L << 31) || (long)B * H * W * g.Cp >= (1L << 31)) return LOFTR_ERR_UNSUPPORTED;
+  const int K = KH * KW * g.Cp;
+  WsAlloc wa(ws, ws_bytes);
+  sp_t* wsp = wa.take<sp_t>((size_t)Cout * K);
+  float* bias = wa.take<float>(Cout);
+  if (!wa.ok()) return LOFTR_ERR_WORKSPACE;
+  hipLaunchKernelGGL(conv_prep_kernel, dim3(ceil_div(K / 32, 8), Cout), dim3(256), 0, st, weight, bn_weight, bn_bias,
+                     bn_mean, bn_var, bn_eps, Cin, g.Cp, KH, KW, weight_strides[0], weight_strides[1], weight_strides[2],
+                     weight_strides[3], wsp, bias);
+  ConvArgs p;
+  p.a = asrc_conv(x_sp, g);
+  p.w = wsp; p.K = K; p.bias = bias; p.residual = residual_sp; p.y_sp = y_sp; p.y_f32 = y_f32;
+  p.M = (int)M; p.Cout = Cout; p.Coutp = ceil32(Cout); p.act = act;
+  { TimedLaunch tl(LOFTR_T_CONV, st);
+    hipLaunchKernelGGL(conv_kernel, dim3(xcd_grid(ceil_div(p.M, Cfg::BM), ceil_div(p.Coutp, Cfg::BN))), dim3(Cfg::THREADS),
+                       0, st, p); }
+  LOFTR_CHECK_LAUNCH();
+  return LOFTR_OK;
+}
+
+extern "C" int loftr_upsample2x_add(const uint32_t* low_sp, const uint32_t* lateral_sp, uint32_t* out_sp, int B, int Hl,
+                                    int Wl, int C, void* stream) {
+  LOFTR_CHECK_ARG(low_sp && lateral_sp && out_sp && B >= 0 && Hl > 0 && Wl > 0 && C > 0);
+  if (B == 0) return LOFTR_OK;
+  const int Cp = ceil32(C);
+  const long pixels = (long)B * 4 * Hl * Wl;
+  if (pixels >= (1L << 31)) return LOFTR_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(upsample_add_kernel, dim3((unsigned)pixels), dim3(Cp > 256 ? 256 : Cp), 0, (hipStream_t)stream,
+                     low_sp, lateral_sp, out_sp, Hl, Wl, Cp);
+  LOFTR_CHECK_LAUNCH();
+  return LOFTR_OK;
+}
+
+extern "C" int loftr_sp_from_f32(const float* src, uint32_t* dst_sp, long rows, int C, void* stream) {
+  LOFTR_CHECK_ARG(src && dst_sp && rows >= 0 && C > 0);
+  return launch_sp_convert1(src, C, dst_sp, rows, C, (hipStream_t)stream);
+}
+
+extern "C" int loftr_sp_to_f32(const uint32_t* src_sp, float* dst, long rows, int C, void* stream) {
+  LOFTR_CHECK_ARG(src_sp && dst && rows >= 0 && C > 0);
+  if (rows == 0) return LOFTR_OK;
+  const int Cp = ceil32(C);
+  hipLaunchKernelGGL(sp_to_f32_kernel, dim3((unsigned)rows), dim3(Cp > 256 ? 256 : Cp), 0, (hipStream_t)stream, src_sp,
+                     dst, rows, C, Cp);
+  LOFTR_CHECK_LAUNCH();
+  return LOFTR_OK;
+}

@@ -60,17 +60,27 @@ typedef uint32_t sp_t;            // one dword of an SP tensor (two halfs); a ro
 //                       materialising the concatenation); same row pitch, ksplit % 32 == 0
 //   * gathered rows:    r -> gather[r]  (fine_preprocess.py:51-52 picks coarse features at
 //                       (b_ids, i_ids) -- the index already folds b*L + i)
+//   * implicit im2col:  (CONV mode of the main loop) row m = output pixel (b, yo, xo) of a KH x KW
+//                       convolution over an NHWC SP activation tensor [B, H, W, Cp]; k runs over
+//                       (tap, channel); k-tile kt covers channels 32*(kt % (Cp/32)) .. +31 of tap
+//                       kt / (Cp/32) and reads pixel (yo*stride - pad + ky, xo*stride - pad + kx), zeros
+//                       outside the image -- no unfolded volume is ever materialised.
+struct ConvGeom { int H, W, Cp, KH, KW, stride, pad, Ho, Wo; };
 struct ASrc {
   const sp_t* p0; int ld0;
   const sp_t* p1; int ksplit;
   const int64_t* gather;
+  ConvGeom cv;
 };
-__host__ __device__ static inline ASrc asrc_plain(const sp_t* p, int ld) { return ASrc{p, ld, nullptr, 1 << 30, nullptr}; }
+__host__ __device__ static inline ASrc asrc_plain(const sp_t* p, int ld) { return ASrc{p, ld, nullptr, 1 << 30, nullptr, {}}; }
 __host__ __device__ static inline ASrc asrc_cat(const sp_t* p0, const sp_t* p1, int ld, int ksplit) {
-  return ASrc{p0, ld, p1, ksplit, nullptr};
+  return ASrc{p0, ld, p1, ksplit, nullptr, {}};
 }
 __host__ __device__ static inline ASrc asrc_gather(const sp_t* p, int ld, const int64_t* idx) {
-  return ASrc{p, ld, nullptr, 1 << 30, idx};
+  return ASrc{p, ld, nullptr, 1 << 30, idx, {}};
+}
+__host__ __device__ static inline ASrc asrc_conv(const sp_t* x, const ConvGeom& g) {
+  return ASrc{x, g.Cp, nullptr, 1 << 30, nullptr, g};
 }
 
 template <int BM_, int BN_, int WM_, int WN_>
@@ -129,6 +139,14 @@ __device__ __forceinline__ void sp_words16(const f32x16& v, bool odd, uint32_t (
 #pragma unroll
   for (int r = 0; r < 16; ++r) w[r] = odd ? (w[r] | (lb[r] << 16)) : (hb[r] | (w[r] << 16));
 }
+// Inverse of sp_word: the lane loads the dword at sp_index(col) of its row (even lanes the hi pair,
+// odd lanes the lo pair) and the pair of lanes exchanges halves.  Both lanes must execute this.
+__device__ __forceinline__ float sp_value(uint32_t w, bool odd) {
+  const uint32_t recv = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w, 0xB1, 0xF, 0xF, true);   // lane ^ 1
+  const uint32_t hb = odd ? (recv >> 16) : (w & 0xffffu);
+  const uint32_t lb = odd ? (w >> 16) : (recv & 0xffffu);
+  return (float)__builtin_bit_cast(_Float16, (uint16_t)hb) + (float)__builtin_bit_cast(_Float16, (uint16_t)lb);
+}
 // dword index inside an SP row of the word sp_word() produces for column `col`
 __device__ __forceinline__ int sp_index(int col) { return (col & ~31) + ((col & 1) ? 16 : 0) + ((col & 31) >> 1); }
 // convenience: predicated single store (row_ptr = first dword of the row)
@@ -154,7 +172,7 @@ struct EpiLane {
 
 // Runs the whole K loop for the block tile at (m0, n0).  M, N are the valid extents (rows beyond
 // them are clamped on load -- the caller masks them in its epilogue).  K % 32 == 0 (SP groups).
-template <typename Cfg>
+template <typename Cfg, bool CONV = false>
 __device__ __forceinline__ void gemm_mainloop(const ASrc& a, const sp_t* __restrict__ Bp, int ldb,
                                               int M, int N, int K, int m0, int n0,
                                               float* lds_f, f32x16 (&acc)[Cfg::TM][Cfg::TN]) {
@@ -168,15 +186,26 @@ __device__ __forceinline__ void gemm_mainloop(const ASrc& a, const sp_t* __restr
   // ---- loader: per-thread dword offsets of its 16-B chunks (32-bit: operands are < 2^31 dwords)
   int aoff[Cfg::A_F4], boff[Cfg::B_F4];
   int a_lds_off[Cfg::A_F4], b_lds_off[Cfg::B_F4];
+  int ayx[Cfg::A_F4];                             // CONV: (yo*stride - pad) << 16 | (xo*stride - pad) & 0xffff
   const int kc = tid & 7;                         // this thread's chunk inside a 128-B row group
 #pragma unroll
   for (int i = 0; i < Cfg::A_F4; ++i) {
     const int r = (tid + i * Cfg::THREADS) >> 3;
     const int gr = min(m0 + r, M - 1);
-    const int row = a.gather ? (int)a.gather[gr] : gr;
-    aoff[i] = row * a.ld0 + kc * 4;
+    if (CONV) {
+      const int hw = a.cv.Ho * a.cv.Wo;
+      const int b = gr / hw, rem = gr - b * hw;
+      const int yo = rem / a.cv.Wo, xo = rem - yo * a.cv.Wo;
+      const int yb = yo * a.cv.stride - a.cv.pad, xb = xo * a.cv.stride - a.cv.pad;
+      ayx[i] = (yb << 16) | (xb & 0xffff);
+      aoff[i] = ((b * a.cv.H + yb) * a.cv.W + xb) * a.cv.Cp + kc * 4;      // tap (0,0); may point before the image
+    } else {
+      const int row = a.gather ? (int)a.gather[gr] : gr;
+      aoff[i] = row * a.ld0 + kc * 4;
+    }
     a_lds_off[i] = lds_chunk_off(r, kc);
   }
+  const int cv_gpt = CONV ? a.cv.Cp / 32 : 1;     // k-tiles per filter tap
 #pragma unroll
   for (int i = 0; i < Cfg::B_F4; ++i) {
     const int r = (tid + i * Cfg::THREADS) >> 3;
@@ -189,7 +218,17 @@ __device__ __forceinline__ void gemm_mainloop(const ASrc& a, const sp_t* __restr
   // (macros, not lambdas: capturing the staging registers by reference makes hipcc keep a
   //  scratch copy of them)
 #define GEMM_LOAD_A(k0_, ra_)                                                                 \
-  {                                                                                           \
+  if (CONV) {                                                                                 \
+    const int kt__ = (k0_) / BK;                    /* all block-uniform scalars */           \
+    const int tap__ = kt__ / cv_gpt, cg__ = kt__ - tap__ * cv_gpt;                            \
+    const int ky__ = tap__ / a.cv.KW, kx__ = tap__ - ky__ * a.cv.KW;                          \
+    const int toff__ = (ky__ * a.cv.W + kx__) * a.cv.Cp + cg__ * 32;                          \
+    _Pragma("unroll") for (int i = 0; i < Cfg::A_F4; ++i) {                                   \
+      const int y__ = (ayx[i] >> 16) + ky__, x__ = (int)(short)(ayx[i] & 0xffff) + kx__;      \
+      const bool in__ = (unsigned)y__ < (unsigned)a.cv.H && (unsigned)x__ < (unsigned)a.cv.W; \
+      ra_[i] = in__ ? *reinterpret_cast<const u32x4*>(a.p0 + (aoff[i] + toff__)) : u32x4{0u, 0u, 0u, 0u}; \
+    }                                                                                         \
+  } else {                                                                                    \
     const int k0__ = (k0_);                                                                   \
     const bool second__ = k0__ >= a.ksplit; /* block-uniform */                               \
     const sp_t* ap__ = second__ ? a.p1 : a.p0;                                                \

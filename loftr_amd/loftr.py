@@ -232,6 +232,8 @@ class LoFTR(nn.Module):
         # HIP path [.., H, W, C]-ordered maps: the flatten and the fine-window gather then read
         # fully coalesced.  Pure storage-order choice: parameter names / shapes are unchanged.
         self.backbone = build_backbone(config).to(memory_format=torch.channels_last)
+        # 'hip': convolutions on the library's implicit-GEMM kernels (backbone.forward_hip); 'torch': MIOpen.
+        self.backbone_impl = "hip"
         self.pos_encoding = PositionEncodingSine(config["coarse"]["d_model"],
                                                  temp_bug_fix=config["coarse"]["temp_bug_fix"])
         self.loftr_coarse = LocalFeatureTransformer(config["coarse"])
@@ -245,11 +247,13 @@ class LoFTR(nn.Module):
         data.update({"bs": data["image0"].size(0),
                      "hw0_i": data["image0"].shape[2:], "hw1_i": data["image1"].shape[2:]})
         cl = lambda img: img.contiguous(memory_format=torch.channels_last)   # C == 1: a restride, no copy
+        use_hip = self.backbone_impl == "hip" and data["image0"].is_cuda and not self.training
+        run = self.backbone.forward_hip if use_hip else self.backbone
         if data["hw0_i"] == data["hw1_i"]:
-            feats_c, feats_f = self.backbone(cl(torch.cat([data["image0"], data["image1"]], dim=0)))
+            feats_c, feats_f = run(cl(torch.cat([data["image0"], data["image1"]], dim=0)))
             (feat_c0, feat_c1), (feat_f0, feat_f1) = feats_c.split(data["bs"]), feats_f.split(data["bs"])
         else:
-            (feat_c0, feat_f0), (feat_c1, feat_f1) = self.backbone(cl(data["image0"])), self.backbone(cl(data["image1"]))
+            (feat_c0, feat_f0), (feat_c1, feat_f1) = run(cl(data["image0"])), run(cl(data["image1"]))
         return feat_c0, feat_c1, feat_f0, feat_f1
 
     def match_from_features(self, feat_c0, feat_c1, feat_f0, feat_f1, data):

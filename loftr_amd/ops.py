@@ -229,3 +229,65 @@ def fine_match(feat_f0, feat_f1, mkpts1_c, b_ids, scale, scale1=None):
                                        _ptr(_need(b_ids, "b_ids", torch.int64)), float(scale), _ptr(s1), _ptr(expec),
                                        _ptr(mk1f), _stream()), "loftr_fine_match")
     return expec, mk1f
+
+
+# ---------------------------------------------------------------------------------------------
+# ResNet-FPN building blocks.  An SP activation is carried as (tensor int32 [B,H,W,Cp], C).
+def ceil32(c):
+    return (c + 31) // 32 * 32
+
+
+def sp_from_nhwc(x_nhwc):
+    """fp32 [B,H,W,C] contiguous -> SP int32 [B,H,W,ceil32(C)]."""
+    _need(x_nhwc, "x_nhwc")
+    B, H, W, Cc = x_nhwc.shape
+    out = torch.empty(B, H, W, ceil32(Cc), dtype=torch.int32, device=x_nhwc.device)
+    check(_lib.load().loftr_sp_from_f32(_ptr(x_nhwc), _ptr(out), B * H * W, Cc, _stream()), "loftr_sp_from_f32")
+    return out
+
+
+def sp_to_nhwc(x_sp, Cc):
+    """SP int32 [B,H,W,Cp] -> fp32 [B,H,W,C]."""
+    B, H, W, _ = x_sp.shape
+    out = torch.empty(B, H, W, Cc, dtype=torch.float32, device=x_sp.device)
+    check(_lib.load().loftr_sp_to_f32(_ptr(x_sp), _ptr(out), B * H * W, Cc, _stream()), "loftr_sp_to_f32")
+    return out
+
+
+def conv_bn_act(x_sp, Cin, conv, bn=None, act=0, residual=None, want_sp=True, want_f32=False):
+    """nn.Conv2d(bias=False) [+ eval BatchNorm2d] [+ residual] [+ act] on an SP activation.
+
+    x_sp int32 [B,H,W,ceil32(Cin)]; returns (y_sp or None, y_f32 [B,Ho,Wo,Cout] or None)."""
+    w = conv.weight
+    if not w.is_cuda or w.dtype != torch.float32:
+        raise _lib.LoftrHipError("conv.weight: expected a float32 GPU tensor")
+    wst = (C.c_long * 4)(*w.stride())                       # contiguous or channels-last storage
+    Cout, Cin_w, KH, KW = w.shape
+    assert Cin_w == Cin and conv.bias is None and conv.dilation == (1, 1) and conv.groups == 1
+    stride, pad = conv.stride[0], conv.padding[0]
+    B, H, W, Cp = x_sp.shape
+    assert Cp == ceil32(Cin) and x_sp.dtype == torch.int32 and x_sp.is_contiguous()
+    Ho, Wo = (H + 2 * pad - KH) // stride + 1, (W + 2 * pad - KW) // stride + 1
+    dev = x_sp.device
+    y_sp = torch.empty(B, Ho, Wo, ceil32(Cout), dtype=torch.int32, device=dev) if want_sp else None
+    y_f32 = torch.empty(B, Ho, Wo, Cout, dtype=torch.float32, device=dev) if want_f32 else None
+    lib = _lib.load()
+    ws = workspace(lib.loftr_conv_workspace_bytes(Cin, Cout, KH, KW), dev)
+    bnp = [None] * 4 if bn is None else [bn.weight, bn.bias, bn.running_mean, bn.running_var]
+    if bn is not None and bn.training:
+        raise _lib.LoftrHipError("conv_bn_act folds eval-mode BatchNorm only; call .eval()")
+    check(lib.loftr_conv_bn_act(_ptr(x_sp), B, H, W, Cin, _ptr(w), wst, Cout, KH, KW, stride, pad, _ptr(bnp[0]), _ptr(bnp[1]),
+                                _ptr(bnp[2]), _ptr(bnp[3]), float(bn.eps) if bn is not None else 0.0, int(act),
+                                _ptr(residual), _ptr(y_sp), _ptr(y_f32), _ptr(ws), ws.numel(), _stream()),
+          "loftr_conv_bn_act")
+    return y_sp, y_f32
+
+
+def upsample2x_add(low_sp, lateral_sp, Cc):
+    """lateral + bilinear x2 (align_corners=True) of low; SP in, SP out."""
+    B, Hl, Wl, Cp = low_sp.shape
+    assert lateral_sp.shape == (B, 2 * Hl, 2 * Wl, Cp)
+    out = torch.empty_like(lateral_sp)
+    check(_lib.load().loftr_upsample2x_add(_ptr(low_sp), _ptr(lateral_sp), _ptr(out), B, Hl, Wl, Cc, _stream()),
+          "loftr_upsample2x_add")
+    return out

@@ -1,0 +1,131 @@
+"""GPU tests of the HIP ResNet-FPN path: implicit-GEMM convolutions with folded
+eval BatchNorm / residual / activation, FPN upsample+add, and the whole backbone against PyTorch in fp64.
+
+Tolerance: features are O(1); the split-fp16 GEMM core is fp32-class, so the HIP path must
+sit as close to an fp64 evaluation as MIOpen's own fp32 kernels do (bounded here at 5e-5 of the feature
+scale) -- far inside what the 1e-4 / 1e-3 px matching tolerances need."""
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _randomize_bn(m, g):
+    for mod in m.modules():
+        if isinstance(mod, nn.BatchNorm2d):
+            n = mod.num_features
+            mod.weight.data = 1.0 + 0.2 * torch.randn(n, generator=g)
+            mod.bias.data = 0.1 * torch.randn(n, generator=g)
+            mod.running_mean.data = 0.1 * torch.randn(n, generator=g)
+            mod.running_var.data = 0.5 + torch.rand(n, generator=g)
+
+
+@pytest.mark.parametrize("cin,cout,k,stride,act,use_bn,use_res", [
+    (128, 128, 3, 1, 1, True, False),
+    (128, 196, 3, 2, 1, True, False),
+    (196, 196, 3, 1, 1, True, True),
+    (128, 196, 1, 2, 0, True, False),
+    (196, 256, 1, 1, 0, False, False),
+    (256, 196, 3, 1, 0, False, False),
+    (256, 256, 3, 1, 2, True, False),
+    (64, 40, 3, 1, 2, True, True),
+])
+def test_conv_bn_act_vs_torch(cin, cout, k, stride, act, use_bn, use_res):
+    from loftr_amd import ops
+    g = torch.Generator().manual_seed(cin * 7 + cout + k)
+    B, H, W = 2, 22, 30
+    conv = nn.Conv2d(cin, cout, k, stride=stride, padding=k // 2, bias=False)
+    conv.weight.data = torch.randn(conv.weight.shape, generator=g) * (2.0 / (cin * k * k)) ** 0.5
+    bn = nn.BatchNorm2d(cout).eval() if use_bn else None
+    if bn is not None:
+        _randomize_bn(bn, g)
+    x = torch.randn(B, cin, H, W, generator=g)
+    Ho, Wo = (H + 2 * (k // 2) - k) // stride + 1, (W + 2 * (k // 2) - k) // stride + 1
+    res = torch.randn(B, cout, Ho, Wo, generator=g) if use_res else None
+    # fp64 reference
+    y = F.conv2d(x.double(), conv.weight.double(), stride=stride, padding=k // 2)
+    if bn is not None:
+        y = F.batch_norm(y, bn.running_mean.double(), bn.running_var.double(), bn.weight.double(), bn.bias.double(),
+                         False, 0.0, bn.eps)
+    if res is not None:
+        y = y + res.double()
+    y = {0: lambda t: t, 1: F.relu, 2: lambda t: F.leaky_relu(t, 0.01)}[act](y)
+    # HIP
+    dev = "cuda:0"
+    conv, bn = conv.to(dev), (bn.to(dev) if bn is not None else None)
+    x_sp = ops.sp_from_nhwc(x.permute(0, 2, 3, 1).contiguous().to(dev))
+    r_sp = ops.sp_from_nhwc(res.permute(0, 2, 3, 1).contiguous().to(dev)) if res is not None else None
+    y_sp, y_f32 = ops.conv_bn_act(x_sp, cin, conv, bn, act=act, residual=r_sp, want_sp=True, want_f32=True)
+    got = y_f32.permute(0, 3, 1, 2).cpu().double()
+    scale = y.abs().max().item()
+    assert (got - y).abs().max().item() <= 2e-5 * scale, ((got - y).abs().max().item(), scale)
+    # the SP output decodes to the same values (<= 2^-21 relative) and its pad channels are zero
+    back = ops.sp_to_nhwc(y_sp, cout).permute(0, 3, 1, 2).cpu().double()
+    assert (back - got).abs().max().item() <= 1e-6 * scale
+    if y_sp.shape[-1] != cout:
+        full = ops.sp_to_nhwc(y_sp, y_sp.shape[-1]).cpu()
+        assert (full[..., cout:] == 0).all()
+
+
+def test_upsample2x_add_vs_torch():
+    from loftr_amd import ops
+    g = torch.Generator().manual_seed(3)
+    for C in (196, 256):
+        low = torch.randn(2, C, 15, 20, generator=g)
+        lat = torch.randn(2, C, 30, 40, generator=g)
+        ref = lat.double() + F.interpolate(low.double(), scale_factor=2.0, mode="bilinear", align_corners=True)
+        dev = "cuda:0"
+        l_sp = ops.sp_from_nhwc(low.permute(0, 2, 3, 1).contiguous().to(dev))
+        a_sp = ops.sp_from_nhwc(lat.permute(0, 2, 3, 1).contiguous().to(dev))
+        out = ops.sp_to_nhwc(ops.upsample2x_add(l_sp, a_sp, C), C).permute(0, 3, 1, 2).cpu().double()
+        assert (out - ref).abs().max().item() <= 2e-6 * ref.abs().max().item()
+
+
+@pytest.mark.parametrize("resolution,dims,hw", [((8, 2), [128, 196, 256], (96, 128)),
+                                               ((16, 4), [128, 196, 256, 512], (96, 128))])
+def test_backbone_hip_vs_fp64(resolution, dims, hw):
+    from loftr_amd.backbone import build_backbone
+    cfg = {"backbone_type": "ResNetFPN", "resolution": resolution, "resnetfpn": {"initial_dim": 128, "block_dims": dims}}
+    torch.manual_seed(0)
+    m = build_backbone(cfg).eval()
+    _randomize_bn(m, torch.Generator().manual_seed(1))
+    x = torch.rand(2, 1, *hw, generator=torch.Generator().manual_seed(2))
+    with torch.no_grad():
+        ref = [t.clone() for t in m.double()(x.double())]
+    m = m.float().to("cuda:0").to(memory_format=torch.channels_last)
+    xc = x.to("cuda:0").contiguous(memory_format=torch.channels_last)
+    with torch.no_grad():
+        hip = m.forward_hip(xc)
+        tor = m(xc)
+    for name, r, h, t in zip(("coarse", "fine"), ref, hip, tor):
+        assert h.shape == r.shape and h.dtype == torch.float32
+        scale = r.abs().max().item()
+        e_hip = (h.cpu().double() - r).abs().max().item() / scale
+        e_tor = (t.cpu().double() - r).abs().max().item() / scale
+        print(f"{name}: hip err {e_hip:.2e}  miopen-fp32 err {e_tor:.2e}  (relative to max |feature| = {scale:.3g})")
+        assert e_hip <= 5e-5, (name, e_hip, e_tor)
+
+
+def test_full_forward_hip_backbone_matches_torch_backbone():
+    """End to end: LoFTR.forward with the HIP backbone vs the MIOpen backbone on the same weights / images.
+    The two backbones differ at the 1e-5 level, so matches agree except provably borderline ones."""
+    from loftr_amd import LoFTR, get_cfg
+    torch.manual_seed(0)
+    model = LoFTR(get_cfg(thr=0.0)).eval().cuda()
+    g = torch.Generator().manual_seed(5)
+    img0 = torch.rand(2, 1, 240, 320, generator=g).cuda()
+    img1 = torch.roll(img0, (8, 16), (2, 3)) + 0.02 * torch.rand(2, 1, 240, 320, generator=g).cuda()
+    outs = {}
+    for impl in ("torch", "hip"):
+        model.backbone_impl = impl
+        d = {"image0": img0, "image1": img1}
+        model(d)
+        outs[impl] = d
+    a, b = outs["torch"], outs["hip"]
+    assert (a["conf_matrix"] - b["conf_matrix"]).abs().max().item() <= 1e-3
+    ka = set(zip(a["b_ids"].tolist(), a["i_ids"].tolist(), a["j_ids"].tolist()))
+    kb = set(zip(b["b_ids"].tolist(), b["i_ids"].tolist(), b["j_ids"].tolist()))
+    assert len(ka ^ kb) <= max(2, len(ka) // 50), (len(ka), len(kb), len(ka ^ kb))
