@@ -46,15 +46,19 @@ struct TimedLaunch {          // RAII: records an event pair around the launches
 // XCD has a private 4 MB L2.  Column tiles that share the same A rows must therefore sit on the SAME
 // XCD at the same time or the A panel is fetched from HBM once per column tile (measured: 4-6x the
 // algorithmic read traffic).  1-D launches of xcd_grid(tiles_m, tiles_n) workgroups are mapped as
-//   xcd = id % 8, slot = id / 8  ->  tile_n = slot % tiles_n, tile_m = (slot / tiles_n) * 8 + xcd
-// so each XCD sweeps all column tiles of its own row tiles back to back.
+//   xcd = id % 8, slot = id / 8  ->  tile_n = slot % tiles_n, tile_m = xcd * ceil(tiles_m / 8) + slot / tiles_n
+// so each XCD owns one contiguous eighth of the row tiles and sweeps all column tiles of a row tile
+// back to back; consecutive row tiles (which share the 3x3 halo rows in the implicit-GEMM
+// convolutions) also stay on one XCD and run close in time.
 constexpr int NUM_XCD = 8;
 static inline unsigned xcd_grid(int tiles_m, int tiles_n) { return (unsigned)(NUM_XCD * ceil_div(tiles_m, NUM_XCD) * tiles_n); }
 __device__ __forceinline__ bool xcd_tile(int tiles_m, int tiles_n, int& tile_m, int& tile_n) {
   const int id = blockIdx.x, xcd = id % NUM_XCD, slot = id / NUM_XCD;
+  const int chunk = ceil_div(tiles_m, NUM_XCD);
   tile_n = slot % tiles_n;
-  tile_m = (slot / tiles_n) * NUM_XCD + xcd;
-  return tile_m < tiles_m;
+  const int local = slot / tiles_n;
+  tile_m = xcd * chunk + local;
+  return local < chunk && tile_m < tiles_m;
 }
 
 // Bump allocator over the caller-supplied workspace (the library never mallocs device memory).

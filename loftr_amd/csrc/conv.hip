@@ -9,10 +9,12 @@
 // bias while they are re-laid out [Cout, Cin, KH, KW] fp32 -> [Cout, KH*KW*Cp] SP; the epilogue adds
 // the bias and the residual branch and applies ReLU / LeakyReLU.
 #include "gemm.h"
+#include <stdlib.h>
 
 namespace {
 
-using Cfg = GemmCfg<128, 128, 2, 2>;
+using CfgR = GemmCfg<128, 128, 2, 2>;        // register-staged, 2 workgroups per CU
+using CfgD = GemmCfg<256, 128, 4, 2, 3>;     // 8 waves, 3-stage global_load_lds ring, 1 workgroup per CU
 
 struct ConvArgs {
   ASrc a;                       // asrc_conv(x, geometry)
@@ -25,7 +27,7 @@ struct ConvArgs {
   int act;                      // 0 none, 1 ReLU, 2 LeakyReLU(0.01)
 };
 
-template <bool FULL>
+template <typename Cfg, bool FULL>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[Cfg::TM][Cfg::TN], int m0, int n0) {
   const EpiLane<Cfg> e;
   const sp_t* rs = p.residual ? p.residual + (long)m0 * p.Coutp + n0 : nullptr;
@@ -78,6 +80,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[C
   }
 }
 
+template <typename Cfg>
 __global__ __launch_bounds__(Cfg::THREADS, 2) void conv_kernel(ConvArgs p) {
   __shared__ __attribute__((aligned(16))) float lds[Cfg::LDS_FLOATS];
   int tm, tn;
@@ -85,8 +88,8 @@ __global__ __launch_bounds__(Cfg::THREADS, 2) void conv_kernel(ConvArgs p) {
   const int m0 = tm * Cfg::BM, n0 = tn * Cfg::BN;
   f32x16 acc[Cfg::TM][Cfg::TN];
   gemm_mainloop<Cfg, true>(p.a, p.w, p.K, p.M, p.Cout, p.K, m0, n0, lds, acc);
-  if (m0 + Cfg::BM <= p.M) conv_epilogue<true>(p, acc, m0, n0);
-  else conv_epilogue<false>(p, acc, m0, n0);
+  if (m0 + Cfg::BM <= p.M) conv_epilogue<Cfg, true>(p, acc, m0, n0);
+  else conv_epilogue<Cfg, false>(p, acc, m0, n0);
 }
 
 // Weight preparation: fold eval-mode BN, transpose to tap-major, pad channels, encode as SP.
@@ -115,11 +118,13 @@ __global__ __launch_bounds__(256) void conv_prep_kernel(const float* __restrict_
 }
 
 // out = lateral + bilinear_x2(low), align_corners=True       (resnet_fpn.py:111-116: F.interpolate + add)
-//   low [B, Hl, Wl, Cp], lateral / out [B, 2Hl, 2Wl, Cp], all SP.   grid (pixels), Cp threads
-__global__ void upsample_add_kernel(const sp_t* __restrict__ low, const sp_t* __restrict__ lat, sp_t* __restrict__ out,
-                                    int Hl, int Wl, int Cp) {
+//   low [B, Hl, Wl, Cp], lateral / out [B, 2Hl, 2Wl, Cp], all SP.   grid (ceil(pixels / 8)), 256 threads =
+//   8 pixels x 32 lanes; a half-wave walks the 32-channel SP groups of its pixel (128-B lines).
+__global__ __launch_bounds__(256) void upsample_add_kernel(const sp_t* __restrict__ low, const sp_t* __restrict__ lat,
+                                                           sp_t* __restrict__ out, int Hl, int Wl, int Cp, long npix) {
   const int Ho = 2 * Hl, Wo = 2 * Wl;
-  const long pix = blockIdx.x;
+  const long pix = (long)blockIdx.x * 8 + (threadIdx.x >> 5);
+  if (pix >= npix) return;
   const int x = (int)(pix % Wo), y = (int)((pix / Wo) % Ho);
   const long b = pix / ((long)Wo * Ho);
   // torch upsample_bilinear2d, align_corners=True: src = dst * (in - 1) / (out - 1)
@@ -135,7 +140,7 @@ __global__ void upsample_add_kernel(const sp_t* __restrict__ low, const sp_t* __
   const sp_t* l11 = low + ((b * Hl + y1) * Wl + x1) * Cp;
   const sp_t* la = lat + pix * Cp;
   sp_t* o = out + pix * Cp;
-  for (int c = threadIdx.x; c < Cp; c += blockDim.x) {
+  for (int c = threadIdx.x & 31; c < Cp; c += 32) {
     const int idx = sp_index(c);
     const bool odd = c & 1;
     const float v00 = sp_value(l00[idx], odd), v01 = sp_value(l01[idx], odd);
@@ -159,7 +164,7 @@ __global__ void sp_to_f32_kernel(const sp_t* __restrict__ src, float* __restrict
 
 extern "C" size_t loftr_conv_workspace_bytes(int Cin, int Cout, int KH, int KW) {
   if (Cin <= 0 || Cout <= 0 || KH <= 0 || KW <= 0) return 0;
-  return align_up((size_t)Cout * KH * KW * ceil32(Cin) * 4, 256) + align_up((size_t)Cout * 4, 256) + 1024;
+  return align_up((size_t)Cout * KH * KW * ceil32(Cin) * 4, 256) + align_up((size_t)Cout * 4, 256) + 2048;
 }
 
 extern "C" int loftr_conv_bn_act(const uint32_t* x_sp, int B, int H, int W, int Cin, const float* weight,
@@ -184,7 +189,10 @@ extern "C" int loftr_conv_bn_act(const uint32_t* x_sp, int B, int H, int W, int 
   WsAlloc wa(ws, ws_bytes);
   sp_t* wsp = wa.take<sp_t>((size_t)Cout * K);
   float* bias = wa.take<float>(Cout);
+  sp_t* zeros = wa.take<sp_t>(64);
   if (!wa.ok()) return LOFTR_ERR_WORKSPACE;
+  (void)hipMemsetAsync(zeros, 0, 256, st);
+  g.zeros = zeros;
   hipLaunchKernelGGL(conv_prep_kernel, dim3(ceil_div(K / 32, 8), Cout), dim3(256), 0, st, weight, bn_weight, bn_bias,
                      bn_mean, bn_var, bn_eps, Cin, g.Cp, KH, KW, weight_strides[0], weight_strides[1], weight_strides[2],
                      weight_strides[3], wsp, bias);
@@ -192,9 +200,17 @@ extern "C" int loftr_conv_bn_act(const uint32_t* x_sp, int B, int H, int W, int 
   p.a = asrc_conv(x_sp, g);
   p.w = wsp; p.K = K; p.bias = bias; p.residual = residual_sp; p.y_sp = y_sp; p.y_f32 = y_f32;
   p.M = (int)M; p.Cout = Cout; p.Coutp = ceil32(Cout); p.act = act;
-  { TimedLaunch tl(LOFTR_T_CONV, st);
-    hipLaunchKernelGGL(conv_kernel, dim3(xcd_grid(ceil_div(p.M, Cfg::BM), ceil_div(p.Coutp, Cfg::BN))), dim3(Cfg::THREADS),
-                       0, st, p); }
+  {
+    // LOFTR_CONV_DMA=0 selects the register-staged 128x128 configuration (A/B experiments; DMA ring is ~7 % faster)
+    static const int use_dma = []() { const char* e = getenv("LOFTR_CONV_DMA"); return e ? atoi(e) : 1; }();
+    TimedLaunch tl(LOFTR_T_CONV, st);
+    if (use_dma)
+      hipLaunchKernelGGL((conv_kernel<CfgD>), dim3(xcd_grid(ceil_div(p.M, CfgD::BM), ceil_div(p.Coutp, CfgD::BN))),
+                         dim3(CfgD::THREADS), 0, st, p);
+    else
+      hipLaunchKernelGGL((conv_kernel<CfgR>), dim3(xcd_grid(ceil_div(p.M, CfgR::BM), ceil_div(p.Coutp, CfgR::BN))),
+                         dim3(CfgR::THREADS), 0, st, p);
+  }
   LOFTR_CHECK_LAUNCH();
   return LOFTR_OK;
 }
@@ -206,8 +222,8 @@ extern "C" int loftr_upsample2x_add(const uint32_t* low_sp, const uint32_t* late
   const int Cp = ceil32(C);
   const long pixels = (long)B * 4 * Hl * Wl;
   if (pixels >= (1L << 31)) return LOFTR_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(upsample_add_kernel, dim3((unsigned)pixels), dim3(Cp > 256 ? 256 : Cp), 0, (hipStream_t)stream,
-                     low_sp, lateral_sp, out_sp, Hl, Wl, Cp);
+  hipLaunchKernelGGL(upsample_add_kernel, dim3((unsigned)((pixels + 7) / 8)), dim3(256), 0, (hipStream_t)stream,
+                     low_sp, lateral_sp, out_sp, Hl, Wl, Cp, pixels);
   LOFTR_CHECK_LAUNCH();
   return LOFTR_OK;
 }

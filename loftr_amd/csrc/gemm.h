@@ -65,7 +65,7 @@ typedef uint32_t sp_t;            // one dword of an SP tensor (two halfs); a ro
 //                       (tap, channel); k-tile kt covers channels 32*(kt % (Cp/32)) .. +31 of tap
 //                       kt / (Cp/32) and reads pixel (yo*stride - pad + ky, xo*stride - pad + kx), zeros
 //                       outside the image -- no unfolded volume is ever materialised.
-struct ConvGeom { int H, W, Cp, KH, KW, stride, pad, Ho, Wo; };
+struct ConvGeom { int H, W, Cp, KH, KW, stride, pad, Ho, Wo; const sp_t* zeros; };   // zeros: >= 16 B of zeros (DMA source of out-of-image taps)
 struct ASrc {
   const sp_t* p0; int ld0;
   const sp_t* p1; int ksplit;
@@ -83,9 +83,12 @@ __host__ __device__ static inline ASrc asrc_conv(const sp_t* x, const ConvGeom& 
   return ASrc{x, g.Cp, nullptr, 1 << 30, nullptr, g};
 }
 
-template <int BM_, int BN_, int WM_, int WN_>
+// NS_ = 0: register-staged double buffering (below); NS_ >= 2: NS_-stage LDS ring filled by
+// global_load_lds (direct global -> LDS DMA, no staging registers) -- gemm_mainloop_dma.
+template <int BM_, int BN_, int WM_, int WN_, int NS_ = 0>
 struct GemmCfg {
-  static constexpr int BM = BM_, BN = BN_, BK = 32, WM = WM_, WN = WN_;
+  static constexpr int BM = BM_, BN = BN_, BK = 32, WM = WM_, WN = WN_, NS = NS_;
+  static constexpr int WAVES = WM * WN;
   static constexpr int THREADS = WM * WN * 64;
   static constexpr int WTM = BM / WM, WTN = BN / WN;           // wave sub-tile
   static constexpr int TM = WTM / 32, TN = WTN / 32;           // 32x32 MFMA tiles per wave
@@ -93,8 +96,10 @@ struct GemmCfg {
   static constexpr int B_F4 = BN * 8 / THREADS;
   static constexpr int TILE_A = BM * 128, TILE_B = BN * 128;   // bytes
   static constexpr int STAGE_BYTES = TILE_A + TILE_B;
-  static constexpr size_t LDS_BYTES = 2 * (size_t)STAGE_BYTES; // double buffered
+  static constexpr size_t LDS_BYTES = (NS ? NS : 2) * (size_t)STAGE_BYTES;
   static constexpr int LDS_FLOATS = (int)(LDS_BYTES / 4);
+  static constexpr int A_DMA = BM / (8 * WAVES), B_DMA = BN / (8 * WAVES);   // DMA instructions per wave per tile
+  static_assert(NS == 0 || (BM % (8 * WAVES) == 0 && BN % (8 * WAVES) == 0), "DMA mapping: 8 rows per wave instruction");
   static_assert(BM % (WM * 32) == 0 && BN % (WN * 32) == 0, "wave tile must be a multiple of 32");
   static_assert((BM * 8) % THREADS == 0 && (BN * 8) % THREADS == 0, "loader mapping");
 };
@@ -173,7 +178,7 @@ struct EpiLane {
 // Runs the whole K loop for the block tile at (m0, n0).  M, N are the valid extents (rows beyond
 // them are clamped on load -- the caller masks them in its epilogue).  K % 32 == 0 (SP groups).
 template <typename Cfg, bool CONV = false>
-__device__ __forceinline__ void gemm_mainloop(const ASrc& a, const sp_t* __restrict__ Bp, int ldb,
+__device__ __forceinline__ void gemm_mainloop_regs(const ASrc& a, const sp_t* __restrict__ Bp, int ldb,
                                               int M, int N, int K, int m0, int n0,
                                               float* lds_f, f32x16 (&acc)[Cfg::TM][Cfg::TN]) {
   constexpr int BK = Cfg::BK;
@@ -324,6 +329,149 @@ __device__ __forceinline__ void gemm_mainloop(const ASrc& a, const sp_t* __restr
 #undef GEMM_LOAD_B
 #undef GEMM_COMPUTE_TILE
 #undef GEMM_STORE_TILE
+}
+
+// ---- DMA variant -----------------------------------------------------------------------------
+// NS-stage LDS ring; every k-tile is brought in by global_load_lds_dwordx4 (64 lanes x 16 B = 8 tile
+// rows of 128 B per instruction; the LDS destination is wave-uniform base + lane*16, so the XOR
+// swizzle is applied to the per-lane GLOBAL address instead).  Tile t+NS-1 is issued right after the
+// barrier that starts k-tile t, i.e. NS-1 tiles (several microseconds of matrix work) ahead of its
+// use -- the register-staged loop could only afford one tile of lookahead for B and two for A, and
+// measured latency-bound (profiles/, r01 v4).  One s_barrier per k-tile, explicit vmcnt waits.
+#define LOFTR_WAITCNT_VM(n_) __builtin_amdgcn_s_waitcnt((((n_) & 0xF) | (((n_) >> 4) << 14) | (0x7 << 4) | (0xF << 8)))
+template <typename Cfg, bool CONV = false>
+__device__ __forceinline__ void gemm_mainloop_dma(const ASrc& a, const sp_t* __restrict__ Bp, int ldb,
+                                                  int M, int N, int K, int m0, int n0,
+                                                  float* lds_f, f32x16 (&acc)[Cfg::TM][Cfg::TN]) {
+  constexpr int BK = Cfg::BK, NS = Cfg::NS, WAVES = Cfg::WAVES;
+  constexpr int TM = Cfg::TM, TN = Cfg::TN;
+  constexpr int PER_TILE = Cfg::A_DMA + Cfg::B_DMA;            // DMA instructions per wave per k-tile
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+  typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+  char* lds = reinterpret_cast<char*>(lds_f);
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / Cfg::WN, wn = wave % Cfg::WN;
+  const int rsub = lane >> 3, slot = lane & 7;                 // row inside the 8-row group, LDS slot
+
+  int aoff[Cfg::A_DMA], boff[Cfg::B_DMA], ayx[Cfg::A_DMA];
+#pragma unroll
+  for (int q = 0; q < Cfg::A_DMA; ++q) {
+    const int r = (q * WAVES + wave) * 8 + rsub;
+    const int chunk = slot ^ ((r >> 1) & 7);                   // which 16-B chunk of the row lands in this slot
+    const int gr = min(m0 + r, M - 1);
+    if (CONV) {
+      const int hw = a.cv.Ho * a.cv.Wo;
+      const int b = gr / hw, rem = gr - b * hw;
+      const int yo = rem / a.cv.Wo, xo = rem - yo * a.cv.Wo;
+      const int yb = yo * a.cv.stride - a.cv.pad, xb = xo * a.cv.stride - a.cv.pad;
+      ayx[q] = (yb << 16) | (xb & 0xffff);
+      aoff[q] = ((b * a.cv.H + yb) * a.cv.W + xb) * a.cv.Cp + chunk * 4;
+    } else {
+      const int row = a.gather ? (int)a.gather[gr] : gr;
+      aoff[q] = row * a.ld0 + chunk * 4;
+      ayx[q] = 0;
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < Cfg::B_DMA; ++q) {
+    const int r = (q * WAVES + wave) * 8 + rsub;
+    const int chunk = slot ^ ((r >> 1) & 7);
+    boff[q] = min(n0 + r, N - 1) * ldb + chunk * 4;
+  }
+  const int cv_gpt = CONV ? a.cv.Cp / 32 : 1;
+
+#define GEMM_ISSUE(kt_, stage_)                                                               \
+  {                                                                                           \
+    char* s__ = lds + (stage_) * Cfg::STAGE_BYTES + wave * 1024;                              \
+    const int k0__ = (kt_) * BK;                                                              \
+    if (CONV) {                                                                               \
+      const int tap__ = (kt_) / cv_gpt, cg__ = (kt_) - tap__ * cv_gpt;                        \
+      const int ky__ = tap__ / a.cv.KW, kx__ = tap__ - ky__ * a.cv.KW;                        \
+      const int toff__ = (ky__ * a.cv.W + kx__) * a.cv.Cp + cg__ * 32;                        \
+      _Pragma("unroll") for (int q = 0; q < Cfg::A_DMA; ++q) {                                \
+        const int y__ = (ayx[q] >> 16) + ky__, x__ = (int)(short)(ayx[q] & 0xffff) + kx__;    \
+        const bool in__ = (unsigned)y__ < (unsigned)a.cv.H && (unsigned)x__ < (unsigned)a.cv.W; \
+        const sp_t* g__ = in__ ? a.p0 + (aoff[q] + toff__) : a.cv.zeros;                      \
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)g__, (lds_ptr_t)(s__ + q * WAVES * 1024), 16, 0, 0); \
+      }                                                                                       \
+    } else {                                                                                  \
+      const bool second__ = k0__ >= a.ksplit; /* block-uniform */                             \
+      const sp_t* ap__ = second__ ? a.p1 : a.p0;                                              \
+      const int ka__ = second__ ? k0__ - a.ksplit : k0__;                                     \
+      _Pragma("unroll") for (int q = 0; q < Cfg::A_DMA; ++q)                                  \
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(ap__ + (aoff[q] + ka__)),                \
+                                         (lds_ptr_t)(s__ + q * WAVES * 1024), 16, 0, 0);     \
+    }                                                                                         \
+    _Pragma("unroll") for (int q = 0; q < Cfg::B_DMA; ++q)                                    \
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(Bp + (boff[q] + k0__)),                    \
+                                       (lds_ptr_t)(s__ + Cfg::TILE_A + q * WAVES * 1024), 16, 0, 0); \
+  }
+#define GEMM_COMPUTE_STAGE(stage_)                                                            \
+  {                                                                                           \
+    const char* sA__ = lds + (stage_) * Cfg::STAGE_BYTES;                                     \
+    const char* sB__ = sA__ + Cfg::TILE_A;                                                    \
+    _Pragma("unroll") for (int ks = 0; ks < BK / 16; ++ks) {                                  \
+      h16x8 ah[TM], al[TM], bh[TN], bl[TN];                                                   \
+      _Pragma("unroll") for (int i = 0; i < TM; ++i) {                                        \
+        ah[i] = *reinterpret_cast<const h16x8*>(sA__ + lds_chunk_off(a_r0 + i * 32, ks * 2 + g));     \
+        al[i] = *reinterpret_cast<const h16x8*>(sA__ + lds_chunk_off(a_r0 + i * 32, 4 + ks * 2 + g)); \
+      }                                                                                       \
+      _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                        \
+        bh[j] = *reinterpret_cast<const h16x8*>(sB__ + lds_chunk_off(b_r0 + j * 32, ks * 2 + g));     \
+        bl[j] = *reinterpret_cast<const h16x8*>(sB__ + lds_chunk_off(b_r0 + j * 32, 4 + ks * 2 + g)); \
+      }                                                                                       \
+      _Pragma("unroll") for (int i = 0; i < TM; ++i)                                          \
+        _Pragma("unroll") for (int j = 0; j < TN; ++j)                                        \
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0); \
+      _Pragma("unroll") for (int i = 0; i < TM; ++i)                                          \
+        _Pragma("unroll") for (int j = 0; j < TN; ++j)                                        \
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0); \
+      _Pragma("unroll") for (int i = 0; i < TM; ++i)                                          \
+        _Pragma("unroll") for (int j = 0; j < TN; ++j)                                        \
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0); \
+    }                                                                                         \
+  }
+
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int g = lane >> 5;
+  const int a_r0 = wm * Cfg::WTM + (lane & 31);
+  const int b_r0 = wn * Cfg::WTN + (lane & 31);
+
+  const int nk = K / BK;
+#pragma unroll
+  for (int s = 0; s < NS - 1; ++s)
+    if (s < nk) GEMM_ISSUE(s, s);
+  int stage = 0, istage = NS - 1;                     // stage of tile kt / of the tile issued in iteration kt
+  for (int kt = 0; kt < nk; ++kt) {
+    // tile kt has landed once at most the newer tiles' DMAs are still outstanding
+    const int newer = min(NS - 2, nk - 1 - kt);
+    if (NS >= 4 && newer >= 2) LOFTR_WAITCNT_VM(2 * PER_TILE);
+    else if (newer >= 1) LOFTR_WAITCNT_VM(PER_TILE);
+    else LOFTR_WAITCNT_VM(0);
+    __builtin_amdgcn_s_barrier();                     // ... for every wave's share of it; also: all waves are done reading stage istage
+    if (kt + NS - 1 < nk) GEMM_ISSUE(kt + NS - 1, istage);
+    GEMM_COMPUTE_STAGE(stage);
+    stage = stage + 1 == NS ? 0 : stage + 1;
+    istage = istage + 1 == NS ? 0 : istage + 1;
+  }
+  __builtin_amdgcn_s_barrier();                       // callers reuse the LDS in their epilogues
+#undef GEMM_ISSUE
+#undef GEMM_COMPUTE_STAGE
+}
+
+template <typename Cfg, bool CONV = false>
+__device__ __forceinline__ void gemm_mainloop(const ASrc& a, const sp_t* __restrict__ Bp, int ldb,
+                                              int M, int N, int K, int m0, int n0,
+                                              float* lds_f, f32x16 (&acc)[Cfg::TM][Cfg::TN]) {
+  if constexpr (Cfg::NS >= 2) gemm_mainloop_dma<Cfg, CONV>(a, Bp, ldb, M, N, K, m0, n0, lds_f, acc);
+  else gemm_mainloop_regs<Cfg, CONV>(a, Bp, ldb, M, N, K, m0, n0, lds_f, acc);
 }
 
 // Coordinates of accumulator element `reg` of MFMA tile (i, j) for this lane.

@@ -13,22 +13,45 @@
 #include "../../loftr_amd/csrc/gemm.h"
 #include <stdio.h>
 #include <vector>
-using Cfg = GemmCfg<128, 128, 2, 2>;
+#include <math.h>
+#ifndef PCFG
+#define PCFG 128, 128, 2, 2
+#endif
+using Cfg = GemmCfg<PCFG>;
 __global__ __launch_bounds__(Cfg::THREADS, 2) void probe(const sp_t* a, const sp_t* b, float* out, int M, int N, int K) {
   __shared__ __attribute__((aligned(16))) float lds[Cfg::LDS_FLOATS];
   int tm, tn;
   if (!xcd_tile(ceil_div(M, Cfg::BM), ceil_div(N, Cfg::BN), tm, tn)) return;
   const int m0 = tm * Cfg::BM, n0 = tn * Cfg::BN;
   f32x16 acc[Cfg::TM][Cfg::TN];
+#if VARIANT == 5      // epilogue only
+  for (int i = 0; i < Cfg::TM; ++i) for (int j = 0; j < Cfg::TN; ++j) for (int r = 0; r < 16; ++r) acc[i][j][r] = (float)(m0 + n0 + r);
+#else
   gemm_mainloop<Cfg>(asrc_plain(a, K), b, K, M, N, K, m0, n0, lds, acc);
+#endif
+#if VARIANT == 4      // no output traffic: one conditional store keeps the accumulators alive
+  float t = 0.f;
+  for (int i = 0; i < Cfg::TM; ++i) for (int j = 0; j < Cfg::TN; ++j) for (int r = 0; r < 16; ++r) t += acc[i][j][r];
+  if (t == 12345.678f) out[threadIdx.x] = t;
+#else
   for (int i = 0; i < Cfg::TM; ++i) for (int j = 0; j < Cfg::TN; ++j) for (int r = 0; r < 16; ++r)
     out[(long)acc_row<Cfg>(m0, i, r) * N + acc_col<Cfg>(n0, j)] = acc[i][j][r];
+#endif
 }
 int main() {
   const int M = 76800, N = 512, K = 512;
   sp_t *a, *b; float* o;
   hipMalloc(&a, (size_t)M * K * 4); hipMalloc(&b, (size_t)N * K * 4); hipMalloc(&o, (size_t)M * N * 4);
-  hipMemset(a, 0, (size_t)M * K * 4); hipMemset(b, 0, (size_t)N * K * 4);
+  {  // non-trivial SP data: hi = small integers (exact), lo = 0 -> out[m][n] = sum_k a*b checkable
+    std::vector<unsigned> ha((size_t)M * K), hb((size_t)N * K);
+    auto enc = [](int m, int k) { _Float16 h = (_Float16)(float)((m * 7 + k * 3) % 5 - 2); unsigned short u; __builtin_memcpy(&u, &h, 2); return u; };
+    auto fill = [&](std::vector<unsigned>& v, int rows, int salt) {
+      for (int r = 0; r < rows; ++r) for (int g = 0; g < K / 32; ++g) for (int c = 0; c < 16; ++c) {
+        v[(size_t)r * K + g * 32 + c] = enc(r + salt, g * 32 + 2 * c) | ((unsigned)enc(r + salt, g * 32 + 2 * c + 1) << 16);
+        v[(size_t)r * K + g * 32 + 16 + c] = 0; } };
+    fill(ha, M, 0); fill(hb, N, 11);
+    hipMemcpy(a, ha.data(), ha.size() * 4, hipMemcpyHostToDevice); hipMemcpy(b, hb.data(), hb.size() * 4, hipMemcpyHostToDevice);
+  }
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   dim3 grid(xcd_grid(ceil_div(M, Cfg::BM), ceil_div(N, Cfg::BN)));
   for (int it = 0; it < 3; ++it) hipLaunchKernelGGL(probe, grid, dim3(Cfg::THREADS), 0, 0, a, b, o, M, N, K);
@@ -37,6 +60,14 @@ int main() {
   for (int it = 0; it < reps; ++it) hipLaunchKernelGGL(probe, grid, dim3(Cfg::THREADS), 0, 0, a, b, o, M, N, K);
   hipEventRecord(e1); hipEventSynchronize(e1);
   float ms; hipEventElapsedTime(&ms, e0, e1);
-  printf("variant %d: %.1f us per launch, %.1f TFLOP/s fp32-equivalent\n", VARIANT, ms / reps * 1e3, 2.0 * M * N * K / (ms / reps * 1e-3) / 1e12);
+  printf("variant %d: %.1f us per launch, %.1f TFLOP/s fp32-equivalent", VARIANT, ms / reps * 1e3, 2.0 * M * N * K / (ms / reps * 1e-3) / 1e12);
+  if (VARIANT == 0) {   // spot-check a few outputs against the integer reference
+    std::vector<float> ho((size_t)M * N); hipMemcpy(ho.data(), o, ho.size() * 4, hipMemcpyDeviceToHost);
+    auto val = [](int m, int k) { return (float)((m * 7 + k * 3) % 5 - 2); };
+    double maxerr = 0; const int ms_[] = {0, 1, 127, 128, 255, 256, 4799, 76799}; const int ns_[] = {0, 1, 63, 127, 128, 300, 511};
+    for (int mi : ms_) for (int ni : ns_) { double r = 0; for (int k = 0; k < K; ++k) r += val(mi, k) * val(ni + 11, k); maxerr = fmax(maxerr, fabs(r - ho[(size_t)mi * N + ni])); }
+    printf("   max |err| on spot checks = %g", maxerr);
+  }
+  printf("\n");
   return 0;
 }
