@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libloftr_hip.so")
+# LOFTR_HIP_LIB selects another build of the same library (A/B experiments, tools/ab_build.sh)
+LIB_PATH = os.environ.get("LOFTR_HIP_LIB") or os.path.join(HERE, "libloftr_hip.so")
 
 _p = C.c_void_p
 _i = C.c_int

@@ -32,8 +32,20 @@ def _deps_mtime():
     return max(os.path.getmtime(p) for p in paths)
 
 
-def build(force=False, verbose=True):
-    """Compile every HIP source for gfx950 and link libloftr_hip.so.  Returns its path."""
+def build(force=False, verbose=True, extra_flags=(), lib_path=None, obj_dir=None):
+    """Compile every HIP source for gfx950 and link libloftr_hip.so.  Returns its path.
+    extra_flags / lib_path / obj_dir build a variant next to the product library (A/B experiments)."""
+    global LIB_PATH, OBJ_DIR
+    lib_default, obj_default = LIB_PATH, OBJ_DIR
+    if lib_path:
+        LIB_PATH, OBJ_DIR, force = lib_path, obj_dir or (OBJ_DIR + "_variant"), True
+    try:
+        return _build(force, verbose, tuple(extra_flags))
+    finally:
+        LIB_PATH, OBJ_DIR = lib_default, obj_default
+
+
+def _build(force, verbose, extra_flags):
     if not force and os.path.exists(LIB_PATH) and os.path.getmtime(LIB_PATH) >= _deps_mtime():
         return LIB_PATH
     os.makedirs(OBJ_DIR, exist_ok=True)
@@ -41,7 +53,7 @@ def build(force=False, verbose=True):
 
     def compile_one(src):
         obj = os.path.join(OBJ_DIR, src.replace(".hip", ".o"))
-        cmd = [hipcc, *FLAGS, "-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [hipcc, *FLAGS, *extra_flags, "-c", os.path.join(CSRC, src), "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed on {src}:\n{r.stderr}")
@@ -61,4 +73,11 @@ def build(force=False, verbose=True):
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
+    # python -m loftr_amd.build [--force] [--variant NAME -DFLAG ...]  ->  libloftr_hip_NAME.so
+    if "--variant" in sys.argv:
+        i = sys.argv.index("--variant")
+        name = sys.argv[i + 1]
+        build(extra_flags=[a for a in sys.argv[i + 2:] if a.startswith("-")],
+              lib_path=os.path.join(HERE, f"libloftr_hip_{name}.so"))
+    else:
+        build(force="--force" in sys.argv)

@@ -16,18 +16,25 @@
 // straight from global memory (lane (d, half) reads K[s0 + half][d]: 128-B coalesced rows), the
 // S axis split over blocks and waves; partials are summed in a fixed order (deterministic).
 //   grid (splits, H, nb), 256 threads; each wave contracts KV_CHUNK/4 consecutive s.
-constexpr int KV_CHUNK = 256;     // s-values per block
+// s-values per block: 256 for small batches; larger (fewer partials for kv_finalize to sum) once the
+// grid already holds >= ~1024 workgroups.  Always a multiple of 8.
+static inline int kv_chunk(int nb, int S) {
+  const int splits_min = ceil_div(1024, 8 * nb);                 // keep >= ~1024 workgroups
+  int splits = ceil_div(S, 256);
+  if (splits > splits_min) splits = splits_min < 1 ? 1 : splits_min;
+  return ceil_div(ceil_div(S, splits), 8) * 8;
+}
 
 __global__ __launch_bounds__(256) void kv_partial_kernel(const float* __restrict__ Kf,
                                                          const float* __restrict__ Vf,
                                                          float* __restrict__ part,  // [nb,H,splits,33,32]
-                                                         int S, int C, int splits) {
+                                                         int S, int C, int splits, int chunk) {
   __shared__ float red[4][33][32];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int split = blockIdx.x, h = blockIdx.y, n = blockIdx.z;
   const int H = gridDim.y;
   const int d = lane & 31, half = lane >> 5;
-  const int s_begin = split * KV_CHUNK + wave * (KV_CHUNK / 4);
+  const int s_begin = split * chunk + wave * (chunk / 4);
   const float* kp = Kf + ((long)n * S) * C + h * 32 + d;
   const float* vp = Vf + ((long)n * S) * C + h * 32 + d;
   f32x16 acc;
@@ -35,7 +42,7 @@ __global__ __launch_bounds__(256) void kv_partial_kernel(const float* __restrict
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
   float ksum = 0.f;
 #pragma unroll 8
-  for (int t = 0; t < KV_CHUNK / 4 / 2; ++t) {
+  for (int t = 0; t < chunk / 4 / 2; ++t) {
     const int s = s_begin + 2 * t + half;
     float a = 0.f, b = 0.f;
     if (s < S) { a = kp[(long)s * C]; b = vp[(long)s * C]; }
@@ -156,7 +163,7 @@ __global__ __launch_bounds__(128) void attn_small_kernel(const float* __restrict
 // ------------------------------------------------------------------------------------------
 size_t attention_workspace_bytes(int nb, int S, int C) {
   if (C != 256) return 0;
-  const int splits = ceil_div(S, KV_CHUNK);
+  const int splits = ceil_div(S, 256);       // upper bound (kv_chunk >= 256)
   return align_up((size_t)nb * 8 * splits * 33 * 32 * sizeof(float), 256) +
          align_up((size_t)nb * 8 * 33 * 32 * sizeof(float), 256) +
          align_up((size_t)nb * C * C * sizeof(sp_t), 256) + 1024;
@@ -165,14 +172,14 @@ size_t attention_workspace_bytes(int nb, int S, int C) {
 int launch_attention_kv(const float* Kf, const float* Vf, const float* merge_w, int nb, int S, int C, int H,
                         void* ws, size_t ws_bytes, const float** kv_out, const sp_t** pm_out, hipStream_t st) {
   if (!(C == 256 && H == 8)) return LOFTR_ERR_UNSUPPORTED;
-  const int splits = ceil_div(S, KV_CHUNK);
+  const int chunk = kv_chunk(nb, S), splits = ceil_div(S, chunk);
   WsAlloc wa(ws, ws_bytes);
   float* part = wa.take<float>((size_t)nb * 8 * splits * 33 * 32);
   float* kv = wa.take<float>((size_t)nb * 8 * 33 * 32);
   sp_t* pm = wa.take<sp_t>((size_t)nb * C * C);
   if (!wa.ok()) return LOFTR_ERR_WORKSPACE;
   { TimedLaunch tl(LOFTR_T_KV, st);
-    hipLaunchKernelGGL(kv_partial_kernel, dim3(splits, 8, nb), dim3(256), 0, st, Kf, Vf, part, S, C, splits); }
+    hipLaunchKernelGGL(kv_partial_kernel, dim3(splits, 8, nb), dim3(256), 0, st, Kf, Vf, part, S, C, splits, chunk); }
   hipLaunchKernelGGL(kv_finalize_kernel, dim3(8, nb), dim3(256), 0, st, part, kv, splits, merge_w, pm);
   LOFTR_CHECK_LAUNCH();
   *kv_out = kv;

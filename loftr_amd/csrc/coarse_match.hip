@@ -102,7 +102,7 @@ template <bool FULL>
 __device__ __forceinline__ void stats_epilogue(f32x16 (&acc)[Cfg::TM][Cfg::TN], const Geometry& g, int n, int ti,
                                                int tj, float2* __restrict__ rowpart, float2* __restrict__ colpart) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int wm = wave / Cfg::WN, wn = wave % Cfg::WN;
+  const int wm = wave % Cfg::WM, wn = wave / Cfg::WM;
   const EpiLane<Cfg> e;
   const int m0 = ti * Cfg::BM, n0 = tj * Cfg::BN;
   // rows: reduce over the TN tiles of the lane and the 32 lanes of the half-wave
@@ -200,7 +200,7 @@ __device__ __forceinline__ void conf_partials(f32x16 (&acc)[Cfg::TM][Cfg::TN], i
                                               float2* __restrict__ rowmax_part,
                                               float* __restrict__ colmax_part) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int wm = wave / Cfg::WN, wn = wave % Cfg::WN;
+  const int wm = wave % Cfg::WM, wn = wave / Cfg::WM;
   const int pj = bx * Cfg::WN + wn, pi = by * Cfg::WM + wm;
   const EpiLane<Cfg> e;
   float2* rp = rowmax_part + ((long)n * g.L + m0) * g.PJ + pj;

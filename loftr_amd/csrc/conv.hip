@@ -87,7 +87,7 @@ __global__ __launch_bounds__(Cfg::THREADS, 2) void conv_kernel(ConvArgs p) {
   if (!xcd_tile(ceil_div(p.M, Cfg::BM), ceil_div(p.Coutp, Cfg::BN), tm, tn)) return;
   const int m0 = tm * Cfg::BM, n0 = tn * Cfg::BN;
   f32x16 acc[Cfg::TM][Cfg::TN];
-  gemm_mainloop<Cfg, true>(p.a, p.w, p.K, p.M, p.Cout, p.K, m0, n0, lds, acc);
+  gemm_mainloop<Cfg, true>(p.a, p.w, p.K, p.M, p.Cout, p.K, m0, n0, lds, acc, p.Coutp);
   if (m0 + Cfg::BM <= p.M) conv_epilogue<Cfg, true>(p, acc, m0, n0);
   else conv_epilogue<Cfg, false>(p, acc, m0, n0);
 }

@@ -160,6 +160,10 @@ __device__ __forceinline__ void sp_store(sp_t* row_ptr, int col, float v, bool p
   if (pred) row_ptr[sp_index(col)] = w;
 }
 
+// Wave w of a workgroup owns sub-tile (wm, wn) = (w % WM, w / WM): consecutive waves -- which the
+// hardware spreads over the four SIMDs -- walk down the M direction first, so the two waves sharing a SIMD
+// in an 8-wave workgroup sit in different column strips (balances the matrix pipes when the last
+// column strip of a tile is only partly active, `nact` below).
 // Per-lane coordinates of the accumulators inside the BM x BN block tile (C/D layout above):
 //   element (i, j, r) -> tile row  lrow + i*32 + (r&3) + 8*(r>>2),  tile column  lcol + j*32.
 template <typename Cfg>
@@ -167,10 +171,10 @@ struct EpiLane {
   int lrow, lcol, spcol; bool odd;
   __device__ __forceinline__ EpiLane() {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    lrow = (wave / Cfg::WN) * Cfg::WTM + 4 * (lane >> 5);
-    lcol = (wave % Cfg::WN) * Cfg::WTN + (lane & 31);
+    lrow = (wave % Cfg::WM) * Cfg::WTM + 4 * (lane >> 5);
+    lcol = (wave / Cfg::WM) * Cfg::WTN + (lane & 31);
     odd = lane & 1;
-    spcol = (wave % Cfg::WN) * Cfg::WTN + (odd ? 16 : 0) + ((lane & 31) >> 1);   // + j*32
+    spcol = (wave / Cfg::WM) * Cfg::WTN + (odd ? 16 : 0) + ((lane & 31) >> 1);   // + j*32
   }
   static __device__ __forceinline__ constexpr int rr(int i, int r) { return i * 32 + (r & 3) + 8 * (r >> 2); }
 };
@@ -180,13 +184,14 @@ struct EpiLane {
 template <typename Cfg, bool CONV = false>
 __device__ __forceinline__ void gemm_mainloop_regs(const ASrc& a, const sp_t* __restrict__ Bp, int ldb,
                                               int M, int N, int K, int m0, int n0,
-                                              float* lds_f, f32x16 (&acc)[Cfg::TM][Cfg::TN]) {
+                                              float* lds_f, f32x16 (&acc)[Cfg::TM][Cfg::TN], int ncols = 1 << 30) {
   constexpr int BK = Cfg::BK;
   constexpr int TM = Cfg::TM, TN = Cfg::TN;
   char* lds = reinterpret_cast<char*>(lds_f);
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
-  const int wm = wave / Cfg::WN, wn = wave % Cfg::WN;
+  const int wm = wave % Cfg::WM, wn = wave / Cfg::WM;
+  const int nact = min(TN, (ncols - (n0 + wn * Cfg::WTN) + 31) / 32);   // active 32-column MFMA tiles (wave-uniform)
 
   // ---- loader: per-thread dword offsets of its 16-B chunks (32-bit: operands are < 2^31 dwords)
   int aoff[Cfg::A_F4], boff[Cfg::B_F4];
@@ -273,15 +278,18 @@ __device__ __forceinline__ void gemm_mainloop_regs(const ASrc& a, const sp_t* __
       /* the two cross terms first, the leading term last; TM*TN independent accumulators */  \
       /* between two MFMAs on the same accumulator */                                         \
       if (GEMM_PROBE_MFMA) {                                                                  \
-      _Pragma("unroll") for (int i = 0; i < TM; ++i)                                          \
-        _Pragma("unroll") for (int j = 0; j < TN; ++j)                                        \
+      _Pragma("unroll") for (int j = 0; j < TN; ++j) if (j < nact) {   /* wave-uniform: skip dead column tiles */ \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i)                                        \
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0); \
-      _Pragma("unroll") for (int i = 0; i < TM; ++i)                                          \
-        _Pragma("unroll") for (int j = 0; j < TN; ++j)                                        \
+      }                                                                                       \
+      _Pragma("unroll") for (int j = 0; j < TN; ++j) if (j < nact) {                          \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i)                                        \
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0); \
-      _Pragma("unroll") for (int i = 0; i < TM; ++i)                                          \
-        _Pragma("unroll") for (int j = 0; j < TN; ++j)                                        \
+      }                                                                                       \
+      _Pragma("unroll") for (int j = 0; j < TN; ++j) if (j < nact) {                          \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i)                                        \
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0); \
+      }                                                                                       \
       } else {  /* probe: keep the LDS reads alive without the matrix pipe */                 \
         _Pragma("unroll") for (int i = 0; i < TM; ++i)                                        \
           _Pragma("unroll") for (int j = 0; j < TN; ++j)                                      \
@@ -342,7 +350,7 @@ __device__ __forceinline__ void gemm_mainloop_regs(const ASrc& a, const sp_t* __
 template <typename Cfg, bool CONV = false>
 __device__ __forceinline__ void gemm_mainloop_dma(const ASrc& a, const sp_t* __restrict__ Bp, int ldb,
                                                   int M, int N, int K, int m0, int n0,
-                                                  float* lds_f, f32x16 (&acc)[Cfg::TM][Cfg::TN]) {
+                                                  float* lds_f, f32x16 (&acc)[Cfg::TM][Cfg::TN], int ncols = 1 << 30) {
   constexpr int BK = Cfg::BK, NS = Cfg::NS, WAVES = Cfg::WAVES;
   constexpr int TM = Cfg::TM, TN = Cfg::TN;
   constexpr int PER_TILE = Cfg::A_DMA + Cfg::B_DMA;            // DMA instructions per wave per k-tile
@@ -351,7 +359,8 @@ __device__ __forceinline__ void gemm_mainloop_dma(const ASrc& a, const sp_t* __r
   char* lds = reinterpret_cast<char*>(lds_f);
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
-  const int wm = wave / Cfg::WN, wn = wave % Cfg::WN;
+  const int wm = wave % Cfg::WM, wn = wave / Cfg::WM;
+  const int nact = min(TN, (ncols - (n0 + wn * Cfg::WTN) + 31) / 32);   // active 32-column MFMA tiles (wave-uniform)
   const int rsub = lane >> 3, slot = lane & 7;                 // row inside the 8-row group, LDS slot
 
   int aoff[Cfg::A_DMA], boff[Cfg::B_DMA], ayx[Cfg::A_DMA];
@@ -421,15 +430,18 @@ __device__ __forceinline__ void gemm_mainloop_dma(const ASrc& a, const sp_t* __r
         bh[j] = *reinterpret_cast<const h16x8*>(sB__ + lds_chunk_off(b_r0 + j * 32, ks * 2 + g));     \
         bl[j] = *reinterpret_cast<const h16x8*>(sB__ + lds_chunk_off(b_r0 + j * 32, 4 + ks * 2 + g)); \
       }                                                                                       \
-      _Pragma("unroll") for (int i = 0; i < TM; ++i)                                          \
-        _Pragma("unroll") for (int j = 0; j < TN; ++j)                                        \
+      _Pragma("unroll") for (int j = 0; j < TN; ++j) if (j < nact) {   /* wave-uniform: skip dead column tiles */ \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i)                                        \
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0); \
-      _Pragma("unroll") for (int i = 0; i < TM; ++i)                                          \
-        _Pragma("unroll") for (int j = 0; j < TN; ++j)                                        \
+      }                                                                                       \
+      _Pragma("unroll") for (int j = 0; j < TN; ++j) if (j < nact) {                          \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i)                                        \
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0); \
-      _Pragma("unroll") for (int i = 0; i < TM; ++i)                                          \
-        _Pragma("unroll") for (int j = 0; j < TN; ++j)                                        \
+      }                                                                                       \
+      _Pragma("unroll") for (int j = 0; j < TN; ++j) if (j < nact) {                          \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i)                                        \
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0); \
+      }                                                                                       \
     }                                                                                         \
   }
 
@@ -469,21 +481,22 @@ __device__ __forceinline__ void gemm_mainloop_dma(const ASrc& a, const sp_t* __r
 template <typename Cfg, bool CONV = false>
 __device__ __forceinline__ void gemm_mainloop(const ASrc& a, const sp_t* __restrict__ Bp, int ldb,
                                               int M, int N, int K, int m0, int n0,
-                                              float* lds_f, f32x16 (&acc)[Cfg::TM][Cfg::TN]) {
-  if constexpr (Cfg::NS >= 2) gemm_mainloop_dma<Cfg, CONV>(a, Bp, ldb, M, N, K, m0, n0, lds_f, acc);
-  else gemm_mainloop_regs<Cfg, CONV>(a, Bp, ldb, M, N, K, m0, n0, lds_f, acc);
+                                              float* lds_f, f32x16 (&acc)[Cfg::TM][Cfg::TN], int ncols = 1 << 30) {
+  // ncols: columns >= ncols are never used by the caller -> their MFMAs are skipped (32-column granularity)
+  if constexpr (Cfg::NS >= 2) gemm_mainloop_dma<Cfg, CONV>(a, Bp, ldb, M, N, K, m0, n0, lds_f, acc, ncols);
+  else gemm_mainloop_regs<Cfg, CONV>(a, Bp, ldb, M, N, K, m0, n0, lds_f, acc, ncols);
 }
 
 // Coordinates of accumulator element `reg` of MFMA tile (i, j) for this lane.
 template <typename Cfg>
 __device__ __forceinline__ int acc_row(int m0, int i, int reg) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  return m0 + (wave / Cfg::WN) * Cfg::WTM + i * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+  return m0 + (wave % Cfg::WM) * Cfg::WTM + i * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
 }
 template <typename Cfg>
 __device__ __forceinline__ int acc_col(int n0, int j) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  return n0 + (wave % Cfg::WN) * Cfg::WTN + j * 32 + (lane & 31);
+  return n0 + (wave / Cfg::WM) * Cfg::WTN + j * 32 + (lane & 31);
 }
 
 // ---- fp32 -> SP conversion of whole tensors (sp_convert.hip) --------------------------------

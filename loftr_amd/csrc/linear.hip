@@ -4,7 +4,11 @@
 #include "linear.h"
 
 using CfgGen = GemmCfg<128, 128, 2, 2>;     // generic tile: 4 waves, 64x64 per wave
+#ifdef LOFTR_LN_DMA
+using CfgLN256 = GemmCfg<128, 256, 2, 4, 3>;  // full 256-wide rows in one block (LayerNorm), 8 waves, DMA ring
+#else
 using CfgLN256 = GemmCfg<64, 256, 1, 4>;    // full 256-wide rows in one block (LayerNorm)
+#endif
 using CfgLN128 = GemmCfg<128, 128, 2, 2>;   // full 128-wide rows in one block
 
 // ------------------------------------------------------------------------------------------
@@ -187,7 +191,7 @@ __global__ __launch_bounds__(Cfg::THREADS, 2) void linear_ln_kernel(LinearLNArgs
   }
   __syncthreads();                                  // all waves done with the staging buffers
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int wn = wave % Cfg::WN;
+  const int wn = wave / Cfg::WM;
   const float inv_c = 1.f / (float)p.C;
   const EpiLane<Cfg> e;
   const bool full = m0 + Cfg::BM <= p.M;            // block-uniform
