@@ -34,7 +34,7 @@ typedef enum {
   LOFTR_ERR_NO_DEVICE = -5      /* no gfx950 device visible                                    */
 } loftr_status;
 
-#define LOFTR_HIP_ABI_VERSION 4
+#define LOFTR_HIP_ABI_VERSION 5
 
 int loftr_hip_abi_version(void);
 const char* loftr_hip_status_string(int status);
@@ -189,6 +189,11 @@ int loftr_conv_bn_act(const uint32_t* x_sp, int B, int H, int W, int Cin, const 
                       const float* bn_mean, const float* bn_var, float bn_eps, int act,
                       const uint32_t* residual_sp, uint32_t* y_sp, float* y_f32, void* ws, size_t ws_bytes,
                       void* stream);
+/* Stem: nn.Conv2d(1, C0, 7, stride 2, padding 3, bias=False) + eval BatchNorm2d + ReLU (resnet_fpn.py:52-54,101),
+ * direct convolution; x [B,1,H,W] fp32 through its element strides (sb, sc, sh, sw), y_sp [B,Ho,Wo,ceil32(C0)]. */
+int loftr_stem_conv_bn_relu(const float* x, const long* x_strides, int B, int H, int W, const float* weight,
+                            const long* weight_strides, int C0, const float* bn_weight, const float* bn_bias,
+                            const float* bn_mean, const float* bn_var, float bn_eps, uint32_t* y_sp, void* stream);
 int loftr_upsample2x_add(const uint32_t* low_sp, const uint32_t* lateral_sp, uint32_t* out_sp, int B, int Hl,
                          int Wl, int C, void* stream);
 int loftr_sp_from_f32(const float* src, uint32_t* dst_sp, long rows, int C, void* stream);

@@ -56,6 +56,7 @@ SIGNATURES = {
     "loftr_fine_match": (_i, [_p, _p, _i, _i, _i, _p, _p, _f, _p, _p, _p, _p]),
     "loftr_conv_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "loftr_conv_bn_act": (_i, [_p, _i, _i, _i, _i, _p, C.POINTER(_l), _i, _i, _i, _i, _i, _p, _p, _p, _p, _f, _i, _p, _p, _p, _p, _sz, _p]),
+    "loftr_stem_conv_bn_relu": (_i, [_p, C.POINTER(_l), _i, _i, _i, _p, C.POINTER(_l), _i, _p, _p, _p, _p, _f, _p, _p]),
     "loftr_upsample2x_add": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
     "loftr_sp_from_f32": (_i, [_p, _p, _l, _i, _p]),
     "loftr_sp_to_f32": (_i, [_p, _p, _l, _i, _p]),
@@ -67,7 +68,7 @@ SIGNATURES = {
     "loftr_linear_fwd": (_i, [_p, _p, _p, _i, _i, _i, _p, _sz, _p]),
 }
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 _lib = None
 
 

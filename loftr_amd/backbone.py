@@ -11,7 +11,7 @@ Two execution paths over the same parameters:
   * ``forward_hip``  -- SURVEY.md §8(f) rank 1, the caller side of the hot path: every conv3x3 / conv1x1
                         (+ folded eval BatchNorm + residual + ReLU / LeakyReLU) is one implicit-GEMM
                         launch of the library's split-fp16 MFMA core (csrc/conv.hip), the FPN
-                        upsample+add one more kernel; only the 1-channel 7x7 stem stays in MIOpen.
+                        upsample+add one more kernel, the 1-channel 7x7 stem a direct convolution.
 ``LoFTR`` uses ``forward_hip`` on the GPU in eval mode (``backbone_impl='hip'``).
 """
 import torch
@@ -73,9 +73,8 @@ class _ResNetFPN(nn.Module):
 
     # ---- HIP path helpers: an activation is (SP int32 tensor [B,H,W,ceil32(C)], C) -----------------
     def _stem_hip(self, x):
-        """conv1 (7x7, one input channel) + bn1 + relu stay in MIOpen; hand over as SP NHWC."""
-        x0 = self.relu(self.bn1(self.conv1(x)))                       # channels-last fp32
-        return ops.sp_from_nhwc(x0.permute(0, 2, 3, 1).contiguous()), x0.shape[1]
+        """conv1 (7x7, one input channel) + bn1 + relu: direct-convolution kernel, output already SP NHWC."""
+        return ops.stem_conv_bn_relu(x, self.conv1, self.bn1), self.conv1.out_channels
 
     @staticmethod
     def _block_hip(blk, a):

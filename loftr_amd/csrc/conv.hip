@@ -151,6 +151,57 @@ __global__ __launch_bounds__(256) void upsample_add_kernel(const sp_t* __restric
   }
 }
 
+// Stem: nn.Conv2d(1, C0, 7, stride 2, pad 3, bias=False) + eval BatchNorm + ReLU (resnet_fpn.py:52-54,101)
+// as a direct convolution on the vector units: K = 49 is far too short for the matrix pipeline and the
+// single input channel would waste 31/32 of an SP group.  One workgroup computes a TY x TX patch of
+// output pixels for all C0 channels: the (2TY+5) x (2TX+5) input window lives in LDS and is read as
+// wave-wide broadcasts, each lane keeps the 49 folded weights of its channel in registers, and the
+// result is written straight in the SP operand format (32 consecutive channels = one 128-B group).
+//   grid (ceil(Wo/TX), ceil(Ho/TY), B), 256 threads = 2 pixel slots x (C0 = 128 channels)
+constexpr int STEM_TY = 8, STEM_TX = 32;
+__global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict__ x, long sxb, long sxh, long sxw,
+                                                        int H, int W, const float* __restrict__ w, long s_co, long s_ky,
+                                                        long s_kx, const float* __restrict__ bn_w,
+                                                        const float* __restrict__ bn_b, const float* __restrict__ bn_m,
+                                                        const float* __restrict__ bn_v, float eps, int C0, int Ho, int Wo,
+                                                        sp_t* __restrict__ y) {
+  constexpr int IH = 2 * STEM_TY + 5, IW = 2 * STEM_TX + 5;
+  __shared__ float tile[IH][IW + 3];
+  const int b = blockIdx.z, oy0 = blockIdx.y * STEM_TY, ox0 = blockIdx.x * STEM_TX;
+  const float* xb = x + (long)b * sxb;
+  for (int e = threadIdx.x; e < IH * IW; e += 256) {
+    const int r = e / IW, c = e - r * IW;
+    const int iy = 2 * oy0 - 3 + r, ix = 2 * ox0 - 3 + c;
+    tile[r][c] = ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) ? xb[iy * sxh + ix * sxw] : 0.f;
+  }
+  const int ch = threadIdx.x & 127, slot = threadIdx.x >> 7;            // channel, pixel slot (0/1)
+  float wr[49];
+  float scale = 1.f, shift = 0.f;
+  if (ch < C0) {
+    if (bn_w) { scale = bn_w[ch] / sqrtf(bn_v[ch] + eps); shift = bn_b[ch] - bn_m[ch] * scale; }
+#pragma unroll
+    for (int t = 0; t < 49; ++t) wr[t] = w[ch * s_co + (t / 7) * s_ky + (t % 7) * s_kx] * scale;
+  } else {
+#pragma unroll
+    for (int t = 0; t < 49; ++t) wr[t] = 0.f;
+  }
+  __syncthreads();
+  const int Cp = (C0 + 31) / 32 * 32;
+  for (int p = slot; p < STEM_TY * STEM_TX; p += 2) {
+    const int py = p / STEM_TX, px = p - py * STEM_TX;
+    float acc = shift;
+#pragma unroll
+    for (int ky = 0; ky < 7; ++ky)
+#pragma unroll
+      for (int kx = 0; kx < 7; ++kx) acc += tile[2 * py + ky][2 * px + kx] * wr[ky * 7 + kx];
+    acc = fmaxf(acc, 0.f);
+    const int oy = oy0 + py, ox = ox0 + px;
+    const bool ok = oy < Ho && ox < Wo && ch < Cp;
+    const uint32_t word = sp_word(ch < C0 ? acc : 0.f, ch & 1);
+    if (ok) y[(((long)b * Ho + oy) * Wo + ox) * Cp + sp_index(ch)] = word;
+  }
+}
+
 // SP [rows, Cp] -> fp32 [rows, C]   (debug / hand-over helper)
 __global__ void sp_to_f32_kernel(const sp_t* __restrict__ src, float* __restrict__ dst, long rows, int C, int Cp) {
   const long row = blockIdx.x;
@@ -211,6 +262,23 @@ extern "C" int loftr_conv_bn_act(const uint32_t* x_sp, int B, int H, int W, int 
       hipLaunchKernelGGL((conv_kernel<CfgR>), dim3(xcd_grid(ceil_div(p.M, CfgR::BM), ceil_div(p.Coutp, CfgR::BN))),
                          dim3(CfgR::THREADS), 0, st, p);
   }
+  LOFTR_CHECK_LAUNCH();
+  return LOFTR_OK;
+}
+
+extern "C" int loftr_stem_conv_bn_relu(const float* x, const long* x_strides, int B, int H, int W, const float* weight,
+                                       const long* weight_strides, int C0, const float* bn_weight, const float* bn_bias,
+                                       const float* bn_mean, const float* bn_var, float bn_eps, uint32_t* y_sp,
+                                       void* stream) {
+  LOFTR_CHECK_ARG(x && x_strides && weight && weight_strides && y_sp && B >= 0 && H > 0 && W > 0 && C0 > 0);
+  LOFTR_CHECK_ARG((bn_weight == nullptr) == (bn_bias == nullptr) && (bn_weight == nullptr) == (bn_mean == nullptr) &&
+                  (bn_weight == nullptr) == (bn_var == nullptr));
+  if (C0 > 128) return LOFTR_ERR_UNSUPPORTED;                 // one lane per channel, 128 channel lanes per workgroup
+  if (B == 0) return LOFTR_OK;
+  const int Ho = (H + 6 - 7) / 2 + 1, Wo = (W + 6 - 7) / 2 + 1;
+  hipLaunchKernelGGL(stem_conv_kernel, dim3(ceil_div(Wo, STEM_TX), ceil_div(Ho, STEM_TY), B), dim3(256), 0,
+                     (hipStream_t)stream, x, x_strides[0], x_strides[2], x_strides[3], H, W, weight, weight_strides[0],
+                     weight_strides[2], weight_strides[3], bn_weight, bn_bias, bn_mean, bn_var, bn_eps, C0, Ho, Wo, y_sp);
   LOFTR_CHECK_LAUNCH();
   return LOFTR_OK;
 }

@@ -283,6 +283,25 @@ def conv_bn_act(x_sp, Cin, conv, bn=None, act=0, residual=None, want_sp=True, wa
     return y_sp, y_f32
 
 
+def stem_conv_bn_relu(x, conv, bn):
+    """conv1 (7x7, stride 2, one input channel) + eval bn1 + relu -> SP int32 [B,Ho,Wo,ceil32(C0)]."""
+    if not x.is_cuda or x.dtype != torch.float32 or x.shape[1] != 1:
+        raise _lib.LoftrHipError("stem: expected a float32 GPU tensor [B,1,H,W]")
+    w = conv.weight
+    assert tuple(w.shape[1:]) == (1, 7, 7) and conv.stride == (2, 2) and conv.padding == (3, 3) and conv.bias is None
+    if bn.training:
+        raise _lib.LoftrHipError("stem folds eval-mode BatchNorm only; call .eval()")
+    B, _, H, W = x.shape
+    C0 = w.shape[0]
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    y = torch.empty(B, Ho, Wo, ceil32(C0), dtype=torch.int32, device=x.device)
+    xs, wst = (C.c_long * 4)(*x.stride()), (C.c_long * 4)(*w.stride())
+    check(_lib.load().loftr_stem_conv_bn_relu(_ptr(x), xs, B, H, W, _ptr(w), wst, C0, _ptr(bn.weight), _ptr(bn.bias),
+                                              _ptr(bn.running_mean), _ptr(bn.running_var), float(bn.eps), _ptr(y),
+                                              _stream()), "loftr_stem_conv_bn_relu")
+    return y
+
+
 def upsample2x_add(low_sp, lateral_sp, Cc):
     """lateral + bilinear x2 (align_corners=True) of low; SP in, SP out."""
     B, Hl, Wl, Cp = low_sp.shape

@@ -70,6 +70,24 @@ def test_conv_bn_act_vs_torch(cin, cout, k, stride, act, use_bn, use_res):
         assert (full[..., cout:] == 0).all()
 
 
+def test_stem_vs_torch():
+    from loftr_amd import ops
+    g = torch.Generator().manual_seed(9)
+    conv = nn.Conv2d(1, 128, 7, stride=2, padding=3, bias=False)
+    conv.weight.data = torch.randn(conv.weight.shape, generator=g) * 0.1
+    bn = nn.BatchNorm2d(128).eval()
+    _randomize_bn(bn, g)
+    for hw in ((96, 128), (50, 70), (480, 640)):
+        x = torch.rand(2, 1, *hw, generator=g)
+        ref = F.relu(F.batch_norm(F.conv2d(x.double(), conv.weight.double(), stride=2, padding=3), bn.running_mean.double(),
+                                  bn.running_var.double(), bn.weight.double(), bn.bias.double(), False, 0.0, bn.eps))
+        y = ops.stem_conv_bn_relu(x.cuda(), conv.cuda(), bn.cuda())
+        got = ops.sp_to_nhwc(y, 128).permute(0, 3, 1, 2).cpu().double()
+        assert got.shape == ref.shape
+        assert (got - ref).abs().max().item() <= 3e-6 * ref.abs().max().item()
+        conv, bn = conv.cpu(), bn.cpu()
+
+
 def test_upsample2x_add_vs_torch():
     from loftr_amd import ops
     g = torch.Generator().manual_seed(3)
