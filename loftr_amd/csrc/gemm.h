@@ -49,6 +49,15 @@
 #ifndef GEMM_PROBE_MFMA
 #define GEMM_PROBE_MFMA 1
 #endif
+#ifndef GEMM_PROBE_BARRIER
+#define GEMM_PROBE_BARRIER 1      // 0: drop the per-k-tile barrier (wrong results, timing only)
+#endif
+#ifndef GEMM_PROBE_DMA
+#define GEMM_PROBE_DMA 1          // 0: issue the ring's DMAs only in the prologue
+#endif
+#ifndef GEMM_PROBE_DSREAD
+#define GEMM_PROBE_DSREAD 1       // 0: read the fragments of the first k-tile only
+#endif
 
 typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -467,9 +476,9 @@ __device__ __forceinline__ void gemm_mainloop_dma(const ASrc& a, const sp_t* __r
     if (NS >= 4 && newer >= 2) LOFTR_WAITCNT_VM(2 * PER_TILE);
     else if (newer >= 1) LOFTR_WAITCNT_VM(PER_TILE);
     else LOFTR_WAITCNT_VM(0);
-    __builtin_amdgcn_s_barrier();                     // ... for every wave's share of it; also: all waves are done reading stage istage
-    if (kt + NS - 1 < nk) GEMM_ISSUE(kt + NS - 1, istage);
-    GEMM_COMPUTE_STAGE(stage);
+    if (GEMM_PROBE_BARRIER) __builtin_amdgcn_s_barrier();   // ... for every wave's share of it; also: all waves are done reading stage istage
+    if (GEMM_PROBE_DMA && kt + NS - 1 < nk) GEMM_ISSUE(kt + NS - 1, istage);
+    GEMM_COMPUTE_STAGE(GEMM_PROBE_DSREAD ? stage : 0);
     stage = stage + 1 == NS ? 0 : stage + 1;
     istage = istage + 1 == NS ? 0 : istage + 1;
   }
