@@ -1,6 +1,6 @@
 #!/bin/bash
 # round-1 GPU session: parity tests, smoke, bench, rocprofv3 kernel stats
-R=${GRAFT_REPO_ROOT:-/root/repo}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 O=$R/gpurun_out
 mkdir -p $O
 cd $R

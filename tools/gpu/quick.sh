@@ -1,6 +1,6 @@
 #!/bin/bash
 # quick GPU loop: parity tests + GEMM microbench + bench (no cpu baseline, no rocprof)
-R=${GRAFT_REPO_ROOT:-/root/repo}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 O=$R/gpurun_out
 mkdir -p $O
 cd $R
