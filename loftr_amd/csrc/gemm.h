@@ -270,7 +270,7 @@ __device__ __forceinline__ void gemm_mainloop_regs(const ASrc& a, const sp_t* __
       *reinterpret_cast<u32x4*>(s__ + b_lds_off[i]) = rb[i];                                 \
   }
   // all MFMAs of one k-tile held in LDS stage buf_
-#define GEMM_COMPUTE_TILE(buf_)                                                               \
+#define GEMM_COMPUTE_TILE(buf_, FULL_)                                                             \
   {                                                                                           \
     const char* sA__ = lds + (buf_) * Cfg::STAGE_BYTES;                                       \
     const char* sB__ = sA__ + Cfg::TILE_A;                                                    \
@@ -287,17 +287,24 @@ __device__ __forceinline__ void gemm_mainloop_regs(const ASrc& a, const sp_t* __
       /* the two cross terms first, the leading term last; TM*TN independent accumulators */  \
       /* between two MFMAs on the same accumulator */                                         \
       if (GEMM_PROBE_MFMA) {                                                                  \
-      _Pragma("unroll") for (int j = 0; j < TN; ++j) if (j < nact) {   /* wave-uniform: skip dead column tiles */ \
+      if (FULL_) {               /* all column tiles live: straight-line MFMA block */        \
         _Pragma("unroll") for (int i = 0; i < TM; ++i)                                        \
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0); \
-      }                                                                                       \
-      _Pragma("unroll") for (int j = 0; j < TN; ++j) if (j < nact) {                          \
+          _Pragma("unroll") for (int j = 0; j < TN; ++j)                                      \
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0); \
         _Pragma("unroll") for (int i = 0; i < TM; ++i)                                        \
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0); \
-      }                                                                                       \
-      _Pragma("unroll") for (int j = 0; j < TN; ++j) if (j < nact) {                          \
+          _Pragma("unroll") for (int j = 0; j < TN; ++j)                                      \
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0); \
         _Pragma("unroll") for (int i = 0; i < TM; ++i)                                        \
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0); \
+          _Pragma("unroll") for (int j = 0; j < TN; ++j)                                      \
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0); \
+      } else {                   /* wave-uniform: skip dead 32-column tiles */                \
+        _Pragma("unroll") for (int j = 0; j < TN; ++j) if (j < nact) {                        \
+          _Pragma("unroll") for (int i = 0; i < TM; ++i) {                                    \
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0); \
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0); \
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0); \
+          }                                                                                   \
+        }                                                                                     \
       }                                                                                       \
       } else {  /* probe: keep the LDS reads alive without the matrix pipe */                 \
         _Pragma("unroll") for (int i = 0; i < TM; ++i)                                        \
@@ -325,22 +332,42 @@ __device__ __forceinline__ void gemm_mainloop_regs(const ASrc& a, const sp_t* __
   if (nk > 1) GEMM_LOAD_A(BK, ra1);
   GEMM_STORE_TILE(0, ra0);
   __syncthreads();
+  if (nact == TN) {          // k loop instantiated twice: the common all-tiles-live case stays branch free
   for (int kt = 0; kt < nk; kt += 2) {
     // even k-tile: in LDS stage 0; A of tile kt+1 is landing in register set 1; set 0 is free
     if (kt + 2 < nk) GEMM_LOAD_A((kt + 2) * BK, ra0);
     if (kt + 1 < nk) GEMM_LOAD_B((kt + 1) * BK);
-    GEMM_COMPUTE_TILE(0);
+    GEMM_COMPUTE_TILE(0, 1);
     if (kt + 1 >= nk) break;
     GEMM_STORE_TILE(1, ra1);              // stage 1 was last read in iteration kt-1 (barrier since)
     __syncthreads();
     // odd k-tile: in LDS stage 1; A of tile kt+2 is landing in register set 0; set 1 is free
     if (kt + 3 < nk) GEMM_LOAD_A((kt + 3) * BK, ra1);
     if (kt + 2 < nk) GEMM_LOAD_B((kt + 2) * BK);
-    GEMM_COMPUTE_TILE(1);
+    GEMM_COMPUTE_TILE(1, 1);
     if (kt + 2 < nk) {
       GEMM_STORE_TILE(0, ra0);
       __syncthreads();
     }
+  }
+  } else {
+  for (int kt = 0; kt < nk; kt += 2) {
+    // even k-tile: in LDS stage 0; A of tile kt+1 is landing in register set 1; set 0 is free
+    if (kt + 2 < nk) GEMM_LOAD_A((kt + 2) * BK, ra0);
+    if (kt + 1 < nk) GEMM_LOAD_B((kt + 1) * BK);
+    GEMM_COMPUTE_TILE(0, 0);
+    if (kt + 1 >= nk) break;
+    GEMM_STORE_TILE(1, ra1);              // stage 1 was last read in iteration kt-1 (barrier since)
+    __syncthreads();
+    // odd k-tile: in LDS stage 1; A of tile kt+2 is landing in register set 0; set 1 is free
+    if (kt + 3 < nk) GEMM_LOAD_A((kt + 3) * BK, ra1);
+    if (kt + 2 < nk) GEMM_LOAD_B((kt + 2) * BK);
+    GEMM_COMPUTE_TILE(1, 0);
+    if (kt + 2 < nk) {
+      GEMM_STORE_TILE(0, ra0);
+      __syncthreads();
+    }
+  }
   }
 #undef GEMM_LOAD_A
 #undef GEMM_LOAD_B
@@ -425,7 +452,7 @@ __device__ __forceinline__ void gemm_mainloop_dma(const ASrc& a, const sp_t* __r
       __builtin_amdgcn_global_load_lds((gbl_ptr_t)(Bp + (boff[q] + k0__)),                    \
                                        (lds_ptr_t)(s__ + Cfg::TILE_A + q * WAVES * 1024), 16, 0, 0); \
   }
-#define GEMM_COMPUTE_STAGE(stage_)                                                            \
+#define GEMM_COMPUTE_STAGE(stage_, FULL_)                                                            \
   {                                                                                           \
     const char* sA__ = lds + (stage_) * Cfg::STAGE_BYTES;                                     \
     const char* sB__ = sA__ + Cfg::TILE_A;                                                    \
@@ -439,17 +466,24 @@ __device__ __forceinline__ void gemm_mainloop_dma(const ASrc& a, const sp_t* __r
         bh[j] = *reinterpret_cast<const h16x8*>(sB__ + lds_chunk_off(b_r0 + j * 32, ks * 2 + g));     \
         bl[j] = *reinterpret_cast<const h16x8*>(sB__ + lds_chunk_off(b_r0 + j * 32, 4 + ks * 2 + g)); \
       }                                                                                       \
-      _Pragma("unroll") for (int j = 0; j < TN; ++j) if (j < nact) {   /* wave-uniform: skip dead column tiles */ \
+      if (FULL_) {               /* all column tiles live: straight-line MFMA block */        \
         _Pragma("unroll") for (int i = 0; i < TM; ++i)                                        \
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0); \
-      }                                                                                       \
-      _Pragma("unroll") for (int j = 0; j < TN; ++j) if (j < nact) {                          \
+          _Pragma("unroll") for (int j = 0; j < TN; ++j)                                      \
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0); \
         _Pragma("unroll") for (int i = 0; i < TM; ++i)                                        \
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0); \
-      }                                                                                       \
-      _Pragma("unroll") for (int j = 0; j < TN; ++j) if (j < nact) {                          \
+          _Pragma("unroll") for (int j = 0; j < TN; ++j)                                      \
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0); \
         _Pragma("unroll") for (int i = 0; i < TM; ++i)                                        \
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0); \
+          _Pragma("unroll") for (int j = 0; j < TN; ++j)                                      \
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0); \
+      } else {                   /* wave-uniform: skip dead 32-column tiles */                \
+        _Pragma("unroll") for (int j = 0; j < TN; ++j) if (j < nact) {                        \
+          _Pragma("unroll") for (int i = 0; i < TM; ++i) {                                    \
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0); \
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0); \
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0); \
+          }                                                                                   \
+        }                                                                                     \
       }                                                                                       \
     }                                                                                         \
   }
@@ -470,6 +504,7 @@ __device__ __forceinline__ void gemm_mainloop_dma(const ASrc& a, const sp_t* __r
   for (int s = 0; s < NS - 1; ++s)
     if (s < nk) GEMM_ISSUE(s, s);
   int stage = 0, istage = NS - 1;                     // stage of tile kt / of the tile issued in iteration kt
+  if (nact == TN) {          // k loop instantiated twice: the common all-tiles-live case stays branch free
   for (int kt = 0; kt < nk; ++kt) {
     // tile kt has landed once at most the newer tiles' DMAs are still outstanding
     const int newer = min(NS - 2, nk - 1 - kt);
@@ -478,9 +513,23 @@ __device__ __forceinline__ void gemm_mainloop_dma(const ASrc& a, const sp_t* __r
     else LOFTR_WAITCNT_VM(0);
     if (GEMM_PROBE_BARRIER) __builtin_amdgcn_s_barrier();   // ... for every wave's share of it; also: all waves are done reading stage istage
     if (GEMM_PROBE_DMA && kt + NS - 1 < nk) GEMM_ISSUE(kt + NS - 1, istage);
-    GEMM_COMPUTE_STAGE(GEMM_PROBE_DSREAD ? stage : 0);
+    GEMM_COMPUTE_STAGE(GEMM_PROBE_DSREAD ? stage : 0, 1);
     stage = stage + 1 == NS ? 0 : stage + 1;
     istage = istage + 1 == NS ? 0 : istage + 1;
+  }
+  } else {
+  for (int kt = 0; kt < nk; ++kt) {
+    // tile kt has landed once at most the newer tiles' DMAs are still outstanding
+    const int newer = min(NS - 2, nk - 1 - kt);
+    if (NS >= 4 && newer >= 2) LOFTR_WAITCNT_VM(2 * PER_TILE);
+    else if (newer >= 1) LOFTR_WAITCNT_VM(PER_TILE);
+    else LOFTR_WAITCNT_VM(0);
+    if (GEMM_PROBE_BARRIER) __builtin_amdgcn_s_barrier();   // ... for every wave's share of it; also: all waves are done reading stage istage
+    if (GEMM_PROBE_DMA && kt + NS - 1 < nk) GEMM_ISSUE(kt + NS - 1, istage);
+    GEMM_COMPUTE_STAGE(GEMM_PROBE_DSREAD ? stage : 0, 0);
+    stage = stage + 1 == NS ? 0 : stage + 1;
+    istage = istage + 1 == NS ? 0 : istage + 1;
+  }
   }
   __builtin_amdgcn_s_barrier();                       // callers reuse the LDS in their epilogues
 #undef GEMM_ISSUE
