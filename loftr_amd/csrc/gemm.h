@@ -425,20 +425,23 @@ __device__ __forceinline__ void gemm_mainloop_dma(const ASrc& a, const sp_t* __r
     boff[q] = min(n0 + r, N - 1) * ldb + chunk * 4;
   }
   const int cv_gpt = CONV ? a.cv.Cp / 32 : 1;
+  int cv_cg = 0, cv_ky = 0, cv_kx = 0, cv_toff = 0;             // CONV: position of the next k-tile to issue (uniform)
 
 #define GEMM_ISSUE(kt_, stage_)                                                               \
   {                                                                                           \
     char* s__ = lds + (stage_) * Cfg::STAGE_BYTES + wave * 1024;                              \
     const int k0__ = (kt_) * BK;                                                              \
-    if (CONV) {                                                                               \
-      const int tap__ = (kt_) / cv_gpt, cg__ = (kt_) - tap__ * cv_gpt;                        \
-      const int ky__ = tap__ / a.cv.KW, kx__ = tap__ - ky__ * a.cv.KW;                        \
-      const int toff__ = (ky__ * a.cv.W + kx__) * a.cv.Cp + cg__ * 32;                        \
+    if (CONV) {              /* k-tiles are issued in increasing order: (ky, kx, channel group) advance incrementally */ \
       _Pragma("unroll") for (int q = 0; q < Cfg::A_DMA; ++q) {                                \
-        const int y__ = (ayx[q] >> 16) + ky__, x__ = (int)(short)(ayx[q] & 0xffff) + kx__;    \
+        const int y__ = (ayx[q] >> 16) + cv_ky, x__ = (int)(short)(ayx[q] & 0xffff) + cv_kx;  \
         const bool in__ = (unsigned)y__ < (unsigned)a.cv.H && (unsigned)x__ < (unsigned)a.cv.W; \
-        const sp_t* g__ = in__ ? a.p0 + (aoff[q] + toff__) : a.cv.zeros;                      \
+        const sp_t* g__ = in__ ? a.p0 + (aoff[q] + cv_toff) : a.cv.zeros;                     \
         __builtin_amdgcn_global_load_lds((gbl_ptr_t)g__, (lds_ptr_t)(s__ + q * WAVES * 1024), 16, 0, 0); \
+      }                                                                                       \
+      cv_toff += 32;                                                                          \
+      if (++cv_cg == cv_gpt) {                                                                \
+        cv_cg = 0;              /* cv_toff is now (ky*W + kx + 1) * Cp: the next tap */        \
+        if (++cv_kx == a.cv.KW) { cv_kx = 0; ++cv_ky; cv_toff += (a.cv.W - a.cv.KW) * a.cv.Cp; } \
       }                                                                                       \
     } else {                                                                                  \
       const bool second__ = k0__ >= a.ksplit; /* block-uniform */                             \
