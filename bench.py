@@ -186,6 +186,8 @@ def main():
     ap.add_argument("--no-conf", action="store_true", help="elide data['conf_matrix'] (not the headline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--roofline-kernel", default="auto")
+    ap.add_argument("--match-type", default="dual_softmax", choices=["dual_softmax", "sinkhorn"],
+                    help="sinkhorn = BASELINE configs[4] (indoor_ot); not the headline")
     ap.add_argument("--backbone", default="hip", choices=["hip", "torch"],
                     help="hip: implicit-GEMM convolutions of this library (default); torch: MIOpen fp32")
     args = ap.parse_args()
@@ -212,6 +214,8 @@ def main():
     torch.manual_seed(0)                                   # backbone init
     cfg = get_cfg(thr=args.thr)
     cfg["coarse"]["temp_bug_fix"] = True                   # indoor_ds_new / notebook setting
+    if args.match_type == "sinkhorn":                      # configs/loftr/indoor/loftr_ot.py + default.py:29-36
+        cfg["match_coarse"].update(match_type="sinkhorn", skh_prefilter=False, sparse_spvs=True)
     model = LoFTR(cfg).eval()
     sd = {k: torch.from_numpy(np.ascontiguousarray(np.asarray(v))) for k, v in make_weights(0, cfg).items()}
     model.load_state_dict(sd, strict=False)
@@ -310,7 +314,7 @@ def main():
                                    f"(BASELINE configs[1]), full LoFTR.forward = ResNet-FPN backbone ({'HIP implicit-GEMM convs, 7x7 stem in MIOpen' if args.backbone == 'hip' else 'PyTorch-ROCm / MIOpen fp32'}) + HIP matching path",
                        "weights": "seeded random init (no checkpoint on the box)", "thr": args.thr,
                        "thr_note": "stock thr 0.2 gives 0 matches with random weights; thr 0.0 keeps the fine stage loaded",
-                       "conf_matrix_materialised": not args.no_conf, "matches_per_pair": round(m_total / (world * B), 1),
+                       "conf_matrix_materialised": not args.no_conf, "match_type": args.match_type, "matches_per_pair": round(m_total / (world * B), 1),
                        "global_batch": world * B, "parallelism": f"dp{world} (pairs sharded; RCCL all-gather of match counts)"},
             "stage_ms": {"backbone": round(backbone_ms, 3), "backbone_impl": args.backbone, "hot_path_hip": round(hot_ms, 3),
                          "note": "mean of 3 instrumented steps, torch.cuda events on the launch stream"},

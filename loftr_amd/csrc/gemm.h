@@ -237,7 +237,7 @@ __device__ __forceinline__ void gemm_mainloop_regs(const ASrc& a, const sp_t* __
   // (macros, not lambdas: capturing the staging registers by reference makes hipcc keep a
   //  scratch copy of them)
 #define GEMM_LOAD_A(k0_, ra_)                                                                 \
-  if (CONV) {                                                                                 \
+  { if (CONV) {                                                                               \
     const int kt__ = (k0_) / BK;                    /* all block-uniform scalars */           \
     const int tap__ = kt__ / cv_gpt, cg__ = kt__ - tap__ * cv_gpt;                            \
     const int ky__ = tap__ / a.cv.KW, kx__ = tap__ - ky__ * a.cv.KW;                          \
@@ -254,7 +254,7 @@ __device__ __forceinline__ void gemm_mainloop_regs(const ASrc& a, const sp_t* __
     const int ka__ = second__ ? k0__ - a.ksplit : k0__;                                       \
     _Pragma("unroll") for (int i = 0; i < Cfg::A_F4; ++i)                                     \
       ra_[i] = *reinterpret_cast<const u32x4*>(ap__ + (aoff[i] + GEMM_PROBE_K(ka__)));       \
-  }
+  } }
 #define GEMM_LOAD_B(k0_)                                                                      \
   {                                                                                           \
     const int k0__ = (k0_);                                                                   \
