@@ -140,14 +140,28 @@ __global__ __launch_bounds__(256) void upsample_add_kernel(const sp_t* __restric
   const sp_t* l11 = low + ((b * Hl + y1) * Wl + x1) * Cp;
   const sp_t* la = lat + pix * Cp;
   sp_t* o = out + pix * Cp;
-  for (int c = threadIdx.x & 31; c < Cp; c += 32) {
-    const int idx = sp_index(c);
-    const bool odd = c & 1;
-    const float v00 = sp_value(l00[idx], odd), v01 = sp_value(l01[idx], odd);
-    const float v10 = sp_value(l10[idx], odd), v11 = sp_value(l11[idx], odd);
-    const float up = hy * (hx * v00 + lx * v01) + ly * (hx * v10 + lx * v11);
-    const float r = sp_value(la[idx], odd) + up;
-    o[idx] = sp_word(r, odd);
+  // all loads of up to 8 channel groups are issued before any arithmetic (memory-level parallelism)
+  constexpr int MAXG = 8;
+  const int lane = threadIdx.x & 31;
+  const bool odd = lane & 1;
+  for (int c0 = 0; c0 < Cp; c0 += 32 * MAXG) {
+    uint32_t w00[MAXG], w01[MAXG], w10[MAXG], w11[MAXG], wl[MAXG];
+#pragma unroll
+    for (int gidx = 0; gidx < MAXG; ++gidx) {
+      const int c = c0 + gidx * 32 + lane;
+      const int idx = c < Cp ? sp_index(c) : 0;
+      w00[gidx] = l00[idx]; w01[gidx] = l01[idx]; w10[gidx] = l10[idx]; w11[gidx] = l11[idx]; wl[gidx] = la[idx];
+    }
+#pragma unroll
+    for (int gidx = 0; gidx < MAXG; ++gidx) {
+      const int c = c0 + gidx * 32 + lane;
+      const float v00 = sp_value(w00[gidx], odd), v01 = sp_value(w01[gidx], odd);
+      const float v10 = sp_value(w10[gidx], odd), v11 = sp_value(w11[gidx], odd);
+      const float up = hy * (hx * v00 + lx * v01) + ly * (hx * v10 + lx * v11);
+      const float r = sp_value(wl[gidx], odd) + up;
+      const uint32_t word = sp_word(r, odd);
+      if (c < Cp) o[sp_index(c)] = word;
+    }
   }
 }
 
