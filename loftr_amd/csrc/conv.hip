@@ -118,13 +118,16 @@ __global__ __launch_bounds__(256) void conv_prep_kernel(const float* __restrict_
 }
 
 // out = lateral + bilinear_x2(low), align_corners=True       (resnet_fpn.py:111-116: F.interpolate + add)
-//   low [B, Hl, Wl, Cp], lateral / out [B, 2Hl, 2Wl, Cp], all SP.   grid (ceil(pixels / 8)), 256 threads =
-//   8 pixels x 32 lanes; a half-wave walks the 32-channel SP groups of its pixel (128-B lines).
+//   low [B, Hl, Wl, Cp], lateral / out [B, 2Hl, 2Wl, Cp], all SP.   One thread per (pixel, channel octet):
+//   five pairs of 16-B loads (4 taps + lateral, hi and lo chunk each), 8 lerps, one pair of 16-B stores.
 __global__ __launch_bounds__(256) void upsample_add_kernel(const sp_t* __restrict__ low, const sp_t* __restrict__ lat,
-                                                           sp_t* __restrict__ out, int Hl, int Wl, int Cp, long npix) {
+                                                           sp_t* __restrict__ out, int Hl, int Wl, int Cp, long nitems) {
+  const long item = (long)blockIdx.x * 256 + threadIdx.x;
+  if (item >= nitems) return;
+  const int octs = Cp >> 3;
+  const long pix = item / octs;
+  const int oct = (int)(item - pix * octs);
   const int Ho = 2 * Hl, Wo = 2 * Wl;
-  const long pix = (long)blockIdx.x * 8 + (threadIdx.x >> 5);
-  if (pix >= npix) return;
   const int x = (int)(pix % Wo), y = (int)((pix / Wo) % Ho);
   const long b = pix / ((long)Wo * Ho);
   // torch upsample_bilinear2d, align_corners=True: src = dst * (in - 1) / (out - 1)
@@ -134,35 +137,28 @@ __global__ __launch_bounds__(256) void upsample_add_kernel(const sp_t* __restric
   const int y1 = y0 + (y0 < Hl - 1 ? 1 : 0), x1 = x0 + (x0 < Wl - 1 ? 1 : 0);
   const float ly = fy - (float)y0, lx = fx - (float)x0;
   const float hy = 1.f - ly, hx = 1.f - lx;
-  const sp_t* l00 = low + ((b * Hl + y0) * Wl + x0) * Cp;
-  const sp_t* l01 = low + ((b * Hl + y0) * Wl + x1) * Cp;
-  const sp_t* l10 = low + ((b * Hl + y1) * Wl + x0) * Cp;
-  const sp_t* l11 = low + ((b * Hl + y1) * Wl + x1) * Cp;
-  const sp_t* la = lat + pix * Cp;
-  sp_t* o = out + pix * Cp;
-  // all loads of up to 8 channel groups are issued before any arithmetic (memory-level parallelism)
-  constexpr int MAXG = 8;
-  const int lane = threadIdx.x & 31;
-  const bool odd = lane & 1;
-  for (int c0 = 0; c0 < Cp; c0 += 32 * MAXG) {
-    uint32_t w00[MAXG], w01[MAXG], w10[MAXG], w11[MAXG], wl[MAXG];
+  const int off = sp_octet_off(oct);
+  const sp_t* src[5] = {low + ((b * Hl + y0) * Wl + x0) * Cp + off, low + ((b * Hl + y0) * Wl + x1) * Cp + off,
+                        low + ((b * Hl + y1) * Wl + x0) * Cp + off, low + ((b * Hl + y1) * Wl + x1) * Cp + off,
+                        lat + pix * Cp + off};
+  u32x4 hi[5], lo[5];
 #pragma unroll
-    for (int gidx = 0; gidx < MAXG; ++gidx) {
-      const int c = c0 + gidx * 32 + lane;
-      const int idx = c < Cp ? sp_index(c) : 0;
-      w00[gidx] = l00[idx]; w01[gidx] = l01[idx]; w10[gidx] = l10[idx]; w11[gidx] = l11[idx]; wl[gidx] = la[idx];
-    }
-#pragma unroll
-    for (int gidx = 0; gidx < MAXG; ++gidx) {
-      const int c = c0 + gidx * 32 + lane;
-      const float v00 = sp_value(w00[gidx], odd), v01 = sp_value(w01[gidx], odd);
-      const float v10 = sp_value(w10[gidx], odd), v11 = sp_value(w11[gidx], odd);
-      const float up = hy * (hx * v00 + lx * v01) + ly * (hx * v10 + lx * v11);
-      const float r = sp_value(wl[gidx], odd) + up;
-      const uint32_t word = sp_word(r, odd);
-      if (c < Cp) o[sp_index(c)] = word;
-    }
+  for (int t = 0; t < 5; ++t) {
+    hi[t] = *reinterpret_cast<const u32x4*>(src[t]);
+    lo[t] = *reinterpret_cast<const u32x4*>(src[t] + 16);
   }
+  float v[5][8];
+#pragma unroll
+  for (int t = 0; t < 5; ++t) sp_unpack8(hi[t], lo[t], v[t]);
+  float r[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e)
+    r[e] = v[4][e] + (hy * (hx * v[0][e] + lx * v[1][e]) + ly * (hx * v[2][e] + lx * v[3][e]));
+  u32x4 oh, ol;
+  sp_pack8(r, oh, ol);
+  sp_t* o = out + pix * Cp + off;
+  *reinterpret_cast<u32x4*>(o) = oh;
+  *reinterpret_cast<u32x4*>(o + 16) = ol;
 }
 
 // Stem: nn.Conv2d(1, C0, 7, stride 2, pad 3, bias=False) + eval BatchNorm + ReLU (resnet_fpn.py:52-54,101)
@@ -304,8 +300,10 @@ extern "C" int loftr_upsample2x_add(const uint32_t* low_sp, const uint32_t* late
   const int Cp = ceil32(C);
   const long pixels = (long)B * 4 * Hl * Wl;
   if (pixels >= (1L << 31)) return LOFTR_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(upsample_add_kernel, dim3((unsigned)((pixels + 7) / 8)), dim3(256), 0, (hipStream_t)stream,
-                     low_sp, lateral_sp, out_sp, Hl, Wl, Cp, pixels);
+  const long nitems = pixels * (Cp / 8);
+  if ((nitems + 255) / 256 >= (1L << 31)) return LOFTR_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(upsample_add_kernel, dim3((unsigned)((nitems + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     low_sp, lateral_sp, out_sp, Hl, Wl, Cp, nitems);
   LOFTR_CHECK_LAUNCH();
   return LOFTR_OK;
 }

@@ -161,6 +161,28 @@ __device__ __forceinline__ float sp_value(uint32_t w, bool odd) {
   const uint32_t lb = odd ? (w >> 16) : (recv & 0xffffu);
   return (float)__builtin_bit_cast(_Float16, (uint16_t)hb) + (float)__builtin_bit_cast(_Float16, (uint16_t)lb);
 }
+// Eight consecutive channels (8q .. 8q+7 of one 32-channel group) <-> the 16-B hi chunk (dwords 4q .. 4q+3
+// of the group) and the 16-B lo chunk (dwords 16+4q ..): the form used by the streaming (non-GEMM) kernels,
+// one thread per octet, 16-B accesses, no cross-lane traffic.
+__device__ __forceinline__ void sp_pack8(const float (&v)[8], u32x4& hi, u32x4& lo) {
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const uint32_t a = sp_pack(v[2 * e]), b = sp_pack(v[2 * e + 1]);
+    hi[e] = (a & 0xffffu) | (b << 16);
+    lo[e] = (a >> 16) | (b & 0xffff0000u);
+  }
+}
+__device__ __forceinline__ void sp_unpack8(const u32x4& hi, const u32x4& lo, float (&v)[8]) {
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    v[2 * e] = (float)__builtin_bit_cast(_Float16, (uint16_t)(hi[e] & 0xffffu)) +
+               (float)__builtin_bit_cast(_Float16, (uint16_t)(lo[e] & 0xffffu));
+    v[2 * e + 1] = (float)__builtin_bit_cast(_Float16, (uint16_t)(hi[e] >> 16)) +
+                   (float)__builtin_bit_cast(_Float16, (uint16_t)(lo[e] >> 16));
+  }
+}
+// dword offset of the hi chunk of channel octet `oct` (= channel / 8) inside an SP row; the lo chunk is 16 dwords later
+__device__ __forceinline__ int sp_octet_off(int oct) { return (oct >> 2) * 32 + (oct & 3) * 4; }
 // dword index inside an SP row of the word sp_word() produces for column `col`
 __device__ __forceinline__ int sp_index(int col) { return (col & ~31) + ((col & 1) ? 16 : 0) + ((col & 31) >> 1); }
 // convenience: predicated single store (row_ptr = first dword of the row)

@@ -2,24 +2,35 @@
 #include "gemm.h"
 
 namespace {
-// one wave handles two 32-column groups of one row per iteration: lane l -> column 2-group layout
-//   thread t of a 256-thread block: group-in-block = t / 32, column c = t % 32
-// Each half-wave converts one 128-B group: reads 32 floats (128 B, coalesced), writes 32 dwords.
+// One thread per (row, channel octet): two 16-B loads of fp32, one 16-B store each of the hi and the lo chunk.
+// Sources whose row pitch is not a multiple of 4 floats (or K not a multiple of 8) take the scalar tail path.
 __global__ __launch_bounds__(256) void sp_convert_kernel(SpJobs jobs) {
   const int job = blockIdx.y;
   const float* src = jobs.src[job];
   sp_t* dst = jobs.dst[job];
   const int K = jobs.K[job], ld = jobs.ld[job];
   const int Kp = (K + 31) / 32 * 32;
-  const int gpr = Kp / 32;                                  // groups per row
-  const long ngroups = (long)jobs.rows[job] * gpr;
-  const int c = threadIdx.x & 31;
-  for (long gidx = (long)blockIdx.x * 8 + (threadIdx.x >> 5); gidx < ngroups; gidx += (long)gridDim.x * 8) {
-    const long row = gidx / gpr;
-    const int grp = (int)(gidx - row * gpr);
-    const int col = grp * 32 + c;
-    const float v = col < K ? src[row * ld + col] : 0.f;
-    sp_store(dst + row * Kp, col, v, true);
+  const int octs = Kp >> 3;
+  const long nitems = (long)jobs.rows[job] * octs;
+  const bool vec = (ld & 3) == 0 && (((size_t)src) & 15) == 0;
+  for (long item = (long)blockIdx.x * 256 + threadIdx.x; item < nitems; item += (long)gridDim.x * 256) {
+    const long row = item / octs;
+    const int oct = (int)(item - row * octs);
+    const int c0 = oct * 8;
+    float v[8];
+    const float* p = src + row * ld + c0;
+    if (vec && c0 + 8 <= K) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(p), b2 = *reinterpret_cast<const f32x4*>(p + 4);
+      v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b2.x; v[5] = b2.y; v[6] = b2.z; v[7] = b2.w;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = c0 + e < K ? p[e] : 0.f;
+    }
+    u32x4 hi, lo;
+    sp_pack8(v, hi, lo);
+    sp_t* o = dst + row * Kp + sp_octet_off(oct);
+    *reinterpret_cast<u32x4*>(o) = hi;
+    *reinterpret_cast<u32x4*>(o + 16) = lo;
   }
 }
 }  // namespace
@@ -28,12 +39,12 @@ int launch_sp_convert(const SpJobs& jobs, hipStream_t st) {
   if (jobs.n <= 0) return LOFTR_OK;
   long maxg = 0;
   for (int i = 0; i < jobs.n; ++i) {
-    const long g = (long)jobs.rows[i] * ((jobs.K[i] + 31) / 32);
+    const long g = (long)jobs.rows[i] * ((jobs.K[i] + 31) / 32) * 4;      // octets
     if (g > maxg) maxg = g;
   }
   if (maxg == 0) return LOFTR_OK;
-  long bx = (maxg + 7) / 8;
-  if (bx > 16384) bx = 16384;
+  long bx = (maxg + 255) / 256;
+  if (bx > 32768) bx = 32768;
   hipLaunchKernelGGL(sp_convert_kernel, dim3((unsigned)bx, jobs.n), dim3(256), 0, st, jobs);
   LOFTR_CHECK_LAUNCH();
   return LOFTR_OK;
