@@ -61,10 +61,11 @@ __global__ __launch_bounds__(256) void kv_partial_kernel(const float* __restrict
   }
 }
 
-// kv [nb,H,33,32]: rows 0..31 = KV[d][v], row 32 = Ksum[d].   grid (H, nb), 256 threads.
-// Also folds KV into the merge projection: pm[n][j][h*32+d] = sum_v KV[n,h,d,v] * Wm[j][h*32+v],
-// written as SP (one whole 128-B group per thread: row j, group h).  Thread j owns output row j
-// (C == 256 == blockDim).
+// kv [nb,H,33,32]: rows 0..31 = KV[d][v], row 32 = Ksum[d].   grid (H, nb, 4), 256 threads.
+// Also folds KV into the merge projection: pm[n][j][h*32+d] = sum_v KV[n,h,d,v] * Wm[j][h*32+v], written as SP.
+// Block z handles output rows j = 64z .. 64z+63; thread (j, q) computes the channel octet d = 8q .. 8q+7 of
+// row j (256 FMAs) and stores it as one hi and one lo 16-B chunk.  Every block re-sums the split partials
+// (cheap) so the launch stays a single wave of work.
 __global__ __launch_bounds__(256) void kv_finalize_kernel(const float* __restrict__ part,
                                                           float* __restrict__ kv, int splits,
                                                           const float* __restrict__ wm,
@@ -77,39 +78,32 @@ __global__ __launch_bounds__(256) void kv_finalize_kernel(const float* __restric
   for (int e = threadIdx.x; e < 33 * 32; e += 256) {
     float s = 0.f;
     for (int k = 0; k < splits; ++k) s += p[(long)k * (33 * 32) + e];
-    o[e] = s;
+    if (blockIdx.z == 0) o[e] = s;
     skv[e] = s;
   }
   __syncthreads();
-  const int C = H * 32, j = threadIdx.x;
+  const int C = H * 32;
+  const int j = blockIdx.z * 64 + (threadIdx.x >> 2), q = threadIdx.x & 3;
   f32x4 w4[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) w4[i] = reinterpret_cast<const f32x4*>(wm + (long)j * C + h * 32)[i];
-  uint32_t packed[32];                                   // hi | lo << 16 of P[j][h*32 + d]
+  float r[8];
 #pragma unroll
-  for (int d = 0; d < 32; ++d) {
-    const float* kvrow = &skv[d * 32];
+  for (int dd = 0; dd < 8; ++dd) {
+    const float* kvrow = &skv[(q * 8 + dd) * 32];
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      const f32x4 k4 = *reinterpret_cast<const f32x4*>(kvrow + i * 4);      // LDS broadcast
+      const f32x4 k4 = *reinterpret_cast<const f32x4*>(kvrow + i * 4);
       s += k4.x * w4[i].x + k4.y * w4[i].y + k4.z * w4[i].z + k4.w * w4[i].w;
     }
-    packed[d] = sp_pack(s);
+    r[dd] = s;
   }
-  u32x4* dst = reinterpret_cast<u32x4*>(pm + ((long)n * C + j) * C + h * 32);
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {                          // hi halfs of d = 8q .. 8q+7
-    u32x4 hi, lo;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const uint32_t a = packed[q * 8 + 2 * e], b2 = packed[q * 8 + 2 * e + 1];
-      hi[e] = (a & 0xffffu) | (b2 << 16);
-      lo[e] = (a >> 16) | (b2 & 0xffff0000u);
-    }
-    dst[q] = hi;
-    dst[4 + q] = lo;
-  }
+  u32x4 hi, lo;
+  sp_pack8(r, hi, lo);
+  sp_t* dst = pm + ((long)n * C + j) * C + h * 32 + q * 4;
+  *reinterpret_cast<u32x4*>(dst) = hi;
+  *reinterpret_cast<u32x4*>(dst + 16) = lo;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -180,7 +174,7 @@ int launch_attention_kv(const float* Kf, const float* Vf, const float* merge_w, 
   if (!wa.ok()) return LOFTR_ERR_WORKSPACE;
   { TimedLaunch tl(LOFTR_T_KV, st);
     hipLaunchKernelGGL(kv_partial_kernel, dim3(splits, 8, nb), dim3(256), 0, st, Kf, Vf, part, S, C, splits, chunk); }
-  hipLaunchKernelGGL(kv_finalize_kernel, dim3(8, nb), dim3(256), 0, st, part, kv, splits, merge_w, pm);
+  hipLaunchKernelGGL(kv_finalize_kernel, dim3(8, nb, 4), dim3(256), 0, st, part, kv, splits, merge_w, pm);
   LOFTR_CHECK_LAUNCH();
   *kv_out = kv;
   *pm_out = pm;

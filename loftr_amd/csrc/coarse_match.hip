@@ -107,7 +107,7 @@ __device__ __forceinline__ void stats_epilogue(f32x16 (&acc)[Cfg::TM][Cfg::TN], 
   const int m0 = ti * Cfg::BM, n0 = tj * Cfg::BN;
   // rows: reduce over the TN tiles of the lane and the 32 lanes of the half-wave
   const int pj = tj * Cfg::WN + wn;
-  float2* rp = rowpart + ((long)n * g.L + m0) * g.PJ + pj;
+  float2* rp = rowpart + ((long)n * g.PJ + pj) * g.L + m0;      // partials are strip-major: [n][strip][row]
 #pragma unroll
   for (int i = 0; i < Cfg::TM; ++i) {
     f32x16 m = acc[i][0];
@@ -130,7 +130,7 @@ __device__ __forceinline__ void stats_epilogue(f32x16 (&acc)[Cfg::TM][Cfg::TN], 
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int trow = e.lrow + e.rr(i, r);
-      if ((lane & 31) == 0 && (FULL || m0 + trow < g.L)) rp[(unsigned)(trow * g.PJ)] = make_float2(m[r], s[r]);
+      if ((lane & 31) == 0 && (FULL || m0 + trow < g.L)) rp[trow] = make_float2(m[r], s[r]);
     }
   }
   // columns: reduce over the TM*16 rows of the lane and the other half-wave
@@ -153,7 +153,7 @@ __device__ __forceinline__ void stats_epilogue(f32x16 (&acc)[Cfg::TM][Cfg::TN], 
       }
     s += swap32(s);
     const int col = n0 + e.lcol + j * 32;
-    if (lane < 32 && (FULL || col < g.S)) colpart[((long)n * g.S + col) * g.PI + pi] = make_float2(m, s);
+    if (lane < 32 && (FULL || col < g.S)) colpart[((long)n * g.PI + pi) * g.S + col] = make_float2(m, s);
   }
 }
 
@@ -182,14 +182,16 @@ __global__ __launch_bounds__(Cfg::THREADS, 2) void score_stats_kernel(
 }
 
 // (max, sum) partials -> (max, 1/sum).   one thread per row (or column)
-__global__ void merge_stats_kernel(const float2* __restrict__ part, float2* __restrict__ stat, long rows, int P) {
+//   part [N][P][len] (strip-major: consecutive threads read consecutive addresses), stat [N][len]
+__global__ void merge_stats_kernel(const float2* __restrict__ part, float2* __restrict__ stat, long rows, int P, int len) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= rows) return;
-  const float2* p = part + i * P;
+  const long n = i / len;
+  const float2* p = part + (n * P) * len + (i - n * len);
   float m = SENTINEL;
-  for (int k = 0; k < P; ++k) m = fmaxf(m, p[k].x);
+  for (int k = 0; k < P; ++k) m = fmaxf(m, p[(long)k * len].x);
   float s = 0.f;
-  for (int k = 0; k < P; ++k) s += in_range(p[k].x) ? p[k].y * fexp(p[k].x - m) : 0.f;
+  for (int k = 0; k < P; ++k) { const float2 e = p[(long)k * len]; s += in_range(e.x) ? e.y * fexp(e.x - m) : 0.f; }
   stat[i] = make_float2(m, 1.f / s);
 }
 
@@ -203,7 +205,7 @@ __device__ __forceinline__ void conf_partials(f32x16 (&acc)[Cfg::TM][Cfg::TN], i
   const int wm = wave % Cfg::WM, wn = wave / Cfg::WM;
   const int pj = bx * Cfg::WN + wn, pi = by * Cfg::WM + wm;
   const EpiLane<Cfg> e;
-  float2* rp = rowmax_part + ((long)n * g.L + m0) * g.PJ + pj;
+  float2* rp = rowmax_part + ((long)n * g.PJ + pj) * g.L + m0;
 #pragma unroll
   for (int i = 0; i < Cfg::TM; ++i) {
     f32x16 bv = acc[i][0];
@@ -221,7 +223,7 @@ __device__ __forceinline__ void conf_partials(f32x16 (&acc)[Cfg::TM][Cfg::TN], i
       bc = half_min_i32(bc);
       const int trow = e.lrow + e.rr(i, r);
       if ((lane & 31) == 0 && (FULL || m0 + trow < g.L))
-        rp[(unsigned)(trow * g.PJ)] = make_float2(bv[r], __int_as_float(bc));
+        rp[trow] = make_float2(bv[r], __int_as_float(bc));
     }
   }
 #pragma unroll
@@ -233,7 +235,7 @@ __device__ __forceinline__ void conf_partials(f32x16 (&acc)[Cfg::TM][Cfg::TN], i
       for (int r = 0; r < 16; ++r) m = fmaxf(m, acc[i][j][r]);
     m = fmaxf(m, swap32(m));
     const int col = n0 + e.lcol + j * 32;
-    if (lane < 32 && (FULL || col < g.S)) colmax_part[((long)n * g.S + col) * g.PI + pi] = m;
+    if (lane < 32 && (FULL || col < g.S)) colmax_part[((long)n * g.PI + pi) * g.S + col] = m;
   }
 }
 
@@ -296,11 +298,13 @@ __global__ __launch_bounds__(Cfg::THREADS, 2) void score_conf_kernel(
   }
 }
 
-__global__ void merge_colmax_kernel(const float* __restrict__ part, float* __restrict__ colmax, long cols, int P) {
+__global__ void merge_colmax_kernel(const float* __restrict__ part, float* __restrict__ colmax, long cols, int P, int len) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= cols) return;
   float m = -1.f;
-  for (int k = 0; k < P; ++k) m = fmaxf(m, part[i * P + k]);
+  const long n = i / len;
+  const float* p = part + (n * P) * len + (i - n * len);
+  for (int k = 0; k < P; ++k) m = fmaxf(m, p[(long)k * len]);
   colmax[i] = m;
 }
 
@@ -358,10 +362,10 @@ __global__ __launch_bounds__(256) void select_kernel(SelectParams sp, const floa
   if (row < rows) {
     n = (int)(row / g.L);
     const int i = (int)(row - (long)n * g.L);
-    const float2* p = rowmax_part + row * g.PJ;
+    const float2* p = rowmax_part + ((long)n * g.PJ) * g.L + i;
     bv = -1.f; bj = 0;
     for (int k = 0; k < g.PJ; ++k) {                 // ascending column chunks: > keeps the first
-      const float2 e = p[k];
+      const float2 e = p[(long)k * g.L];
       if (e.x > bv) { bv = e.x; bj = __float_as_int(e.y); }
     }
     // 1. confidence threshold (:172)  2. borders (:176-183)  3. mutual nearest (:187-189)
@@ -708,7 +712,7 @@ bool params_ok(const loftr_coarse_params* p, const loftr_match_out* o) {
 int select_and_compact(const Geometry& g, const loftr_coarse_params& p, const loftr_match_out& out,
                        const MatchWs& w, hipStream_t st) {
   const long NL = (long)g.N * g.L, NS = (long)g.N * g.S;
-  hipLaunchKernelGGL(merge_colmax_kernel, dim3(ceil_div((int)NS, 256)), dim3(256), 0, st, w.colmax_part, w.colmax, NS, g.PI);
+  hipLaunchKernelGGL(merge_colmax_kernel, dim3(ceil_div((int)NS, 256)), dim3(256), 0, st, w.colmax_part, w.colmax, NS, g.PI, g.S);
   const int* valid = nullptr;
   if (p.mask0) {
     hipLaunchKernelGGL(valid_hw_kernel, dim3(g.N), dim3(128), 0, st, p.mask0, p.mask1, g.h0c, g.w0c, g.h1c, g.w1c, w.valid);
@@ -767,8 +771,8 @@ extern "C" int loftr_coarse_match_dual_softmax(const float* feat_c0, const float
     else
       hipLaunchKernelGGL((score_stats_kernel<false>), sgrid, block, 0, st, w.f0sp, w.f1sp, g, scale, p->mask0, p->mask1, w.rowpart, w.colpart);
   }
-  hipLaunchKernelGGL(merge_stats_kernel, dim3(ceil_div((int)NL, 256)), dim3(256), 0, st, w.rowpart, w.rowstat, NL, g.PJ);
-  hipLaunchKernelGGL(merge_stats_kernel, dim3(ceil_div((int)NS, 256)), dim3(256), 0, st, w.colpart, w.colstat, NS, g.PI);
+  hipLaunchKernelGGL(merge_stats_kernel, dim3(ceil_div((int)NL, 256)), dim3(256), 0, st, w.rowpart, w.rowstat, NL, g.PJ, g.L);
+  hipLaunchKernelGGL(merge_stats_kernel, dim3(ceil_div((int)NS, 256)), dim3(256), 0, st, w.colpart, w.colstat, NS, g.PI, g.S);
   {
     TimedLaunch tl(LOFTR_T_SCORE_CONF, st);
     if (p->mask0)
