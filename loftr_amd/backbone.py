@@ -139,22 +139,32 @@ class ResNetFPN_8_2(_ResNetFPN):
         return [x3_out, x1_out]
 
     @torch.no_grad()
-    def forward_hip(self, x):
-        """Same function as ``forward`` (resnet_fpn.py:100-118) on the HIP implicit-GEMM convolutions."""
+    def forward_hip(self, x, defer_fine=False):
+        """Same function as ``forward`` (resnet_fpn.py:100-118) on the HIP implicit-GEMM convolutions.
+
+        defer_fine=True returns ``[coarse, fine_fn]``: ``fine_fn()`` runs the FPN top-down branch (everything
+        after ``layer3_outconv``) and returns the fine map.  The coarse map does not depend on it, so the caller
+        can enqueue it on a second HIP stream next to the coarse matching stage."""
         a0 = self._stem_hip(x)
         a1 = self._stage_hip(self.layer1, a0)       # 1/2
         a2 = self._stage_hip(self.layer2, a1)       # 1/4
         a3 = self._stage_hip(self.layer3, a2)       # 1/8
         d3 = self.layer3_outconv.out_channels
         x3_sp, x3_f32 = ops.conv_bn_act(a3[0], a3[1], self.layer3_outconv, want_f32=True)
-        x2_lat, _ = ops.conv_bn_act(a2[0], a2[1], self.layer2_outconv)
-        t2 = ops.upsample2x_add(x3_sp, x2_lat, d3)
-        x2_out, _ = self._head_hip(self.layer2_outconv2, (t2, d3), want_f32=False)
-        d2 = self.layer2_outconv2[3].out_channels
-        x1_lat, _ = ops.conv_bn_act(a1[0], a1[1], self.layer1_outconv)
-        t1 = ops.upsample2x_add(x2_out, x1_lat, d2)
-        _, x1_f32 = self._head_hip(self.layer1_outconv2, (t1, d2), want_f32=True)
-        return [self._nchw_view(x3_f32), self._nchw_view(x1_f32)]
+
+        def fine():
+            x2_lat, _ = ops.conv_bn_act(a2[0], a2[1], self.layer2_outconv)
+            t2 = ops.upsample2x_add(x3_sp, x2_lat, d3)
+            x2_out, _ = self._head_hip(self.layer2_outconv2, (t2, d3), want_f32=False)
+            d2 = self.layer2_outconv2[3].out_channels
+            x1_lat, _ = ops.conv_bn_act(a1[0], a1[1], self.layer1_outconv)
+            t1 = ops.upsample2x_add(x2_out, x1_lat, d2)
+            _, x1_f32 = self._head_hip(self.layer1_outconv2, (t1, d2), want_f32=True)
+            return self._nchw_view(x1_f32)
+
+        if defer_fine:
+            return [self._nchw_view(x3_f32), fine]
+        return [self._nchw_view(x3_f32), fine()]
 
 
 class ResNetFPN_16_4(_ResNetFPN):
@@ -191,8 +201,9 @@ class ResNetFPN_16_4(_ResNetFPN):
         return [x4_out, x2_out]
 
     @torch.no_grad()
-    def forward_hip(self, x):
-        """Same function as ``forward`` (resnet_fpn.py:178-199) on the HIP implicit-GEMM convolutions."""
+    def forward_hip(self, x, defer_fine=False):
+        """Same function as ``forward`` (resnet_fpn.py:178-199) on the HIP implicit-GEMM convolutions
+        (``defer_fine``: see ResNetFPN_8_2.forward_hip)."""
         a0 = self._stem_hip(x)
         a1 = self._stage_hip(self.layer1, a0)       # 1/2
         a2 = self._stage_hip(self.layer2, a1)       # 1/4
@@ -200,14 +211,20 @@ class ResNetFPN_16_4(_ResNetFPN):
         a4 = self._stage_hip(self.layer4, a3)       # 1/16
         d4 = self.layer4_outconv.out_channels
         x4_sp, x4_f32 = ops.conv_bn_act(a4[0], a4[1], self.layer4_outconv, want_f32=True)
-        x3_lat, _ = ops.conv_bn_act(a3[0], a3[1], self.layer3_outconv)
-        t3 = ops.upsample2x_add(x4_sp, x3_lat, d4)
-        x3_out, _ = self._head_hip(self.layer3_outconv2, (t3, d4), want_f32=False)
-        d3 = self.layer3_outconv2[3].out_channels
-        x2_lat, _ = ops.conv_bn_act(a2[0], a2[1], self.layer2_outconv)
-        t2 = ops.upsample2x_add(x3_out, x2_lat, d3)
-        _, x2_f32 = self._head_hip(self.layer2_outconv2, (t2, d3), want_f32=True)
-        return [self._nchw_view(x4_f32), self._nchw_view(x2_f32)]
+
+        def fine():
+            x3_lat, _ = ops.conv_bn_act(a3[0], a3[1], self.layer3_outconv)
+            t3 = ops.upsample2x_add(x4_sp, x3_lat, d4)
+            x3_out, _ = self._head_hip(self.layer3_outconv2, (t3, d4), want_f32=False)
+            d3 = self.layer3_outconv2[3].out_channels
+            x2_lat, _ = ops.conv_bn_act(a2[0], a2[1], self.layer2_outconv)
+            t2 = ops.upsample2x_add(x3_out, x2_lat, d3)
+            _, x2_f32 = self._head_hip(self.layer2_outconv2, (t2, d3), want_f32=True)
+            return self._nchw_view(x2_f32)
+
+        if defer_fine:
+            return [self._nchw_view(x4_f32), fine]
+        return [self._nchw_view(x4_f32), fine()]
 
 
 def build_backbone(config):

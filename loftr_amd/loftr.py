@@ -71,8 +71,9 @@ class LoFTREncoderLayer(nn.Module):
               "norm1_w": self.norm1.weight, "norm1_b": self.norm1.bias,
               "norm2_w": self.norm2.weight, "norm2_b": self.norm2.bias}
         for k, v in sd.items():
-            if not v.is_contiguous():
-                raise RuntimeError(f"{k}: parameter must be contiguous")
+            if not v.is_contiguous() or v.dtype != torch.float32 or not v.is_cuda:
+                raise ops._lib.LoftrHipError(f"{k}: parameters must be contiguous float32 GPU tensors "
+                                             f"(got {v.dtype}, {v.device}); the HIP path computes in fp32")
         return ops.layer_weights_struct(sd)
 
     def forward(self, x, source, x_mask=None, source_mask=None):
@@ -234,6 +235,10 @@ class LoFTR(nn.Module):
         self.backbone = build_backbone(config).to(memory_format=torch.channels_last)
         # 'hip': convolutions on the library's implicit-GEMM kernels (backbone.forward_hip); 'torch': MIOpen.
         self.backbone_impl = "hip"
+        # With the HIP backbone the FPN top-down (fine) branch runs on a second HIP stream, concurrently with the
+        # coarse transformer + coarse matching it does not feed; joined before FinePreprocess.
+        self.overlap_fine_branch = True
+        self._side_stream = None
         self.pos_encoding = PositionEncodingSine(config["coarse"]["d_model"],
                                                  temp_bug_fix=config["coarse"]["temp_bug_fix"])
         self.loftr_coarse = LocalFeatureTransformer(config["coarse"])
@@ -249,8 +254,21 @@ class LoFTR(nn.Module):
         cl = lambda img: img.contiguous(memory_format=torch.channels_last)   # C == 1: a restride, no copy
         use_hip = self.backbone_impl == "hip" and data["image0"].is_cuda and not self.training
         run = self.backbone.forward_hip if use_hip else self.backbone
+        self._fine_join = None
         if data["hw0_i"] == data["hw1_i"]:
-            feats_c, feats_f = run(cl(torch.cat([data["image0"], data["image1"]], dim=0)))
+            x = cl(torch.cat([data["image0"], data["image1"]], dim=0))
+            if use_hip and self.overlap_fine_branch:
+                feats_c, fine_fn = run(x, defer_fine=True)
+                main = torch.cuda.current_stream()
+                if self._side_stream is None:
+                    self._side_stream = torch.cuda.Stream(device=x.device)
+                side = self._side_stream
+                side.wait_stream(main)                       # the fine branch reads what the trunk produced
+                with torch.cuda.stream(side):
+                    feats_f = fine_fn()
+                self._fine_join = side                       # joined in match_from_features before FinePreprocess
+            else:
+                feats_c, feats_f = run(x)
             (feat_c0, feat_c1), (feat_f0, feat_f1) = feats_c.split(data["bs"]), feats_f.split(data["bs"])
         else:
             (feat_c0, feat_f0), (feat_c1, feat_f1) = run(cl(data["image0"])), run(cl(data["image1"]))
@@ -267,6 +285,9 @@ class LoFTR(nn.Module):
             mask_c0, mask_c1 = data["mask0"].flatten(-2), data["mask1"].flatten(-2)
         feat_c0, feat_c1 = self.loftr_coarse(feat_c0, feat_c1, mask_c0, mask_c1)
         self.coarse_matching(feat_c0, feat_c1, data, mask_c0=mask_c0, mask_c1=mask_c1)
+        if getattr(self, "_fine_join", None) is not None:    # fine maps come from the side stream
+            torch.cuda.current_stream().wait_stream(self._fine_join)
+            self._fine_join = None
         feat_f0_unfold, feat_f1_unfold = self.fine_preprocess(feat_f0, feat_f1, feat_c0, feat_c1, data)
         if feat_f0_unfold.size(0) != 0:
             feat_f0_unfold, feat_f1_unfold = self.loftr_fine(feat_f0_unfold, feat_f1_unfold)

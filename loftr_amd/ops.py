@@ -38,8 +38,10 @@ def _stream():
 
 
 def workspace(nbytes, device):
-    """Cached scratch buffer of at least nbytes on `device` (safe to share: stream ordered)."""
-    idx = device.index if device.index is not None else torch.cuda.current_device()
+    """Cached scratch buffer of at least nbytes on `device`, one per (device, current stream): calls on one
+    stream may share it (stream ordered), concurrent streams must not."""
+    idx = (device.index if device.index is not None else torch.cuda.current_device(),
+           torch.cuda.current_stream().cuda_stream)
     buf = _WS.get(idx)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(int(nbytes * 1.25) + 4096, dtype=torch.uint8, device=device)
