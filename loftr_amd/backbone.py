@@ -144,7 +144,8 @@ class ResNetFPN_8_2(_ResNetFPN):
 
         defer_fine=True returns ``[coarse, fine_fn]``: ``fine_fn()`` runs the FPN top-down branch (everything
         after ``layer3_outconv``) and returns the fine map.  The coarse map does not depend on it, so the caller
-        can enqueue it on a second HIP stream next to the coarse matching stage."""
+        can enqueue it on a second HIP stream next to the coarse matching stage (``fine_fn.reads`` lists the
+        tensors it consumes, for ``Tensor.record_stream``)."""
         a0 = self._stem_hip(x)
         a1 = self._stage_hip(self.layer1, a0)       # 1/2
         a2 = self._stage_hip(self.layer2, a1)       # 1/4
@@ -163,6 +164,7 @@ class ResNetFPN_8_2(_ResNetFPN):
             return self._nchw_view(x1_f32)
 
         if defer_fine:
+            fine.reads = (a1[0], a2[0], x3_sp)       # tensors of this stream the deferred branch reads
             return [self._nchw_view(x3_f32), fine]
         return [self._nchw_view(x3_f32), fine()]
 
@@ -223,6 +225,7 @@ class ResNetFPN_16_4(_ResNetFPN):
             return self._nchw_view(x2_f32)
 
         if defer_fine:
+            fine.reads = (a2[0], a3[0], x4_sp)
             return [self._nchw_view(x4_f32), fine]
         return [self._nchw_view(x4_f32), fine()]
 

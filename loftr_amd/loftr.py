@@ -264,8 +264,11 @@ class LoFTR(nn.Module):
                     self._side_stream = torch.cuda.Stream(device=x.device)
                 side = self._side_stream
                 side.wait_stream(main)                       # the fine branch reads what the trunk produced
+                for t in fine_fn.reads:                      # ... and the caching allocator must not recycle those
+                    t.record_stream(side)                    #     buffers for this stream while the side stream reads them
                 with torch.cuda.stream(side):
                     feats_f = fine_fn()
+                feats_f.record_stream(main)                  # allocated on the side stream, consumed on this one
                 self._fine_join = side                       # joined in match_from_features before FinePreprocess
             else:
                 feats_c, feats_f = run(x)

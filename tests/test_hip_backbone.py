@@ -147,3 +147,28 @@ def test_full_forward_hip_backbone_matches_torch_backbone():
     ka = set(zip(a["b_ids"].tolist(), a["i_ids"].tolist(), a["j_ids"].tolist()))
     kb = set(zip(b["b_ids"].tolist(), b["i_ids"].tolist(), b["j_ids"].tolist()))
     assert len(ka ^ kb) <= max(2, len(ka) // 50), (len(ka), len(kb), len(ka ^ kb))
+
+
+def test_two_stream_overlap_is_bitwise_identical():
+    """The FPN fine branch on a second HIP stream (LoFTR.overlap_fine_branch) must not change a single bit, also
+    when forwards run back to back (caching-allocator reuse across the two streams)."""
+    from loftr_amd import LoFTR, get_cfg
+    torch.manual_seed(0)
+    model = LoFTR(get_cfg(thr=0.0)).eval().cuda()
+    g = torch.Generator().manual_seed(7)
+    imgs = [(torch.rand(2, 1, 240, 320, generator=g).cuda(), torch.rand(2, 1, 240, 320, generator=g).cuda()) for _ in range(3)]
+    ref = []
+    model.overlap_fine_branch = False
+    for a, b in imgs:
+        d = {"image0": a, "image1": b}
+        model(d)
+        ref.append({k: d[k].clone() for k in ("conf_matrix", "mkpts1_f", "mconf", "j_ids")})
+    model.overlap_fine_branch = True
+    for rep in range(3):
+        for (a, b), r in zip(imgs, ref):
+            d = {"image0": a, "image1": b}
+            model(d)
+            junk = torch.empty(64 << 20, device="cuda").fill_(float("nan"))    # provoke allocator reuse
+            del junk
+            for k in r:
+                assert torch.equal(d[k], r[k]), (rep, k)
