@@ -157,3 +157,30 @@ def test_properties_full_size():
         assert (y >= br).all() and (y < h - br).all() and (x >= br).all() and (x < w - br).all()
     assert np.array_equal(out["_match_counts"][1:], np.bincount(b, minlength=2))
     assert out["_match_counts"][0] == len(b)
+
+
+def test_batch_consistency_full_size():
+    """Pairs are independent: a batch of 3 pairs at the BASELINE size must give bitwise the same
+    per-pair results as the three pairs run one at a time -- tiles of the batched launches straddle pair
+    boundaries (3 * 4800 rows is not a multiple of any tile height), the arithmetic per output element may not."""
+    import copy
+    from loftr_amd.synth import make_features
+    from _cases import build_hip_matcher
+    rc, inp, g = load_case("full_ds_thr0")
+    c0, c1, f0, f1 = make_features(123, 3, (60, 80), (60, 80), corr=0.4)
+    model = build_hip_matcher(inp["cfg"], inp["w"])
+    base = dict(inp, feat_c0=c0, feat_c1=c1, feat_f0=f0, feat_f1=f1)
+    full = run_hip(base, model=model)
+    off = 0
+    for b in range(3):
+        one = run_hip(dict(base, feat_c0=c0[b:b + 1], feat_c1=c1[b:b + 1], feat_f0=f0[b:b + 1], feat_f1=f1[b:b + 1]),
+                      model=model)
+        m = int(full["_match_counts"][1 + b])
+        assert m == len(one["mconf"]) and m > 100
+        sl = slice(off, off + m)
+        assert np.array_equal(full["conf_matrix"][b], one["conf_matrix"][0])
+        for k in ("i_ids", "j_ids", "mconf", "mkpts0_f", "mkpts1_f", "expec_f"):
+            assert np.array_equal(full[k][sl], one[k]), (b, k)
+        assert (full["b_ids"][sl] == b).all()
+        off += m
+    assert off == len(full["mconf"])
