@@ -45,7 +45,7 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F16_PEAK_TF = 2500.0      # MI355X_MICROARCH.md: dense fp16/bf16 MFMA peak
 MFMA_F32_PEAK_TF = 157.3       # MI355X_MICROARCH.md: fp32-input MFMA = fp32 vector peak (for context only)
 SPLIT_FACTOR = 3               # every fp32 product = 3 fp16 MFMAs (hi*hi + hi*lo + lo*hi), csrc/gemm.h
-GEMM_KERNELS = ("proj_kernel", "linear_kernel", "linear_ln_kernel", "score_stats_kernel", "score_conf_kernel",
+GEMM_KERNELS = ("proj_kernel", "proj_kv_kernel", "linear_kernel", "linear_ln_kernel", "score_stats_kernel", "score_conf_kernel",
                 "conv_kernel")
 
 K_IDS = {}
@@ -71,15 +71,17 @@ def algorithmic_work(B, L, S, M, C_=256, Cf=128, WW=25):
     rows_c = 2 * B * L                      # both images, L == S
     n_self = n_cross = 4
 
-    def enc(rows, c, layers):
+    def enc(rows, c, layers, fused_kv=False):
         # per encoder-layer pass over `rows` tokens of width c
         proj = (2 * rows * c * 3 * c, 4 * (rows * c + 3 * c * c + 3 * rows * c))
+        if fused_kv:      # coarse level: proj_kernel computes q only; k, v (+ the KV reduction) live in proj_kv_kernel
+            proj = (2 * rows * c * c, 4 * (rows * c + c * c + rows * c))
         mlp0 = (2 * rows * (2 * c) * (2 * c), 4 * (2 * rows * c + 4 * c * c + 2 * rows * c))
         ln = (2 * rows * c * c + 2 * rows * 2 * c * c,
               4 * (rows * c + c * c + rows * c) + 4 * (2 * rows * c + 2 * c * c + 2 * rows * c))
         return {k: (v[0] * layers, v[1] * layers) for k, v in dict(proj_kernel=proj, linear_kernel=mlp0,
                                                                      linear_ln_kernel=ln).items()}
-    coarse = enc(rows_c, C_, n_self + n_cross)
+    coarse = enc(rows_c, C_, n_self + n_cross, fused_kv=True)
     fine = enc(2 * M * WW, Cf, 2)
     for k in coarse:
         w[k] = (coarse[k][0] + fine[k][0], coarse[k][1] + fine[k][1])
@@ -88,7 +90,7 @@ def algorithmic_work(B, L, S, M, C_=256, Cf=128, WW=25):
     fp_b = 2 * 4 * (M * C_ + Cf * C_ + M * Cf + M * Cf + Cf * Cf + M * Cf + 2 * M * WW * Cf + Cf * Cf)
     w["linear_kernel"] = (w["linear_kernel"][0] + fp_f, w["linear_kernel"][1] + fp_b)
     nl = n_self + n_cross
-    w["kv_partial_kernel"] = (nl * 2 * rows_c * C_ * 32 + nl * rows_c * C_, nl * 4 * 2 * rows_c * C_)
+    w["proj_kv_kernel"] = (nl * (2 * rows_c * C_ * 2 * C_ + 2 * rows_c * C_ * 32), nl * 4 * (rows_c * C_ + 2 * C_ * C_))
     w["attn_small_kernel"] = (2 * 2 * (2 * 2 * M * WW * Cf * 16), 2 * 4 * 4 * 2 * M * WW * Cf)
     w["score_stats_kernel"] = (2 * B * L * S * C_, 4 * B * (L + S) * C_)
     w["score_conf_kernel"] = (2 * B * L * S * C_, 4 * B * ((L + S) * C_ + L * S))

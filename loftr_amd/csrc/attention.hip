@@ -12,55 +12,9 @@
 #include "attention.h"
 
 // ------------------------------------------------------------------------------------------
-// Coarse level (D = 32): K^T V is a [32 x S] x [S x 32] product per (n, head) -> fp32 MFMA fed
-// straight from global memory (lane (d, half) reads K[s0 + half][d]: 128-B coalesced rows), the
-// S axis split over blocks and waves; partials are summed in a fixed order (deterministic).
-//   grid (splits, H, nb), 256 threads; each wave contracts KV_CHUNK/4 consecutive s.
-// s-values per block: 256 for small batches; larger (fewer partials for kv_finalize to sum) once the
-// grid already holds >= ~1024 workgroups.  Always a multiple of 8.
-static inline int kv_chunk(int nb, int S) {
-  const int splits_min = ceil_div(1024, 8 * nb);                 // keep >= ~1024 workgroups
-  int splits = ceil_div(S, 256);
-  if (splits > splits_min) splits = splits_min < 1 ? 1 : splits_min;
-  return ceil_div(ceil_div(S, splits), 8) * 8;
-}
-
-__global__ __launch_bounds__(256) void kv_partial_kernel(const float* __restrict__ Kf,
-                                                         const float* __restrict__ Vf,
-                                                         float* __restrict__ part,  // [nb,H,splits,33,32]
-                                                         int S, int C, int splits, int chunk) {
-  __shared__ float red[4][33][32];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int split = blockIdx.x, h = blockIdx.y, n = blockIdx.z;
-  const int H = gridDim.y;
-  const int d = lane & 31, half = lane >> 5;
-  const int s_begin = split * chunk + wave * (chunk / 4);
-  const float* kp = Kf + ((long)n * S) * C + h * 32 + d;
-  const float* vp = Vf + ((long)n * S) * C + h * 32 + d;
-  f32x16 acc;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  float ksum = 0.f;
-#pragma unroll 8
-  for (int t = 0; t < chunk / 4 / 2; ++t) {
-    const int s = s_begin + 2 * t + half;
-    float a = 0.f, b = 0.f;
-    if (s < S) { a = kp[(long)s * C]; b = vp[(long)s * C]; }
-    ksum += a;
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);   // A[i=d][k=s], B[k=s][j=v]
-  }
-  ksum += __shfl_xor(ksum, 32, 64);
-#pragma unroll
-  for (int r = 0; r < 16; ++r) red[wave][(r & 3) + 8 * (r >> 2) + 4 * half][d] = acc[r];   // [d][v]
-  if (half == 0) red[wave][32][d] = ksum;
-  __syncthreads();
-  float* out = part + (((long)n * H + h) * splits + split) * (33 * 32);
-  for (int e = threadIdx.x; e < 33 * 32; e += 256) {
-    const float* r0 = &red[0][0][0];
-    out[e] = (r0[e] + r0[33 * 32 + e]) + (r0[2 * 33 * 32 + e] + r0[3 * 33 * 32 + e]);
-  }
-}
-
+// Coarse level (D = 32): the K^T V / Ksum reduction itself runs in the epilogue of the k/v projection
+// (linear.hip: proj_kv_kernel, one partial per 128-row tile); what is left here is the deterministic
+// fixed-order sum of those partials and the fold of KV into the merge projection.
 // kv [nb,H,33,32]: rows 0..31 = KV[d][v], row 32 = Ksum[d].   grid (H, nb, 4), 256 threads.
 // Also folds KV into the merge projection: pm[n][j][h*32+d] = sum_v KV[n,h,d,v] * Wm[j][h*32+v], written as SP.
 // Block z handles output rows j = 64z .. 64z+63; thread (j, q) computes the channel octet d = 8q .. 8q+7 of
@@ -157,23 +111,27 @@ __global__ __launch_bounds__(128) void attn_small_kernel(const float* __restrict
 // ------------------------------------------------------------------------------------------
 size_t attention_workspace_bytes(int nb, int S, int C) {
   if (C != 256) return 0;
-  const int splits = ceil_div(S, 256);       // upper bound (kv_chunk >= 256)
+  const int splits = ceil_div(S, 128);       // one partial per 128-row tile of the fused k/v projection
   return align_up((size_t)nb * 8 * splits * 33 * 32 * sizeof(float), 256) +
          align_up((size_t)nb * 8 * 33 * 32 * sizeof(float), 256) +
          align_up((size_t)nb * C * C * sizeof(sp_t), 256) + 1024;
 }
 
-int launch_attention_kv(const float* Kf, const float* Vf, const float* merge_w, int nb, int S, int C, int H,
-                        void* ws, size_t ws_bytes, const float** kv_out, const sp_t** pm_out, hipStream_t st) {
+float* attention_part_buffer(void* ws, size_t ws_bytes, int nb, int S) {
+  WsAlloc wa(ws, ws_bytes);
+  float* part = wa.take<float>((size_t)nb * 8 * ceil_div(S, 128) * 33 * 32);
+  return wa.ok() ? part : nullptr;
+}
+
+int launch_attention_finalize(const float* merge_w, int nb, int S, int C, int H, void* ws, size_t ws_bytes,
+                              const float** kv_out, const sp_t** pm_out, hipStream_t st) {
   if (!(C == 256 && H == 8)) return LOFTR_ERR_UNSUPPORTED;
-  const int chunk = kv_chunk(nb, S), splits = ceil_div(S, chunk);
+  const int splits = ceil_div(S, 128);
   WsAlloc wa(ws, ws_bytes);
   float* part = wa.take<float>((size_t)nb * 8 * splits * 33 * 32);
   float* kv = wa.take<float>((size_t)nb * 8 * 33 * 32);
   sp_t* pm = wa.take<sp_t>((size_t)nb * C * C);
   if (!wa.ok()) return LOFTR_ERR_WORKSPACE;
-  { TimedLaunch tl(LOFTR_T_KV, st);
-    hipLaunchKernelGGL(kv_partial_kernel, dim3(splits, 8, nb), dim3(256), 0, st, Kf, Vf, part, S, C, splits, chunk); }
   hipLaunchKernelGGL(kv_finalize_kernel, dim3(8, nb, 4), dim3(256), 0, st, part, kv, splits, merge_w, pm);
   LOFTR_CHECK_LAUNCH();
   *kv_out = kv;

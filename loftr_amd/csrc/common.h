@@ -23,7 +23,7 @@ enum LoftrTimedKernel {
   LOFTR_T_PROJ = 2,          // linear.hip: proj_kernel                (q/k/v + feature map)
   LOFTR_T_LINEAR = 3,        // linear.hip: linear_kernel              (mlp.0 + relu, fine merges)
   LOFTR_T_LINEAR_LN = 4,     // linear.hip: linear_ln_kernel           (merge+LN, mlp.2+LN+residual)
-  LOFTR_T_KV = 5,            // attention.hip: kv_partial_kernel
+  LOFTR_T_KV = 5,            // linear.hip: proj_kv_kernel             (k/v projection + fused KV reduction)
   LOFTR_T_ATTN_APPLY = 6,    // attention.hip: attn_apply_kernel
   LOFTR_T_ATTN_SMALL = 7,    // attention.hip: attn_small_kernel       (fine level)
   LOFTR_T_GATHER = 8,        // fine.hip: gather_windows_kernel

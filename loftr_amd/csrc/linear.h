@@ -37,6 +37,23 @@ struct ProjArgs {
 };
 int launch_proj(const ProjArgs& p, hipStream_t st);
 
+// Coarse level (C = 256, 8 heads of 32): k / v projections of the source with the KV reduction of linear
+// attention fused into the epilogue -- K and V never go to HBM.
+//   w_kv: SP [2C, C], rows interleaved per head [K_h (32 rows) | V_h (32 rows)] (transformer.hip stages it so),
+//   so a 128-column tile holds two heads and each wave's 64 columns are [K_h | V_h] of ONE head for its 64 rows;
+//   the epilogue applies elu+1 / masks / 1/S and contracts over the rows with 32 fp32 MFMAs fed straight from the
+//   accumulators (KV_h[d][v] += K[row][d] * V[row][v]), plus Ksum.  Output: per (batch element, head, row tile)
+//   partials part[nb][8][splits][33][32] (rows 0..31 = KV[d][v], row 32 = Ksum[d]), splits = ceil(S / 128);
+//   kv_finalize_kernel (attention.hip) sums them.
+struct ProjKVArgs {
+  const sp_t* a; int S; int C; int nbatch;       // source [nbatch, S, C] SP
+  const sp_t* w_kv;
+  const uint8_t* mask;                           // [nbatch * S] or null
+  float inv_s;
+  float* part; int splits;
+};
+int launch_proj_kv(const ProjKVArgs& p, hipStream_t st);
+
 // out = [residual +] LayerNorm(A @ W^T) * gamma + beta     (N == C, one block spans the row)
 //   merge + norm1 (transformer.py:51-52) and mlp.2 + norm2 + residual (:55-58).
 //   Written as fp32 (out_f32) and / or SP (out_sp).  With w_batch_stride != 0 the rows are nbatch

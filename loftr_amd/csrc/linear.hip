@@ -175,6 +175,77 @@ int launch_proj(const ProjArgs& p, hipStream_t st) {
 }
 
 // ------------------------------------------------------------------------------------------
+// k / v projection + fused KV reduction (see linear.h: ProjKVArgs).   grid (xcd tiles, nbatch), 256 threads.
+template <typename Cfg>
+__global__ __launch_bounds__(Cfg::THREADS, 2) void proj_kv_kernel(ProjKVArgs p) {
+  static_assert(Cfg::WM == 2 && Cfg::WN == 2 && Cfg::TM == 2 && Cfg::TN == 2, "one head ([K|V] = 64 columns) per wave");
+  __shared__ __attribute__((aligned(16))) float lds[Cfg::LDS_FLOATS];
+  int tm, tn;
+  if (!xcd_tile(ceil_div(p.S, Cfg::BM), 2 * p.C / Cfg::BN, tm, tn)) return;
+  const int m0 = tm * Cfg::BM, n0 = tn * Cfg::BN;
+  const long n = blockIdx.y;
+  f32x16 acc[Cfg::TM][Cfg::TN];
+  gemm_mainloop<Cfg>(asrc_plain(p.a + n * p.S * p.C, p.C), p.w_kv, p.C, p.S, 2 * p.C, p.C, m0, n0, lds, acc);
+  const EpiLane<Cfg> e;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave % Cfg::WM, wn = wave / Cfg::WM;
+  const uint8_t* mask = p.mask ? p.mask + n * p.S : nullptr;
+  // feature map / masks on the accumulators: tile j = 0 holds K (elu+1), j = 1 holds V (1/S); rows >= S contribute 0
+  float ksum = 0.f;
+#pragma unroll
+  for (int i = 0; i < Cfg::TM; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = m0 + e.lrow + e.rr(i, r);
+      float mk = row < p.S ? 1.f : 0.f;
+      if (mask) mk = (row < p.S && mask[row]) ? 1.f : 0.f;
+      const float k = acc[i][0][r];
+      acc[i][0][r] = (k > 0.f ? k + 1.f : __expf(k)) * mk;            // elu(k)+1, linear_attention.py:31-32,37-38
+      acc[i][1][r] = acc[i][1][r] * (mk * p.inv_s);                    // values * mask / v_length   :39-42
+      ksum += acc[i][0][r];
+    }
+  // KV[d][v] += sum_rows K[row][d] V[row][v]: register r of the K tile IS the A operand of v_mfma_f32_32x32x2_f32
+  // (A[i = d = lane&31][k = lane>>5] = K[row(r, lane>>5)][d]) and register r of the V tile the B operand.
+  f32x16 kv;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) kv[r] = 0.f;
+#pragma unroll
+  for (int i = 0; i < Cfg::TM; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) kv = __builtin_amdgcn_mfma_f32_32x32x2f32(acc[i][0][r], acc[i][1][r], kv, 0, 0, 0);
+  ksum += swap32(ksum);                                               // both halves hold rows of the same d
+  // the two waves that share a head (wm = 0, 1) are summed through LDS in a fixed order
+  float* red = lds + wn * (33 * 32);                                  // [wn][33][32]
+  __syncthreads();                                                    // staging buffers no longer read
+  if (wm == 1) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * 32 + (lane & 31)] = kv[r];
+    if (lane < 32) red[32 * 32 + lane] = ksum;
+  }
+  __syncthreads();
+  if (wm == 0) {
+    const int head = 2 * tn + wn;
+    float* out = p.part + (((long)n * 8 + head) * p.splits + tm) * (33 * 32);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int o = ((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * 32 + (lane & 31);
+      out[o] = kv[r] + red[o];
+    }
+    if (lane < 32) out[32 * 32 + lane] = ksum + red[32 * 32 + lane];
+  }
+}
+
+int launch_proj_kv(const ProjKVArgs& p, hipStream_t st) {
+  if (p.S <= 0 || p.nbatch <= 0) return LOFTR_OK;
+  if (p.C != 256 || p.splits != ceil_div(p.S, CfgGen::BM)) return LOFTR_ERR_UNSUPPORTED;
+  dim3 grid(xcd_grid(ceil_div(p.S, CfgGen::BM), 2 * p.C / CfgGen::BN), p.nbatch);
+  TimedLaunch tl(LOFTR_T_KV, st);
+  hipLaunchKernelGGL((proj_kv_kernel<CfgGen>), grid, dim3(CfgGen::THREADS), 0, st, p);
+  LOFTR_CHECK_LAUNCH();
+  return LOFTR_OK;
+}
+
+// ------------------------------------------------------------------------------------------
 // GEMM + LayerNorm (+ residual).  One block spans the whole row (BN == C), so the row statistics
 // are a reduction over the TN tiles of a lane, the 32 lanes of a half-wave and the WN waves.
 template <typename Cfg, bool HAS_RES, bool OUT_F32, bool OUT_SP>

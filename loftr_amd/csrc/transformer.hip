@@ -2,7 +2,7 @@
 //   reference: src/loftr/loftr_module/transformer.py:35-58 (layer), :80-101 (layer schedule).
 //
 // Data flow of one coarse layer call (x attends to source; SP = split-fp16 GEMM operand format):
-//   source_sp --proj(k,v)--> K, V fp32 --kv_partial/finalize--> KV, Ksum, P (= KV folded into merge, SP)
+//   source_sp --proj(k,v) + KV reduction in the epilogue--> partials --finalize--> KV, Ksum, P (= KV folded into merge, SP)
 //   x_sp --proj(q) + normaliser z--> Q' SP --GEMM with P + LN(norm1)--> message SP
 //   cat[x_sp, message] --GEMM mlp.0 + ReLU--> hidden SP --GEMM mlp.2 + LN(norm2) + x--> x' (fp32 and SP)
 // The residual stream is kept in fp32 (in place in the caller's buffers); its SP mirror only feeds GEMMs.
@@ -15,6 +15,7 @@ constexpr int MAX_LAYERS = 16;
 
 struct LayerSp {                 // SP copies of one layer's matrices (workspace) + the fp32 originals needed
   const sp_t *q, *k, *v, *merge, *mlp0, *mlp2;
+  const sp_t* kv;                // C == 256: [2C, C], rows interleaved per head [K_h | V_h] (linear.h: ProjKVArgs)
   const float* merge_f32;
   const float *n1w, *n1b, *n2w, *n2b;
 };
@@ -27,7 +28,8 @@ struct EncoderWs {
   bool ok;
 };
 
-size_t weights_sp_dwords(int C) { return (size_t)10 * C * C; }
+size_t weights_sp_dwords(int C) { return (size_t)12 * C * C; }     // q k v merge (4) + mlp0 (4) + mlp2 (2) + interleaved kv (2)
+constexpr int JOBS_PER_LAYER = 6 + 16;
 
 size_t encoder_ws_bytes(int nb, int L, int S, int C) {
   size_t rows_l = (size_t)nb * L, rows_s = (size_t)nb * S;
@@ -75,6 +77,14 @@ LayerSp stage_layer(const loftr_layer_weights& w, sp_t* dst, int C, SpJobs& jobs
   l.merge = add(w.merge, C, C);
   l.mlp0 = add(w.mlp0, 2 * C, 2 * C);
   l.mlp2 = add(w.mlp2, C, 2 * C);
+  l.kv = nullptr;
+  if (C == 256) {                // per head: 32 rows of k_proj then 32 rows of v_proj
+    l.kv = dst;
+    for (int h = 0; h < 8; ++h) {
+      add(w.k_proj + (size_t)h * 32 * C, 32, C);
+      add(w.v_proj + (size_t)h * 32 * C, 32, C);
+    }
+  }
   l.merge_f32 = w.merge;
   l.n1w = w.norm1_w; l.n1b = w.norm1_b; l.n2w = w.norm2_w; l.n2b = w.norm2_b;
   return l;
@@ -90,12 +100,15 @@ int encoder_layer(const float* x_f32, const sp_t* x_sp, const sp_t* src_sp, bool
   const float attn_eps = 1e-6f;                       // LinearAttention(eps=1e-6), linear_attention.py:15
   int rc;
   if (C == 256) {
-    // k, v projections of the source -> KV / Ksum reduction -> P (KV folded into merge)
-    ProjArgs pkv{src_sp, Ms, C, 1, 2, {w.k, w.v, nullptr}, {e.k, e.v, nullptr}, {1, 2, 0}, src_mask, inv_s,
-                 nullptr, 0.f, 0.f};
-    if ((rc = launch_proj(pkv, st))) return rc;
+    // k, v projections of the source with the KV / Ksum reduction in their epilogue (K, V never reach HBM)
+    // -> finalize: sum of the row-tile partials + P (KV folded into merge)
+    float* part = attention_part_buffer(e.attn, e.attn_bytes, nb, S);
+    if (!part) return LOFTR_ERR_WORKSPACE;
+    ProjKVArgs pkv{src_sp, S, C, nb, w.kv, src_mask, inv_s, part, ceil_div(S, 128)};
+    if ((rc = launch_proj_kv(pkv, st))) return rc;
     const float* kv = nullptr; const sp_t* pm = nullptr;
-    if ((rc = launch_attention_kv(e.k, e.v, w.merge_f32, nb, S, C, H, e.attn, e.attn_bytes, &kv, &pm, st))) return rc;
+    if ((rc = launch_attention_finalize(w.merge_f32, nb, S, C, H, e.attn, e.attn_bytes, &kv, &pm, st))) return rc;
+    (void)Ms;
     // q projection with the normaliser applied in its epilogue (per pair: grid.z = nb)
     ProjArgs pq{x_sp, L, C, nb, 1, {w.q, nullptr, nullptr}, {e.q, nullptr, nullptr}, {0, 0, 0}, x_mask, inv_s,
                 kv, (float)S, attn_eps};
@@ -201,7 +214,7 @@ extern "C" int loftr_transformer_fwd(float* feat0, float* feat1, const uint8_t* 
     add(feat0, sp0, (long)N * L);
     add(feat1, sp1, (long)N * S);
     for (int i = 0; i < n_layers; ++i) {
-      if (jobs.n + 6 > SP_MAX_JOBS) {
+      if (jobs.n + JOBS_PER_LAYER > SP_MAX_JOBS) {
         if ((rc = launch_sp_convert(jobs, st))) return rc;
         jobs.n = 0;
       }
