@@ -184,3 +184,35 @@ def test_batch_consistency_full_size():
         assert (full["b_ids"][sl] == b).all()
         off += m
     assert off == len(full["mconf"])
+
+
+@pytest.mark.parametrize("C,L,S,masked", [(256, 300, 300, False), (256, 130, 75, True), (128, 25, 25, False)])
+def test_single_encoder_layer_vs_oracle(C, L, S, masked):
+    """loftr_encoder_layer_fwd (the per-layer entry point, transformer.py:35-58) against the numpy oracle:
+    self- and cross-attention, unequal lengths, padding masks, both widths."""
+    import torch
+    from oracle import loftr_oracle as O
+    from loftr_amd.loftr import LoFTREncoderLayer
+    from loftr_amd.synth import _encoder_layer
+    rng = np.random.default_rng(C + L)
+    w = {}
+    _encoder_layer(rng, "l.", C, w)
+    layer = LoFTREncoderLayer(C, 8).eval()
+    layer.load_state_dict({k[2:]: torch.from_numpy(v) for k, v in w.items()})
+    layer = layer.cuda()
+    nb = 3
+    x = rng.standard_normal((nb, L, C)).astype(np.float32)
+    src = rng.standard_normal((nb, S, C)).astype(np.float32)
+    xm = sm = None
+    if masked:
+        xm = np.ones((nb, L), bool); xm[1, L // 2:] = False
+        sm = np.ones((nb, S), bool); sm[2, S // 3:] = False
+    t = lambda a: None if a is None else torch.from_numpy(a).cuda()
+    for self_attn in (False, True):
+        if self_attn:
+            got = layer(t(x), t(x), t(xm), t(xm)).cpu().numpy()
+            ref = O.encoder_layer(x, x, w, "l.", 8, xm, xm)
+        else:
+            got = layer(t(x), t(src), t(xm), t(sm)).cpu().numpy()
+            ref = O.encoder_layer(x, src, w, "l.", 8, xm, sm)
+        assert np.abs(got - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max()), (self_attn, np.abs(got - ref).max())
