@@ -92,6 +92,231 @@ __global__ __launch_bounds__(Cfg::THREADS, 2) void conv_kernel(ConvArgs p) {
   else conv_epilogue<Cfg, false>(p, acc, m0, n0);
 }
 
+// ------------------------------------------------------------------------------------------
+// 3x3 / stride 1 / pad 1 convolutions (12 of the 21 backbone convolutions, ~85 % of their time): the nine
+// filter taps of one 32-channel group read nine shifted views of the SAME pixels, so instead of DMA-ing a
+// 256-row A tile per (tap, channel group) k-tile the workgroup keeps the (8+2) x (32+2) input patch of its
+// 8 x 32 output tile in LDS -- one patch load per channel group serves nine k-tiles (A traffic / 9, and with
+// it the DMA issue + LDS fill work the isolation runs in DESIGN.md §5 identified as the main-loop overhead).
+//   tile   : 8 x 32 output pixels of one image = 256 GEMM rows, x 128 output channels; 8 waves (4 x 2): wave
+//            (wm, wn) owns output rows 2wm, 2wm+1 (two 32-pixel MFMA row tiles) x 64 channels.
+//   LDS    : patch ring 2 x 344 rows x 128 B (zero rows outside the image come from a zero page), weight ring
+//            3 x 128 rows x 128 B, same 16-B-chunk XOR swizzle as gemm.h (applied to the global address).
+//   k order: channel group outermost, taps innermost: k-tile t = (cg = t / 9, tap = t % 9).
+//   DMA    : per wave 6 patch instructions per channel group (issued at the group's first k-tile for the NEXT
+//            group) and 2 weight instructions per k-tile (two tiles ahead); loads retire in order, so "weight
+//            tile t landed" is vmcnt(2 [+6 if a patch was issued in one of the last two iterations]).
+namespace c3 {
+constexpr int TY = 8, TX = 32, PW = TX + 2, PH = TY + 2, PROWS = PW * PH;            // 340 patch pixels
+constexpr int PSLOTS = 43, PQ = 6;                                                     // ceil(340 / 8) DMA slots, 6 per wave
+constexpr int PATCH_BYTES = PSLOTS * 1024, BTILE_BYTES = 128 * 128;
+constexpr int LDS_BYTES = 2 * PATCH_BYTES + 3 * BTILE_BYTES + 1024;                     // + 1 KB scratch for the unused slots
+using Cfg = GemmCfg<256, 128, 4, 2, 3>;                                                 // wave layout / epilogue helpers only
+}  // namespace c3
+
+struct Conv3Args {
+  const sp_t* x; int B, H, W, Cp;
+  const sp_t* w; int K;
+  const float* bias; const sp_t* residual; sp_t* y_sp; float* y_f32;
+  int Cout, Coutp, act;
+  const sp_t* zeros;
+  int tiles_x, tiles_y;
+};
+
+__global__ __launch_bounds__(512, 2) void conv3x3_kernel(Conv3Args p) {
+  using namespace c3;
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+  typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+  __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
+  char* const patch_base = lds;
+  char* const bring_base = lds + 2 * PATCH_BYTES;
+  char* const scratch = lds + 2 * PATCH_BYTES + 3 * BTILE_BYTES;
+
+  int tm, tn;
+  const int tiles_m = p.B * p.tiles_y * p.tiles_x;
+  if (!xcd_tile(tiles_m, ceil_div(p.Coutp, 128), tm, tn)) return;
+  const int b = tm / (p.tiles_y * p.tiles_x), trem = tm - b * (p.tiles_y * p.tiles_x);
+  const int y0 = (trem / p.tiles_x) * TY, x0 = (trem % p.tiles_x) * TX, n0 = tn * 128;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave & 3, wn = wave >> 2;
+  const int rsub = lane >> 3, slot = lane & 7;
+  const int nact = min(2, (p.Coutp - (n0 + wn * 64) + 31) / 32);
+
+  // ---- DMA source offsets (dwords) ----------------------------------------------------------
+  int poff[PQ];                       // patch rows: -1 = outside the image / unused slot -> zero page
+#pragma unroll
+  for (int q = 0; q < PQ; ++q) {
+    const int s = q * 8 + wave, r = s * 8 + rsub;
+    const int py = r / PW, px = r - py * PW;
+    const int gy = y0 - 1 + py, gx = x0 - 1 + px;
+    const bool in = s < PSLOTS && r < PROWS && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+    poff[q] = in ? ((b * p.H + gy) * p.W + gx) * p.Cp + ((slot ^ ((r >> 1) & 7)) << 2) : -1;
+  }
+  int boff[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int r = (q * 8 + wave) * 8 + rsub;
+    boff[q] = min(n0 + r, p.Cout - 1) * p.K + ((slot ^ ((r >> 1) & 7)) << 2);
+  }
+  const int gpt = p.Cp >> 5, nk = 9 * gpt;
+
+#define C3_ISSUE_PATCH(cg_, stage_)                                                                         \
+  {                                                                                                         \
+    _Pragma("unroll") for (int q = 0; q < PQ; ++q) {                                                        \
+      const sp_t* g__ = poff[q] >= 0 ? p.x + (poff[q] + (cg_) * 32) : p.zeros;                              \
+      char* d__ = (q * 8 + wave < PSLOTS) ? patch_base + (stage_) * PATCH_BYTES + (q * 8 + wave) * 1024 : scratch; \
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)g__, (lds_ptr_t)d__, 16, 0, 0);                           \
+    }                                                                                                       \
+  }
+#define C3_ISSUE_B(cg_, tap_, stage_)                                                                       \
+  {                                                                                                         \
+    const int k0__ = (tap_) * p.Cp + (cg_) * 32;                                                            \
+    _Pragma("unroll") for (int q = 0; q < 2; ++q)                                                           \
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(p.w + (boff[q] + k0__)),                                 \
+                                       (lds_ptr_t)(bring_base + (stage_) * BTILE_BYTES + (q * 8 + wave) * 1024), 16, 0, 0); \
+  }
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int g = lane >> 5, tx = lane & 31;
+  int bbase[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int br = wn * 64 + j * 32 + tx;
+    bbase[j] = br * 128 + ((g ^ ((br >> 1) & 7)) << 4);
+  }
+
+  // prologue: patch 0, weight tiles 0 and 1
+  C3_ISSUE_PATCH(0, 0);
+  C3_ISSUE_B(0, 0, 0);
+  C3_ISSUE_B(0, 1, 1);                                   // nk >= 9
+  int bstage = 0, istage = 2;
+  int cg = 0, tap = 0;                                   // of k-tile t
+  int cg2 = 0, tap2 = 2;                                 // of k-tile t + 2 (the one issued in iteration t)
+  bool patch_m1 = false, patch_m2 = false;               // a patch was issued in iteration t-1 / t-2
+  for (int t = 0; t < nk; ++t) {
+    // weight tile t (and, in order before it, patch cg) landed; younger loads may stay in flight
+    const int newer = (t + 1 < nk ? 2 : 0) + ((patch_m1 || patch_m2) ? PQ : 0);
+    if (newer >= 2 + PQ) LOFTR_WAITCNT_VM(2 + PQ);
+    else if (newer >= PQ) LOFTR_WAITCNT_VM(PQ);
+    else if (newer >= 2) LOFTR_WAITCNT_VM(2);
+    else LOFTR_WAITCNT_VM(0);
+    __builtin_amdgcn_s_barrier();
+    if (t + 2 < nk) C3_ISSUE_B(cg2, tap2, istage);
+    if (++tap2 == 9) { tap2 = 0; ++cg2; }
+    patch_m2 = patch_m1;
+    patch_m1 = false;
+    if (tap == 0 && cg + 1 < gpt) { C3_ISSUE_PATCH(cg + 1, (cg + 1) & 1); patch_m1 = true; }
+
+    // ---- MFMAs of k-tile (cg, tap) ------------------------------------------------------------
+    const int ky = tap / 3, kx = tap - ky * 3;
+    const char* sP = patch_base + (cg & 1) * PATCH_BYTES;
+    const char* sB = bring_base + bstage * BTILE_BYTES;
+    // fragment addresses: chunk c = g | ks << 1 | lo << 2 (disjoint bits), so c ^ swz = (g ^ swz) ^ const and the
+    // four chunks of a row are one base address XOR {0, 32, 64, 96}
+    int abase[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int pr = (wm * 2 + i + ky) * PW + kx + tx;                 // patch pixel of this lane's output pixel
+      abase[i] = pr * 128 + ((g ^ ((pr >> 1) & 7)) << 4);
+    }
+#define C3_KSTEP(ks_, FULL_)                                                                                \
+    {                                                                                                       \
+      h16x8 ah[2], al[2], bh[2], bl[2];                                                                     \
+      _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                       \
+        ah[i] = *reinterpret_cast<const h16x8*>(sP + (abase[i] ^ ((ks_) << 5)));                            \
+        al[i] = *reinterpret_cast<const h16x8*>(sP + (abase[i] ^ (((ks_) << 5) | 64)));                     \
+      }                                                                                                     \
+      _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                       \
+        bh[j] = *reinterpret_cast<const h16x8*>(sB + (bbase[j] ^ ((ks_) << 5)));                            \
+        bl[j] = *reinterpret_cast<const h16x8*>(sB + (bbase[j] ^ (((ks_) << 5) | 64)));                     \
+      }                                                                                                     \
+      if (FULL_) {                                                                                          \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                       \
+          _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                     \
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);           \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                       \
+          _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                     \
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);           \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                       \
+          _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                     \
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);           \
+      } else {                                                                                              \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                     \
+          acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[0], acc[i][0], 0, 0, 0);             \
+          acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[0], acc[i][0], 0, 0, 0);             \
+          acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[0], acc[i][0], 0, 0, 0);             \
+        }                                                                                                   \
+      }                                                                                                     \
+    }
+    if (nact == 2) { C3_KSTEP(0, 1); C3_KSTEP(1, 1); }
+    else if (nact == 1) { C3_KSTEP(0, 0); C3_KSTEP(1, 0); }
+#undef C3_KSTEP
+    bstage = bstage == 2 ? 0 : bstage + 1;
+    istage = istage == 2 ? 0 : istage + 1;
+    if (++tap == 9) { tap = 0; ++cg; }
+  }
+#undef C3_ISSUE_PATCH
+#undef C3_ISSUE_B
+
+  // ---- epilogue: bias (folded BN shift), residual, activation, SP / fp32 stores ---------------------
+  const bool odd = lane & 1;
+  const int Ho = p.H, Wo = p.W;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int col = n0 + wn * 64 + j * 32 + tx;
+    const bool creal = col < p.Cout, cpad = col < p.Coutp;
+    const float bia = (p.bias && creal) ? p.bias[col] : 0.f;
+    const int spc = (col & ~31) + (odd ? 16 : 0) + ((col & 31) >> 1);      // dword of this lane inside the SP row
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int y = y0 + wm * 2 + i;
+      f32x16 v = acc[i][j];
+      uint32_t rw[16];
+      if (p.residual) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int x = x0 + (r & 3) + 8 * (r >> 2) + 4 * g;
+          const bool ok = y < Ho && x < Wo && cpad;
+          rw[r] = ok ? p.residual[(unsigned)(((b * Ho + y) * Wo + x) * p.Coutp + spc)] : 0u;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] += sp_value(rw[r], odd);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float xv = v[r] + bia;
+        if (p.act == 1) xv = fmaxf(xv, 0.f);
+        if (p.act == 2) xv = xv > 0.f ? xv : 0.01f * xv;
+        v[r] = creal ? xv : 0.f;
+      }
+      if (p.y_f32) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int x = x0 + (r & 3) + 8 * (r >> 2) + 4 * g;
+          if (y < Ho && x < Wo && creal) p.y_f32[(unsigned)(((b * Ho + y) * Wo + x) * p.Cout + col)] = v[r];
+        }
+      }
+      if (p.y_sp) {
+        uint32_t w16[16];
+        sp_words16(v, odd, w16);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int x = x0 + (r & 3) + 8 * (r >> 2) + 4 * g;
+          if (y < Ho && x < Wo && cpad) p.y_sp[(unsigned)(((b * Ho + y) * Wo + x) * p.Coutp + spc)] = w16[r];
+        }
+      }
+    }
+  }
+}
+
 // Weight preparation: fold eval-mode BN, transpose to tap-major, pad channels, encode as SP.
 //   w [Cout, Cin, KH, KW] -> wsp [Cout, KH*KW*Cp];  bias[co] = beta - mean * scale,  scale = gamma / sqrt(var + eps)
 //   grid (ceil(groups_per_row / 8), Cout), 256 threads: one half-wave per 32-column SP group.
@@ -261,6 +486,17 @@ extern "C" int loftr_conv_bn_act(const uint32_t* x_sp, int B, int H, int W, int 
   p.a = asrc_conv(x_sp, g);
   p.w = wsp; p.K = K; p.bias = bias; p.residual = residual_sp; p.y_sp = y_sp; p.y_f32 = y_f32;
   p.M = (int)M; p.Cout = Cout; p.Coutp = ceil32(Cout); p.act = act;
+  static const int use_patch = []() { const char* e = getenv("LOFTR_CONV_PATCH"); return e ? atoi(e) : 1; }();
+  if (use_patch && KH == 3 && KW == 3 && stride == 1 && pad == 1) {
+    Conv3Args c;
+    c.x = x_sp; c.B = B; c.H = H; c.W = W; c.Cp = g.Cp; c.w = wsp; c.K = K; c.bias = bias; c.residual = residual_sp;
+    c.y_sp = y_sp; c.y_f32 = y_f32; c.Cout = Cout; c.Coutp = ceil32(Cout); c.act = act; c.zeros = zeros;
+    c.tiles_x = ceil_div(W, c3::TX); c.tiles_y = ceil_div(H, c3::TY);
+    TimedLaunch tl(LOFTR_T_CONV, st);
+    hipLaunchKernelGGL(conv3x3_kernel, dim3(xcd_grid(B * c.tiles_x * c.tiles_y, ceil_div(c.Coutp, 128))), dim3(512), 0, st, c);
+    LOFTR_CHECK_LAUNCH();
+    return LOFTR_OK;
+  }
   {
     // LOFTR_CONV_DMA=0 selects the register-staged 128x128 configuration (A/B experiments; DMA ring is ~7 % faster)
     static const int use_dma = []() { const char* e = getenv("LOFTR_CONV_DMA"); return e ? atoi(e) : 1; }();

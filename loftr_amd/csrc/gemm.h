@@ -55,6 +55,9 @@
 #ifndef GEMM_PROBE_DMA
 #define GEMM_PROBE_DMA 1          // 0: issue the ring's DMAs only in the prologue
 #endif
+#ifndef GEMM_PROBE_A_EVERY
+#define GEMM_PROBE_A_EVERY 1      // n > 1: issue the A-operand DMAs only for every n-th k-tile (emulates a patch-in-LDS conv)
+#endif
 #ifndef GEMM_PROBE_DSREAD
 #define GEMM_PROBE_DSREAD 1       // 0: read the fragments of the first k-tile only
 #endif
@@ -465,13 +468,16 @@ __device__ __forceinline__ void gemm_mainloop_dma(const ASrc& a, const sp_t* __r
         cv_cg = 0;              /* cv_toff is now (ky*W + kx + 1) * Cp: the next tap */        \
         if (++cv_kx == a.cv.KW) { cv_kx = 0; ++cv_ky; cv_toff += (a.cv.W - a.cv.KW) * a.cv.Cp; } \
       }                                                                                       \
-    } else {                                                                                  \
+    } else if (GEMM_PROBE_A_EVERY == 1 || (kt_) % GEMM_PROBE_A_EVERY == 0) {                   \
       const bool second__ = k0__ >= a.ksplit; /* block-uniform */                             \
       const sp_t* ap__ = second__ ? a.p1 : a.p0;                                              \
       const int ka__ = second__ ? k0__ - a.ksplit : k0__;                                     \
       _Pragma("unroll") for (int q = 0; q < Cfg::A_DMA; ++q)                                  \
         __builtin_amdgcn_global_load_lds((gbl_ptr_t)(ap__ + (aoff[q] + ka__)),                \
                                          (lds_ptr_t)(s__ + q * WAVES * 1024), 16, 0, 0);     \
+    } else {  /* probe: keep the per-tile DMA count (vmcnt bookkeeping) with a single cheap load */ \
+      _Pragma("unroll") for (int q = 0; q < Cfg::A_DMA; ++q)                                  \
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(a.p0), (lds_ptr_t)(s__ + q * WAVES * 1024), 4, 0, 0); \
     }                                                                                         \
     _Pragma("unroll") for (int q = 0; q < Cfg::B_DMA; ++q)                                    \
       __builtin_amdgcn_global_load_lds((gbl_ptr_t)(Bp + (boff[q] + k0__)),                    \
