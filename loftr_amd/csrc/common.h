@@ -28,8 +28,9 @@ enum LoftrTimedKernel {
   LOFTR_T_ATTN_SMALL = 7,    // attention.hip: attn_small_kernel       (fine level)
   LOFTR_T_GATHER = 8,        // fine.hip: gather_windows_kernel
   LOFTR_T_OT_STORE = 9,      // coarse_match.hip: score_store_kernel   (sinkhorn)
-  LOFTR_T_CONV = 10,         // conv.hip: conv_kernel               (backbone implicit GEMM)
-  LOFTR_T_COUNT = 11
+  LOFTR_T_CONV = 10,         // conv.hip: conv_kernel               (backbone implicit GEMM: strided / 1x1)
+  LOFTR_T_CONV3 = 11,        // conv.hip: conv3x3_kernel            (3x3 stride-1, input patch in LDS)
+  LOFTR_T_COUNT = 12
 };
 extern unsigned g_loftr_timing_mask;
 void loftr_timing_mark(int id, hipStream_t st, bool end);

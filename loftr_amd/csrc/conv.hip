@@ -492,7 +492,7 @@ extern "C" int loftr_conv_bn_act(const uint32_t* x_sp, int B, int H, int W, int 
     c.x = x_sp; c.B = B; c.H = H; c.W = W; c.Cp = g.Cp; c.w = wsp; c.K = K; c.bias = bias; c.residual = residual_sp;
     c.y_sp = y_sp; c.y_f32 = y_f32; c.Cout = Cout; c.Coutp = ceil32(Cout); c.act = act; c.zeros = zeros;
     c.tiles_x = ceil_div(W, c3::TX); c.tiles_y = ceil_div(H, c3::TY);
-    TimedLaunch tl(LOFTR_T_CONV, st);
+    TimedLaunch tl(LOFTR_T_CONV3, st);
     hipLaunchKernelGGL(conv3x3_kernel, dim3(xcd_grid(B * c.tiles_x * c.tiles_y, ceil_div(c.Coutp, 128))), dim3(512), 0, st, c);
     LOFTR_CHECK_LAUNCH();
     return LOFTR_OK;
