@@ -316,8 +316,8 @@ def main():
             "metric": "image-pairs/sec @640x480 indoor-ds", "value": round(value, 3), "unit": "image-pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "dtype_note": "fp32 data everywhere; backbone = MIOpen fp32; HIP GEMMs evaluate every fp32 product as 3 fp16 "
-                          "MFMAs on a (hi, lo) fp16 split with fp32 accumulation (fp32-class accuracy, csrc/gemm.h)",
+            "dtype_note": "fp32 data everywhere; every GEMM / convolution evaluates each fp32 product as 3 fp16 MFMAs on a "
+                          "(hi, lo) fp16 split with fp32 accumulation (fp32-class accuracy, csrc/gemm.h); --backbone torch = MIOpen fp32",
             "config": {"workload": f"batch={B} 640x480 synthetic grayscale pairs per GPU, indoor_ds dual-softmax "
                                    f"(BASELINE configs[1]), full LoFTR.forward = ResNet-FPN backbone ({'HIP implicit-GEMM convs, 7x7 stem in MIOpen' if args.backbone == 'hip' else 'PyTorch-ROCm / MIOpen fp32'}) + HIP matching path",
                        "weights": "seeded random init (no checkpoint on the box)", "thr": args.thr,
