@@ -172,3 +172,25 @@ def test_two_stream_overlap_is_bitwise_identical():
             del junk
             for k in r:
                 assert torch.equal(d[k], r[k]), (rep, k)
+
+
+def test_sp_format_round_trip():
+    """fp32 -> SP (fp16 hi + fp16 lo per value, 32-channel groups) -> fp32: |x - (hi + lo)| <= 2^-21 |x| inside the
+    fp16 range, exact zeros in the channel padding, and the documented memory layout (hi halves then lo halves)."""
+    from loftr_amd import ops
+    g = torch.Generator().manual_seed(11)
+    for C in (128, 196, 40):
+        x = (torch.randn(3, 7, 9, C, generator=g) * torch.logspace(-3, 3, C)).contiguous()
+        sp = ops.sp_from_nhwc(x.cuda())
+        Cp = (C + 31) // 32 * 32
+        assert sp.shape == (3, 7, 9, Cp) and sp.dtype == torch.int32
+        back = ops.sp_to_nhwc(sp, C).cpu()
+        assert ((back - x).abs() <= 2.0 ** -21 * x.abs() + 1e-7).all()
+        # layout: per 32-channel group 16 dwords of hi halves (channels 2k, 2k+1) then 16 dwords of lo halves
+        raw = sp.cpu().numpy().view(np.uint32).reshape(-1, Cp // 32, 2, 16)
+        halves = raw.view(np.float16).reshape(-1, Cp // 32, 2, 32).astype(np.float32)
+        recon = (halves[:, :, 0, :] + halves[:, :, 1, :]).reshape(-1, Cp)
+        assert np.array_equal(recon[:, :C], back.numpy().reshape(-1, C))
+        assert (recon[:, C:] == 0).all()
+        hi = halves[:, :, 0, :].reshape(-1, Cp)[:, :C]
+        assert np.array_equal(hi, x.numpy().reshape(-1, C).astype(np.float16).astype(np.float32))
