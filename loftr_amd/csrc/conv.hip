@@ -425,18 +425,30 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict_
   }
   __syncthreads();
   const int Cp = (C0 + 31) / 32 * 32;
-  for (int p = slot; p < STEM_TY * STEM_TX; p += 2) {
-    const int py = p / STEM_TX, px = p - py * STEM_TX;
-    float acc = shift;
+  // four horizontally adjacent output pixels at a time: their 7 x 13 input footprint is read once (91 LDS
+  // broadcasts instead of 4 x 49) and feeds four accumulators
+  for (int q = slot; q < STEM_TY * STEM_TX / 4; q += 2) {
+    const int py = q / (STEM_TX / 4), px = (q - py * (STEM_TX / 4)) * 4;
+    float acc[4] = {shift, shift, shift, shift};
 #pragma unroll
-    for (int ky = 0; ky < 7; ++ky)
+    for (int ky = 0; ky < 7; ++ky) {
+      float row[13];
 #pragma unroll
-      for (int kx = 0; kx < 7; ++kx) acc += tile[2 * py + ky][2 * px + kx] * wr[ky * 7 + kx];
-    acc = fmaxf(acc, 0.f);
-    const int oy = oy0 + py, ox = ox0 + px;
-    const bool ok = oy < Ho && ox < Wo && ch < Cp;
-    const uint32_t word = sp_word(ch < C0 ? acc : 0.f, ch & 1);
-    if (ok) y[(((long)b * Ho + oy) * Wo + ox) * Cp + sp_index(ch)] = word;
+      for (int c = 0; c < 13; ++c) row[c] = tile[2 * py + ky][2 * px + c];
+#pragma unroll
+      for (int kx = 0; kx < 7; ++kx)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] += row[2 * e + kx] * wr[ky * 7 + kx];
+    }
+    const int oy = oy0 + py;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int ox = ox0 + px + e;
+      const float v = fmaxf(acc[e], 0.f);
+      const bool ok = oy < Ho && ox < Wo && ch < Cp;
+      const uint32_t word = sp_word(ch < C0 ? v : 0.f, ch & 1);
+      if (ok) y[(((long)b * Ho + oy) * Wo + ox) * Cp + sp_index(ch)] = word;
+    }
   }
 }
 
