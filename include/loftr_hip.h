@@ -34,7 +34,7 @@ typedef enum {
   LOFTR_ERR_NO_DEVICE = -5      /* no gfx950 device visible                                    */
 } loftr_status;
 
-#define LOFTR_HIP_ABI_VERSION 5
+#define LOFTR_HIP_ABI_VERSION 6
 
 int loftr_hip_abi_version(void);
 const char* loftr_hip_status_string(int status);
@@ -196,6 +196,14 @@ int loftr_stem_conv_bn_relu(const float* x, const long* x_strides, int B, int H,
                             const float* bn_mean, const float* bn_var, float bn_eps, uint32_t* y_sp, void* stream);
 int loftr_upsample2x_add(const uint32_t* low_sp, const uint32_t* lateral_sp, uint32_t* out_sp, int B, int Hl,
                          int Wl, int C, void* stream);
+/* One FPN top-down step (resnet_fpn.py:110-112 / :115-117) in one launch:
+ *   y = conv1x1(x, weight) + F.interpolate(low, scale_factor=2, mode='bilinear', align_corners=True)
+ * x_sp [B,H,W,ceil32(Cin)], weight [Cout,Cin,1,1] (bias-free lateral `layerK_outconv`), low_sp
+ * [B,H/2,W/2,ceil32(Cout)], y_sp [B,H,W,ceil32(Cout)]; H and W even.  The lateral map never reaches HBM
+ * and is added in fp32 (the two-call form rounds it to SP first).  Workspace: loftr_conv_workspace_bytes(Cin,Cout,1,1). */
+int loftr_conv1x1_upsample_add(const uint32_t* x_sp, int B, int H, int W, int Cin, const float* weight,
+                               const long* weight_strides, int Cout, const uint32_t* low_sp, uint32_t* y_sp,
+                               void* ws, size_t ws_bytes, void* stream);
 int loftr_sp_from_f32(const float* src, uint32_t* dst_sp, long rows, int C, void* stream);
 int loftr_sp_to_f32(const uint32_t* src_sp, float* dst, long rows, int C, void* stream);
 

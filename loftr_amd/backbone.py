@@ -14,11 +14,16 @@ Two execution paths over the same parameters:
                         upsample+add one more kernel, the 1-channel 7x7 stem a direct convolution.
 ``LoFTR`` uses ``forward_hip`` on the GPU in eval mode (``backbone_impl='hip'``).
 """
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
 from . import ops
+
+# A/B switch: LOFTR_FUSE_TOPDOWN=0 runs the lateral conv and the upsample-add as two launches
+FUSE_TOPDOWN = os.environ.get("LOFTR_FUSE_TOPDOWN", "1") != "0"
 
 
 def _c1(cin, cout, stride=1):
@@ -95,6 +100,16 @@ class _ResNetFPN(nn.Module):
         return a
 
     @staticmethod
+    def _topdown_hip(a, lateral_conv, low_sp, d):
+        """One FPN top-down step, lateral 1x1 conv + upsampled coarser map (resnet_fpn.py:110-112): one launch
+        when the map halves exactly, otherwise the lateral conv followed by the stand-alone upsample-add."""
+        x, cin = a
+        if FUSE_TOPDOWN and x.shape[1] == 2 * low_sp.shape[1] and x.shape[2] == 2 * low_sp.shape[2]:
+            return ops.conv1x1_upsample_add(x, cin, lateral_conv, low_sp)
+        lat, _ = ops.conv_bn_act(x, cin, lateral_conv)
+        return ops.upsample2x_add(low_sp, lat, d)
+
+    @staticmethod
     def _head_hip(head, a, want_f32):
         """_fuse_head: conv3x3 + BN + LeakyReLU + conv3x3 (resnet_fpn.py:66-77)."""
         x, cin = a
@@ -154,12 +169,10 @@ class ResNetFPN_8_2(_ResNetFPN):
         x3_sp, x3_f32 = ops.conv_bn_act(a3[0], a3[1], self.layer3_outconv, want_f32=True)
 
         def fine():
-            x2_lat, _ = ops.conv_bn_act(a2[0], a2[1], self.layer2_outconv)
-            t2 = ops.upsample2x_add(x3_sp, x2_lat, d3)
+            t2 = self._topdown_hip(a2, self.layer2_outconv, x3_sp, d3)
             x2_out, _ = self._head_hip(self.layer2_outconv2, (t2, d3), want_f32=False)
             d2 = self.layer2_outconv2[3].out_channels
-            x1_lat, _ = ops.conv_bn_act(a1[0], a1[1], self.layer1_outconv)
-            t1 = ops.upsample2x_add(x2_out, x1_lat, d2)
+            t1 = self._topdown_hip(a1, self.layer1_outconv, x2_out, d2)
             _, x1_f32 = self._head_hip(self.layer1_outconv2, (t1, d2), want_f32=True)
             return self._nchw_view(x1_f32)
 
@@ -215,12 +228,10 @@ class ResNetFPN_16_4(_ResNetFPN):
         x4_sp, x4_f32 = ops.conv_bn_act(a4[0], a4[1], self.layer4_outconv, want_f32=True)
 
         def fine():
-            x3_lat, _ = ops.conv_bn_act(a3[0], a3[1], self.layer3_outconv)
-            t3 = ops.upsample2x_add(x4_sp, x3_lat, d4)
+            t3 = self._topdown_hip(a3, self.layer3_outconv, x4_sp, d4)
             x3_out, _ = self._head_hip(self.layer3_outconv2, (t3, d4), want_f32=False)
             d3 = self.layer3_outconv2[3].out_channels
-            x2_lat, _ = ops.conv_bn_act(a2[0], a2[1], self.layer2_outconv)
-            t2 = ops.upsample2x_add(x3_out, x2_lat, d3)
+            t2 = self._topdown_hip(a2, self.layer2_outconv, x3_out, d3)
             _, x2_f32 = self._head_hip(self.layer2_outconv2, (t2, d3), want_f32=True)
             return self._nchw_view(x2_f32)
 

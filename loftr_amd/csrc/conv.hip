@@ -25,6 +25,9 @@ struct ConvArgs {
   float* y_f32;                 // [M, Cout] fp32 (NHWC) or null
   int M, Cout, Coutp;
   int act;                      // 0 none, 1 ReLU, 2 LeakyReLU(0.01)
+  const sp_t* up;               // FPN top-down input [B, Hl, Wl, Coutp] SP or null: y += bilinear_x2(up), align_corners
+  int Hl, Wl;                   // (output pixels are then [B, 2Hl, 2Wl])
+  float sy, sx;                 // (Hl-1)/(2Hl-1), (Wl-1)/(2Wl-1)
 };
 
 template <typename Cfg, bool FULL>
@@ -80,7 +83,66 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[C
   }
 }
 
+// FPN top-down epilogue (resnet_fpn.py:110-112 / :115-117): y = acc + bilinear_x2(up), SP out.  The accumulators
+// are parked in LDS (the operand ring is dead by now) so that the gather of the half-resolution map and the
+// stores run in (pixel, channel-octet) form -- 16-B accesses, one geometry computation per eight channels --
+// instead of four scalar gathers per accumulator register.
 template <typename Cfg>
+__device__ __forceinline__ void conv_epilogue_up(const ConvArgs& p, f32x16 (&acc)[Cfg::TM][Cfg::TN], int m0, int n0,
+                                                 float* lds) {
+  constexpr int LD = Cfg::BN + 4;
+  static_assert(Cfg::BM * LD <= Cfg::LDS_FLOATS, "accumulator tile does not fit the operand ring");
+  const EpiLane<Cfg> e;
+  __syncthreads();                                  // every wave is done reading the last k-tile
+#pragma unroll
+  for (int j = 0; j < Cfg::TN; ++j)
+#pragma unroll
+    for (int i = 0; i < Cfg::TM; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) lds[(e.lrow + e.rr(i, r)) * LD + e.lcol + j * 32] = acc[i][j][r];
+  __syncthreads();
+  const int Wo = 2 * p.Wl, Ho = 2 * p.Hl;
+  constexpr int OCTS = Cfg::BN / 8;
+  for (int it = threadIdx.x; it < Cfg::BM * OCTS; it += Cfg::THREADS) {
+    const int row = it / OCTS, oct = it - row * OCTS;
+    const int pix = m0 + row, col0 = n0 + oct * 8;
+    if (pix >= p.M || col0 >= p.Coutp) continue;
+    const int t = pix / Wo, x = pix - t * Wo;
+    const int bb = t / Ho, y = t - bb * Ho;
+    // torch upsample_bilinear2d, align_corners=True: src = dst * (in - 1) / (out - 1)
+    const float fy = p.sy * (float)y, fx = p.sx * (float)x;
+    const int y0 = (int)fy, x0 = (int)fx;
+    const int dy = y0 < p.Hl - 1 ? p.Wl * p.Coutp : 0, dx = x0 < p.Wl - 1 ? p.Coutp : 0;
+    const float ly = fy - (float)y0, lx = fx - (float)x0;
+    const float hy = 1.f - ly, hx = 1.f - lx;
+    const int off = sp_octet_off(col0 >> 3);
+    const sp_t* s00 = p.up + (unsigned)(((bb * p.Hl + y0) * p.Wl + x0) * p.Coutp + off);
+    const sp_t* src[4] = {s00, s00 + dx, s00 + dy, s00 + dy + dx};
+    u32x4 hi[4], lo[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      hi[k] = *reinterpret_cast<const u32x4*>(src[k]);
+      lo[k] = *reinterpret_cast<const u32x4*>(src[k] + 16);
+    }
+    float v[4][8], o[8];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) sp_unpack8(hi[k], lo[k], v[k]);
+    const f32x4 a0 = *reinterpret_cast<const f32x4*>(&lds[row * LD + oct * 8]);
+    const f32x4 a1 = *reinterpret_cast<const f32x4*>(&lds[row * LD + oct * 8 + 4]);
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+      o[c] = col0 + c < p.Cout      // pad channels of the SP row are written as 0 (their weight rows are clamped reads)
+                 ? (c < 4 ? a0[c] : a1[c - 4]) + (hy * (hx * v[0][c] + lx * v[1][c]) + ly * (hx * v[2][c] + lx * v[3][c]))
+                 : 0.f;
+    u32x4 oh, ol;
+    sp_pack8(o, oh, ol);
+    sp_t* dst = p.y_sp + (unsigned)(pix * p.Coutp + off);
+    *reinterpret_cast<u32x4*>(dst) = oh;
+    *reinterpret_cast<u32x4*>(dst + 16) = ol;
+  }
+}
+
+template <typename Cfg, bool UP>
 __global__ __launch_bounds__(Cfg::THREADS, 2) void conv_kernel(ConvArgs p) {
   __shared__ __attribute__((aligned(16))) float lds[Cfg::LDS_FLOATS];
   int tm, tn;
@@ -88,7 +150,8 @@ __global__ __launch_bounds__(Cfg::THREADS, 2) void conv_kernel(ConvArgs p) {
   const int m0 = tm * Cfg::BM, n0 = tn * Cfg::BN;
   f32x16 acc[Cfg::TM][Cfg::TN];
   gemm_mainloop<Cfg, true>(p.a, p.w, p.K, p.M, p.Cout, p.K, m0, n0, lds, acc, p.Coutp);
-  if (m0 + Cfg::BM <= p.M) conv_epilogue<Cfg, true>(p, acc, m0, n0);
+  if constexpr (UP) conv_epilogue_up<Cfg>(p, acc, m0, n0, lds);
+  else if (m0 + Cfg::BM <= p.M) conv_epilogue<Cfg, true>(p, acc, m0, n0);
   else conv_epilogue<Cfg, false>(p, acc, m0, n0);
 }
 
@@ -468,11 +531,11 @@ extern "C" size_t loftr_conv_workspace_bytes(int Cin, int Cout, int KH, int KW) 
   return align_up((size_t)Cout * KH * KW * ceil32(Cin) * 4, 256) + align_up((size_t)Cout * 4, 256) + 2048;
 }
 
-extern "C" int loftr_conv_bn_act(const uint32_t* x_sp, int B, int H, int W, int Cin, const float* weight,
-                                 const long* weight_strides, int Cout, int KH, int KW, int stride, int pad, const float* bn_weight, const float* bn_bias,
-                                 const float* bn_mean, const float* bn_var, float bn_eps, int act,
-                                 const uint32_t* residual_sp, uint32_t* y_sp, float* y_f32, void* ws, size_t ws_bytes,
-                                 void* stream) {
+static int conv_launch(const uint32_t* x_sp, int B, int H, int W, int Cin, const float* weight,
+                       const long* weight_strides, int Cout, int KH, int KW, int stride, int pad, const float* bn_weight, const float* bn_bias,
+                       const float* bn_mean, const float* bn_var, float bn_eps, int act,
+                       const uint32_t* residual_sp, const uint32_t* up_sp, uint32_t* y_sp, float* y_f32, void* ws, size_t ws_bytes,
+                       void* stream) {
   LOFTR_CHECK_ARG(x_sp && weight && weight_strides && (y_sp || y_f32) && ws && B >= 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0);
   LOFTR_CHECK_ARG(KH > 0 && KW > 0 && stride > 0 && pad >= 0 && act >= 0 && act <= 2);
   LOFTR_CHECK_ARG((bn_weight == nullptr) == (bn_bias == nullptr) && (bn_weight == nullptr) == (bn_mean == nullptr) &&
@@ -501,8 +564,11 @@ extern "C" int loftr_conv_bn_act(const uint32_t* x_sp, int B, int H, int W, int 
   p.a = asrc_conv(x_sp, g);
   p.w = wsp; p.K = K; p.bias = bias; p.residual = residual_sp; p.y_sp = y_sp; p.y_f32 = y_f32;
   p.M = (int)M; p.Cout = Cout; p.Coutp = ceil32(Cout); p.act = act;
+  p.up = up_sp; p.Hl = g.Ho / 2; p.Wl = g.Wo / 2;
+  p.sy = g.Ho > 1 ? (float)(p.Hl - 1) / (float)(g.Ho - 1) : 0.f;
+  p.sx = g.Wo > 1 ? (float)(p.Wl - 1) / (float)(g.Wo - 1) : 0.f;
   static const int use_patch = []() { const char* e = getenv("LOFTR_CONV_PATCH"); return e ? atoi(e) : 1; }();
-  if (use_patch && KH == 3 && KW == 3 && stride == 1 && pad == 1) {
+  if (use_patch && KH == 3 && KW == 3 && stride == 1 && pad == 1 && !up_sp) {
     Conv3Args c;
     c.x = x_sp; c.B = B; c.H = H; c.W = W; c.Cp = g.Cp; c.Cin = Cin; c.w = wsp; c.K = K; c.bias = bias; c.residual = residual_sp;
     c.y_sp = y_sp; c.y_f32 = y_f32; c.Cout = Cout; c.Coutp = ceil32(Cout); c.act = act; c.zeros = zeros;
@@ -516,15 +582,36 @@ extern "C" int loftr_conv_bn_act(const uint32_t* x_sp, int B, int H, int W, int 
     // LOFTR_CONV_DMA=0 selects the register-staged 128x128 configuration (A/B experiments; DMA ring is ~7 % faster)
     static const int use_dma = []() { const char* e = getenv("LOFTR_CONV_DMA"); return e ? atoi(e) : 1; }();
     TimedLaunch tl(LOFTR_T_CONV, st);
-    if (use_dma)
-      hipLaunchKernelGGL((conv_kernel<CfgD>), dim3(xcd_grid(ceil_div(p.M, CfgD::BM), ceil_div(p.Coutp, CfgD::BN))),
+    if (up_sp)
+      hipLaunchKernelGGL((conv_kernel<CfgD, true>), dim3(xcd_grid(ceil_div(p.M, CfgD::BM), ceil_div(p.Coutp, CfgD::BN))),
+                         dim3(CfgD::THREADS), 0, st, p);
+    else if (use_dma)
+      hipLaunchKernelGGL((conv_kernel<CfgD, false>), dim3(xcd_grid(ceil_div(p.M, CfgD::BM), ceil_div(p.Coutp, CfgD::BN))),
                          dim3(CfgD::THREADS), 0, st, p);
     else
-      hipLaunchKernelGGL((conv_kernel<CfgR>), dim3(xcd_grid(ceil_div(p.M, CfgR::BM), ceil_div(p.Coutp, CfgR::BN))),
+      hipLaunchKernelGGL((conv_kernel<CfgR, false>), dim3(xcd_grid(ceil_div(p.M, CfgR::BM), ceil_div(p.Coutp, CfgR::BN))),
                          dim3(CfgR::THREADS), 0, st, p);
   }
   LOFTR_CHECK_LAUNCH();
   return LOFTR_OK;
+}
+
+extern "C" int loftr_conv_bn_act(const uint32_t* x_sp, int B, int H, int W, int Cin, const float* weight,
+                                 const long* weight_strides, int Cout, int KH, int KW, int stride, int pad, const float* bn_weight, const float* bn_bias,
+                                 const float* bn_mean, const float* bn_var, float bn_eps, int act,
+                                 const uint32_t* residual_sp, uint32_t* y_sp, float* y_f32, void* ws, size_t ws_bytes,
+                                 void* stream) {
+  return conv_launch(x_sp, B, H, W, Cin, weight, weight_strides, Cout, KH, KW, stride, pad, bn_weight, bn_bias, bn_mean,
+                     bn_var, bn_eps, act, residual_sp, nullptr, y_sp, y_f32, ws, ws_bytes, stream);
+}
+
+extern "C" int loftr_conv1x1_upsample_add(const uint32_t* x_sp, int B, int H, int W, int Cin, const float* weight,
+                                          const long* weight_strides, int Cout, const uint32_t* low_sp, uint32_t* y_sp,
+                                          void* ws, size_t ws_bytes, void* stream) {
+  LOFTR_CHECK_ARG(low_sp && y_sp && H > 0 && W > 0);
+  if ((H & 1) || (W & 1)) return LOFTR_ERR_UNSUPPORTED;        // the low map is exactly [B, H/2, W/2, ceil32(Cout)]
+  return conv_launch(x_sp, B, H, W, Cin, weight, weight_strides, Cout, 1, 1, 1, 0, nullptr, nullptr, nullptr, nullptr, 0.f, 0,
+                     nullptr, low_sp, y_sp, nullptr, ws, ws_bytes, stream);
 }
 
 extern "C" int loftr_stem_conv_bn_relu(const float* x, const long* x_strides, int B, int H, int W, const float* weight,

@@ -304,6 +304,26 @@ def stem_conv_bn_relu(x, conv, bn):
     return y
 
 
+def conv1x1_upsample_add(x_sp, Cin, conv, low_sp):
+    """conv1x1(x) + bilinear x2 (align_corners=True) of low in one launch (one FPN top-down step); SP in / out."""
+    w = conv.weight
+    if not w.is_cuda or w.dtype != torch.float32:
+        raise _lib.LoftrHipError("conv.weight: expected a float32 GPU tensor")
+    Cout = w.shape[0]
+    assert tuple(w.shape[1:]) == (Cin, 1, 1) and conv.bias is None and conv.stride == (1, 1) and conv.padding == (0, 0)
+    B, H, W, Cp = x_sp.shape
+    assert Cp == ceil32(Cin) and x_sp.dtype == torch.int32 and x_sp.is_contiguous()
+    if low_sp.shape != (B, H // 2, W // 2, ceil32(Cout)) or H % 2 or W % 2 or not low_sp.is_contiguous():
+        raise _lib.LoftrHipError(f"conv1x1_upsample_add: low map {tuple(low_sp.shape)} is not half of {tuple(x_sp.shape)}")
+    y = torch.empty(B, H, W, ceil32(Cout), dtype=torch.int32, device=x_sp.device)
+    lib = _lib.load()
+    ws = workspace(lib.loftr_conv_workspace_bytes(Cin, Cout, 1, 1), x_sp.device)
+    wst = (C.c_long * 4)(*w.stride())
+    check(lib.loftr_conv1x1_upsample_add(_ptr(x_sp), B, H, W, Cin, _ptr(w), wst, Cout, _ptr(low_sp), _ptr(y), _ptr(ws),
+                                         ws.numel(), _stream()), "loftr_conv1x1_upsample_add")
+    return y
+
+
 def upsample2x_add(low_sp, lateral_sp, Cc):
     """lateral + bilinear x2 (align_corners=True) of low; SP in, SP out."""
     B, Hl, Wl, Cp = low_sp.shape

@@ -102,6 +102,35 @@ def test_upsample2x_add_vs_torch():
         assert (out - ref).abs().max().item() <= 2e-6 * ref.abs().max().item()
 
 
+@pytest.mark.parametrize("Cin,Cout,hw", [(128, 196, (30, 40)), (196, 256, (12, 16)), (128, 128, (34, 22))])
+def test_conv1x1_upsample_add_vs_torch(Cin, Cout, hw):
+    """One FPN top-down step in one launch (resnet_fpn.py:110-112): lateral 1x1 conv + bilinear x2 of the coarser
+    map, against fp64 torch; covers a ragged last row tile, a padded channel count and a 2-column-tile Cout."""
+    from loftr_amd import ops
+    g = torch.Generator().manual_seed(5)
+    H, W = hw
+    x = torch.randn(2, Cin, H, W, generator=g)
+    low = torch.randn(2, Cout, H // 2, W // 2, generator=g)
+    conv = torch.nn.Conv2d(Cin, Cout, 1, bias=False)
+    with torch.no_grad():
+        conv.weight.copy_(torch.randn(conv.weight.shape, generator=g) / Cin ** 0.5)
+        ref = F.conv2d(x.double(), conv.weight.double()) + F.interpolate(low.double(), scale_factor=2.0, mode="bilinear",
+                                                                          align_corners=True)
+    dev = "cuda:0"
+    conv = conv.to(dev)
+    x_sp = ops.sp_from_nhwc(x.permute(0, 2, 3, 1).contiguous().to(dev))
+    l_sp = ops.sp_from_nhwc(low.permute(0, 2, 3, 1).contiguous().to(dev))
+    y = ops.conv1x1_upsample_add(x_sp, Cin, conv, l_sp)
+    assert y.shape == (2, H, W, (Cout + 31) // 32 * 32)
+    out = ops.sp_to_nhwc(y, Cout).permute(0, 3, 1, 2).cpu().double()
+    assert (out - ref).abs().max().item() <= 3e-6 * ref.abs().max().item()
+    if Cout % 32:                                   # pad channels of the SP row stay exactly zero
+        pad = ops.sp_to_nhwc(y, y.shape[-1])[..., Cout:]
+        assert pad.abs().max().item() == 0.0
+    with pytest.raises(Exception):
+        ops.conv1x1_upsample_add(x_sp, Cin, conv, l_sp[:, :-1].contiguous())
+
+
 @pytest.mark.parametrize("resolution,dims,hw", [((8, 2), [128, 196, 256], (96, 128)),
                                                ((16, 4), [128, 196, 256, 512], (96, 128))])
 def test_backbone_hip_vs_fp64(resolution, dims, hw):
