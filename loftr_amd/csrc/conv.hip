@@ -165,7 +165,8 @@ __global__ __launch_bounds__(Cfg::THREADS, 2) void conv_kernel(ConvArgs p) {
 //            (wm, wn) owns output rows 2wm, 2wm+1 (two 32-pixel MFMA row tiles) x 64 channels.
 //   LDS    : patch ring 2 x 344 rows x 128 B (zero rows outside the image come from a zero page), weight ring
 //            3 x 128 rows x 128 B, same 16-B-chunk XOR swizzle as gemm.h (applied to the global address).
-//   k order: channel group outermost, taps innermost: k-tile t = (cg = t / 9, tap = t % 9).
+//   k order: channel group outermost, then the tap column kx, tap row ky innermost: k-tile t = (cg, kx, ky) reads
+//            weight tap ky * 3 + kx; consecutive ky share one of their two patch rows, kept in registers.
 //   DMA    : per wave 6 patch instructions per channel group (issued at the group's first k-tile for the NEXT
 //            group) and 2 weight instructions per k-tile (two tiles ahead); loads retire in order, so "weight
 //            tile t landed" is vmcnt(2 [+6 if a patch was issued in one of the last two iterations]).
@@ -259,76 +260,91 @@ __global__ __launch_bounds__(512, 2) void conv3x3_kernel(Conv3Args p) {
   // prologue: patch 0, weight tiles 0 and 1
   C3_ISSUE_PATCH(0, 0);
   C3_ISSUE_B(0, 0, 0);
-  C3_ISSUE_B(0, 1, 1);                                   // nk >= 9
+  C3_ISSUE_B(0, 3, 1);                                   // sequence position 1 = (kx 0, ky 1) = tap 3;  nk >= 9
   int bstage = 0, istage = 2;
-  int cg = 0, tap = 0;                                   // of k-tile t
-  int cg2 = 0, tap2 = 2;                                 // of k-tile t + 2 (the one issued in iteration t)
+  int cg = 0, kx = 0;                                    // this trip runs k-tiles (cg, kx, ky = 0, 1, 2)
+  int cg2 = 0, q2 = 2;                                   // sequence position (kx * 3 + ky) of the k-tile issued next, two ahead
   bool patch_m1 = false, patch_m2 = false;               // a patch was issued in iteration t-1 / t-2
-  for (int t = 0; t < nk; ++t) {
-    // weight tile t (and, in order before it, patch cg) landed; younger loads may stay in flight
-    const int newer = (t + 1 < nk ? 2 : 0) + ((patch_m1 || patch_m2) ? PQ : 0);
-    if (newer >= 2 + PQ) LOFTR_WAITCNT_VM(2 + PQ);
-    else if (newer >= PQ) LOFTR_WAITCNT_VM(PQ);
-    else if (newer >= 2) LOFTR_WAITCNT_VM(2);
-    else LOFTR_WAITCNT_VM(0);
-    __builtin_amdgcn_s_barrier();
-    if (t + 2 < nk) C3_ISSUE_B(cg2, tap2, istage);
-    if (++tap2 == 9) { tap2 = 0; ++cg2; }
-    patch_m2 = patch_m1;
-    patch_m1 = false;
-    if (tap == 0 && cg + 1 < gpt) { C3_ISSUE_PATCH(cg + 1, (cg + 1) & 1); patch_m1 = true; }
+  // A fragments of the wave's four patch rows 2wm .. 2wm+3 at column offset kx, [row][16-wide k-step]: output rows
+  // (2wm, 2wm+1) read patch rows (ky, ky+1), so walking ky innermost each k-tile after the first needs ONE new row
+  // (4 instead of 6 row reads per kx: a third of the A-side LDS traffic stays in registers).
+  h16x8 fh[4][2], fl[4][2];
 
-    // ---- MFMAs of k-tile (cg, tap) ------------------------------------------------------------
-    const int ky = tap / 3, kx = tap - ky * 3;
-    const char* sP = patch_base + (cg & 1) * PATCH_BYTES;
-    const char* sB = bring_base + bstage * BTILE_BYTES;
-    // fragment addresses: chunk c = g | ks << 1 | lo << 2 (disjoint bits), so c ^ swz = (g ^ swz) ^ const and the
-    // four chunks of a row are one base address XOR {0, 32, 64, 96}
-    int abase[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int pr = (wm * 2 + i + ky) * PW + kx + tx;                 // patch pixel of this lane's output pixel
-      abase[i] = pr * 128 + ((g ^ ((pr >> 1) & 7)) << 4);
-    }
-#define C3_KSTEP(ks_, FULL_)                                                                                \
-    {                                                                                                       \
-      h16x8 ah[2], al[2], bh[2], bl[2];                                                                     \
+#define C3_LOAD_ROW(jr_)                                                                                    \
+  {                                                                                                         \
+    const int pr__ = (wm * 2 + (jr_)) * PW + kx + tx;              /* patch pixel of this lane's output pixel */ \
+    const int ab__ = pr__ * 128 + ((g ^ ((pr__ >> 1) & 7)) << 4);                                            \
+    /* chunk c = g | ks << 1 | lo << 2 (disjoint bits): the four chunks of a row are one address XOR {0,32,64,96} */ \
+    fh[jr_][0] = *reinterpret_cast<const h16x8*>(sP + ab__);                                                \
+    fl[jr_][0] = *reinterpret_cast<const h16x8*>(sP + (ab__ ^ 64));                                         \
+    if (!dead2) {                                                                                           \
+      fh[jr_][1] = *reinterpret_cast<const h16x8*>(sP + (ab__ ^ 32));                                       \
+      fl[jr_][1] = *reinterpret_cast<const h16x8*>(sP + (ab__ ^ 96));                                       \
+    }                                                                                                       \
+  }
+#define C3_KSTEP(ks_, R0_, FULL_)                                                                           \
+  {                                                                                                         \
+    h16x8 bh[2], bl[2];                                                                                     \
+    _Pragma("unroll") for (int j = 0; j < ((FULL_) ? 2 : 1); ++j) {                                         \
+      bh[j] = *reinterpret_cast<const h16x8*>(sB + (bbase[j] ^ ((ks_) << 5)));                              \
+      bl[j] = *reinterpret_cast<const h16x8*>(sB + (bbase[j] ^ (((ks_) << 5) | 64)));                       \
+    }                                                                                                       \
+    if (FULL_) {                                                                                            \
+      _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                         \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                       \
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fl[(R0_) + i][ks_], bh[j], acc[i][j], 0, 0, 0); \
+      _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                         \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                       \
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[(R0_) + i][ks_], bl[j], acc[i][j], 0, 0, 0); \
+      _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                         \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                       \
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[(R0_) + i][ks_], bh[j], acc[i][j], 0, 0, 0); \
+    } else {                                                                                                \
       _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                       \
-        ah[i] = *reinterpret_cast<const h16x8*>(sP + (abase[i] ^ ((ks_) << 5)));                            \
-        al[i] = *reinterpret_cast<const h16x8*>(sP + (abase[i] ^ (((ks_) << 5) | 64)));                     \
+        acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fl[(R0_) + i][ks_], bh[0], acc[i][0], 0, 0, 0);  \
+        acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[(R0_) + i][ks_], bl[0], acc[i][0], 0, 0, 0);  \
+        acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[(R0_) + i][ks_], bh[0], acc[i][0], 0, 0, 0);  \
       }                                                                                                     \
-      _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                       \
-        bh[j] = *reinterpret_cast<const h16x8*>(sB + (bbase[j] ^ ((ks_) << 5)));                            \
-        bl[j] = *reinterpret_cast<const h16x8*>(sB + (bbase[j] ^ (((ks_) << 5) | 64)));                     \
-      }                                                                                                     \
-      if (FULL_) {                                                                                          \
-        _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                       \
-          _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                     \
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);           \
-        _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                       \
-          _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                     \
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);           \
-        _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                       \
-          _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                     \
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);           \
-      } else {                                                                                              \
-        _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                     \
-          acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[0], acc[i][0], 0, 0, 0);             \
-          acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[0], acc[i][0], 0, 0, 0);             \
-          acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[0], acc[i][0], 0, 0, 0);             \
-        }                                                                                                   \
-      }                                                                                                     \
-    }
+    }                                                                                                       \
+  }
+  // one k-tile: (cg, tap = KY * 3 + kx)
+#define C3_ITER(KY)                                                                                         \
+  {                                                                                                         \
+    const int tt__ = t + (KY);                                                                              \
+    /* weight tile tt (and, in order before it, patch cg) landed; younger loads may stay in flight */       \
+    const int newer__ = (tt__ + 1 < nk ? 2 : 0) + ((patch_m1 || patch_m2) ? PQ : 0);                        \
+    if (newer__ >= 2 + PQ) LOFTR_WAITCNT_VM(2 + PQ);                                                        \
+    else if (newer__ >= PQ) LOFTR_WAITCNT_VM(PQ);                                                           \
+    else if (newer__ >= 2) LOFTR_WAITCNT_VM(2);                                                             \
+    else LOFTR_WAITCNT_VM(0);                                                                               \
+    __builtin_amdgcn_s_barrier();                                                                           \
+    if (tt__ + 2 < nk) C3_ISSUE_B(cg2, (q2 % 3) * 3 + q2 / 3, istage);                                      \
+    if (++q2 == 9) { q2 = 0; ++cg2; }                                                                       \
+    patch_m2 = patch_m1;                                                                                    \
+    patch_m1 = false;                                                                                       \
+    if ((KY) == 0 && kx == 0 && cg + 1 < gpt) { C3_ISSUE_PATCH(cg + 1, (cg + 1) & 1); patch_m1 = true; }    \
+    const char* sB = bring_base + bstage * BTILE_BYTES;                                                     \
+    if ((KY) == 0) { C3_LOAD_ROW(0); C3_LOAD_ROW(1); }                                                      \
+    else C3_LOAD_ROW((KY) + 1);                                                                             \
+    if (nact == 2) { C3_KSTEP(0, KY, 1); if (!dead2) C3_KSTEP(1, KY, 1); }                                  \
+    else if (nact == 1) { C3_KSTEP(0, KY, 0); if (!dead2) C3_KSTEP(1, KY, 0); }                             \
+    bstage = bstage == 2 ? 0 : bstage + 1;                                                                  \
+    istage = istage == 2 ? 0 : istage + 1;                                                                  \
+  }
+
+  for (int t = 0; t < nk; t += 3) {
     // channels >= Cin of the last group are zero padding (activations AND folded weights): when they fill the whole
     // second 16-wide k-step (e.g. Cin = 196 -> 192..207 | 208..223) its MFMAs are skipped -- exact, 1/14 of the work
     const bool dead2 = cg == gpt - 1 && p.Cin <= cg * 32 + 16;
-    if (nact == 2) { C3_KSTEP(0, 1); if (!dead2) C3_KSTEP(1, 1); }
-    else if (nact == 1) { C3_KSTEP(0, 0); if (!dead2) C3_KSTEP(1, 0); }
-#undef C3_KSTEP
-    bstage = bstage == 2 ? 0 : bstage + 1;
-    istage = istage == 2 ? 0 : istage + 1;
-    if (++tap == 9) { tap = 0; ++cg; }
+    const char* sP = patch_base + (cg & 1) * PATCH_BYTES;
+    C3_ITER(0)
+    C3_ITER(1)
+    C3_ITER(2)
+    if (++kx == 3) { kx = 0; ++cg; }
   }
+#undef C3_ITER
+#undef C3_KSTEP
+#undef C3_LOAD_ROW
 #undef C3_ISSUE_PATCH
 #undef C3_ISSUE_B
 
