@@ -270,45 +270,40 @@ __global__ __launch_bounds__(512, 2) void conv3x3_kernel(Conv3Args p) {
   // (4 instead of 6 row reads per kx: a third of the A-side LDS traffic stays in registers).
   h16x8 fh[4][2], fl[4][2];
 
-#define C3_LOAD_ROW(jr_)                                                                                    \
+  // The trip body is instantiated per (active column tiles NJ_, dead second k-step DEAD_) so that the k-loop itself
+  // is free of data-dependent branches: all fragment reads of a k-tile are issued up front and the compiler
+  // places partial lgkmcnt waits between the two 16-wide k-steps.
+#define C3_LOAD_ROW(jr_, ks_)                                                                               \
   {                                                                                                         \
     const int pr__ = (wm * 2 + (jr_)) * PW + kx + tx;              /* patch pixel of this lane's output pixel */ \
     const int ab__ = pr__ * 128 + ((g ^ ((pr__ >> 1) & 7)) << 4);                                            \
     /* chunk c = g | ks << 1 | lo << 2 (disjoint bits): the four chunks of a row are one address XOR {0,32,64,96} */ \
-    fh[jr_][0] = *reinterpret_cast<const h16x8*>(sP + ab__);                                                \
-    fl[jr_][0] = *reinterpret_cast<const h16x8*>(sP + (ab__ ^ 64));                                         \
-    if (!dead2) {                                                                                           \
-      fh[jr_][1] = *reinterpret_cast<const h16x8*>(sP + (ab__ ^ 32));                                       \
-      fl[jr_][1] = *reinterpret_cast<const h16x8*>(sP + (ab__ ^ 96));                                       \
+    fh[jr_][ks_] = *reinterpret_cast<const h16x8*>(sP + (ab__ ^ ((ks_) << 5)));                             \
+    fl[jr_][ks_] = *reinterpret_cast<const h16x8*>(sP + (ab__ ^ (((ks_) << 5) | 64)));                      \
+  }
+#define C3_LOAD_KS(KY, ks_, NJ_)                                                                            \
+  {                                                                                                         \
+    if ((KY) == 0) { C3_LOAD_ROW(0, ks_); C3_LOAD_ROW(1, ks_); }                                            \
+    else C3_LOAD_ROW((KY) + 1, ks_);                                                                        \
+    _Pragma("unroll") for (int j = 0; j < (NJ_); ++j) {                                                     \
+      bh[ks_][j] = *reinterpret_cast<const h16x8*>(sB + (bbase[j] ^ ((ks_) << 5)));                         \
+      bl[ks_][j] = *reinterpret_cast<const h16x8*>(sB + (bbase[j] ^ (((ks_) << 5) | 64)));                  \
     }                                                                                                       \
   }
-#define C3_KSTEP(ks_, R0_, FULL_)                                                                           \
+#define C3_MFMAS(ks_, R0_, NJ_)                                                                             \
   {                                                                                                         \
-    h16x8 bh[2], bl[2];                                                                                     \
-    _Pragma("unroll") for (int j = 0; j < ((FULL_) ? 2 : 1); ++j) {                                         \
-      bh[j] = *reinterpret_cast<const h16x8*>(sB + (bbase[j] ^ ((ks_) << 5)));                              \
-      bl[j] = *reinterpret_cast<const h16x8*>(sB + (bbase[j] ^ (((ks_) << 5) | 64)));                       \
-    }                                                                                                       \
-    if (FULL_) {                                                                                            \
-      _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                         \
-        _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                       \
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fl[(R0_) + i][ks_], bh[j], acc[i][j], 0, 0, 0); \
-      _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                         \
-        _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                       \
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[(R0_) + i][ks_], bl[j], acc[i][j], 0, 0, 0); \
-      _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                         \
-        _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                       \
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[(R0_) + i][ks_], bh[j], acc[i][j], 0, 0, 0); \
-    } else {                                                                                                \
-      _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                       \
-        acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fl[(R0_) + i][ks_], bh[0], acc[i][0], 0, 0, 0);  \
-        acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[(R0_) + i][ks_], bl[0], acc[i][0], 0, 0, 0);  \
-        acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[(R0_) + i][ks_], bh[0], acc[i][0], 0, 0, 0);  \
-      }                                                                                                     \
-    }                                                                                                       \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                           \
+      _Pragma("unroll") for (int j = 0; j < (NJ_); ++j)                                                     \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fl[(R0_) + i][ks_], bh[ks_][j], acc[i][j], 0, 0, 0); \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                           \
+      _Pragma("unroll") for (int j = 0; j < (NJ_); ++j)                                                     \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[(R0_) + i][ks_], bl[ks_][j], acc[i][j], 0, 0, 0); \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                           \
+      _Pragma("unroll") for (int j = 0; j < (NJ_); ++j)                                                     \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[(R0_) + i][ks_], bh[ks_][j], acc[i][j], 0, 0, 0); \
   }
   // one k-tile: (cg, tap = KY * 3 + kx)
-#define C3_ITER(KY)                                                                                         \
+#define C3_ITER(KY, NJ_, DEAD_)                                                                             \
   {                                                                                                         \
     const int tt__ = t + (KY);                                                                              \
     /* weight tile tt (and, in order before it, patch cg) landed; younger loads may stay in flight */       \
@@ -323,27 +318,55 @@ __global__ __launch_bounds__(512, 2) void conv3x3_kernel(Conv3Args p) {
     patch_m2 = patch_m1;                                                                                    \
     patch_m1 = false;                                                                                       \
     if ((KY) == 0 && kx == 0 && cg + 1 < gpt) { C3_ISSUE_PATCH(cg + 1, (cg + 1) & 1); patch_m1 = true; }    \
-    const char* sB = bring_base + bstage * BTILE_BYTES;                                                     \
-    if ((KY) == 0) { C3_LOAD_ROW(0); C3_LOAD_ROW(1); }                                                      \
-    else C3_LOAD_ROW((KY) + 1);                                                                             \
-    if (nact == 2) { C3_KSTEP(0, KY, 1); if (!dead2) C3_KSTEP(1, KY, 1); }                                  \
-    else if (nact == 1) { C3_KSTEP(0, KY, 0); if (!dead2) C3_KSTEP(1, KY, 0); }                             \
+    if ((NJ_) > 0) {                                                                                        \
+      const char* sB = bring_base + bstage * BTILE_BYTES;                                                   \
+      h16x8 bh[2][2], bl[2][2];                                                                             \
+      C3_LOAD_KS(KY, 0, NJ_);                                                                               \
+      if (!(DEAD_)) C3_LOAD_KS(KY, 1, NJ_);                                                                 \
+      C3_MFMAS(0, KY, NJ_);                                                                                 \
+      if (!(DEAD_)) C3_MFMAS(1, KY, NJ_);                                                                   \
+      /* pin the order: k-step 0 operand reads, then k-step 1 reads slotted between the first MFMAs (partial    */ \
+      /* lgkmcnt waits), then the remaining MFMAs                                                               */ \
+      __builtin_amdgcn_sched_group_barrier(0x100, ((KY) == 0 ? 4 : 2) + 2 * (NJ_), 0);                      \
+      if (!(DEAD_)) {                                                                                       \
+        _Pragma("unroll") for (int u = 0; u < ((KY) == 0 ? 4 : 2) + 2 * (NJ_); ++u) {                       \
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                \
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                \
+        }                                                                                                   \
+        __builtin_amdgcn_sched_group_barrier(0x008, 12 * (NJ_) - (((KY) == 0 ? 4 : 2) + 2 * (NJ_)), 0);     \
+      } else {                                                                                              \
+        __builtin_amdgcn_sched_group_barrier(0x008, 6 * (NJ_), 0);                                          \
+      }                                                                                                     \
+    }                                                                                                       \
     bstage = bstage == 2 ? 0 : bstage + 1;                                                                  \
     istage = istage == 2 ? 0 : istage + 1;                                                                  \
   }
-
-  for (int t = 0; t < nk; t += 3) {
-    // channels >= Cin of the last group are zero padding (activations AND folded weights): when they fill the whole
-    // second 16-wide k-step (e.g. Cin = 196 -> 192..207 | 208..223) its MFMAs are skipped -- exact, 1/14 of the work
-    const bool dead2 = cg == gpt - 1 && p.Cin <= cg * 32 + 16;
-    const char* sP = patch_base + (cg & 1) * PATCH_BYTES;
-    C3_ITER(0)
-    C3_ITER(1)
-    C3_ITER(2)
-    if (++kx == 3) { kx = 0; ++cg; }
+  // three k-tiles (ky = 0, 1, 2) at (cg, kx)
+#define C3_TRIP(NJ_, DEAD_)                                                                                 \
+  {                                                                                                         \
+    const char* sP = patch_base + (cg & 1) * PATCH_BYTES;                                                   \
+    C3_ITER(0, NJ_, DEAD_)                                                                                  \
+    C3_ITER(1, NJ_, DEAD_)                                                                                  \
+    C3_ITER(2, NJ_, DEAD_)                                                                                  \
+    if (++kx == 3) { kx = 0; ++cg; }                                                                        \
   }
+  // channels >= Cin of the last group are zero padding (activations AND folded weights): when they fill the whole
+  // second 16-wide k-step (e.g. Cin = 196 -> 192..207 | 208..223) its MFMAs are skipped -- exact, 1/14 of the work
+  const bool dead_last = p.Cin <= (gpt - 1) * 32 + 16;
+#define C3_LOOP(NJ_)                                                                                        \
+  {                                                                                                         \
+    int t = 0;                                                                                              \
+    for (; t < nk - 9; t += 3) C3_TRIP(NJ_, 0)                                                              \
+    if (dead_last) { for (; t < nk; t += 3) C3_TRIP(NJ_, 1) }                                               \
+    else { for (; t < nk; t += 3) C3_TRIP(NJ_, 0) }                                                         \
+  }
+  if (nact == 2) C3_LOOP(2)
+  else if (nact == 1) C3_LOOP(1)
+  else C3_LOOP(0)
+#undef C3_LOOP
+#undef C3_TRIP
 #undef C3_ITER
-#undef C3_KSTEP
+#undef C3_MFMAS
 #undef C3_LOAD_ROW
 #undef C3_ISSUE_PATCH
 #undef C3_ISSUE_B
