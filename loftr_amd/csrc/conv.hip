@@ -196,33 +196,55 @@ __global__ __launch_bounds__(512, 2) void conv3x3_kernel(Conv3Args p) {
   char* const bring_base = lds + 2 * PATCH_BYTES;
   char* const scratch = lds + 2 * PATCH_BYTES + 3 * BTILE_BYTES;
 
-  int tm, tn;
-  const int tiles_m = p.B * p.tiles_y * p.tiles_x;
-  if (!xcd_tile(tiles_m, ceil_div(p.Coutp, 128), tm, tn)) return;
-  const int b = tm / (p.tiles_y * p.tiles_x), trem = tm - b * (p.tiles_y * p.tiles_x);
-  const int y0 = (trem / p.tiles_x) * TY, x0 = (trem % p.tiles_x) * TX, n0 = tn * 128;
-
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave & 3, wn = wave >> 2;
   const int rsub = lane >> 3, slot = lane & 7;
-  const int nact = min(2, (p.Coutp - (n0 + wn * 64) + 31) / 32);
 
-  // ---- DMA source offsets (dwords) ----------------------------------------------------------
+  // ---- persistent workgroup: one per CU, walking the XCD-chunked tile order of common.h with a grid stride
+  // (a multiple of 8, so a workgroup stays on its XCD).  The DMA prologue of the NEXT tile is issued before the
+  // epilogue of the current one: the ~2 us patch / weight fetch latency at the start of a tile and the store
+  // drain at its end no longer leave the matrix pipe idle (1 workgroup per CU: nothing else would cover them).
+  const int tiles_m = p.B * p.tiles_y * p.tiles_x, tiles_n = ceil_div(p.Coutp, 128);
+  const int chunk_m = ceil_div(tiles_m, NUM_XCD), nvirt = NUM_XCD * chunk_m * tiles_n;
+  int vid = blockIdx.x;
+  int nb = 0, ny0 = 0, nx0 = 0, nn0 = 0;       // next tile: image, first output row / column, first output channel
+  bool have = false;
+#define C3_NEXT_TILE()                                                                                      \
+  {                                                                                                         \
+    have = false;                                                                                           \
+    for (; vid < nvirt; vid += gridDim.x) {                                                                 \
+      const int xcd__ = vid % NUM_XCD, slot__ = vid / NUM_XCD;                                              \
+      const int local__ = slot__ / tiles_n, tm__ = xcd__ * chunk_m + local__;                               \
+      if (local__ < chunk_m && tm__ < tiles_m) {                                                            \
+        nb = tm__ / (p.tiles_y * p.tiles_x);                                                                \
+        const int trem__ = tm__ - nb * (p.tiles_y * p.tiles_x);                                             \
+        ny0 = (trem__ / p.tiles_x) * TY; nx0 = (trem__ % p.tiles_x) * TX; nn0 = (slot__ % tiles_n) * 128;   \
+        have = true;                                                                                        \
+        break;                                                                                              \
+      }                                                                                                     \
+    }                                                                                                       \
+  }
+  C3_NEXT_TILE()
+  if (!have) return;
+
+  // ---- DMA source offsets (dwords) of the next tile -------------------------------------------
   int poff[PQ];                       // patch rows: -1 = outside the image / unused slot -> zero page
-#pragma unroll
-  for (int q = 0; q < PQ; ++q) {
-    const int s = q * 8 + wave, r = s * 8 + rsub;
-    const int py = r / PW, px = r - py * PW;
-    const int gy = y0 - 1 + py, gx = x0 - 1 + px;
-    const bool in = s < PSLOTS && r < PROWS && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
-    poff[q] = in ? ((b * p.H + gy) * p.W + gx) * p.Cp + ((slot ^ ((r >> 1) & 7)) << 2) : -1;
-  }
   int boff[2];
-#pragma unroll
-  for (int q = 0; q < 2; ++q) {
-    const int r = (q * 8 + wave) * 8 + rsub;
-    boff[q] = min(n0 + r, p.Cout - 1) * p.K + ((slot ^ ((r >> 1) & 7)) << 2);
+#define C3_DMA_OFFSETS()                                                                                    \
+  {                                                                                                         \
+    _Pragma("unroll") for (int q = 0; q < PQ; ++q) {                                                        \
+      const int s = q * 8 + wave, r = s * 8 + rsub;                                                         \
+      const int py = r / PW, px = r - py * PW;                                                              \
+      const int gy = ny0 - 1 + py, gx = nx0 - 1 + px;                                                       \
+      const bool in = s < PSLOTS && r < PROWS && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W; \
+      poff[q] = in ? ((nb * p.H + gy) * p.W + gx) * p.Cp + ((slot ^ ((r >> 1) & 7)) << 2) : -1;             \
+    }                                                                                                       \
+    _Pragma("unroll") for (int q = 0; q < 2; ++q) {                                                         \
+      const int r = (q * 8 + wave) * 8 + rsub;                                                              \
+      boff[q] = min(nn0 + r, p.Cout - 1) * p.K + ((slot ^ ((r >> 1) & 7)) << 2);                            \
+    }                                                                                                       \
   }
+  C3_DMA_OFFSETS()
   const int gpt = p.Cp >> 5, nk = 9 * gpt;
 
 #define C3_ISSUE_PATCH(cg_, stage_)                                                                         \
@@ -242,13 +264,6 @@ __global__ __launch_bounds__(512, 2) void conv3x3_kernel(Conv3Args p) {
   }
 
   f32x16 acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
   const int g = lane >> 5, tx = lane & 31;
   int bbase[2];
 #pragma unroll
@@ -257,10 +272,19 @@ __global__ __launch_bounds__(512, 2) void conv3x3_kernel(Conv3Args p) {
     bbase[j] = br * 128 + ((g ^ ((br >> 1) & 7)) << 4);
   }
 
-  // prologue: patch 0, weight tiles 0 and 1
+  // prologue of the first tile: patch 0, weight tiles 0 and 1
   C3_ISSUE_PATCH(0, 0);
   C3_ISSUE_B(0, 0, 0);
   C3_ISSUE_B(0, 3, 1);                                   // sequence position 1 = (kx 0, ky 1) = tap 3;  nk >= 9
+  for (;;) {                                             // ---- tiles of this workgroup ----
+  const int b = nb, y0 = ny0, x0 = nx0, n0 = nn0;
+  const int nact = min(2, (p.Coutp - (n0 + wn * 64) + 31) / 32);
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   int bstage = 0, istage = 2;
   int cg = 0, kx = 0;                                    // this trip runs k-tiles (cg, kx, ky = 0, 1, 2)
   int cg2 = 0, q2 = 2;                                   // sequence position (kx * 3 + ky) of the k-tile issued next, two ahead
@@ -375,10 +399,21 @@ __global__ __launch_bounds__(512, 2) void conv3x3_kernel(Conv3Args p) {
 #undef C3_PIN
 #undef C3_MFMAS
 #undef C3_LOAD_ROW
-#undef C3_ISSUE_PATCH
-#undef C3_ISSUE_B
+
+  // ---- next tile: its DMA prologue goes out before this tile's epilogue -----------------------------
+  vid += gridDim.x;
+  C3_NEXT_TILE()
+  __builtin_amdgcn_s_barrier();                          // every wave is done reading the patch / weight rings
+  if (have) {
+    C3_DMA_OFFSETS()
+    C3_ISSUE_PATCH(0, 0);
+    C3_ISSUE_B(0, 0, 0);
+    C3_ISSUE_B(0, 3, 1);
+  }
 
   // ---- epilogue: bias (folded BN shift), residual, activation, SP / fp32 stores ---------------------
+  // (its loads and stores are younger than the prologue DMAs above: the vmcnt waits of the next tile's first
+  //  k-tiles, which count only DMA instructions, are then stricter than needed, never weaker)
   const bool odd = lane & 1;
   const int Ho = p.H, Wo = p.W;
 #pragma unroll
@@ -427,6 +462,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_kernel(Conv3Args p) {
       }
     }
   }
+  if (!have) break;
+  }                                                      // ---- tiles of this workgroup ----
+#undef C3_ISSUE_PATCH
+#undef C3_ISSUE_B
+#undef C3_DMA_OFFSETS
+#undef C3_NEXT_TILE
 }
 
 // 3x3 convolutions whose padded output width is 7 MFMA column tiles (Cout = 196 -> 224, the FPN's middle
@@ -795,6 +836,20 @@ extern "C" size_t loftr_conv_workspace_bytes(int Cin, int Cout, int KH, int KW) 
   return align_up((size_t)Cout * KH * KW * ceil32(Cin) * 4, 256) + align_up((size_t)Cout * 4, 256) + 2048;
 }
 
+// Grid of a persistent kernel that holds one workgroup per CU: min(virtual workgroups, CUs), CUs rounded down to a
+// multiple of the XCD count so that the grid stride keeps every workgroup on its XCD (LOFTR_CONV_PERSIST=0: one
+// workgroup per tile, the non-persistent schedule, for A/B runs).
+static unsigned persistent_grid(unsigned nvirt) {
+  static const int cus = []() {
+    const char* e = getenv("LOFTR_CONV_PERSIST");
+    if (e && atoi(e) == 0) return 0;
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+    return n / NUM_XCD * NUM_XCD;
+  }();
+  return cus > 0 && nvirt > (unsigned)cus ? (unsigned)cus : nvirt;
+}
+
 static int conv_launch(const uint32_t* x_sp, int B, int H, int W, int Cin, const float* weight,
                        const long* weight_strides, int Cout, int KH, int KW, int stride, int pad, const float* bn_weight, const float* bn_bias,
                        const float* bn_mean, const float* bn_var, float bn_eps, int act,
@@ -843,7 +898,8 @@ static int conv_launch(const uint32_t* x_sp, int B, int H, int W, int Cin, const
     if (use_wide && c.Coutp == 32 * c3w::NT)
       hipLaunchKernelGGL(conv3x3_wide_kernel, dim3(xcd_grid(B * c.tiles_x * c.tiles_y, 1)), dim3(512), 0, st, c);
     else
-      hipLaunchKernelGGL(conv3x3_kernel, dim3(xcd_grid(B * c.tiles_x * c.tiles_y, ceil_div(c.Coutp, 128))), dim3(512), 0, st, c);
+      hipLaunchKernelGGL(conv3x3_kernel, dim3(persistent_grid(xcd_grid(B * c.tiles_x * c.tiles_y, ceil_div(c.Coutp, 128)))),
+                         dim3(512), 0, st, c);
     LOFTR_CHECK_LAUNCH();
     return LOFTR_OK;
   }

@@ -32,6 +32,7 @@ def _randomize_bn(m, g):
     (256, 196, 3, 1, 0, False, False),
     (256, 256, 3, 1, 2, True, False),
     (64, 40, 3, 1, 2, True, True),
+    (96, 200, 3, 1, 2, True, True),          # 7 column tiles with Cout != 196: the 224-column kernel, 3 channel groups
 ])
 def test_conv_bn_act_vs_torch(cin, cout, k, stride, act, use_bn, use_res):
     from loftr_amd import ops
