@@ -25,13 +25,36 @@ __global__ __launch_bounds__(256) void kv_finalize_kernel(const float* __restric
                                                           const float* __restrict__ wm,
                                                           sp_t* __restrict__ pm) {
   __shared__ __attribute__((aligned(16))) float skv[33 * 32];
+  __shared__ __attribute__((aligned(16))) float sgrp[4][33 * 32];
   const int h = blockIdx.x, n = blockIdx.y, H = gridDim.x;
   const long base = (long)n * H + h;
   const float* p = part + base * splits * (33 * 32);
   float* o = kv + base * (33 * 32);
+  // wave w sums the partials k = w, w+4, ... as 16-B vectors (264 per partial, <= 5 per lane), then the four group
+  // sums are added in a fixed order: ~4x fewer and 4x wider dependent loads than one thread per element
+  {
+    constexpr int NV = 33 * 32 / 4;
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    f32x4 a[5];
+#pragma unroll
+    for (int u = 0; u < 5; ++u) a[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int k = w; k < splits; k += 4) {
+      const f32x4* pk = reinterpret_cast<const f32x4*>(p + (long)k * (33 * 32));
+#pragma unroll
+      for (int u = 0; u < 5; ++u) {
+        const int v = lane + u * 64;
+        if (v < NV) a[u] += pk[v];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 5; ++u) {
+      const int v = lane + u * 64;
+      if (v < NV) reinterpret_cast<f32x4*>(sgrp[w])[v] = a[u];
+    }
+  }
+  __syncthreads();
   for (int e = threadIdx.x; e < 33 * 32; e += 256) {
-    float s = 0.f;
-    for (int k = 0; k < splits; ++k) s += p[(long)k * (33 * 32) + e];
+    const float s = ((sgrp[0][e] + sgrp[1][e]) + sgrp[2][e]) + sgrp[3][e];
     if (blockIdx.z == 0) o[e] = s;
     skv[e] = s;
   }

@@ -107,14 +107,16 @@ class LocalFeatureTransformer(nn.Module):
                     nn.init.xavier_uniform_(p)
         del first
 
-    def forward(self, feat0, feat1, mask0=None, mask1=None):
+    def forward(self, feat0, feat1, mask0=None, mask1=None, inplace=False):
+        """``inplace`` (not in the reference signature): the caller owns feat0 / feat1 and does not need their
+        input values any more; when they are the two halves of one buffer the layers then run on it directly."""
         assert self.d_model == feat0.size(2), "the feature number of src and transformer must be equal"
         for name in self.layer_names:
             if name not in ("self", "cross"):
                 raise KeyError
         structs = [layer.weight_struct() for layer in self.layers]
         return ops.transformer(feat0.contiguous(), feat1.contiguous(), structs, self.layer_names, self.nhead,
-                               mask0, mask1)
+                               mask0, mask1, inplace=inplace)
 
 
 class CoarseMatching(nn.Module):
@@ -281,19 +283,23 @@ class LoFTR(nn.Module):
         """Steps 2-5 of forward (loftr.py:51-75): THE hot path.  `data` needs bs, hw0_i, hw1_i."""
         data.update({"hw0_c": feat_c0.shape[2:], "hw1_c": feat_c1.shape[2:],
                      "hw0_f": feat_f0.shape[2:], "hw1_f": feat_f1.shape[2:]})
-        feat_c0 = self.pos_encoding(feat_c0)
-        feat_c1 = self.pos_encoding(feat_c1)
+        both = ops.stacked_halves(feat_c0, feat_c1) if feat_c0.shape == feat_c1.shape else None
+        if both is not None:         # the two coarse maps are halves of one backbone batch: one launch, one buffer
+            feat_c0, feat_c1 = self.pos_encoding(both).split(feat_c0.shape[0])
+        else:
+            feat_c0 = self.pos_encoding(feat_c0)
+            feat_c1 = self.pos_encoding(feat_c1)
         mask_c0 = mask_c1 = None
         if "mask0" in data:
             mask_c0, mask_c1 = data["mask0"].flatten(-2), data["mask1"].flatten(-2)
-        feat_c0, feat_c1 = self.loftr_coarse(feat_c0, feat_c1, mask_c0, mask_c1)
+        feat_c0, feat_c1 = self.loftr_coarse(feat_c0, feat_c1, mask_c0, mask_c1, inplace=True)   # fresh pos-encoded copies
         self.coarse_matching(feat_c0, feat_c1, data, mask_c0=mask_c0, mask_c1=mask_c1)
         if getattr(self, "_fine_join", None) is not None:    # fine maps come from the side stream
             torch.cuda.current_stream().wait_stream(self._fine_join)
             self._fine_join = None
         feat_f0_unfold, feat_f1_unfold = self.fine_preprocess(feat_f0, feat_f1, feat_c0, feat_c1, data)
         if feat_f0_unfold.size(0) != 0:
-            feat_f0_unfold, feat_f1_unfold = self.loftr_fine(feat_f0_unfold, feat_f1_unfold)
+            feat_f0_unfold, feat_f1_unfold = self.loftr_fine(feat_f0_unfold, feat_f1_unfold, inplace=True)
         self.fine_matching(feat_f0_unfold, feat_f1_unfold, data)
 
     @torch.no_grad()

@@ -109,14 +109,29 @@ def encoder_layer(x, source, w_struct, nhead, x_mask=None, source_mask=None, out
     return out
 
 
-def transformer(feat0, feat1, layer_structs, layer_names, nhead, mask0=None, mask1=None):
-    """LocalFeatureTransformer.forward.  Returns new (feat0, feat1); inputs are not modified."""
+def stacked_halves(a, b):
+    """The tensor [a; b] WITHOUT a copy when a and b already are the two batch halves of one buffer
+    (e.g. ``x.split(n)`` of a stacked pair batch, or the outputs of pos_encode_flatten / fine_preprocess);
+    None otherwise."""
+    if (a.shape[1:] != b.shape[1:] or a.stride() != b.stride() or a.dtype != b.dtype or a.device != b.device
+            or a.untyped_storage().data_ptr() != b.untyped_storage().data_ptr()
+            or b.storage_offset() != a.storage_offset() + a.shape[0] * a.stride(0)):
+        return None
+    return torch.as_strided(a, (a.shape[0] + b.shape[0],) + tuple(a.shape[1:]), a.stride(), a.storage_offset())
+
+
+def transformer(feat0, feat1, layer_structs, layer_names, nhead, mask0=None, mask1=None, inplace=False):
+    """LocalFeatureTransformer.forward.  Returns new (feat0, feat1); inputs are not modified unless
+    ``inplace`` (then, when feat0 / feat1 are the contiguous halves of one buffer, the layers run on
+    that buffer directly instead of on a torch.cat copy of it)."""
     _need(feat0, "feat0"); _need(feat1, "feat1")
     N, L, Cc = feat0.shape
     S = feat1.shape[1]
     m0, m1 = _mask_u8(mask0, "mask0"), _mask_u8(mask1, "mask1")
     if L == S:          # stack -> the two self-attention calls of a layer run as one batch of 2N
-        both = torch.cat([feat0, feat1], 0)
+        both = stacked_halves(feat0, feat1) if inplace and feat0.shape[0] == feat1.shape[0] else None
+        if both is None:
+            both = torch.cat([feat0, feat1], 0)
         f0, f1 = both[:N], both[N:]
         if m0 is not None:
             mb = torch.cat([m0, m1], 0)
@@ -202,8 +217,8 @@ def fine_preprocess(feat_f0, feat_f1, feat_c0, feat_c1, b_ids, i_ids, j_ids, hw0
     M = b_ids.shape[0]
     Cf = feat_f0.shape[1]
     dev = feat_f0.device
-    out0 = torch.empty(M, W * W, Cf, device=dev, dtype=torch.float32)
-    out1 = torch.empty(M, W * W, Cf, device=dev, dtype=torch.float32)
+    out = torch.empty(2 * M, W * W, Cf, device=dev, dtype=torch.float32)     # one buffer: the fine transformer
+    out0, out1 = out[:M], out[M:]                                            # runs on it in place (no torch.cat)
     if M == 0:
         return out0, out1
     lib = _lib.load()
