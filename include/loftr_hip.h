@@ -34,7 +34,7 @@ typedef enum {
   LOFTR_ERR_NO_DEVICE = -5      /* no gfx950 device visible                                    */
 } loftr_status;
 
-#define LOFTR_HIP_ABI_VERSION 6
+#define LOFTR_HIP_ABI_VERSION 7
 
 int loftr_hip_abi_version(void);
 const char* loftr_hip_status_string(int status);
@@ -189,6 +189,18 @@ int loftr_conv_bn_act(const uint32_t* x_sp, int B, int H, int W, int Cin, const 
                       const float* bn_mean, const float* bn_var, float bn_eps, int act,
                       const uint32_t* residual_sp, uint32_t* y_sp, float* y_f32, void* ws, size_t ws_bytes,
                       void* stream);
+/* Inference with constant weights: fold BN + encode the filter once, then run any number of convolutions on it.
+ * loftr_conv_prepare fills `prepared` (loftr_conv_workspace_bytes(Cin, Cout, KH, KW) bytes, caller-owned, must
+ * stay untouched while in use); loftr_conv_bn_act_prepared is loftr_conv_bn_act (low_sp == NULL) or
+ * loftr_conv1x1_upsample_add (low_sp != NULL: 1x1 / stride 1 / no act / SP output only) without the per-call
+ * weight preparation (two launches and a memset per convolution).  loftr_conv_bn_act == prepare into ws + this. */
+int loftr_conv_prepare(const float* weight, const long* weight_strides, int Cin, int Cout, int KH, int KW,
+                       const float* bn_weight, const float* bn_bias, const float* bn_mean, const float* bn_var,
+                       float bn_eps, void* prepared, size_t prepared_bytes, void* stream);
+int loftr_conv_bn_act_prepared(const uint32_t* x_sp, int B, int H, int W, int Cin, const void* prepared,
+                               size_t prepared_bytes, int Cout, int KH, int KW, int stride, int pad, int act,
+                               const uint32_t* residual_sp, const uint32_t* low_sp, uint32_t* y_sp, float* y_f32,
+                               void* stream);
 /* Stem: nn.Conv2d(1, C0, 7, stride 2, padding 3, bias=False) + eval BatchNorm2d + ReLU (resnet_fpn.py:52-54,101),
  * direct convolution; x [B,1,H,W] fp32 through its element strides (sb, sc, sh, sw), y_sp [B,Ho,Wo,ceil32(C0)]. */
 int loftr_stem_conv_bn_relu(const float* x, const long* x_strides, int B, int H, int W, const float* weight,

@@ -850,15 +850,39 @@ static unsigned persistent_grid(unsigned nvirt) {
   return cus > 0 && nvirt > (unsigned)cus ? (unsigned)cus : nvirt;
 }
 
-static int conv_launch(const uint32_t* x_sp, int B, int H, int W, int Cin, const float* weight,
-                       const long* weight_strides, int Cout, int KH, int KW, int stride, int pad, const float* bn_weight, const float* bn_bias,
-                       const float* bn_mean, const float* bn_var, float bn_eps, int act,
-                       const uint32_t* residual_sp, const uint32_t* up_sp, uint32_t* y_sp, float* y_f32, void* ws, size_t ws_bytes,
-                       void* stream) {
-  LOFTR_CHECK_ARG(x_sp && weight && weight_strides && (y_sp || y_f32) && ws && B >= 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0);
-  LOFTR_CHECK_ARG(KH > 0 && KW > 0 && stride > 0 && pad >= 0 && act >= 0 && act <= 2);
+// Folded weights live in a caller-owned buffer laid out [SP weights Cout x K][bias Cout][zero page 256 B]
+// (loftr_conv_workspace_bytes): conv_prepare fills it, conv_run consumes it.
+struct ConvPrepared { sp_t* wsp; float* bias; sp_t* zeros; };
+static bool conv_prepared_layout(void* buf, size_t bytes, int Cin, int Cout, int KH, int KW, ConvPrepared& o) {
+  WsAlloc wa(buf, bytes);
+  o.wsp = wa.take<sp_t>((size_t)Cout * KH * KW * ceil32(Cin));
+  o.bias = wa.take<float>(Cout);
+  o.zeros = wa.take<sp_t>(64);
+  return wa.ok();
+}
+
+static int conv_prepare(const float* weight, const long* weight_strides, int Cin, int Cout, int KH, int KW,
+                        const float* bn_weight, const float* bn_bias, const float* bn_mean, const float* bn_var, float bn_eps,
+                        void* buf, size_t bytes, hipStream_t st) {
+  LOFTR_CHECK_ARG(weight && weight_strides && buf && Cin > 0 && Cout > 0 && KH > 0 && KW > 0);
   LOFTR_CHECK_ARG((bn_weight == nullptr) == (bn_bias == nullptr) && (bn_weight == nullptr) == (bn_mean == nullptr) &&
                   (bn_weight == nullptr) == (bn_var == nullptr));
+  ConvPrepared pr;
+  if (!conv_prepared_layout(buf, bytes, Cin, Cout, KH, KW, pr)) return LOFTR_ERR_WORKSPACE;
+  const int Cp = ceil32(Cin), K = KH * KW * Cp;
+  (void)hipMemsetAsync(pr.zeros, 0, 256, st);
+  hipLaunchKernelGGL(conv_prep_kernel, dim3(ceil_div(K / 32, 8), Cout), dim3(256), 0, st, weight, bn_weight, bn_bias,
+                     bn_mean, bn_var, bn_eps, Cin, Cp, KH, KW, weight_strides[0], weight_strides[1], weight_strides[2],
+                     weight_strides[3], pr.wsp, pr.bias);
+  LOFTR_CHECK_LAUNCH();
+  return LOFTR_OK;
+}
+
+static int conv_run(const uint32_t* x_sp, int B, int H, int W, int Cin, const void* prepared, size_t prepared_bytes, int Cout,
+                    int KH, int KW, int stride, int pad, int act, const uint32_t* residual_sp, const uint32_t* up_sp,
+                    uint32_t* y_sp, float* y_f32, void* stream) {
+  LOFTR_CHECK_ARG(x_sp && prepared && (y_sp || y_f32) && B >= 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0);
+  LOFTR_CHECK_ARG(KH > 0 && KW > 0 && stride > 0 && pad >= 0 && act >= 0 && act <= 2);
   if (B == 0) return LOFTR_OK;
   hipStream_t st = (hipStream_t)stream;
   ConvGeom g;
@@ -866,19 +890,17 @@ static int conv_launch(const uint32_t* x_sp, int B, int H, int W, int Cin, const
   g.Ho = (H + 2 * pad - KH) / stride + 1;
   g.Wo = (W + 2 * pad - KW) / stride + 1;
   if (g.Ho <= 0 || g.Wo <= 0 || H >= 32768 || W >= 32768) return LOFTR_ERR_UNSUPPORTED;
+  if (up_sp && ((g.Ho & 1) || (g.Wo & 1) || KH != 1 || KW != 1 || stride != 1 || pad != 0 || !y_sp || y_f32 || residual_sp || act != 0))
+    return LOFTR_ERR_UNSUPPORTED;                 // top-down step: 1x1 lateral conv, low map exactly [B, H/2, W/2, ceil32(Cout)]
   const long M = (long)B * g.Ho * g.Wo;
   if (M * (long)ceil32(Cout) >= (1L << 31) || (long)B * H * W * g.Cp >= (1L << 31)) return LOFTR_ERR_UNSUPPORTED;
   const int K = KH * KW * g.Cp;
-  WsAlloc wa(ws, ws_bytes);
-  sp_t* wsp = wa.take<sp_t>((size_t)Cout * K);
-  float* bias = wa.take<float>(Cout);
-  sp_t* zeros = wa.take<sp_t>(64);
-  if (!wa.ok()) return LOFTR_ERR_WORKSPACE;
-  (void)hipMemsetAsync(zeros, 0, 256, st);
+  ConvPrepared pr;
+  if (!conv_prepared_layout(const_cast<void*>(prepared), prepared_bytes, Cin, Cout, KH, KW, pr)) return LOFTR_ERR_WORKSPACE;
+  sp_t* wsp = pr.wsp;
+  float* bias = pr.bias;
+  sp_t* zeros = pr.zeros;
   g.zeros = zeros;
-  hipLaunchKernelGGL(conv_prep_kernel, dim3(ceil_div(K / 32, 8), Cout), dim3(256), 0, st, weight, bn_weight, bn_bias,
-                     bn_mean, bn_var, bn_eps, Cin, g.Cp, KH, KW, weight_strides[0], weight_strides[1], weight_strides[2],
-                     weight_strides[3], wsp, bias);
   ConvArgs p;
   p.a = asrc_conv(x_sp, g);
   p.w = wsp; p.K = K; p.bias = bias; p.residual = residual_sp; p.y_sp = y_sp; p.y_f32 = y_f32;
@@ -921,22 +943,43 @@ static int conv_launch(const uint32_t* x_sp, int B, int H, int W, int Cin, const
   return LOFTR_OK;
 }
 
+extern "C" int loftr_conv_prepare(const float* weight, const long* weight_strides, int Cin, int Cout, int KH, int KW,
+                                  const float* bn_weight, const float* bn_bias, const float* bn_mean, const float* bn_var,
+                                  float bn_eps, void* prepared, size_t prepared_bytes, void* stream) {
+  return conv_prepare(weight, weight_strides, Cin, Cout, KH, KW, bn_weight, bn_bias, bn_mean, bn_var, bn_eps, prepared,
+                      prepared_bytes, (hipStream_t)stream);
+}
+
+extern "C" int loftr_conv_bn_act_prepared(const uint32_t* x_sp, int B, int H, int W, int Cin, const void* prepared,
+                                          size_t prepared_bytes, int Cout, int KH, int KW, int stride, int pad, int act,
+                                          const uint32_t* residual_sp, const uint32_t* low_sp, uint32_t* y_sp, float* y_f32,
+                                          void* stream) {
+  return conv_run(x_sp, B, H, W, Cin, prepared, prepared_bytes, Cout, KH, KW, stride, pad, act, residual_sp, low_sp, y_sp, y_f32,
+                  stream);
+}
+
 extern "C" int loftr_conv_bn_act(const uint32_t* x_sp, int B, int H, int W, int Cin, const float* weight,
                                  const long* weight_strides, int Cout, int KH, int KW, int stride, int pad, const float* bn_weight, const float* bn_bias,
                                  const float* bn_mean, const float* bn_var, float bn_eps, int act,
                                  const uint32_t* residual_sp, uint32_t* y_sp, float* y_f32, void* ws, size_t ws_bytes,
                                  void* stream) {
-  return conv_launch(x_sp, B, H, W, Cin, weight, weight_strides, Cout, KH, KW, stride, pad, bn_weight, bn_bias, bn_mean,
-                     bn_var, bn_eps, act, residual_sp, nullptr, y_sp, y_f32, ws, ws_bytes, stream);
+  LOFTR_CHECK_ARG(x_sp && (y_sp || y_f32) && B >= 0 && H > 0 && W > 0);
+  if (B == 0) return LOFTR_OK;
+  const int rc = conv_prepare(weight, weight_strides, Cin, Cout, KH, KW, bn_weight, bn_bias, bn_mean, bn_var, bn_eps, ws, ws_bytes,
+                              (hipStream_t)stream);
+  if (rc != LOFTR_OK) return rc;
+  return conv_run(x_sp, B, H, W, Cin, ws, ws_bytes, Cout, KH, KW, stride, pad, act, residual_sp, nullptr, y_sp, y_f32, stream);
 }
 
 extern "C" int loftr_conv1x1_upsample_add(const uint32_t* x_sp, int B, int H, int W, int Cin, const float* weight,
                                           const long* weight_strides, int Cout, const uint32_t* low_sp, uint32_t* y_sp,
                                           void* ws, size_t ws_bytes, void* stream) {
-  LOFTR_CHECK_ARG(low_sp && y_sp && H > 0 && W > 0);
-  if ((H & 1) || (W & 1)) return LOFTR_ERR_UNSUPPORTED;        // the low map is exactly [B, H/2, W/2, ceil32(Cout)]
-  return conv_launch(x_sp, B, H, W, Cin, weight, weight_strides, Cout, 1, 1, 1, 0, nullptr, nullptr, nullptr, nullptr, 0.f, 0,
-                     nullptr, low_sp, y_sp, nullptr, ws, ws_bytes, stream);
+  LOFTR_CHECK_ARG(x_sp && low_sp && y_sp && B >= 0 && H > 0 && W > 0);
+  if (B == 0) return LOFTR_OK;
+  const int rc = conv_prepare(weight, weight_strides, Cin, Cout, 1, 1, nullptr, nullptr, nullptr, nullptr, 0.f, ws, ws_bytes,
+                              (hipStream_t)stream);
+  if (rc != LOFTR_OK) return rc;
+  return conv_run(x_sp, B, H, W, Cin, ws, ws_bytes, Cout, 1, 1, 1, 0, 0, nullptr, low_sp, y_sp, nullptr, stream);
 }
 
 extern "C" int loftr_stem_conv_bn_relu(const float* x, const long* x_strides, int B, int H, int W, const float* weight,

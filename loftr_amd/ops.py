@@ -271,32 +271,51 @@ def sp_to_nhwc(x_sp, Cc):
     return out
 
 
-def conv_bn_act(x_sp, Cin, conv, bn=None, act=0, residual=None, want_sp=True, want_f32=False):
-    """nn.Conv2d(bias=False) [+ eval BatchNorm2d] [+ residual] [+ act] on an SP activation.
-
-    x_sp int32 [B,H,W,ceil32(Cin)]; returns (y_sp or None, y_f32 [B,Ho,Wo,Cout] or None)."""
+def _prepared_conv(conv, bn):
+    """Folded-BN SP filter of (conv, bn), cached on the module and rebuilt when any of the tensors it was built
+    from is modified in place (tensor._version), replaced (data_ptr) or moved.  Inference weights are constant: the
+    per-call weight preparation of loftr_conv_bn_act (two launches + a memset per convolution) runs once."""
     w = conv.weight
     if not w.is_cuda or w.dtype != torch.float32:
         raise _lib.LoftrHipError("conv.weight: expected a float32 GPU tensor")
+    if bn is not None and bn.training:
+        raise _lib.LoftrHipError("conv_bn_act folds eval-mode BatchNorm only; call .eval()")
+    assert conv.bias is None and conv.dilation == (1, 1) and conv.groups == 1
+    bnp = [] if bn is None else [bn.weight, bn.bias, bn.running_mean, bn.running_var]
+    key = tuple((t.data_ptr(), t._version, tuple(t.stride())) for t in [w] + bnp) + (None if bn is None else float(bn.eps), str(w.device))
+    cached = getattr(conv, "_loftr_prepared", None)
+    if cached is not None and cached[0] == key:
+        return cached[1]
+    Cout, Cin, KH, KW = w.shape
+    lib = _lib.load()
+    buf = torch.empty(lib.loftr_conv_workspace_bytes(Cin, Cout, KH, KW), dtype=torch.uint8, device=w.device)
     wst = (C.c_long * 4)(*w.stride())                       # contiguous or channels-last storage
+    ptrs = [_ptr(t) for t in bnp] if bnp else [None] * 4
+    check(lib.loftr_conv_prepare(_ptr(w), wst, Cin, Cout, KH, KW, *ptrs, float(bn.eps) if bn is not None else 0.0, _ptr(buf),
+                                 buf.numel(), _stream()), "loftr_conv_prepare")
+    conv._loftr_prepared = (key, buf)
+    return buf
+
+
+def conv_bn_act(x_sp, Cin, conv, bn=None, act=0, residual=None, want_sp=True, want_f32=False, low_sp=None):
+    """nn.Conv2d(bias=False) [+ eval BatchNorm2d] [+ residual] [+ act] on an SP activation.
+
+    x_sp int32 [B,H,W,ceil32(Cin)]; returns (y_sp or None, y_f32 [B,Ho,Wo,Cout] or None).
+    low_sp (FPN top-down step): y = conv1x1(x) + bilinear_x2(low_sp), SP in / out."""
+    w = conv.weight
     Cout, Cin_w, KH, KW = w.shape
-    assert Cin_w == Cin and conv.bias is None and conv.dilation == (1, 1) and conv.groups == 1
+    assert Cin_w == Cin
     stride, pad = conv.stride[0], conv.padding[0]
     B, H, W, Cp = x_sp.shape
     assert Cp == ceil32(Cin) and x_sp.dtype == torch.int32 and x_sp.is_contiguous()
     Ho, Wo = (H + 2 * pad - KH) // stride + 1, (W + 2 * pad - KW) // stride + 1
     dev = x_sp.device
+    prepared = _prepared_conv(conv, bn)
     y_sp = torch.empty(B, Ho, Wo, ceil32(Cout), dtype=torch.int32, device=dev) if want_sp else None
     y_f32 = torch.empty(B, Ho, Wo, Cout, dtype=torch.float32, device=dev) if want_f32 else None
-    lib = _lib.load()
-    ws = workspace(lib.loftr_conv_workspace_bytes(Cin, Cout, KH, KW), dev)
-    bnp = [None] * 4 if bn is None else [bn.weight, bn.bias, bn.running_mean, bn.running_var]
-    if bn is not None and bn.training:
-        raise _lib.LoftrHipError("conv_bn_act folds eval-mode BatchNorm only; call .eval()")
-    check(lib.loftr_conv_bn_act(_ptr(x_sp), B, H, W, Cin, _ptr(w), wst, Cout, KH, KW, stride, pad, _ptr(bnp[0]), _ptr(bnp[1]),
-                                _ptr(bnp[2]), _ptr(bnp[3]), float(bn.eps) if bn is not None else 0.0, int(act),
-                                _ptr(residual), _ptr(y_sp), _ptr(y_f32), _ptr(ws), ws.numel(), _stream()),
-          "loftr_conv_bn_act")
+    check(_lib.load().loftr_conv_bn_act_prepared(_ptr(x_sp), B, H, W, Cin, _ptr(prepared), prepared.numel(), Cout, KH, KW,
+                                                 stride, pad, int(act), _ptr(residual), _ptr(low_sp), _ptr(y_sp), _ptr(y_f32),
+                                                 _stream()), "loftr_conv_bn_act_prepared")
     return y_sp, y_f32
 
 
@@ -321,22 +340,12 @@ def stem_conv_bn_relu(x, conv, bn):
 
 def conv1x1_upsample_add(x_sp, Cin, conv, low_sp):
     """conv1x1(x) + bilinear x2 (align_corners=True) of low in one launch (one FPN top-down step); SP in / out."""
-    w = conv.weight
-    if not w.is_cuda or w.dtype != torch.float32:
-        raise _lib.LoftrHipError("conv.weight: expected a float32 GPU tensor")
-    Cout = w.shape[0]
-    assert tuple(w.shape[1:]) == (Cin, 1, 1) and conv.bias is None and conv.stride == (1, 1) and conv.padding == (0, 0)
-    B, H, W, Cp = x_sp.shape
-    assert Cp == ceil32(Cin) and x_sp.dtype == torch.int32 and x_sp.is_contiguous()
+    Cout = conv.weight.shape[0]
+    assert tuple(conv.weight.shape[1:]) == (Cin, 1, 1) and conv.stride == (1, 1) and conv.padding == (0, 0)
+    B, H, W, _ = x_sp.shape
     if low_sp.shape != (B, H // 2, W // 2, ceil32(Cout)) or H % 2 or W % 2 or not low_sp.is_contiguous():
         raise _lib.LoftrHipError(f"conv1x1_upsample_add: low map {tuple(low_sp.shape)} is not half of {tuple(x_sp.shape)}")
-    y = torch.empty(B, H, W, ceil32(Cout), dtype=torch.int32, device=x_sp.device)
-    lib = _lib.load()
-    ws = workspace(lib.loftr_conv_workspace_bytes(Cin, Cout, 1, 1), x_sp.device)
-    wst = (C.c_long * 4)(*w.stride())
-    check(lib.loftr_conv1x1_upsample_add(_ptr(x_sp), B, H, W, Cin, _ptr(w), wst, Cout, _ptr(low_sp), _ptr(y), _ptr(ws),
-                                         ws.numel(), _stream()), "loftr_conv1x1_upsample_add")
-    return y
+    return conv_bn_act(x_sp, Cin, conv, low_sp=low_sp)[0]
 
 
 def upsample2x_add(low_sp, lateral_sp, Cc):

@@ -71,6 +71,35 @@ def test_conv_bn_act_vs_torch(cin, cout, k, stride, act, use_bn, use_res):
         assert (full[..., cout:] == 0).all()
 
 
+def test_prepared_weights_follow_inplace_updates():
+    """The folded SP filter is cached on the module (ops._prepared_conv); an in-place weight / BN update or a
+    replaced tensor must rebuild it (tensor._version / data_ptr are part of the cache key)."""
+    from loftr_amd import ops
+    g = torch.Generator().manual_seed(11)
+    conv = nn.Conv2d(64, 64, 3, padding=1, bias=False).cuda()
+    bn = nn.BatchNorm2d(64).eval().cuda()
+    x = torch.randn(1, 64, 16, 32, generator=g).cuda()
+    x_sp = ops.sp_from_nhwc(x.permute(0, 2, 3, 1).contiguous())
+
+    def run():
+        return ops.conv_bn_act(x_sp, 64, conv, bn, act=0, want_sp=False, want_f32=True)[1].permute(0, 3, 1, 2)
+
+    def ref():
+        return bn(conv(x))
+
+    with torch.no_grad():
+        y0 = run()
+        assert (y0 - ref()).abs().max().item() < 1e-4
+        first = conv._loftr_prepared[1]
+        assert run() is not None and conv._loftr_prepared[1] is first          # second call: cache hit
+        conv.weight.mul_(2.0)                                                    # in place -> _version bump
+        assert (run() - ref()).abs().max().item() < 1e-4 and conv._loftr_prepared[1] is not first
+        bn.running_var.add_(1.0)
+        assert (run() - ref()).abs().max().item() < 1e-4
+        conv.weight.data = torch.randn(64, 64, 3, 3, generator=g).cuda() * 0.05  # replaced storage
+        assert (run() - ref()).abs().max().item() < 1e-4
+
+
 def test_stem_vs_torch():
     from loftr_amd import ops
     g = torch.Generator().manual_seed(9)
