@@ -46,7 +46,7 @@ MFMA_F16_PEAK_TF = 2500.0      # MI355X_MICROARCH.md: dense fp16/bf16 MFMA peak
 MFMA_F32_PEAK_TF = 157.3       # MI355X_MICROARCH.md: fp32-input MFMA = fp32 vector peak (for context only)
 SPLIT_FACTOR = 3               # every fp32 product = 3 fp16 MFMAs (hi*hi + hi*lo + lo*hi), csrc/gemm.h
 GEMM_KERNELS = ("proj_kernel", "proj_kv_kernel", "linear_kernel", "linear_ln_kernel", "score_stats_kernel", "score_conf_kernel",
-                "conv_kernel", "conv3x3_kernel")
+                "conv_kernel", "conv3x3_kernel", "conv3x3_wide_kernel")
 
 K_IDS = {}
 
@@ -96,10 +96,12 @@ def algorithmic_work(B, L, S, M, C_=256, Cf=128, WW=25):
     w["score_conf_kernel"] = (2 * B * L * S * C_, 4 * B * ((L + S) * C_ + L * S))
     w["gather_windows_kernel"] = (0, 2 * 4 * 2 * M * WW * Cf)
     # backbone convolutions on the same GEMM core (conv.hip): ResNetFPN_8_2 over 2B images of 480x640
-    acc = {"conv_kernel": [0, 0], "conv3x3_kernel": [0, 0]}      # 3x3 stride-1 layers run the patch-in-LDS kernel
+    # 3x3 stride-1 layers run the patch-in-LDS kernels (the 224-column one when ceil32(Cout) == 224)
+    acc = {"conv_kernel": [0, 0], "conv3x3_kernel": [0, 0], "conv3x3_wide_kernel": [0, 0]}
     for (cin, cout, k, stride, hin, win) in backbone_convs(H_IMG, W_IMG):
         ho, wo = hin // stride, win // stride
-        a = acc["conv3x3_kernel" if (k == 3 and stride == 1) else "conv_kernel"]
+        patch = k == 3 and stride == 1
+        a = acc[("conv3x3_wide_kernel" if (cout + 31) // 32 == 7 else "conv3x3_kernel") if patch else "conv_kernel"]
         a[0] += 2 * 2 * B * ho * wo * cout * cin * k * k
         a[1] += 4 * 2 * B * (hin * win * cin + ho * wo * cout) + 4 * cout * cin * k * k
     for name, (fl, by) in acc.items():

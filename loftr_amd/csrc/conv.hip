@@ -914,10 +914,11 @@ static int conv_run(const uint32_t* x_sp, int B, int H, int W, int Cin, const vo
     c.x = x_sp; c.B = B; c.H = H; c.W = W; c.Cp = g.Cp; c.Cin = Cin; c.w = wsp; c.K = K; c.bias = bias; c.residual = residual_sp;
     c.y_sp = y_sp; c.y_f32 = y_f32; c.Cout = Cout; c.Coutp = ceil32(Cout); c.act = act; c.zeros = zeros;
     c.tiles_x = ceil_div(W, c3::TX); c.tiles_y = ceil_div(H, c3::TY);
-    TimedLaunch tl(LOFTR_T_CONV3, st);
     // LOFTR_CONV_WIDE=0: run 7-column-tile outputs as 128 + 96 columns on the generic kernel (A/B experiments)
     static const int use_wide = []() { const char* e = getenv("LOFTR_CONV_WIDE"); return e ? atoi(e) : 1; }();
-    if (use_wide && c.Coutp == 32 * c3w::NT)
+    const bool wide = use_wide && c.Coutp == 32 * c3w::NT;
+    TimedLaunch tl(wide ? LOFTR_T_CONV3W : LOFTR_T_CONV3, st);
+    if (wide)
       hipLaunchKernelGGL(conv3x3_wide_kernel, dim3(xcd_grid(B * c.tiles_x * c.tiles_y, 1)), dim3(512), 0, st, c);
     else
       hipLaunchKernelGGL(conv3x3_kernel, dim3(persistent_grid(xcd_grid(B * c.tiles_x * c.tiles_y, ceil_div(c.Coutp, 128)))),
