@@ -174,7 +174,8 @@ namespace c3 {
 constexpr int TY = 8, TX = 32, PW = TX + 2, PH = TY + 2, PROWS = PW * PH;            // 340 patch pixels
 constexpr int PSLOTS = 43, PQ = 6;                                                     // ceil(340 / 8) DMA slots, 6 per wave
 constexpr int PATCH_BYTES = PSLOTS * 1024, BTILE_BYTES = 128 * 128;
-constexpr int LDS_BYTES = 2 * PATCH_BYTES + 3 * BTILE_BYTES + 1024;                     // + 1 KB scratch for the unused slots
+constexpr int NB = 4;                                                                  // weight ring stages
+constexpr int LDS_BYTES = 2 * PATCH_BYTES + NB * BTILE_BYTES + 1024;                    // + 1 KB scratch for the unused slots
 using Cfg = GemmCfg<256, 128, 4, 2, 3>;                                                 // wave layout / epilogue helpers only
 }  // namespace c3
 
@@ -194,7 +195,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_kernel(Conv3Args p) {
   __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
   char* const patch_base = lds;
   char* const bring_base = lds + 2 * PATCH_BYTES;
-  char* const scratch = lds + 2 * PATCH_BYTES + 3 * BTILE_BYTES;
+  char* const scratch = lds + 2 * PATCH_BYTES + NB * BTILE_BYTES;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave & 3, wn = wave >> 2;
@@ -272,10 +273,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_kernel(Conv3Args p) {
     bbase[j] = br * 128 + ((g ^ ((br >> 1) & 7)) << 4);
   }
 
-  // prologue of the first tile: patch 0, weight tiles 0 and 1
+  // prologue of the first tile: patch 0, weight tiles 0, 1, 2 (sequence positions (kx 0, ky 0..2) = taps 0, 3, 6; nk >= 9)
   C3_ISSUE_PATCH(0, 0);
   C3_ISSUE_B(0, 0, 0);
-  C3_ISSUE_B(0, 3, 1);                                   // sequence position 1 = (kx 0, ky 1) = tap 3;  nk >= 9
+  C3_ISSUE_B(0, 3, 1);
+  C3_ISSUE_B(0, 6, 2);
   for (;;) {                                             // ---- tiles of this workgroup ----
   const int b = nb, y0 = ny0, x0 = nx0, n0 = nn0;
   const int nact = min(2, (p.Coutp - (n0 + wn * 64) + 31) / 32);
@@ -285,33 +287,35 @@ __global__ __launch_bounds__(512, 2) void conv3x3_kernel(Conv3Args p) {
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-  int bstage = 0, istage = 2;
+  int bstage = 0;                                        // ring stage of k-tile t (tile t+3 is issued into stage t-1)
   int cg = 0, kx = 0;                                    // this trip runs k-tiles (cg, kx, ky = 0, 1, 2)
-  int cg2 = 0, q2 = 2;                                   // sequence position (kx * 3 + ky) of the k-tile issued next, two ahead
+  int cg3 = 0, q3 = 3;                                   // sequence position (kx * 3 + ky) of the k-tile issued next, three ahead
   bool patch_m1 = false, patch_m2 = false;               // a patch was issued in iteration t-1 / t-2
   // A fragments of the wave's four patch rows 2wm .. 2wm+3 at column offset kx, [row][16-wide k-step]: output rows
   // (2wm, 2wm+1) read patch rows (ky, ky+1), so walking ky innermost each k-tile after the first needs ONE new row
   // (4 instead of 6 row reads per kx: a third of the A-side LDS traffic stays in registers).
   h16x8 fh[4][2], fl[4][2];
+  h16x8 bh[2][2], bl[2][2];                              // B fragments [k-step][column tile]
 
-  // The trip body is instantiated per (active column tiles NJ_, dead second k-step DEAD_) so that the k-loop itself
-  // is free of data-dependent branches: all fragment reads of a k-tile are issued up front and the compiler
-  // places partial lgkmcnt waits between the two 16-wide k-steps.
-#define C3_LOAD_ROW(jr_, ks_)                                                                               \
+  // Software pipeline across the k-tile barrier: the barrier of k-tile t guarantees that tiles <= t+1 have landed
+  // (4-stage weight ring, three tiles in flight), so the k-step-0 fragments of tile t+1 are read during the k-step-1
+  // MFMAs of tile t and the first MFMAs of a k-tile issue right after its barrier instead of behind an LDS round
+  // trip.  The trip body is instantiated per (active column tiles NJ_, dead second k-step DEAD_): no
+  // data-dependent branches inside the k-loop.
+#define C3_LOAD_ROW(jr_, ks_, sP_, kx_)                                                                     \
   {                                                                                                         \
-    const int pr__ = (wm * 2 + (jr_)) * PW + kx + tx;              /* patch pixel of this lane's output pixel */ \
+    const int pr__ = (wm * 2 + (jr_)) * PW + (kx_) + tx;           /* patch pixel of this lane's output pixel */ \
     const int ab__ = pr__ * 128 + ((g ^ ((pr__ >> 1) & 7)) << 4);                                            \
     /* chunk c = g | ks << 1 | lo << 2 (disjoint bits): the four chunks of a row are one address XOR {0,32,64,96} */ \
-    fh[jr_][ks_] = *reinterpret_cast<const h16x8*>(sP + (ab__ ^ ((ks_) << 5)));                             \
-    fl[jr_][ks_] = *reinterpret_cast<const h16x8*>(sP + (ab__ ^ (((ks_) << 5) | 64)));                      \
+    fh[jr_][ks_] = *reinterpret_cast<const h16x8*>((sP_) + (ab__ ^ ((ks_) << 5)));                          \
+    fl[jr_][ks_] = *reinterpret_cast<const h16x8*>((sP_) + (ab__ ^ (((ks_) << 5) | 64)));                   \
   }
-#define C3_LOAD_KS(KY, ks_, NJ_)                                                                            \
+#define C3_LOAD_B(ks_, stage_, NJ_)                                                                         \
   {                                                                                                         \
-    if ((KY) == 0) { C3_LOAD_ROW(0, ks_); C3_LOAD_ROW(1, ks_); }                                            \
-    else C3_LOAD_ROW((KY) + 1, ks_);                                                                        \
+    const char* sB__ = bring_base + (stage_) * BTILE_BYTES;                                                 \
     _Pragma("unroll") for (int j = 0; j < (NJ_); ++j) {                                                     \
-      bh[ks_][j] = *reinterpret_cast<const h16x8*>(sB + (bbase[j] ^ ((ks_) << 5)));                         \
-      bl[ks_][j] = *reinterpret_cast<const h16x8*>(sB + (bbase[j] ^ (((ks_) << 5) | 64)));                  \
+      bh[ks_][j] = *reinterpret_cast<const h16x8*>(sB__ + (bbase[j] ^ ((ks_) << 5)));                       \
+      bl[ks_][j] = *reinterpret_cast<const h16x8*>(sB__ + (bbase[j] ^ (((ks_) << 5) | 64)));                \
     }                                                                                                       \
   }
 #define C3_MFMAS(ks_, R0_, NJ_)                                                                             \
@@ -326,55 +330,55 @@ __global__ __launch_bounds__(512, 2) void conv3x3_kernel(Conv3Args p) {
       _Pragma("unroll") for (int j = 0; j < (NJ_); ++j)                                                     \
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[(R0_) + i][ks_], bh[ks_][j], acc[i][j], 0, 0, 0); \
   }
-#ifndef C3_NO_PIN
-#define C3_PIN(KY, NJ_, DEAD_)                                                                              \
-      __builtin_amdgcn_sched_group_barrier(0x100, ((KY) == 0 ? 4 : 2) + 2 * (NJ_), 0);                      \
-      if (!(DEAD_)) {                                                                                       \
-        _Pragma("unroll") for (int u = 0; u < ((KY) == 0 ? 4 : 2) + 2 * (NJ_); ++u) {                       \
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                \
-          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                \
-        }                                                                                                   \
-        __builtin_amdgcn_sched_group_barrier(0x008, 12 * (NJ_) - (((KY) == 0 ? 4 : 2) + 2 * (NJ_)), 0);     \
-      } else {                                                                                              \
-        __builtin_amdgcn_sched_group_barrier(0x008, 6 * (NJ_), 0);                                          \
-      }
-#else
-#define C3_PIN(KY, NJ_, DEAD_)
-#endif
-  // one k-tile: (cg, tap = KY * 3 + kx)
+#define C3_PIN_PAIRS(n_)                                                                                    \
+    _Pragma("unroll") for (int u__ = 0; u__ < (n_); ++u__) {                                                \
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                    \
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                    \
+    }
+  // one k-tile: (cg, tap = KY * 3 + kx); its k-step-0 fragments are already in registers
 #define C3_ITER(KY, NJ_, DEAD_)                                                                             \
   {                                                                                                         \
     const int tt__ = t + (KY);                                                                              \
-    /* weight tile tt (and, in order before it, patch cg) landed; younger loads may stay in flight */       \
-    const int newer__ = (tt__ + 1 < nk ? 2 : 0) + ((patch_m1 || patch_m2) ? PQ : 0);                        \
+    /* weight tile tt+1 (and, in order before it, every patch it can need) landed; younger loads stay in flight */ \
+    const int newer__ = (tt__ + 2 < nk ? 2 : 0) + ((patch_m1 || patch_m2) ? PQ : 0);                        \
     if (newer__ >= 2 + PQ) LOFTR_WAITCNT_VM(2 + PQ);                                                        \
     else if (newer__ >= PQ) LOFTR_WAITCNT_VM(PQ);                                                           \
     else if (newer__ >= 2) LOFTR_WAITCNT_VM(2);                                                             \
     else LOFTR_WAITCNT_VM(0);                                                                               \
     __builtin_amdgcn_s_barrier();                                                                           \
-    if (tt__ + 2 < nk) C3_ISSUE_B(cg2, (q2 % 3) * 3 + q2 / 3, istage);                                      \
-    if (++q2 == 9) { q2 = 0; ++cg2; }                                                                       \
+    if (tt__ + 3 < nk) C3_ISSUE_B(cg3, (q3 % 3) * 3 + q3 / 3, (bstage + 3) & 3);                            \
+    if (++q3 == 9) { q3 = 0; ++cg3; }                                                                       \
     patch_m2 = patch_m1;                                                                                    \
     patch_m1 = false;                                                                                       \
     if ((KY) == 0 && kx == 0 && cg + 1 < gpt) { C3_ISSUE_PATCH(cg + 1, (cg + 1) & 1); patch_m1 = true; }    \
     if ((NJ_) > 0) {                                                                                        \
-      const char* sB = bring_base + bstage * BTILE_BYTES;                                                   \
-      h16x8 bh[2][2], bl[2][2];                                                                             \
-      C3_LOAD_KS(KY, 0, NJ_);                                                                               \
-      if (!(DEAD_)) C3_LOAD_KS(KY, 1, NJ_);                                                                 \
+      constexpr int n1__ = ((KY) == 0 ? 4 : 2) + 2 * (NJ_);        /* k-step-1 reads of this tile */         \
+      constexpr int n0__ = ((KY) == 2 ? 4 : 2) + 2 * (NJ_);        /* k-step-0 reads of the next tile */     \
+      if (!(DEAD_)) {                                                                                       \
+        if ((KY) == 0) { C3_LOAD_ROW(0, 1, sP, kx); C3_LOAD_ROW(1, 1, sP, kx); }                            \
+        else C3_LOAD_ROW((KY) + 1, 1, sP, kx);                                                              \
+        C3_LOAD_B(1, bstage, NJ_);                                                                          \
+      }                                                                                                     \
       C3_MFMAS(0, KY, NJ_);                                                                                 \
+      /* next k-tile (after the last one: harmless reads of stale LDS) */                                   \
+      if ((KY) == 2) { C3_LOAD_ROW(0, 0, sPn, kxn); C3_LOAD_ROW(1, 0, sPn, kxn); }                          \
+      else C3_LOAD_ROW((KY) + 2, 0, sP, kx);                                                                \
+      C3_LOAD_B(0, (bstage + 1) & 3, NJ_);                                                                  \
       if (!(DEAD_)) C3_MFMAS(1, KY, NJ_);                                                                   \
-      /* pin the order: k-step 0 operand reads, then k-step 1 reads slotted between the first MFMAs (partial    */ \
-      /* lgkmcnt waits), then the remaining MFMAs                                                               */ \
-      C3_PIN(KY, NJ_, DEAD_)                                                                                \
+      /* pinned order: one fragment read behind each of the first MFMAs of a k-step */                      \
+      if (!(DEAD_)) {                                                                                       \
+        C3_PIN_PAIRS(n1__) __builtin_amdgcn_sched_group_barrier(0x008, 6 * (NJ_) - n1__, 0);                \
+      }                                                                                                     \
+      C3_PIN_PAIRS(n0__) __builtin_amdgcn_sched_group_barrier(0x008, 6 * (NJ_) - n0__, 0);                  \
     }                                                                                                       \
-    bstage = bstage == 2 ? 0 : bstage + 1;                                                                  \
-    istage = istage == 2 ? 0 : istage + 1;                                                                  \
+    bstage = (bstage + 1) & 3;                                                                              \
   }
   // three k-tiles (ky = 0, 1, 2) at (cg, kx)
 #define C3_TRIP(NJ_, DEAD_)                                                                                 \
   {                                                                                                         \
     const char* sP = patch_base + (cg & 1) * PATCH_BYTES;                                                   \
+    const int kxn = kx == 2 ? 0 : kx + 1;                          /* tap column / patch of the next trip */ \
+    const char* sPn = patch_base + ((cg + (kx == 2 ? 1 : 0)) & 1) * PATCH_BYTES;                            \
     C3_ITER(0, NJ_, DEAD_)                                                                                  \
     C3_ITER(1, NJ_, DEAD_)                                                                                  \
     C3_ITER(2, NJ_, DEAD_)                                                                                  \
@@ -385,6 +389,14 @@ __global__ __launch_bounds__(512, 2) void conv3x3_kernel(Conv3Args p) {
   const bool dead_last = p.Cin <= (gpt - 1) * 32 + 16;
 #define C3_LOOP(NJ_)                                                                                        \
   {                                                                                                         \
+    /* pipeline fill: k-step-0 fragments of k-tile 0 (patch 0 and weight tile 0 landed: tiles 1, 2 may be in flight) */ \
+    LOFTR_WAITCNT_VM(4);                                                                                    \
+    __builtin_amdgcn_s_barrier();                                                                           \
+    if ((NJ_) > 0) {                                                                                        \
+      C3_LOAD_ROW(0, 0, patch_base, 0);                                                                     \
+      C3_LOAD_ROW(1, 0, patch_base, 0);                                                                     \
+      C3_LOAD_B(0, 0, NJ_);                                                                                 \
+    }                                                                                                       \
     int t = 0;                                                                                              \
     for (; t < nk - 9; t += 3) C3_TRIP(NJ_, 0)                                                              \
     if (dead_last) { for (; t < nk; t += 3) C3_TRIP(NJ_, 1) }                                               \
@@ -396,8 +408,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_kernel(Conv3Args p) {
 #undef C3_LOOP
 #undef C3_TRIP
 #undef C3_ITER
-#undef C3_PIN
+#undef C3_PIN_PAIRS
 #undef C3_MFMAS
+#undef C3_LOAD_B
 #undef C3_LOAD_ROW
 
   // ---- next tile: its DMA prologue goes out before this tile's epilogue -----------------------------
@@ -409,6 +422,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_kernel(Conv3Args p) {
     C3_ISSUE_PATCH(0, 0);
     C3_ISSUE_B(0, 0, 0);
     C3_ISSUE_B(0, 3, 1);
+    C3_ISSUE_B(0, 6, 2);
   }
 
   // ---- epilogue: bias (folded BN shift), residual, activation, SP / fp32 stores ---------------------
