@@ -189,9 +189,23 @@ __global__ void merge_stats_kernel(const float2* __restrict__ part, float2* __re
   const long n = i / len;
   const float2* p = part + (n * P) * len + (i - n * len);
   float m = SENTINEL;
-  for (int k = 0; k < P; ++k) m = fmaxf(m, p[(long)k * len].x);
+  // eight independent loads in flight per thread (the grid is only rows / 256 workgroups); the clamped tail re-reads
+  // the last partial, which is harmless for the max and masked out of the sum
+  for (int k0 = 0; k0 < P; k0 += 8) {
+    float2 e[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) e[u] = p[(long)min(k0 + u, P - 1) * len];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) m = fmaxf(m, e[u].x);
+  }
   float s = 0.f;
-  for (int k = 0; k < P; ++k) { const float2 e = p[(long)k * len]; s += in_range(e.x) ? e.y * fexp(e.x - m) : 0.f; }
+  for (int k0 = 0; k0 < P; k0 += 8) {
+    float2 e[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) e[u] = p[(long)min(k0 + u, P - 1) * len];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += (k0 + u < P && in_range(e[u].x)) ? e[u].y * fexp(e[u].x - m) : 0.f;
+  }
   stat[i] = make_float2(m, 1.f / s);
 }
 
@@ -304,7 +318,13 @@ __global__ void merge_colmax_kernel(const float* __restrict__ part, float* __res
   float m = -1.f;
   const long n = i / len;
   const float* p = part + (n * P) * len + (i - n * len);
-  for (int k = 0; k < P; ++k) m = fmaxf(m, p[(long)k * len]);
+  for (int k0 = 0; k0 < P; k0 += 8) {
+    float e[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) e[u] = p[(long)min(k0 + u, P - 1) * len];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) m = fmaxf(m, e[u]);
+  }
   colmax[i] = m;
 }
 
@@ -364,9 +384,15 @@ __global__ __launch_bounds__(256) void select_kernel(SelectParams sp, const floa
     const int i = (int)(row - (long)n * g.L);
     const float2* p = rowmax_part + ((long)n * g.PJ) * g.L + i;
     bv = -1.f; bj = 0;
-    for (int k = 0; k < g.PJ; ++k) {                 // ascending column chunks: > keeps the first
-      const float2 e = p[(long)k * g.L];
-      if (e.x > bv) { bv = e.x; bj = __float_as_int(e.y); }
+    // eight partials in flight per thread (written as one dependent load -> compare chain the 75 strips cost 75 DRAM
+    // round trips: the grid is only rows / 256 workgroups).  The tail re-reads the last strip: `>` never replaces.
+    for (int k0 = 0; k0 < g.PJ; k0 += 8) {
+      float2 e[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) e[u] = p[(long)min(k0 + u, g.PJ - 1) * g.L];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)                      // ascending column chunks: > keeps the first
+        if (e[u].x > bv) { bv = e[u].x; bj = __float_as_int(e[u].y); }
     }
     // 1. confidence threshold (:172)  2. borders (:176-183)  3. mutual nearest (:187-189)
     flag = bv > sp.thr;
@@ -398,7 +424,18 @@ __global__ __launch_bounds__(256) void select_kernel(SelectParams sp, const floa
     cand_j[row] = bj;
     cand_conf[row] = bv;
     cand_rank[row] = flag ? off + within : -1;
-    if (flag) atomicAdd(&counts[1 + n], 1);
+  }
+  // per-pair match counts: one atomic per (wave, pair) instead of one per match (a wave's 64 consecutive rows span
+  // at most two pairs; with a low threshold the per-match atomics on N addresses were the whole kernel time)
+  {
+    const int n_first = __builtin_amdgcn_readfirstlane(n);
+    const unsigned long long same = __ballot(flag && n == n_first), other = bal & ~same;
+    if (lane == 0 && same) atomicAdd(&counts[1 + n_first], __popcll(same));
+    if (other) {
+      const int src = __ffsll((long long)other) - 1;
+      const int n_other = __shfl(n, src);
+      if (lane == 0) atomicAdd(&counts[1 + n_other], __popcll(other));
+    }
   }
   if (threadIdx.x == 0) block_count[blockIdx.x] = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
 }
