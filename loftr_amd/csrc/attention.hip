@@ -86,7 +86,7 @@ __global__ __launch_bounds__(256) void kv_finalize_kernel(const float* __restric
 // ------------------------------------------------------------------------------------------
 // Fine level (per-match windows: L = S = 25, C = 128, 8 heads of 16): the whole attention of one
 // window in one block.  Thread c <-> channel c = (head h, column v).   grid (nb), C threads.
-//   dynamic LDS: Q [L][C] + K [S][C].
+//   dynamic LDS: max(L, S) x C floats (K, then Q).
 template <int D>
 __global__ __launch_bounds__(128) void attn_small_kernel(const float* __restrict__ Qf,
                                                          const float* __restrict__ Kf,
@@ -94,17 +94,23 @@ __global__ __launch_bounds__(128) void attn_small_kernel(const float* __restrict
                                                          sp_t* __restrict__ msg, int L, int S,
                                                          int C, float v_length, float eps) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
-  float* sq = sm;               // [L][C]
-  float* sk = sm + L * C;       // [S][C]
+  float* sk = sm;               // [S][C] during the KV phase, then [L][C] = Q: one buffer, twice the resident windows
+  float* sq = sm;
   const long n = blockIdx.x;
   const int c = threadIdx.x;
   const float* qn = Qf + n * L * C;
   const float* kn = Kf + n * S * C;
   const float* vn = Vf + n * S * C;
-  for (int e = c; e < L * C / 4; e += blockDim.x)
-    reinterpret_cast<f32x4*>(sq)[e] = reinterpret_cast<const f32x4*>(qn)[e];
   for (int e = c; e < S * C / 4; e += blockDim.x)
     reinterpret_cast<f32x4*>(sk)[e] = reinterpret_cast<const f32x4*>(kn)[e];
+  // Q is fetched now (registers) and parked in the same LDS buffer once the KV phase is done with K
+  constexpr int QV = 8;                                       // f32x4 per thread: covers L * C <= 4096 floats
+  f32x4 qreg[QV];
+#pragma unroll
+  for (int u = 0; u < QV; ++u) {
+    const int e = c + u * 128;
+    qreg[u] = e < L * C / 4 ? reinterpret_cast<const f32x4*>(qn)[e] : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
   __syncthreads();
   const int hb = (c / D) * D;   // first channel of this thread's head
   float kvr[D], ks[D];
@@ -119,6 +125,13 @@ __global__ __launch_bounds__(128) void attn_small_kernel(const float* __restrict
       ks[d] += k;
     }
   }
+  __syncthreads();                                            // every thread is done with K
+#pragma unroll
+  for (int u = 0; u < QV; ++u) {
+    const int e = c + u * 128;
+    if (e < L * C / 4) reinterpret_cast<f32x4*>(sq)[e] = qreg[u];
+  }
+  __syncthreads();
   for (int l = 0; l < L; ++l) {
     float num = 0.f, den = 0.f;
 #pragma unroll
@@ -166,8 +179,8 @@ int launch_attention_small(const float* Qf, const float* Kf, const float* Vf, sp
                            int C, int H, hipStream_t st) {
   if (nb <= 0) return LOFTR_OK;
   const float eps = 1e-6f;                         // LinearAttention(eps=1e-6), linear_attention.py:15
-  if (C == 128 && H == 8 && (size_t)(L + S) * C * sizeof(float) <= 64 * 1024) {
-    const size_t lds = (size_t)(L + S) * C * sizeof(float);
+  if (C == 128 && H == 8 && L * C <= 4096 && S * C <= 16384) {
+    const size_t lds = (size_t)(L > S ? L : S) * C * sizeof(float);
     TimedLaunch tl(LOFTR_T_ATTN_SMALL, st);
     hipLaunchKernelGGL((attn_small_kernel<16>), dim3(nb), dim3(128), lds, st, Qf, Kf, Vf, msg, L, S, C,
                        (float)S, eps);
