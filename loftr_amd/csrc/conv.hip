@@ -852,11 +852,12 @@ extern "C" size_t loftr_conv_workspace_bytes(int Cin, int Cout, int KH, int KW) 
 
 // Grid of a persistent kernel that holds one workgroup per CU: min(virtual workgroups, CUs), CUs rounded down to a
 // multiple of the XCD count so that the grid stride keeps every workgroup on its XCD (LOFTR_CONV_PERSIST=0: one
-// workgroup per tile, the non-persistent schedule, for A/B runs).
+// workgroup per tile, the non-persistent schedule, for A/B runs; LOFTR_CONV_PERSIST=n >= 8: cap the grid at n).
 static unsigned persistent_grid(unsigned nvirt) {
   static const int cus = []() {
     const char* e = getenv("LOFTR_CONV_PERSIST");
     if (e && atoi(e) == 0) return 0;
+    if (e && atoi(e) >= NUM_XCD) return atoi(e) / NUM_XCD * NUM_XCD;      // explicit workgroup cap (tests: many tiles per workgroup)
     int dev = 0, n = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
     return n / NUM_XCD * NUM_XCD;

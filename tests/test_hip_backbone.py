@@ -253,3 +253,48 @@ def test_sp_format_round_trip():
         assert (recon[:, C:] == 0).all()
         hi = halves[:, :, 0, :].reshape(-1, Cp)[:, :C]
         assert np.array_equal(hi, x.numpy().reshape(-1, C).astype(np.float16).astype(np.float32))
+
+
+def test_backbone_hip_fullsize_vs_torch_fp32():
+    """640x480 inputs: 600 / 150 / 40 tiles per 3x3 layer, i.e. several tiles per persistent workgroup, the
+    cross-tile DMA prologue and every ragged / full tile mix of the real workload, against the MIOpen fp32 path."""
+    from loftr_amd.backbone import build_backbone
+    cfg = {"backbone_type": "ResNetFPN", "resolution": (8, 2), "resnetfpn": {"initial_dim": 128, "block_dims": [128, 196, 256]}}
+    torch.manual_seed(0)
+    m = build_backbone(cfg).eval()
+    _randomize_bn(m, torch.Generator().manual_seed(1))
+    m = m.to("cuda:0").to(memory_format=torch.channels_last)
+    x = torch.rand(2, 1, 480, 640, generator=torch.Generator().manual_seed(2)).to("cuda:0")
+    with torch.no_grad():
+        hip = m.forward_hip(x)
+        tor = m(x)
+    for name, h, t in zip(("coarse", "fine"), hip, tor):
+        assert h.shape == t.shape
+        scale = t.abs().max().item()
+        err = (h - t).abs().max().item() / scale
+        assert err <= 2e-5, (name, err)          # two fp32-class evaluations of a 20-layer network
+
+
+def test_conv3x3_many_tiles_per_workgroup():
+    """The persistent 3x3 kernel with its grid capped at 8 workgroups (LOFTR_CONV_PERSIST=8, read once per process ->
+    subprocess): 48 tiles, six per workgroup, including the last partly filled round."""
+    import os, subprocess, sys, textwrap
+    code = textwrap.dedent("""
+        import torch, torch.nn as nn, torch.nn.functional as F
+        from loftr_amd import ops
+        g = torch.Generator().manual_seed(3)
+        for cin, cout in ((64, 128), (96, 200), (128, 256)):
+            conv = nn.Conv2d(cin, cout, 3, padding=1, bias=False)
+            conv.weight.data = torch.randn(conv.weight.shape, generator=g) * (2.0 / (cin * 9)) ** 0.5
+            x = torch.randn(2, cin, 60, 100, generator=g)
+            ref = F.conv2d(x.double(), conv.weight.double(), padding=1)
+            x_sp = ops.sp_from_nhwc(x.permute(0, 2, 3, 1).contiguous().cuda())
+            y = ops.conv_bn_act(x_sp, cin, conv.cuda(), None, want_sp=False, want_f32=True)[1].permute(0, 3, 1, 2).cpu().double()
+            err = (y - ref).abs().max().item() / ref.abs().max().item()
+            assert err <= 2e-5, (cin, cout, err)
+        print("ok")
+    """)
+    env = dict(os.environ, LOFTR_CONV_PERSIST="8")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]
