@@ -103,3 +103,25 @@ def test_position_table_matches_oracle():
     for fix in (True, False):
         pe = PositionEncodingSine(256, (64, 64), temp_bug_fix=fix).pe[0].numpy()
         assert np.abs(pe[:, :30, :40] - O.position_encoding_table(256, 30, 40, fix)).max() <= 1e-5
+
+
+def test_stacked_halves_detects_adjacent_batch_views():
+    """ops.stacked_halves: the no-copy [a; b] used to run both images through one pos-encode launch and the
+    transformers in place (host logic only, no GPU)."""
+    import torch
+    from loftr_amd import ops
+    x = torch.arange(4 * 3 * 5, dtype=torch.float32).reshape(4, 3, 5)
+    a, b = x.split(2)
+    s = ops.stacked_halves(a, b)
+    assert s is not None and s.data_ptr() == x.data_ptr() and torch.equal(s, x)
+    assert ops.stacked_halves(b, a) is None                                  # wrong order
+    assert ops.stacked_halves(a, b.clone()) is None                          # different storage
+    assert ops.stacked_halves(x[:1], x[2:3]) is None                         # not adjacent
+    assert ops.stacked_halves(a, x[2:4, :, :4]) is None                      # different shape
+    xc = torch.randn(4, 8, 6, 7).contiguous(memory_format=torch.channels_last)   # channels-last backbone output
+    a, b = xc.split(2)
+    s = ops.stacked_halves(a, b)
+    assert s is not None and s.stride() == xc.stride() and torch.equal(s, xc)
+    # unequal halves still stack (the transformer path additionally requires equal batch sizes)
+    s = ops.stacked_halves(x[:1], x[1:4])
+    assert s is not None and torch.equal(s, x)
