@@ -34,7 +34,7 @@ typedef enum {
   LOFTR_ERR_NO_DEVICE = -5      /* no gfx950 device visible                                    */
 } loftr_status;
 
-#define LOFTR_HIP_ABI_VERSION 7
+#define LOFTR_HIP_ABI_VERSION 8
 
 int loftr_hip_abi_version(void);
 const char* loftr_hip_status_string(int status);
@@ -218,6 +218,15 @@ int loftr_conv1x1_upsample_add(const uint32_t* x_sp, int B, int H, int W, int Ci
                                void* ws, size_t ws_bytes, void* stream);
 int loftr_sp_from_f32(const float* src, uint32_t* dst_sp, long rows, int C, void* stream);
 int loftr_sp_to_f32(const uint32_t* src_sp, float* dst, long rows, int C, void* stream);
+
+/* ---- evaluation caller (the reference's test_step, src/lightning/lightning_loftr.py:205-229) ----------
+ * Replaces compute_symmetrical_epipolar_errors (src/utils/metrics.py:50-68 with :31-47): squared symmetric
+ * epipolar distance of every match under the ground-truth relative pose of its pair, fp32.
+ *   mkpts0_f / mkpts1_f [M,2] f32 pixels, m_bids [M] i64 pair index, T_0to1 [N,4,4], K0 / K1 [N,3,3] f32
+ *   (row-major), epi_errs [M] f32 in match order (= the reference's per-pair concatenation, because the matcher
+ *   emits matches grouped by ascending pair).  A match whose pair index is outside [0,N) gets NaN. */
+int loftr_epipolar_errors(const float* mkpts0_f, const float* mkpts1_f, const long* m_bids, const float* T_0to1,
+                          const float* K0, const float* K1, long M, int N, float* epi_errs, void* stream);
 
 /* ---- per-kernel timing (profiling aid; the only process-global state of the library) ---------
  * When bit `id` of the mask is set, every launch of that kernel is bracketed by hipEvents

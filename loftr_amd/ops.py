@@ -356,3 +356,18 @@ def upsample2x_add(low_sp, lateral_sp, Cc):
     check(_lib.load().loftr_upsample2x_add(_ptr(low_sp), _ptr(lateral_sp), _ptr(out), B, Hl, Wl, Cc, _stream()),
           "loftr_upsample2x_add")
     return out
+
+
+def epipolar_errors(mkpts0_f, mkpts1_f, m_bids, T_0to1, K0, K1):
+    """Squared symmetric epipolar distance of every match (metrics.py:31-68) -> float32 [M], match order."""
+    for name, t, dt in (("mkpts0_f", mkpts0_f, torch.float32), ("mkpts1_f", mkpts1_f, torch.float32), ("m_bids", m_bids, torch.int64),
+                        ("T_0to1", T_0to1, torch.float32), ("K0", K0, torch.float32), ("K1", K1, torch.float32)):
+        if not t.is_cuda or t.dtype != dt:
+            raise _lib.LoftrHipError(f"{name}: expected a {dt} GPU tensor (the evaluation kernels have no CPU fallback)")
+    M, N = mkpts0_f.shape[0], T_0to1.shape[0]
+    assert mkpts0_f.shape == (M, 2) and mkpts1_f.shape == (M, 2) and m_bids.shape == (M,)
+    assert T_0to1.shape == (N, 4, 4) and K0.shape == (N, 3, 3) and K1.shape == (N, 3, 3)
+    out = torch.empty(M, dtype=torch.float32, device=mkpts0_f.device)
+    args = [t.contiguous() for t in (mkpts0_f, mkpts1_f, m_bids, T_0to1, K0, K1)]
+    check(_lib.load().loftr_epipolar_errors(*[_ptr(t) for t in args], M, N, _ptr(out), _stream()), "loftr_epipolar_errors")
+    return out

@@ -116,3 +116,50 @@ def import_reference():
         sys.path.insert(0, REFERENCE_ROOT)
     from src.loftr import LoFTR, default_cfg  # noqa
     return LoFTR, default_cfg
+
+
+# ---- evaluation caller (src/utils/metrics.py): SURVEY.md §8(f) rank 2 ---------------------------
+def _cross_product_matrix(x):
+    """kornia 0.4.1 geometry.epipolar.numeric.cross_product_matrix: [*,3] -> [*,3,3] skew matrices."""
+    x0, x1, x2 = x[..., 0], x[..., 1], x[..., 2]
+    z = torch.zeros_like(x0)
+    return torch.stack([z, -x2, x1, x2, z, -x0, -x1, x0, z], dim=-1).view(*x.shape[:-1], 3, 3)
+
+
+def _convert_points_to_homogeneous(p):
+    """kornia 0.4.1 geometry.conversions.convert_points_to_homogeneous: pad the last dim with 1."""
+    return torch.nn.functional.pad(p, [0, 1], "constant", 1.0)
+
+
+def import_reference_metrics():
+    """The real `src.utils.metrics` module.  cv2 / loguru / kornia are absent here: loguru and cv2 are only
+    touched by the RANSAC pose path and the logger (stubbed with modules that raise on use / swallow logs),
+    the two kornia helpers used by the epipolar error are restated above (published semantics)."""
+    if not reference_available():
+        raise RuntimeError(f"reference not found at {REFERENCE_ROOT}")
+
+    def mod(name, **attrs):
+        m = sys.modules.get(name)
+        if m is None:
+            m = types.ModuleType(name)
+            sys.modules[name] = m
+        for k, v in attrs.items():
+            setattr(m, k, v)
+        return m
+
+    class _Logger:
+        def __getattr__(self, name):
+            return lambda *a, **k: None
+
+    if "cv2" not in sys.modules:
+        mod("cv2")                                   # any attribute access (findEssentialMat ...) raises AttributeError
+    mod("loguru", logger=_Logger())
+    mod("kornia")
+    mod("kornia.geometry")
+    numeric = mod("kornia.geometry.epipolar.numeric", cross_product_matrix=_cross_product_matrix)
+    mod("kornia.geometry.epipolar", numeric=numeric)
+    mod("kornia.geometry.conversions", convert_points_to_homogeneous=_convert_points_to_homogeneous)
+    if REFERENCE_ROOT not in sys.path:
+        sys.path.insert(0, REFERENCE_ROOT)
+    import importlib
+    return importlib.import_module("src.utils.metrics")

@@ -1,0 +1,90 @@
+"""Evaluation caller on the GPU: loftr_epipolar_errors through the C-ABI against the
+reference-generated goldens and the numpy oracle; the Lightning-free test_step / test_epoch_end loop."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import metrics_oracle as mo
+from test_metrics_oracle import GOLD, epi_close
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _dev(npz, case):
+    keys = ("mkpts0_f", "mkpts1_f", "m_bids", "T_0to1", "K0", "K1")
+    return {k: torch.from_numpy(npz[f"{case}_{k}"]).to(DEV) for k in keys}
+
+
+@pytest.mark.parametrize("case", ["a", "b", "c"])
+def test_epipolar_errors_vs_reference_golden(case):
+    from loftr_amd import evaluation
+    npz = np.load(os.path.join(GOLD, "metrics_epi.npz"))
+    data = _dev(npz, case)
+    evaluation.compute_symmetrical_epipolar_errors(data)
+    got = data["epi_errs"]
+    assert got.is_cuda and got.dtype == torch.float32
+    assert epi_close(got.cpu().numpy(), npz[f"{case}_epi_errs"])
+
+
+def test_epipolar_errors_large_and_edge_cases():
+    from loftr_amd import ops
+    from _scenes import make_scene
+    sc = make_scene(900, [20000, 0, 35000, 1, 7], noise_px=1.0)          # ragged, an empty pair, 55k matches
+    ref = mo.compute_symmetrical_epipolar_errors(sc["mkpts0_f"], sc["mkpts1_f"], sc["m_bids"], sc["T_0to1"], sc["K0"], sc["K1"])
+    t = {k: torch.from_numpy(v).to(DEV) for k, v in sc.items()}
+    got = ops.epipolar_errors(t["mkpts0_f"], t["mkpts1_f"], t["m_bids"], t["T_0to1"], t["K0"], t["K1"])
+    assert epi_close(got.cpu().numpy(), ref)
+    # no matches at all
+    e = ops.epipolar_errors(t["mkpts0_f"][:0], t["mkpts1_f"][:0], t["m_bids"][:0], t["T_0to1"], t["K0"], t["K1"])
+    assert e.shape == (0,)
+    # a pair index outside the batch -> NaN (the reference's boolean masks would silently drop the match)
+    bad = t["m_bids"].clone(); bad[3] = 99
+    e = ops.epipolar_errors(t["mkpts0_f"], t["mkpts1_f"], bad, t["T_0to1"], t["K0"], t["K1"])
+    assert torch.isnan(e[3]) and not torch.isnan(e[4])
+    # CPU tensors are refused: no fallback
+    from loftr_amd._lib import LoftrHipError
+    with pytest.raises(LoftrHipError):
+        ops.epipolar_errors(t["mkpts0_f"].cpu(), t["mkpts1_f"], t["m_bids"], t["T_0to1"], t["K0"], t["K1"])
+
+
+def test_test_step_loop_and_dump(tmp_path):
+    """matcher -> metrics -> dumps -> aggregate, with the LoFTR drop-in on synthetic pairs and synthetic geometry
+    (pose estimation needs OpenCV: absent here -> on_missing='inf' records the reference's failure values)."""
+    from loftr_amd import LoFTR, default_cfg, evaluation
+    from _scenes import make_scene
+    import copy
+    cfg = copy.deepcopy(default_cfg)
+    cfg["match_coarse"]["thr"] = 0.0
+    torch.manual_seed(0)
+    matcher = LoFTR(config=cfg).eval().to(DEV)
+    outputs = []
+    for step in range(2):
+        g = torch.Generator().manual_seed(50 + step)
+        N = 2
+        sc = make_scene(300 + step, [1] * N)
+        batch = {"image0": torch.rand(N, 1, 240, 320, generator=g).to(DEV), "image1": torch.rand(N, 1, 240, 320, generator=g).to(DEV),
+                 "T_0to1": torch.from_numpy(sc["T_0to1"]).to(DEV), "K0": torch.from_numpy(sc["K0"]).to(DEV),
+                 "K1": torch.from_numpy(sc["K1"]).to(DEV),
+                 "pair_names": [[f"s{step}/a{b}.jpg" for b in range(N)], [f"s{step}/b{b}.jpg" for b in range(N)]]}
+        out = evaluation.test_step(matcher, batch, dump=True, on_missing="inf")
+        outputs.append(out)
+        M = batch["mkpts0_f"].shape[0]
+        assert M > 0 and batch["epi_errs"].shape == (M,)
+        ref = mo.compute_symmetrical_epipolar_errors(batch["mkpts0_f"].cpu().numpy(), batch["mkpts1_f"].cpu().numpy(),
+                                                     batch["m_bids"].cpu().numpy(), sc["T_0to1"], sc["K0"], sc["K1"])
+        assert epi_close(batch["epi_errs"].cpu().numpy(), ref)
+        m = out["metrics"]
+        assert m["identifiers"] == [f"s{step}/a{b}.jpg#s{step}/b{b}.jpg" for b in range(N)]
+        assert sum(len(e) for e in m["epi_errs"]) == M and len(m["R_errs"]) == N and all(np.isinf(m["R_errs"]))
+        d = out["dumps"]
+        assert len(d) == N and set(d[0]) == {"pair_names", "identifier", "mkpts0_f", "mkpts1_f", "mconf", "epi_errs", "R_errs", "t_errs", "inliers"}
+        assert d[1]["mkpts0_f"].shape == (int((batch["m_bids"] == 1).sum()), 2)
+    res = evaluation.test_epoch_end(outputs, dump_dir=str(tmp_path))
+    assert set(res) == {"auc@5", "auc@10", "auc@20", "prec@5e-04"} and res["auc@5"] == 0.0        # every pose failed
+    dumped = np.load(os.path.join(str(tmp_path), "LoFTR_pred_eval.npy"), allow_pickle=True)
+    assert len(dumped) == 4 and dumped[0]["identifier"] == "s0/a0.jpg#s0/b0.jpg"
+    with pytest.raises(ImportError):
+        evaluation.compute_pose_errors(batch)                                                      # no cv2, no estimator
