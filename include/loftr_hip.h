@@ -34,7 +34,7 @@ typedef enum {
   LOFTR_ERR_NO_DEVICE = -5      /* no gfx950 device visible                                    */
 } loftr_status;
 
-#define LOFTR_HIP_ABI_VERSION 8
+#define LOFTR_HIP_ABI_VERSION 9
 
 int loftr_hip_abi_version(void);
 const char* loftr_hip_status_string(int status);
@@ -227,6 +227,16 @@ int loftr_sp_to_f32(const uint32_t* src_sp, float* dst, long rows, int C, void* 
  *   emits matches grouped by ascending pair).  A match whose pair index is outside [0,N) gets NaN. */
 int loftr_epipolar_errors(const float* mkpts0_f, const float* mkpts1_f, const long* m_bids, const float* T_0to1,
                           const float* K0, const float* K1, long M, int N, float* epi_errs, void* stream);
+
+/* ---- input wire format (the step before the path; src/utils/dataset.py:78-89,111-118,149, megadepth.py:116-121) ----
+ * From resized uint8 grayscale images to the tensors LoFTR.forward consumes: zero padding to [PH,PW] at the
+ * bottom / right (pad_bottom_right), `float / 255`, the padding mask and its coarse version
+ * (F.interpolate(mask, scale_factor=1/coarse_div, mode='nearest') = mask[d*y, d*x]).
+ *   src [N, *, *] uint8 with byte pitches per image / per row; hw [N,2] int32 device: valid (h, w) <= (PH, PW);
+ *   image [N,1,PH,PW] f32; mask [N,PH,PW] u8 or NULL; mask_c [N,PH/coarse_div,PW/coarse_div] u8 or NULL.
+ * Decoding and cv2.resize stay with the caller (OpenCV; not reproducible without the library). */
+int loftr_pack_gray_u8(const uint8_t* src, long src_image_pitch, long src_row_pitch, const int* hw, int N, int PH,
+                       int PW, float* image, uint8_t* mask, uint8_t* mask_c, int coarse_div, void* stream);
 
 /* ---- per-kernel timing (profiling aid; the only process-global state of the library) ---------
  * When bit `id` of the mask is set, every launch of that kernel is bracketed by hipEvents

@@ -163,3 +163,28 @@ def import_reference_metrics():
         sys.path.insert(0, REFERENCE_ROOT)
     import importlib
     return importlib.import_module("src.utils.metrics")
+
+
+# ---- input wire format (src/utils/dataset.py): SURVEY.md §8(f) rank 3 ---------------------------
+def import_reference_dataset_utils():
+    """The real `src.utils.dataset` module.  cv2 / h5py / loguru are absent: they are only touched by the file
+    readers (imread / imdecode / resize, h5py.File), which are NOT part of what is pinned here -- the stubs raise
+    on use.  What is pinned: get_resized_wh, get_divisible_wh, pad_bottom_right (pure numpy)."""
+    if not reference_available():
+        raise RuntimeError(f"reference not found at {REFERENCE_ROOT}")
+
+    class _Logger:
+        def __getattr__(self, name):
+            return lambda *a, **k: None
+
+    for name in ("cv2", "h5py"):
+        if name not in sys.modules:
+            sys.modules[name] = types.ModuleType(name)
+    if "loguru" not in sys.modules:
+        m = types.ModuleType("loguru")
+        m.logger = _Logger()
+        sys.modules["loguru"] = m
+    if REFERENCE_ROOT not in sys.path:
+        sys.path.insert(0, REFERENCE_ROOT)
+    import importlib
+    return importlib.import_module("src.utils.dataset")
