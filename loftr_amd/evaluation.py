@@ -191,17 +191,31 @@ def test_step(matcher, batch, config=None, dump=True, estimator=None, on_missing
     return ret_dict
 
 
+def gather(items):
+    """src/utils/comm.py:gather as test_epoch_end uses it: the per-rank python lists concatenated in rank order on
+    every rank (one process per GPU; metric lists are small host objects -> all_gather_object over the default
+    group, RCCL-free: gloo or the object path of nccl).  Identity without an initialised process group."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return list(items)
+    parts = [None] * dist.get_world_size()
+    dist.all_gather_object(parts, list(items))
+    return [x for part in parts for x in part]
+
+
 def test_epoch_end(outputs, config=None, dump_dir=None):
-    """PL_LoFTR.test_epoch_end (lightning_loftr.py:231-249) for one process: flatten the per-step metrics,
-    aggregate, optionally save ``LoFTR_pred_eval.npy``.  (Multi-process runs gather `outputs` first --
-    loftr_amd.distributed.gather_matches carries the per-rank match rows; the metric lists are python objects
-    and go through torch.distributed.all_gather_object like the reference's `gather`.)"""
+    """PL_LoFTR.test_epoch_end (lightning_loftr.py:231-249): flatten the per-step metrics, gather them over the
+    ranks (duplicates padded in by a DistributedSampler are dropped by identifier in aggregate_metrics), aggregate;
+    rank 0 optionally saves ``LoFTR_pred_eval.npy``.  Every rank returns the aggregated metrics."""
+    import torch.distributed as dist
     keys = outputs[0]["metrics"].keys()
-    metrics = {k: [x for o in outputs for x in o["metrics"][k]] for k in keys}
+    metrics = {k: gather([x for o in outputs for x in o["metrics"][k]]) for k in keys}
     epi_thr = _cfg_get(config, ("TRAINER", "EPI_ERR_THR"), 5e-4)
     result = aggregate_metrics(metrics, epi_thr)
     if dump_dir is not None:
-        os.makedirs(dump_dir, exist_ok=True)
-        dumps = [d for o in outputs for d in o.get("dumps", [])]
-        np.save(os.path.join(dump_dir, "LoFTR_pred_eval"), np.array(dumps, dtype=object), allow_pickle=True)
+        dumps = gather([d for o in outputs for d in o.get("dumps", [])])
+        rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+        if rank == 0:
+            os.makedirs(dump_dir, exist_ok=True)
+            np.save(os.path.join(dump_dir, "LoFTR_pred_eval"), np.array(dumps, dtype=object), allow_pickle=True)
     return result

@@ -77,3 +77,57 @@ def test_gloo_world2(n_global):
     for p in procs:
         p.join(timeout=60)
     assert all(r[1] == "ok" for r in res), res
+
+
+def _fake_outputs(rank, world, n_pairs=12, seed=3):
+    """Per-rank `test_step` outputs the way a DistributedSampler would deal them: pair i goes to rank i % world and the
+    sampler pads the last rank with a repeat of pair 0 (same identifier: must be counted once)."""
+    rng = np.random.default_rng(seed)
+    R = rng.gamma(1.5, 4.0, n_pairs); t = rng.gamma(1.5, 6.0, n_pairs)
+    epi = [rng.gamma(0.6, 4e-4, int(rng.integers(1, 50))).astype(np.float32) for _ in range(n_pairs)]
+    mine = [i for i in range(n_pairs) if i % world == rank]
+    if world > 1 and rank == world - 1:
+        mine.append(0)
+    outs = []
+    for i in mine:
+        outs.append({"metrics": {"identifiers": [f"pair{i}"], "epi_errs": [epi[i]], "R_errs": [R[i]], "t_errs": [t[i]],
+                                 "inliers": [np.zeros(0, bool)]},
+                     "dumps": [{"identifier": f"pair{i}", "epi_errs": epi[i]}]})
+    return outs
+
+
+def _eval_worker(rank, world, port, tmp, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from loftr_amd import evaluation
+        res = evaluation.test_epoch_end(_fake_outputs(rank, world), dump_dir=tmp)
+        q.put((rank, res))
+    except Exception as e:      # pragma: no cover
+        q.put((rank, repr(e)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gloo_world2_evaluation_gather(tmp_path):
+    """test_epoch_end over two ranks == the single-process aggregation of all pairs; one dump file, duplicates kept in
+    the dump (as the reference) but counted once in the metrics."""
+    from loftr_amd import evaluation
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_eval_worker, args=(r, world, port, str(tmp_path), q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+    single = evaluation.test_epoch_end(_fake_outputs(0, 1))
+    assert isinstance(res[0], dict), res
+    assert res[0] == res[1]
+    for k, v in single.items():
+        assert abs(res[0][k] - v) < 1e-12, (k, res[0][k], v)
+    dumped = np.load(os.path.join(str(tmp_path), "LoFTR_pred_eval.npy"), allow_pickle=True)
+    assert len(dumped) == 13 and sum(d["identifier"] == "pair0" for d in dumped) == 2
