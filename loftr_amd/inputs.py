@@ -33,6 +33,32 @@ def get_divisible_wh(w, h, df=None):
     return w, h
 
 
+class _PinnedRing:
+    """A few persistent page-locked staging buffers reused round-robin.  A slot is handed out again only after the
+    event recorded behind its last upload has completed, so the asynchronous H2D copy never races the next fill;
+    allocating / pinning host memory per batch costs milliseconds, this costs a memcpy."""
+
+    def __init__(self, slots=4):
+        self.slots = [dict(buf=None, ev=None) for _ in range(slots)]
+        self.next = 0
+
+    def acquire(self, nbytes):
+        slot = self.slots[self.next]
+        self.next = (self.next + 1) % len(self.slots)
+        if slot["ev"] is not None:
+            slot["ev"].synchronize()
+        if slot["buf"] is None or slot["buf"].numel() < nbytes:
+            slot["buf"] = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, pin_memory=True)
+        return slot
+
+    def release(self, slot):
+        slot["ev"] = torch.cuda.Event()
+        slot["ev"].record(torch.cuda.current_stream())
+
+
+_STAGING = _PinnedRing()
+
+
 def pack_gray(images, pad_hw=None, coarse_div=8, device="cuda", want_mask=True):
     """images: list of uint8 arrays / tensors [h_i, w_i] (already resized) -> (image f32 [N,1,PH,PW] on the device,
     mask bool [N,PH,PW] or None, mask_c bool [N,PH//d,PW//d] or None).  pad_hw None: all images share one size and
@@ -54,18 +80,24 @@ def pack_gray(images, pad_hw=None, coarse_div=8, device="cuda", want_mask=True):
         if PH < hmax or PW < wmax:
             raise AssertionError(f"{(PH, PW)} < {(hmax, wmax)}")           # pad_bottom_right's assert (dataset.py:79)
     N = len(arrs)
-    # staging buffer: pinned host memory, one row pitch for the batch; a single H2D copy of 1 B / pixel
-    pitch = (wmax + 3) // 4 * 4
-    stage = torch.zeros(N, hmax, pitch, dtype=torch.uint8).pin_memory() if torch.cuda.is_available() else None
-    if stage is None:
+    if not torch.cuda.is_available():
         raise _lib.LoftrHipError("pack_gray needs a GPU (no CPU fallback)")
-    hw = torch.empty(N, 2, dtype=torch.int32)
-    for n, a in enumerate(arrs):
-        stage[n, :a.shape[0], :a.shape[1]] = torch.from_numpy(a)
-        hw[n, 0], hw[n, 1] = a.shape
     dev = torch.device(device)
-    src = stage.to(dev, non_blocking=True)
-    hw_d = hw.to(dev, non_blocking=True)
+    # staging: a slot of the persistent pinned ring (one row pitch for the batch, the (h, w) table behind the pixels),
+    # filled with plain memcpys and uploaded by ONE asynchronous H2D copy of ~1 B / pixel
+    pitch = (wmax + 3) // 4 * 4
+    npix = N * hmax * pitch
+    slot = _STAGING.acquire(npix + 8 * N)
+    host = slot["buf"].numpy()
+    pix = host[:npix].reshape(N, hmax, pitch)
+    hw_host = host[npix:npix + 8 * N].view(np.int32).reshape(N, 2)
+    for n, a in enumerate(arrs):
+        pix[n, :a.shape[0], :a.shape[1]] = a
+        hw_host[n] = a.shape
+    both = slot["buf"][:npix + 8 * N].to(dev, non_blocking=True)
+    _STAGING.release(slot)
+    src = both[:npix]
+    hw_d = both[npix:].view(torch.int32)
     image = torch.empty(N, 1, PH, PW, dtype=torch.float32, device=dev)
     mask = torch.empty(N, PH, PW, dtype=torch.uint8, device=dev) if masks else None
     mask_c = torch.empty(N, PH // coarse_div, PW // coarse_div, dtype=torch.uint8, device=dev) if masks and coarse_div else None
