@@ -34,7 +34,7 @@ typedef enum {
   LOFTR_ERR_NO_DEVICE = -5      /* no gfx950 device visible                                    */
 } loftr_status;
 
-#define LOFTR_HIP_ABI_VERSION 9
+#define LOFTR_HIP_ABI_VERSION 10
 
 int loftr_hip_abi_version(void);
 const char* loftr_hip_status_string(int status);
@@ -197,6 +197,12 @@ int loftr_conv_bn_act(const uint32_t* x_sp, int B, int H, int W, int Cin, const 
 int loftr_conv_prepare(const float* weight, const long* weight_strides, int Cin, int Cout, int KH, int KW,
                        const float* bn_weight, const float* bn_bias, const float* bn_mean, const float* bn_var,
                        float bn_eps, void* prepared, size_t prepared_bytes, void* stream);
+/* OR-ed into `act` of loftr_conv_bn_act / loftr_conv_bn_act_prepared: this launch shares the GPU with work on another
+ * stream (e.g. the FPN fine branch next to the coarse matching stage).  The 3x3 kernel then launches one workgroup per
+ * tile instead of one persistent workgroup per CU: a persistent workgroup holds its CU (151 KB of LDS) for the whole
+ * kernel, so the other stream could only start between kernels; with per-tile workgroups it interleaves every ~50 us
+ * (measured: +1 % end to end with the two-stream overlap, -1.2 % on the kernel when it runs alone). */
+#define LOFTR_CONV_SHARED_GPU 0x100
 int loftr_conv_bn_act_prepared(const uint32_t* x_sp, int B, int H, int W, int Cin, const void* prepared,
                                size_t prepared_bytes, int Cout, int KH, int KW, int stride, int pad, int act,
                                const uint32_t* residual_sp, const uint32_t* low_sp, uint32_t* y_sp, float* y_f32,

@@ -110,11 +110,13 @@ class _ResNetFPN(nn.Module):
         return ops.upsample2x_add(low_sp, lat, d)
 
     @staticmethod
-    def _head_hip(head, a, want_f32):
-        """_fuse_head: conv3x3 + BN + LeakyReLU + conv3x3 (resnet_fpn.py:66-77)."""
+    def _head_hip(head, a, want_f32, shared_gpu=False):
+        """_fuse_head: conv3x3 + BN + LeakyReLU + conv3x3 (resnet_fpn.py:66-77).  shared_gpu: the branch runs on a
+        side stream next to the coarse matching stage (ops.conv_bn_act)."""
         x, cin = a
-        y, _ = ops.conv_bn_act(x, cin, head[0], head[1], act=2)
-        return ops.conv_bn_act(y, head[0].out_channels, head[3], None, act=0, want_sp=not want_f32, want_f32=want_f32)
+        y, _ = ops.conv_bn_act(x, cin, head[0], head[1], act=2, shared_gpu=shared_gpu)
+        return ops.conv_bn_act(y, head[0].out_channels, head[3], None, act=0, want_sp=not want_f32, want_f32=want_f32,
+                               shared_gpu=shared_gpu)
 
     @staticmethod
     def _nchw_view(y_nhwc):
@@ -170,10 +172,10 @@ class ResNetFPN_8_2(_ResNetFPN):
 
         def fine():
             t2 = self._topdown_hip(a2, self.layer2_outconv, x3_sp, d3)
-            x2_out, _ = self._head_hip(self.layer2_outconv2, (t2, d3), want_f32=False)
+            x2_out, _ = self._head_hip(self.layer2_outconv2, (t2, d3), want_f32=False, shared_gpu=defer_fine)
             d2 = self.layer2_outconv2[3].out_channels
             t1 = self._topdown_hip(a1, self.layer1_outconv, x2_out, d2)
-            _, x1_f32 = self._head_hip(self.layer1_outconv2, (t1, d2), want_f32=True)
+            _, x1_f32 = self._head_hip(self.layer1_outconv2, (t1, d2), want_f32=True, shared_gpu=defer_fine)
             return self._nchw_view(x1_f32)
 
         if defer_fine:
@@ -229,10 +231,10 @@ class ResNetFPN_16_4(_ResNetFPN):
 
         def fine():
             t3 = self._topdown_hip(a3, self.layer3_outconv, x4_sp, d4)
-            x3_out, _ = self._head_hip(self.layer3_outconv2, (t3, d4), want_f32=False)
+            x3_out, _ = self._head_hip(self.layer3_outconv2, (t3, d4), want_f32=False, shared_gpu=defer_fine)
             d3 = self.layer3_outconv2[3].out_channels
             t2 = self._topdown_hip(a2, self.layer2_outconv, x3_out, d3)
-            _, x2_f32 = self._head_hip(self.layer2_outconv2, (t2, d3), want_f32=True)
+            _, x2_f32 = self._head_hip(self.layer2_outconv2, (t2, d3), want_f32=True, shared_gpu=defer_fine)
             return self._nchw_view(x2_f32)
 
         if defer_fine:

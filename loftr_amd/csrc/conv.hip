@@ -897,6 +897,8 @@ static int conv_run(const uint32_t* x_sp, int B, int H, int W, int Cin, const vo
                     int KH, int KW, int stride, int pad, int act, const uint32_t* residual_sp, const uint32_t* up_sp,
                     uint32_t* y_sp, float* y_f32, void* stream) {
   LOFTR_CHECK_ARG(x_sp && prepared && (y_sp || y_f32) && B >= 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0);
+  const bool shared_gpu = (act & LOFTR_CONV_SHARED_GPU) != 0;      // see loftr_hip.h: no persistent workgroups
+  act &= ~LOFTR_CONV_SHARED_GPU;
   LOFTR_CHECK_ARG(KH > 0 && KW > 0 && stride > 0 && pad >= 0 && act >= 0 && act <= 2);
   if (B == 0) return LOFTR_OK;
   hipStream_t st = (hipStream_t)stream;
@@ -936,7 +938,8 @@ static int conv_run(const uint32_t* x_sp, int B, int H, int W, int Cin, const vo
     if (wide)
       hipLaunchKernelGGL(conv3x3_wide_kernel, dim3(xcd_grid(B * c.tiles_x * c.tiles_y, 1)), dim3(512), 0, st, c);
     else
-      hipLaunchKernelGGL(conv3x3_kernel, dim3(persistent_grid(xcd_grid(B * c.tiles_x * c.tiles_y, ceil_div(c.Coutp, 128)))),
+      hipLaunchKernelGGL(conv3x3_kernel, dim3(shared_gpu ? xcd_grid(B * c.tiles_x * c.tiles_y, ceil_div(c.Coutp, 128))
+                                                         : persistent_grid(xcd_grid(B * c.tiles_x * c.tiles_y, ceil_div(c.Coutp, 128)))),
                          dim3(512), 0, st, c);
     LOFTR_CHECK_LAUNCH();
     return LOFTR_OK;

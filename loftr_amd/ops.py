@@ -297,11 +297,15 @@ def _prepared_conv(conv, bn):
     return buf
 
 
-def conv_bn_act(x_sp, Cin, conv, bn=None, act=0, residual=None, want_sp=True, want_f32=False, low_sp=None):
+CONV_SHARED_GPU = 0x100      # include/loftr_hip.h: LOFTR_CONV_SHARED_GPU
+
+
+def conv_bn_act(x_sp, Cin, conv, bn=None, act=0, residual=None, want_sp=True, want_f32=False, low_sp=None, shared_gpu=False):
     """nn.Conv2d(bias=False) [+ eval BatchNorm2d] [+ residual] [+ act] on an SP activation.
 
     x_sp int32 [B,H,W,ceil32(Cin)]; returns (y_sp or None, y_f32 [B,Ho,Wo,Cout] or None).
-    low_sp (FPN top-down step): y = conv1x1(x) + bilinear_x2(low_sp), SP in / out."""
+    low_sp (FPN top-down step): y = conv1x1(x) + bilinear_x2(low_sp), SP in / out.
+    shared_gpu: the launch runs next to another stream's work (no persistent workgroups, see loftr_hip.h)."""
     w = conv.weight
     Cout, Cin_w, KH, KW = w.shape
     assert Cin_w == Cin
@@ -314,7 +318,8 @@ def conv_bn_act(x_sp, Cin, conv, bn=None, act=0, residual=None, want_sp=True, wa
     y_sp = torch.empty(B, Ho, Wo, ceil32(Cout), dtype=torch.int32, device=dev) if want_sp else None
     y_f32 = torch.empty(B, Ho, Wo, Cout, dtype=torch.float32, device=dev) if want_f32 else None
     check(_lib.load().loftr_conv_bn_act_prepared(_ptr(x_sp), B, H, W, Cin, _ptr(prepared), prepared.numel(), Cout, KH, KW,
-                                                 stride, pad, int(act), _ptr(residual), _ptr(low_sp), _ptr(y_sp), _ptr(y_f32),
+                                                 stride, pad, int(act) | (CONV_SHARED_GPU if shared_gpu else 0), _ptr(residual),
+                                                 _ptr(low_sp), _ptr(y_sp), _ptr(y_f32),
                                                  _stream()), "loftr_conv_bn_act_prepared")
     return y_sp, y_f32
 
