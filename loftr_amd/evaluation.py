@@ -18,7 +18,6 @@ for ``from loftr_amd.evaluation import ...``.
   metrics.py:128-131).  Not re-implemented here: without the library its RANSAC cannot be pinned.
 """
 import os
-from collections import OrderedDict
 
 import numpy as np
 import torch
@@ -34,37 +33,47 @@ def compute_symmetrical_epipolar_errors(data):
                                                  data["K1"].to(torch.float32))})
 
 
+def _angle_deg(cosine):
+    return float(np.degrees(np.arccos(np.clip(cosine, -1.0, 1.0))))
+
+
 def relative_pose_error(T_0to1, R, t, ignore_gt_t_thr=0.0):
-    """metrics.py:12-28: (t_err, R_err) in degrees."""
-    t_gt = T_0to1[:3, 3]
-    n = np.linalg.norm(t) * np.linalg.norm(t_gt)
-    t_err = np.rad2deg(np.arccos(np.clip(np.dot(t, t_gt) / n, -1.0, 1.0)))
-    t_err = np.minimum(t_err, 180 - t_err)              # E ambiguity
-    if np.linalg.norm(t_gt) < ignore_gt_t_thr:          # pure rotation
+    """metrics.py:12-28 -> (t_err, R_err) in degrees: angle between the translation directions (sign-ambiguous, so
+    folded to [0, 90]; ignored when the ground-truth baseline is shorter than `ignore_gt_t_thr`) and the geodesic
+    angle between the rotations."""
+    gt_R, gt_t = T_0to1[:3, :3], T_0to1[:3, 3]
+    baseline = np.linalg.norm(gt_t)
+    if baseline < ignore_gt_t_thr:
         t_err = 0
-    R_gt = T_0to1[:3, :3]
-    cos = np.clip((np.trace(np.dot(R.T, R_gt)) - 1) / 2, -1.0, 1.0)
-    R_err = np.rad2deg(np.abs(np.arccos(cos)))
+    else:
+        ang = _angle_deg(np.dot(t, gt_t) / (np.linalg.norm(t) * baseline))
+        t_err = min(ang, 180.0 - ang)
+    R_err = abs(_angle_deg((np.trace(R.T @ gt_R) - 1.0) / 2.0))
     return t_err, R_err
 
 
+def _normalise(kpts, K):
+    """pixels -> normalised camera coordinates (the reference indexes K[[0,1],[2,2]] / K[[0,1],[0,1]], metrics.py:75-76)."""
+    return (kpts - K[:2, 2][None]) / np.array([K[0, 0], K[1, 1]])[None]
+
+
 def estimate_pose_cv2(kpts0, kpts1, K0, K1, thresh, conf=0.99999):
-    """metrics.py:71-100 verbatim in behaviour: needs OpenCV."""
+    """metrics.py:71-100: OpenCV 5-point RANSAC on normalised points (threshold = pixels / mean focal length as the
+    reference computes it), then the cheirality vote over the returned essential matrices.  Needs cv2."""
     import cv2
     if len(kpts0) < 5:
         return None
-    kpts0 = (kpts0 - K0[[0, 1], [2, 2]][None]) / K0[[0, 1], [0, 1]][None]
-    kpts1 = (kpts1 - K1[[0, 1], [2, 2]][None]) / K1[[0, 1], [0, 1]][None]
-    ransac_thr = thresh / np.mean([K0[0, 0], K1[1, 1], K0[0, 0], K1[1, 1]])
-    E, mask = cv2.findEssentialMat(kpts0, kpts1, np.eye(3), threshold=ransac_thr, prob=conf, method=cv2.RANSAC)
+    n0, n1 = _normalise(kpts0, K0), _normalise(kpts1, K1)
+    focal = np.mean([K0[0, 0], K1[1, 1], K0[0, 0], K1[1, 1]])          # (sic) the reference's choice of entries
+    E, mask = cv2.findEssentialMat(n0, n1, np.eye(3), threshold=thresh / focal, prob=conf, method=cv2.RANSAC)
     if E is None:
         return None
-    best, ret = 0, None
-    for _E in np.split(E, len(E) / 3):
-        n, R, t, _ = cv2.recoverPose(_E, kpts0, kpts1, np.eye(3), 1e9, mask=mask)
-        if n > best:
-            ret, best = (R, t[:, 0], mask.ravel() > 0), n
-    return ret
+    candidates = []
+    for Ei in np.split(E, len(E) // 3):
+        votes, R, t, _ = cv2.recoverPose(Ei, n0, n1, np.eye(3), 1e9, mask=mask)
+        candidates.append((votes, R, t[:, 0]))
+    votes, R, t = max(candidates, key=lambda c: c[0], default=(0, None, None))   # first maximum, like the reference's `>`
+    return None if votes <= 0 else (R, t, mask.ravel() > 0)
 
 
 def _cfg_get(config, path, default):
@@ -112,39 +121,46 @@ def compute_pose_errors(data, config=None, estimator=None, on_missing="raise"):
 
 
 # ---- dataset-level aggregation (host, once per dataset) ----------------------------------------------------
+def _area_under_recall(sorted_errors, recall, thr):
+    """Area (trapezoid rule) under the recall-vs-error step curve from 0 to `thr`, the curve held flat from the last
+    error below `thr` up to `thr`."""
+    k = int(np.searchsorted(sorted_errors, thr))
+    x = np.append(sorted_errors[:k], thr)
+    y = np.append(recall[:k], recall[k - 1])
+    return float(np.sum(np.diff(x) * (y[1:] + y[:-1]) * 0.5))
+
+
 def error_auc(errors, thresholds=(5, 10, 20)):
-    """metrics.py:143-160 (which ignores its `thresholds` argument in favour of [5, 10, 20])."""
-    thresholds = [5, 10, 20]
-    errors = [0] + sorted(list(errors))
-    recall = list(np.linspace(0, 1, len(errors)))
-    aucs = []
-    for thr in thresholds:
-        last = int(np.searchsorted(errors, thr))
-        y = np.asarray(recall[:last] + [recall[last - 1]], dtype=np.float64)
-        x = np.asarray(errors[:last] + [thr], dtype=np.float64)
-        aucs.append(float(np.sum((x[1:] - x[:-1]) * (y[1:] + y[:-1]) / 2.0)) / thr)
-    return {f"auc@{t}": auc for t, auc in zip(thresholds, aucs)}
+    """metrics.py:143-160: normalised AUC of the cumulative pose-error curve at 5 / 10 / 20 degrees (the reference
+    discards its `thresholds` argument in favour of these three)."""
+    e = np.concatenate([[0.0], np.sort(np.asarray(list(errors), dtype=np.float64))])
+    recall = np.linspace(0, 1, len(e))
+    return {f"auc@{t}": _area_under_recall(e, recall, t) / t for t in (5, 10, 20)}
 
 
 def epidist_prec(errors, thresholds, ret_dict=False):
-    """metrics.py:163-174."""
-    precs = []
-    for thr in thresholds:
-        per_pair = [np.mean(np.asarray(e) < thr) if len(e) > 0 else 0 for e in errors]
-        precs.append(np.mean(per_pair) if len(per_pair) > 0 else 0)
-    if ret_dict:
-        return {f"prec@{t:.0e}": p for t, p in zip(thresholds, precs)}
-    return precs
+    """metrics.py:163-174: for each threshold, the mean over pairs of the fraction of that pair's matches whose
+    epipolar error is below it (a pair without matches counts 0)."""
+    def pair_precision(errs, thr):
+        errs = np.asarray(errs)
+        return float(np.count_nonzero(errs < thr)) / errs.size if errs.size else 0
+
+    precs = [np.mean([pair_precision(e, thr) for e in errors]) if len(errors) else 0 for thr in thresholds]
+    return {f"prec@{t:.0e}": p for t, p in zip(thresholds, precs)} if ret_dict else precs
 
 
 def aggregate_metrics(metrics, epi_err_thr=5e-4):
-    """metrics.py:177-198: drop the duplicates a DistributedSampler pads with, pose AUC @5/10/20 deg of
-    max(R_err, t_err), mean matching precision at `epi_err_thr` (5e-4 ScanNet, 1e-4 MegaDepth)."""
-    unq_ids = list(OrderedDict((iden, i) for i, iden in enumerate(metrics["identifiers"])).values())
-    pose_errors = np.max(np.stack([metrics["R_errs"], metrics["t_errs"]]), axis=0)[unq_ids]
-    aucs = error_auc(pose_errors, [5, 10, 20])
-    epi = [metrics["epi_errs"][i] for i in unq_ids]
-    return {**aucs, **epidist_prec(epi, [epi_err_thr], True)}
+    """metrics.py:177-198: one entry per identifier (a DistributedSampler pads the last batch with repeats; a repeat
+    overrides the earlier entry but keeps its position), pose AUC of max(R_err, t_err), matching precision at
+    `epi_err_thr` (5e-4 ScanNet, 1e-4 MegaDepth)."""
+    index_of = {}
+    for i, ident in enumerate(metrics["identifiers"]):
+        index_of[ident] = i
+    keep = list(index_of.values())
+    worst = np.maximum(np.asarray(metrics["R_errs"], dtype=np.float64), np.asarray(metrics["t_errs"], dtype=np.float64))[keep]
+    out = error_auc(worst)
+    out.update(epidist_prec([metrics["epi_errs"][i] for i in keep], [epi_err_thr], ret_dict=True))
+    return out
 
 
 # ---- the loop ----------------------------------------------------------------------------------------------

@@ -60,62 +60,77 @@ def compute_symmetrical_epipolar_errors(mkpts0_f, mkpts1_f, m_bids, T_0to1, K0, 
 
 
 def relative_pose_error(T_0to1, R, t, ignore_gt_t_thr=0.0):
-    """metrics.py:12-28 (float64 numpy like the reference): angular errors in degrees -> (t_err, R_err)."""
-    T_0to1, R, t = np.asarray(T_0to1), np.asarray(R), np.asarray(t)
-    t_gt = T_0to1[:3, 3]
-    n = np.linalg.norm(t) * np.linalg.norm(t_gt)
-    t_err = np.rad2deg(np.arccos(np.clip(np.dot(t, t_gt) / n, -1.0, 1.0)))
-    t_err = np.minimum(t_err, 180 - t_err)
-    if np.linalg.norm(t_gt) < ignore_gt_t_thr:
+    """metrics.py:12-28 in float64: (t_err, R_err) in degrees.
+    t_err: angle between estimated and true translation DIRECTION, folded into [0, 90] (the essential matrix leaves the
+    sign open), forced to 0 when the true baseline is shorter than `ignore_gt_t_thr`;
+    R_err: rotation angle of R^T R_gt, from its trace."""
+    T = np.asarray(T_0to1, np.float64)
+    R = np.asarray(R, np.float64)
+    t = np.asarray(t, np.float64)
+    t_gt = T[:3, 3]
+    len_gt = float(np.sqrt(np.sum(t_gt * t_gt)))
+    len_t = float(np.sqrt(np.sum(t * t)))
+    c = float(np.sum(t * t_gt)) / (len_t * len_gt)
+    c = max(-1.0, min(1.0, c))
+    ang = np.arccos(c) * 180.0 / np.pi
+    t_err = ang if ang <= 180.0 - ang else 180.0 - ang
+    if len_gt < ignore_gt_t_thr:
         t_err = 0
-    R_gt = T_0to1[:3, :3]
-    cos = (np.trace(np.dot(R.T, R_gt)) - 1) / 2
-    cos = np.clip(cos, -1.0, 1.0)
-    R_err = np.rad2deg(np.abs(np.arccos(cos)))
+    tr = 0.0
+    for i in range(3):
+        for k in range(3):
+            tr += R[k, i] * T[k, i]                      # trace(R^T R_gt)
+    c = max(-1.0, min(1.0, (tr - 1.0) / 2.0))
+    R_err = abs(np.arccos(c)) * 180.0 / np.pi
     return t_err, R_err
 
 
 def error_auc(errors, thresholds=(5, 10, 20)):
-    """metrics.py:143-160.  (The reference overwrites its `thresholds` argument with [5, 10, 20].)"""
-    thresholds = [5, 10, 20]
-    errors = [0] + sorted(list(errors))
-    recall = list(np.linspace(0, 1, len(errors)))
-    aucs = []
-    for thr in thresholds:
-        last_index = int(np.searchsorted(errors, thr))
-        y = recall[:last_index] + [recall[last_index - 1]]
-        x = errors[:last_index] + [thr]
-        # trapezoid rule written out (np.trapz was removed in numpy 2)
+    """metrics.py:143-160.  Recall curve: sorted errors e_1..e_n with a leading 0, recall = linspace(0, 1, n+1); for each
+    threshold the curve is cut at the first sample >= thr, extended flat to thr, integrated by the trapezoid rule and
+    divided by thr.  (The reference replaces whatever `thresholds` it is given by [5, 10, 20].)"""
+    xs = [0.0] + sorted(float(e) for e in errors)
+    ys = [float(v) for v in np.linspace(0, 1, len(xs))]
+    out = {}
+    for thr in (5, 10, 20):
+        cut = 0
+        while cut < len(xs) and xs[cut] < thr:          # == np.searchsorted(xs, thr), side='left'
+            cut += 1
+        px = xs[:cut] + [float(thr)]
+        py = ys[:cut] + [ys[cut - 1]]
         area = 0.0
-        for i in range(1, len(x)):
-            area += (x[i] - x[i - 1]) * (y[i] + y[i - 1]) / 2.0
-        aucs.append(area / thr)
-    return {f"auc@{t}": auc for t, auc in zip(thresholds, aucs)}
+        for i in range(1, len(px)):
+            area += (px[i] - px[i - 1]) * (py[i] + py[i - 1]) / 2.0
+        out[f"auc@{thr}"] = area / thr
+    return out
 
 
 def epidist_prec(errors, thresholds, ret_dict=False):
-    """metrics.py:163-174: mean over pairs of the fraction of matches with epipolar error < thr."""
-    precs = []
+    """metrics.py:163-174: per threshold, the average over pairs of (#matches with error < thr) / (#matches), a pair
+    without matches contributing 0."""
+    result = []
     for thr in thresholds:
-        prec_ = []
+        total = 0.0
         for errs in errors:
-            correct = np.asarray(errs) < thr
-            prec_.append(np.mean(correct) if len(correct) > 0 else 0)
-        precs.append(np.mean(prec_) if len(prec_) > 0 else 0)
+            n_ok = sum(1 for e in errs if e < thr)
+            total += (n_ok / len(errs)) if len(errs) > 0 else 0.0
+        result.append(total / len(errors) if len(errors) > 0 else 0)
     if ret_dict:
-        return {f"prec@{t:.0e}": prec for t, prec in zip(thresholds, precs)}
-    return precs
+        return {f"prec@{t:.0e}": r for t, r in zip(thresholds, result)}
+    return result
 
 
 def aggregate_metrics(metrics, epi_err_thr=5e-4):
-    """metrics.py:177-198: de-duplicate by identifier (LAST occurrence's index wins, first occurrence's
-    position orders -- OrderedDict semantics), pose AUC on max(R_err, t_err), matching precision."""
-    unq = {}
+    """metrics.py:177-198.  Duplicated identifiers (sampler padding) are collapsed: the LAST occurrence supplies the
+    values, the FIRST occurrence fixes the position (OrderedDict((iden, id) ...) semantics); pose error of a pair =
+    max(R_err, t_err)."""
+    order, last = [], {}
     for idx, iden in enumerate(metrics["identifiers"]):
-        unq[iden] = idx                                   # dict keeps first-insertion order, last value
-    unq_ids = list(unq.values())
-    pose_errors = np.max(np.stack([metrics["R_errs"], metrics["t_errs"]]), axis=0)[unq_ids]
-    aucs = error_auc(pose_errors)
-    epi = [metrics["epi_errs"][i] for i in unq_ids]
-    precs = epidist_prec(epi, [epi_err_thr], True)
-    return {**aucs, **precs}
+        if iden not in last:
+            order.append(iden)
+        last[iden] = idx
+    picked = [last[iden] for iden in order]
+    pose = [max(metrics["R_errs"][i], metrics["t_errs"][i]) for i in picked]
+    res = dict(error_auc(pose))
+    res.update(epidist_prec([metrics["epi_errs"][i] for i in picked], [epi_err_thr], True))
+    return res

@@ -45,9 +45,14 @@ def test_oracle_epipolar_errors_match_reference(epi, case):
     assert epi_close(got, ref)
 
 
-def test_oracle_relative_pose_error_matches_reference(epi):
+@pytest.mark.parametrize("impl", ["oracle", "product"])
+def test_relative_pose_error_matches_reference(epi, impl):
+    if impl == "oracle":
+        m = mo
+    else:
+        from loftr_amd import evaluation as m
     for key, thr in (("rpe_errs", 0.0), ("rpe_errs_thr", 10.0)):
-        got = np.array([mo.relative_pose_error(epi["rpe_T"][i], epi["rpe_R"][i], epi["rpe_t"][i], thr) for i in range(6)], dtype=np.float64)
+        got = np.array([m.relative_pose_error(epi["rpe_T"][i], epi["rpe_R"][i], epi["rpe_t"][i], thr) for i in range(6)], dtype=np.float64)
         assert np.allclose(got, epi[key], rtol=0, atol=1e-9)
     assert np.all(epi["rpe_errs_thr"][:, 0] == 0)              # |t_gt| < 10: translation error ignored
     assert epi["rpe_errs"][2, 1] < 5e-2                         # identical rotation (fp32-rounded R_gt: ~1e-2 deg)
