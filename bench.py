@@ -301,6 +301,12 @@ def main():
         roof = roofline_entry(dom, ms, n, work[dom][0], work[dom][1], args.steps)
         if roof:
             roof["traffic"] = pmc_traffic(dom)
+            if not args.no_overlap and args.backbone == "hip":
+                solo = next((k for k in kernels if k["kernel"] == dom), None)
+                roof["note"] = ("timed region: the fine-branch launches of this kernel run on the side stream CONCURRENTLY with the "
+                                "coarse stage, so their durations (and this average) include time-slicing with other kernels; "
+                                "running alone (instrumented steps, `kernels`): avg %.1f us, frac %.3f"
+                                % ((solo["avg_launch_us"], solo["frac"]) if solo else (float("nan"), float("nan"))))
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -321,7 +327,7 @@ def main():
             "dtype_note": "fp32 data everywhere; every GEMM / convolution evaluates each fp32 product as 3 fp16 MFMAs on a "
                           "(hi, lo) fp16 split with fp32 accumulation (fp32-class accuracy, csrc/gemm.h); --backbone torch = MIOpen fp32",
             "config": {"workload": f"batch={B} 640x480 synthetic grayscale pairs per GPU, indoor_ds dual-softmax "
-                                   f"(BASELINE configs[1]), full LoFTR.forward = ResNet-FPN backbone ({'HIP implicit-GEMM convs, 7x7 stem in MIOpen' if args.backbone == 'hip' else 'PyTorch-ROCm / MIOpen fp32'}) + HIP matching path",
+                                   f"(BASELINE configs[1]), full LoFTR.forward = ResNet-FPN backbone ({'HIP implicit-GEMM / patch convolutions incl. the 7x7 stem' if args.backbone == 'hip' else 'PyTorch-ROCm / MIOpen fp32'}) + HIP matching path",
                        "weights": "seeded random init (no checkpoint on the box)", "thr": args.thr,
                        "thr_note": "stock thr 0.2 gives 0 matches with random weights; thr 0.0 keeps the fine stage loaded",
                        "conf_matrix_materialised": not args.no_conf, "match_type": args.match_type, "matches_per_pair": round(m_total / (world * B), 1),
