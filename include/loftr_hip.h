@@ -34,7 +34,7 @@ typedef enum {
   LOFTR_ERR_NO_DEVICE = -5      /* no gfx950 device visible                                    */
 } loftr_status;
 
-#define LOFTR_HIP_ABI_VERSION 10
+#define LOFTR_HIP_ABI_VERSION 11
 
 int loftr_hip_abi_version(void);
 const char* loftr_hip_status_string(int status);
@@ -241,6 +241,11 @@ int loftr_epipolar_errors(const float* mkpts0_f, const float* mkpts1_f, const lo
  *   src [N, *, *] uint8 with byte pitches per image / per row; hw [N,2] int32 device: valid (h, w) <= (PH, PW);
  *   image [N,1,PH,PW] f32; mask [N,PH,PW] u8 or NULL; mask_c [N,PH/coarse_div,PW/coarse_div] u8 or NULL.
  * Decoding and cv2.resize stay with the caller (OpenCV; not reproducible without the library). */
+/* cv2.resize(image_u8, (dw, dh)) with the default INTER_LINEAR (dataset.py:108,146) on the device, one grayscale image.
+ * PARITY UNPINNED: restates OpenCV 4.x's fixed-point bilinear (11-bit coefficients, half-pixel centres); OpenCV is not
+ * in this image, so it is verified against the numpy restatement only (oracle/input_oracle.py). */
+int loftr_resize_linear_u8(const uint8_t* src, int sh, int sw, long src_pitch, uint8_t* dst, int dh, int dw,
+                           long dst_pitch, void* stream);
 int loftr_pack_gray_u8(const uint8_t* src, long src_image_pitch, long src_row_pitch, const int* hw, int N, int PH,
                        int PW, float* image, uint8_t* mask, uint8_t* mask_c, int coarse_div, void* stream);
 

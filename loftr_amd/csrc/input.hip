@@ -46,7 +46,50 @@ __global__ __launch_bounds__(256) void coarse_mask_kernel(const int* __restrict_
   maskc[(long)n * CH * CW + i] = (y * d < hw[2 * n] && x * d < hw[2 * n + 1]) ? 1 : 0;
 }
 
+// cv2.resize(uint8 gray, INTER_LINEAR) restated (OpenCV 4.x resize.cpp, 8UC1, fixed point with 11-bit coefficients):
+// one thread per output pixel, both passes fused.  PARITY UNPINNED (OpenCV absent here): pinned to the numpy restatement
+// oracle/input_oracle.py:resize_linear_u8 only.
+__device__ __forceinline__ void resize_axis(int d, int n_dst, int n_src, bool zero_at_border, int& s, int& c0, int& c1) {
+  const double scale = 1.0 / ((double)n_dst / (double)n_src);
+  float f = (float)__dsub_rn(__dmul_rn((double)d + 0.5, scale), 0.5);      // separately rounded like the host code (no fma)
+  s = (int)floorf(f);
+  f -= (float)s;
+  if (zero_at_border) {                       // columns: the coefficient is forced to 0 outside, rows only clamp the index
+    if (s < 0) { f = 0.f; s = 0; }
+    if (s >= n_src - 1) { f = 0.f; s = n_src - 1; }
+  }
+  c0 = __float2int_rn((1.0f - f) * 2048.0f);  // saturate_cast<short>(cvRound(.)): |value| <= 2048, never saturates
+  c1 = __float2int_rn(f * 2048.0f);
+}
+
+__global__ __launch_bounds__(256) void resize_linear_kernel(const uint8_t* __restrict__ src, int sh, int sw, long src_pitch,
+                                                            uint8_t* __restrict__ dst, int dh, int dw, long dst_pitch) {
+  const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+  if (x >= dw) return;
+  int sx, a0, a1, sy, b0, b1;
+  resize_axis(x, dw, sw, true, sx, a0, a1);
+  resize_axis(y, dh, sh, false, sy, b0, b1);
+  const int x1 = min(sx + 1, sw - 1);
+  const int y0 = min(max(sy, 0), sh - 1), y1 = min(max(sy + 1, 0), sh - 1);
+  const uint8_t* r0 = src + y0 * src_pitch;
+  const uint8_t* r1 = src + y1 * src_pitch;
+  const int h0 = (int)r0[sx] * a0 + (int)r0[x1] * a1;            // horizontal pass, scale 2^11
+  const int h1 = (int)r1[sx] * a0 + (int)r1[x1] * a1;
+  const int v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
+  dst[y * dst_pitch + x] = (uint8_t)min(max(v, 0), 255);
+}
+
 }  // namespace
+
+extern "C" int loftr_resize_linear_u8(const uint8_t* src, int sh, int sw, long src_pitch, uint8_t* dst, int dh, int dw,
+                                      long dst_pitch, void* stream) {
+  LOFTR_CHECK_ARG(src && dst && sh > 0 && sw > 0 && dh > 0 && dw > 0 && src_pitch >= sw && dst_pitch >= dw);
+  if (dh > 65535) return LOFTR_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(resize_linear_kernel, dim3(ceil_div(dw, 256), dh), dim3(256), 0, (hipStream_t)stream, src, sh, sw, src_pitch,
+                     dst, dh, dw, dst_pitch);
+  LOFTR_CHECK_LAUNCH();
+  return LOFTR_OK;
+}
 
 extern "C" int loftr_pack_gray_u8(const uint8_t* src, long src_image_pitch, long src_row_pitch, const int* hw, int N, int PH,
                                   int PW, float* image, uint8_t* mask, uint8_t* mask_c, int coarse_div, void* stream) {

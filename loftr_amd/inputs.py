@@ -33,6 +33,20 @@ def get_divisible_wh(w, h, df=None):
     return w, h
 
 
+def resize_linear_u8(img, dsize):
+    """cv2.resize(img, dsize) (default INTER_LINEAR) for a uint8 grayscale DEVICE tensor [h, w] -> [h_new, w_new];
+    dsize = (w_new, h_new).  Parity unpinned (see include/loftr_hip.h): OpenCV's algorithm restated, not verified against
+    the library."""
+    if not (torch.is_tensor(img) and img.is_cuda and img.dtype == torch.uint8 and img.dim() == 2):
+        raise _lib.LoftrHipError("resize_linear_u8: expected a uint8 GPU tensor [h, w]")
+    img = img.contiguous()
+    dw, dh = int(dsize[0]), int(dsize[1])
+    out = torch.empty(dh, dw, dtype=torch.uint8, device=img.device)
+    check(_lib.load().loftr_resize_linear_u8(_ptr(img), img.shape[0], img.shape[1], img.shape[1], _ptr(out), dh, dw, dw, _stream()),
+          "loftr_resize_linear_u8")
+    return out
+
+
 class _PinnedRing:
     """A few persistent page-locked staging buffers reused round-robin.  A slot is handed out again only after the
     event recorded behind its last upload has completed, so the asynchronous H2D copy never races the next fill;

@@ -52,3 +52,40 @@ def pack_gray(images, pad_hw, coarse_scale=0.125):
 def scale_of(w, h, w_new, h_new):
     """dataset.py:109: scale = [w / w_new, h / h_new] (float32)."""
     return np.array([w / w_new, h / h_new], np.float32)
+
+
+# ---- cv2.resize(image, (w_new, h_new)) for uint8 grayscale, default INTER_LINEAR (dataset.py:108,146) -------------
+# PARITY UNPINNED: OpenCV is not installed in this image, so neither the library nor golden vectors made with it are
+# available.  The function below restates the published algorithm of OpenCV 4.x `resize.cpp` for 8UC1 /
+# INTER_LINEAR (fixed point, INTER_RESIZE_COEF_BITS = 11): it pins the device kernel `loftr_resize_linear_u8` to THIS
+# restatement only.  When cv2 becomes available: compare against it and move the resize into the pinned wire format.
+def resize_linear_u8(img, dsize):
+    """img uint8 [h, w] -> uint8 [h_new, w_new], dsize = (w_new, h_new) as in cv2.resize."""
+    img = np.asarray(img)
+    assert img.dtype == np.uint8 and img.ndim == 2
+    sh, sw = img.shape
+    dw, dh = int(dsize[0]), int(dsize[1])
+
+    def axis(n_dst, n_src, zero_at_border):
+        scale = 1.0 / (float(n_dst) / float(n_src))                       # scale_x = 1. / inv_scale_x (doubles)
+        f = ((np.arange(n_dst, dtype=np.float64) + 0.5) * scale - 0.5).astype(np.float32)
+        s = np.floor(f).astype(np.int64)
+        f = (f - s.astype(np.float32)).astype(np.float32)
+        if zero_at_border:                                                # columns: coefficient forced to 0 outside
+            lo, hi = s < 0, s >= n_src - 1
+            f = np.where(lo | hi, np.float32(0), f)
+            s = np.where(lo, 0, np.where(hi, n_src - 1, s))
+        c0 = np.rint((np.float32(1.0) - f) * np.float32(2048)).astype(np.int64)      # saturate_cast<short>(cvRound)
+        c1 = np.rint(f * np.float32(2048)).astype(np.int64)
+        return s, np.clip(c0, -32768, 32767), np.clip(c1, -32768, 32767)
+
+    sx, a0, a1 = axis(dw, sw, True)
+    sy, b0, b1 = axis(dh, sh, False)
+    x1 = np.minimum(sx + 1, sw - 1)
+    y0 = np.clip(sy, 0, sh - 1)                                            # rows: indices clamped, coefficients kept
+    y1 = np.clip(sy + 1, 0, sh - 1)
+    src = img.astype(np.int64)
+    H0 = src[y0][:, sx] * a0[None, :] + src[y0][:, x1] * a1[None, :]       # horizontal pass, scale 2^11
+    H1 = src[y1][:, sx] * a0[None, :] + src[y1][:, x1] * a1[None, :]
+    out = (((b0[:, None] * (H0 >> 4)) >> 16) + ((b1[:, None] * (H1 >> 4)) >> 16) + 2) >> 2
+    return np.clip(out, 0, 255).astype(np.uint8)

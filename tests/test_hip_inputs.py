@@ -72,3 +72,14 @@ def test_packed_batch_feeds_the_matcher():
     b = batch["m_bids"].cpu().numpy()
     k0 = batch["mkpts0_f"].cpu().numpy()
     assert (k0[b == 0][:, 0] < 160 * 4.0).all() and (k0[b == 1][:, 1] < 200 * 4.0).all()
+
+
+def test_resize_linear_u8_matches_restatement():
+    """Device bilinear resize vs the numpy restatement of OpenCV's algorithm, bit-exact (PARITY UNPINNED against cv2)."""
+    from loftr_amd import inputs
+    rng = np.random.default_rng(8)
+    for (h, w), dsize in (((480, 640), (640, 480)), ((1200, 1600), (840, 632)), ((1067, 1599), (840, 560)), ((480, 640), (832, 624)),
+                          ((33, 57), (200, 101)), ((64, 64), (1, 1)), ((5, 7), (7, 5))):
+        img = rng.integers(0, 256, (h, w), dtype=np.uint8)
+        got = inputs.resize_linear_u8(torch.from_numpy(img).cuda(), dsize).cpu().numpy()
+        assert got.shape == (dsize[1], dsize[0]) and np.array_equal(got, io_.resize_linear_u8(img, dsize)), ((h, w), dsize)
