@@ -84,3 +84,26 @@ def checksum(a) -> float:
     a = np.asarray(a, dtype=np.float64).ravel()
     k = np.arange(a.size, dtype=np.float64) % 97 + 1
     return float((a * k).sum())
+
+
+def make_backbone_weights(seed, module):
+    """Seeded state_dict for a ResNet-FPN backbone (ours or the reference's: same parameter names / shapes), with
+    NON-trivial BatchNorm statistics so that eval-mode BN actually scales and shifts.  Filled in state_dict order from
+    one numpy Generator -> loading the result into two modules with strict=True also proves their layouts agree."""
+    import torch
+    rng = np.random.default_rng(seed)
+    out = {}
+    for name, t in module.state_dict().items():
+        shape = tuple(t.shape)
+        if name.endswith("num_batches_tracked"):
+            out[name] = torch.zeros(shape, dtype=t.dtype)
+        elif name.endswith("running_var"):
+            out[name] = torch.from_numpy((0.5 + rng.random(shape)).astype(np.float32))
+        elif name.endswith("running_mean") or (name.endswith(".bias") and t.dim() == 1):
+            out[name] = torch.from_numpy((0.1 * rng.standard_normal(shape)).astype(np.float32))
+        elif t.dim() == 1:                                   # BN weight
+            out[name] = torch.from_numpy((1.0 + 0.2 * rng.standard_normal(shape)).astype(np.float32))
+        else:                                                # conv filters: kaiming-like scale (fan_out)
+            fan_out = shape[0] * int(np.prod(shape[2:]))
+            out[name] = torch.from_numpy((rng.standard_normal(shape) * np.sqrt(2.0 / fan_out)).astype(np.float32))
+    return out
