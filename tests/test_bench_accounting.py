@@ -1,0 +1,67 @@
+"""bench.py's algorithmic work table and roofline classification (host logic, CPU): the numbers behind
+`roofline.achieved` must be the ones DESIGN.md §4 / SURVEY.md §8(d) state."""
+import importlib.util
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def bench():
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    m = importlib.util.module_from_spec(spec)
+    sys.modules["bench_mod"] = m
+    spec.loader.exec_module(m)
+    return m
+
+
+def test_backbone_conv_table(bench):
+    convs = bench.backbone_convs(480, 640)
+    assert len(convs) == 21                                              # ResNetFPN_8_2 minus the stem (resnet_fpn.py:43-118)
+    assert sum(1 for c in convs if c[2] == 3 and c[3] == 1) == 14        # 3x3 stride-1 layers: patch kernels
+    wide = [c for c in convs if c[2] == 3 and c[3] == 1 and (c[1] + 31) // 32 == 7]
+    assert len(wide) == 5                                                # Cout = 196 -> 224 columns
+    flops_per_image = sum(2 * (h // s) * (w // s) * cout * cin * k * k for cin, cout, k, s, h, w in convs)
+    stem = 2 * 240 * 320 * 128 * 49
+    # the backbone is ~595 GFLOP per PAIR (two images)
+    assert abs(2 * (flops_per_image + stem) / 1e9 - 595) < 15
+
+
+def test_algorithmic_work_matches_design_table(bench):
+    B, L, M = 8, 4800, 7663
+    w = bench.algorithmic_work(B, L, L, M)
+    C = 256
+    rows = 2 * B * L
+    # dual-softmax GEMM passes: 2 B L S C flops each
+    assert w["score_stats_kernel"][0] == 2 * B * L * L * C == w["score_conf_kernel"][0]
+    assert w["score_conf_kernel"][1] == 4 * B * ((L + L) * C + L * L)     # conf_matrix written once
+    # k/v projection with the fused KV reduction, 8 layer passes over both images
+    assert w["proj_kv_kernel"][0] == 8 * (2 * rows * C * 2 * C + 2 * rows * C * 32)
+    # encoder per layer pass and pair (6.45 GFLOP per call incl. attention): projections + merge + MLP
+    w0 = bench.algorithmic_work(B, L, L, 0)                                # no matches: the coarse level alone
+    per_call = (w0["proj_kernel"][0] + w0["proj_kv_kernel"][0] + w0["linear_kernel"][0] + w0["linear_ln_kernel"][0]) / 8 / (2 * B)
+    assert abs(per_call / 1e9 - 6.45) < 0.2                                # 6.45 GFLOP per encoder call
+    assert w["linear_kernel"][0] > w0["linear_kernel"][0]                  # the fine level rides on the same kernels
+    # the three conv entries partition the 21 convolutions of 2B images
+    convs = bench.backbone_convs(480, 640)
+    total = sum(2 * 2 * B * (h // s) * (ww // s) * cout * cin * k * k for cin, cout, k, s, h, ww in convs)
+    assert w["conv_kernel"][0] + w["conv3x3_kernel"][0] + w["conv3x3_wide_kernel"][0] == total
+    assert w["conv3x3_wide_kernel"][0] > 0.3 * total and w["conv3x3_kernel"][0] > 0.4 * total
+
+
+def test_roofline_entry_classification(bench):
+    # a GEMM kernel far from the HBM roof: matrix-pipe bound, executed rate = 3 x algorithmic
+    e = bench.roofline_entry("conv3x3_kernel", total_ms=8.0, launches=9, flops=2.5e12, nbytes=8e9, steps=1)
+    assert e["bound"] == "mfma" and e["unit"] == "TFLOP/s" and e["peak"] == 2500.0
+    assert abs(e["executed_fp16_TFLOP_s"] - 3 * 2.5e12 / 8e-3 / 1e12) < 1 and abs(e["frac"] - e["mfma_frac"]) < 1e-9
+    assert abs(e["avg_launch_us"] - 8000 / 9) < 0.01
+    # a streaming kernel: HBM bound against 8 TB/s
+    e = bench.roofline_entry("gather_windows_kernel", total_ms=0.1, launches=1, flops=0, nbytes=4e8, steps=1)
+    assert e["bound"] == "hbm" and e["peak"] == 8000.0 and abs(e["achieved"] - 4000.0) < 1 and abs(e["frac"] - 0.5) < 1e-3
+    # a GEMM kernel whose bytes dominate is reported against the HBM roof
+    e = bench.roofline_entry("linear_ln_kernel", total_ms=0.1, launches=1, flops=2e10, nbytes=3.2e8, steps=1)
+    assert e["bound"] == "hbm" and e["hbm_frac"] > e["mfma_frac"]
+    assert bench.roofline_entry("linear_kernel", 0.0, 0, 1, 1, 1) is None
