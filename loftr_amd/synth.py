@@ -86,23 +86,27 @@ def checksum(a) -> float:
     return float((a * k).sum())
 
 
-def make_backbone_weights(seed, module):
+def make_backbone_weights(seed, module, bn_strength=1.0):
     """Seeded state_dict for a ResNet-FPN backbone (ours or the reference's: same parameter names / shapes), with
     NON-trivial BatchNorm statistics so that eval-mode BN actually scales and shifts.  Filled in state_dict order from
-    one numpy Generator -> loading the result into two modules with strict=True also proves their layouts agree."""
+    one numpy Generator -> loading the result into two modules with strict=True also proves their layouts agree.
+    ``bn_strength`` scales the spread of the BN affine parameters / statistics around the identity (1.0: strong
+    per-channel scales and offsets, descriptors share a large common component -> few, confident matches;
+    0.3: closer to a freshly initialised network -> many low-confidence matches)."""
     import torch
     rng = np.random.default_rng(seed)
+    s = np.float64(bn_strength)
     out = {}
     for name, t in module.state_dict().items():
         shape = tuple(t.shape)
         if name.endswith("num_batches_tracked"):
             out[name] = torch.zeros(shape, dtype=t.dtype)
         elif name.endswith("running_var"):
-            out[name] = torch.from_numpy((0.5 + rng.random(shape)).astype(np.float32))
+            out[name] = torch.from_numpy(((0.5 + rng.random(shape)) if bn_strength == 1.0 else (1.0 + s * (rng.random(shape) - 0.5))).astype(np.float32))
         elif name.endswith("running_mean") or (name.endswith(".bias") and t.dim() == 1):
-            out[name] = torch.from_numpy((0.1 * rng.standard_normal(shape)).astype(np.float32))
+            out[name] = torch.from_numpy((s * 0.1 * rng.standard_normal(shape)).astype(np.float32))
         elif t.dim() == 1:                                   # BN weight
-            out[name] = torch.from_numpy((1.0 + 0.2 * rng.standard_normal(shape)).astype(np.float32))
+            out[name] = torch.from_numpy((1.0 + s * 0.2 * rng.standard_normal(shape)).astype(np.float32))
         else:                                                # conv filters: kaiming-like scale (fan_out)
             fan_out = shape[0] * int(np.prod(shape[2:]))
             out[name] = torch.from_numpy((rng.standard_normal(shape) * np.sqrt(2.0 / fan_out)).astype(np.float32))
