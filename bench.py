@@ -12,21 +12,33 @@ the bench runs thr=0.0 (~0.7-1k mutual-NN matches per pair, the realistic load) 
 matching path (fp32 MFMA) incl. materialising data['conf_matrix'], + (N>1) the RCCL all-gather
 of the per-pair match counts.  Inputs are resident in HBM before the timed region.
 
-Multi-GPU: pairs are independent -> each rank owns its own B pairs (weak scaling); the only
-collective is the count all-gather.
+Multi-GPU: pairs are independent -> each rank owns its own pairs; the only collective is the all-gather of
+the per-pair match counts (RCCL through the library's C-ABI, loftr_rccl_allgather_counts).  `--scaling weak`
+(default): B pairs per GPU (BASELINE configs[1] x N); `--scaling strong`: a fixed total of `--total-batch` 64 pairs
+(BASELINE configs[2]) split over the ranks.  `python bench.py --gpus N` without a launcher spawns the N ranks
+itself (torch.distributed.run on 127.0.0.1); under torchrun it reads RANK / LOCAL_RANK / WORLD_SIZE.
 
 The JSON line also carries
-  roofline      -- the dominant hot-path kernel against its bound: algorithmic bytes/flops per
-                   launch / hipEvent-measured average launch duration (events
-                   recorded by the library on the launch stream inside the timed region);
-  kernels       -- the same for every instrumented kernel (measured in one extra untimed step);
-  cpu_baseline  -- the CPU port (torch-CPU backbone + numpy oracle of the hot path) timed on this
-                   box's host cores on ONE pair of the same workload (rank 0, N=1 only).
+  roofline          -- the north_star's score-volume kernel (score_conf_kernel, dual-softmax pass B) against the HBM
+                       roof: algorithmic bytes per launch / hipEvent-measured average launch
+                       duration (events recorded by the library on the launch stream INSIDE the timed region);
+                       `traffic` = HBM bytes per launch from the rocprofv3 --pmc passes of THIS build
+                       (profiles/pmc_traffic.json carries a hash of csrc/; null when it does not match);
+  roofline_encoder  -- the linear-attention encoder kernels against the dense fp16 MFMA roof (executed MFMA rate
+                       from the same in-region events; `mfma_busy` = SQ_VALU_MFMA_BUSY_CYCLES utilisation from the
+                       PMC pass);
+  kernels           -- the same for every instrumented kernel (serial instrumented steps), backbone included;
+  cpu_baseline      -- the CPU port (torch-CPU backbone = the reference's module + numpy oracle of the matching
+                       path) on the SAME first pair: thread count picked by a 16/32/64/128 probe, 1 warm-up +
+                       median of 3 (rank 0, N=1 only).
 """
 import argparse
 import ctypes as C
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -37,7 +49,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 from loftr_amd import LoFTR, get_cfg, _lib          # noqa: E402
-from loftr_amd.distributed import all_gather_match_counts   # noqa: E402
+from loftr_amd.distributed import all_gather_match_counts, RcclCounts   # noqa: E402
 from loftr_amd.synth import make_images, make_weights   # noqa: E402
 
 H_IMG, W_IMG = 480, 640
@@ -147,39 +159,140 @@ def roofline_entry(name, total_ms, launches, flops, nbytes, steps):
     return e
 
 
-def pmc_traffic(kernel):
-    """HBM bytes per launch from the committed rocprofv3 --pmc pass (profiles/pmc_traffic.json), or None."""
-    p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(p):
+def source_hash():
+    """sha256 over the kernel sources the library is built from (csrc/*.hip, *.h + the C header), 16 hex digits.
+    tools/rocpd_pmc.py stamps the same hash into profiles/pmc_traffic.json when the PMC passes are collected."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "loftr_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    h.update(open(os.path.join(ROOT, "include", "loftr_hip.h"), "rb").read())
+    return h.hexdigest()[:16]
+
+
+_PMC = None
+
+
+def pmc_table():
+    """profiles/pmc_traffic.json (rocprofv3 --pmc passes: FETCH_SIZE x2 + WRITE_SIZE, SQ_VALU_MFMA_BUSY_CYCLES) if it
+    was collected on THIS build of the kernels (source hash match), else {}."""
+    global _PMC
+    if _PMC is None:
+        _PMC = {}
+        p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         try:
-            return json.load(open(p)).get(kernel, {}).get("hbm_bytes_per_launch")
+            t = json.load(open(p))
+            if t.get("_meta", {}).get("source_hash") == source_hash():
+                _PMC = t
         except Exception:
-            return None
-    return None
+            pass
+    return _PMC
+
+
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the PMC passes of this build, or None."""
+    return pmc_table().get(kernel, {}).get("hbm_bytes_per_launch")
+
+
+def pmc_mfma_busy(kernel):
+    return pmc_table().get(kernel, {}).get("mfma_busy")
 
 
 def cpu_baseline(model, img0, img1):
-    """CPU port of the same forward on ONE pair: torch-CPU backbone (the reference's backbone is the
-    same PyTorch module) + oracle/loftr_oracle.py (numpy restatement of the matching path)."""
+    """CPU port of the same forward on the batch's FIRST pair (the same tensors the GPU run consumed): torch-CPU
+    backbone (the reference's backbone is this very PyTorch module) + oracle/loftr_oracle.py (numpy restatement of
+    the matching path).  BASELINE.md §3 protocol: eval / no_grad / fp32, thread count picked by a short probe of the
+    backbone at 16/32/64/128 threads (a 256-thread pool is 3-5x slower than the best on this host), 1 warm-up +
+    3 timed forwards, median.  kind "port": the reference is Python under /root/reference and cannot travel to the
+    GPU box; its own CPU forward on these inputs is recorded in tests/golden/e2e_synth.npz (ref_cpu_seconds)."""
     from oracle import loftr_oracle as O
     cores = os.cpu_count()
-    torch.set_num_threads(cores)
     cpu_model = model.backbone.to("cpu").float()
     w = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items() if not k.startswith("backbone.")}
     x = torch.cat([img0[:1].cpu(), img1[:1].cpu()], 0)
-    t0 = time.perf_counter()
-    with torch.no_grad():
-        fc, ff = cpu_model(x)
-    t1 = time.perf_counter()
-    fc, ff = fc.numpy(), ff.numpy()
-    out = O.loftr_hot_path(fc[:1], fc[1:], ff[:1], ff[1:], w, model.config, (H_IMG, W_IMG), (H_IMG, W_IMG))
-    t2 = time.perf_counter()
+
+    def backbone():
+        with torch.no_grad():
+            fc, ff = cpu_model(x)
+        return fc.numpy(), ff.numpy()
+
+    probe = {}
+    for nt in [t for t in (16, 32, 64, 128) if t <= cores] or [cores]:
+        torch.set_num_threads(nt)
+        backbone()                                            # warm the thread pool / oneDNN primitives at this size
+        t0 = time.perf_counter()
+        backbone()
+        probe[nt] = time.perf_counter() - t0
+    threads = min(probe, key=probe.get)
+    torch.set_num_threads(threads)
+
+    def forward():
+        t0 = time.perf_counter()
+        fc, ff = backbone()
+        t1 = time.perf_counter()
+        out = O.loftr_hot_path(fc[:1], fc[1:], ff[:1], ff[1:], w, model.config, (H_IMG, W_IMG), (H_IMG, W_IMG))
+        t2 = time.perf_counter()
+        return t2 - t0, t1 - t0, t2 - t1, len(out["mconf"])
+
+    forward()                                                 # warm-up
+    runs = sorted(forward() for _ in range(3))
+    total, bb, hot, m = runs[1]                               # median by total time
     model.backbone.to(img0.device)
-    total = t2 - t0
-    return {"value": round(1.0 / total, 4), "unit": "image-pairs/s", "cores": cores, "kind": "port",
-            "sample": f"1 of the batch's 640x480 pairs, 1 run: torch-CPU backbone {t1 - t0:.2f}s + numpy oracle "
-                      f"matching path {t2 - t1:.2f}s (M={len(out['mconf'])})",
-            "backbone_s": round(t1 - t0, 3), "hot_path_s": round(t2 - t1, 3)}
+    return {"value": round(1.0 / total, 4), "unit": "image-pairs/s", "cores": threads, "kind": "port",
+            "sample": f"pair 0 of the GPU batch (640x480), 1 warm-up + median of 3 forwards: torch-CPU backbone {bb:.2f}s + "
+                      f"numpy oracle matching path {hot:.2f}s (M={m}); {threads} torch threads chosen by probe "
+                      f"{ {k: round(v, 2) for k, v in probe.items()} } s/backbone, host has {cores} logical cores",
+            "host_cores": cores, "backbone_s": round(bb, 3), "hot_path_s": round(hot, 3),
+            "runs_s": [round(r[0], 3) for r in runs]}
+
+
+ENCODER_KERNELS = ("proj_kv_kernel", "proj_kernel", "linear_kernel", "linear_ln_kernel", "encoder_phase_b_kernel")
+NORTH_STAR_TIMED = ("score_conf_kernel", "score_stats_kernel") + ENCODER_KERNELS
+
+
+def free_port():
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def self_spawn(argv, n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks exactly as the driver's launcher would."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
+def group_roofline(names, timing, work, steps):
+    """One MFMA-roof entry over a set of GEMM kernels (the encoder): summed executed fp16 MFMA flops / summed time."""
+    ms = sum(timing[n][0] for n in names if n in timing)
+    launches = sum(timing[n][1] for n in names if n in timing)
+    if ms <= 0 or not launches:
+        return None
+    fl = sum(work[n][0] for n in names if n in timing and n in work)
+    by = sum(work[n][1] for n in names if n in timing and n in work)
+    t = ms / steps * 1e-3
+    exec_tf = fl * SPLIT_FACTOR / t / 1e12
+    traffic = [pmc_traffic(n) for n in names if n in timing]
+    busy = [(pmc_mfma_busy(n), timing[n][0]) for n in names if n in timing]
+    e = {"kernels": [n for n in names if n in timing], "bound": "mfma", "achieved": round(exec_tf, 1), "peak": MFMA_F16_PEAK_TF,
+         "unit": "TFLOP/s", "frac": round(exec_tf / MFMA_F16_PEAK_TF, 4), "ms_per_step": round(ms / steps, 4),
+         "launches_per_step": round(launches / steps, 2), "alg_TFLOP_s": round(fl / t / 1e12, 2),
+         "alg_GB_s": round(by / t / 1e9, 1), "hbm_frac": round(by / t / 1e9 / HBM_PEAK_GBS, 4),
+         "traffic": None, "mfma_busy": None,
+         "note": "executed rate = 3 fp16 MFMAs per fp32 product (csrc/gemm.h) against the 2.5 PF dense fp16 peak; "
+                 "mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE * 1024 SIMDs), time-weighted over the kernels"}
+    if all(x is not None for x in traffic) and traffic:
+        # bytes per STEP: per-launch PMC bytes x launches per step of each kernel
+        e["traffic"] = round(sum(pmc_traffic(n) * timing[n][1] / steps for n in names if n in timing))
+        e["traffic_note"] = "HBM bytes per step over these kernels (PMC per-launch bytes x launches per step)"
+    if all(b is not None for b, _ in busy) and busy:
+        e["mfma_busy"] = round(sum(b * w for b, w in busy) / sum(w for _, w in busy), 4)
+    return e
 
 
 def main():
@@ -187,29 +300,54 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=8, help="pairs per GPU per step")
+    ap.add_argument("--batch", type=int, default=8, help="pairs per GPU per step (weak scaling)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: --batch pairs per GPU (configs[1] x N); strong: --total-batch pairs split over the ranks (configs[2])")
+    ap.add_argument("--total-batch", type=int, default=64, help="pairs per step over ALL GPUs with --scaling strong")
     ap.add_argument("--thr", type=float, default=0.0)
     ap.add_argument("--no-conf", action="store_true", help="elide data['conf_matrix'] (not the headline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--roofline-kernel", default="auto")
     ap.add_argument("--no-overlap", action="store_true", help="run the FPN fine branch on the main stream (no second HIP stream)")
     ap.add_argument("--match-type", default="dual_softmax", choices=["dual_softmax", "sinkhorn"],
                     help="sinkhorn = BASELINE configs[4] (indoor_ot); not the headline")
     ap.add_argument("--backbone", default="hip", choices=["hip", "torch"],
-                    help="hip: implicit-GEMM convolutions of this library (default); torch: MIOpen fp32")
+                    help="hip: implicit-GEMM convolutions of this library (default; image-level parity with the reference held at "
+                         "1e-4 / 1e-3 px, profiles/r02_parity_margins.txt); torch: PyTorch-ROCm / MIOpen fp32")
+    ap.add_argument("--collective", default="auto", choices=["auto", "cabi", "torch"],
+                    help="count all-gather transport: the library's C-ABI RCCL call, or torch.distributed (also RCCL); auto = cabi, "
+                         "falling back to torch if the communicator cannot be created (recorded in the JSON)")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_spawn(sys.argv[1:], args.gpus))
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    if world != args.gpus and rank == 0:
+        print(f"[bench] --gpus {args.gpus} but WORLD_SIZE={world}: the launcher's world size is used", file=sys.stderr)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
+    rccl, transport = None, "none"
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
+        transport = "torch.distributed (nccl = RCCL)"
+        if args.collective in ("auto", "cabi"):
+            try:
+                rccl = RcclCounts(dev)
+                transport = "C-ABI loftr_rccl_allgather_counts (RCCL over xGMI)"
+            except Exception as e:                           # noqa: BLE001
+                if args.collective == "cabi":
+                    raise
+                print(f"[bench] rank {rank}: C-ABI RCCL communicator unavailable ({e}); using torch.distributed", file=sys.stderr)
+            # every rank must take the same path: agree on it
+            ok = torch.tensor([1 if rccl is not None else 0], device=dev)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 0 and rccl is not None:
+                rccl.close()
+                rccl, transport = None, "torch.distributed (nccl = RCCL)"
 
     # MIOpen picks its fastest fp32 channels-last kernels only through the find step (47.8 vs 73 ms for
     # the 16-image backbone batch, tools/micro/backbone_variants.py); the search runs during warm-up.
@@ -230,7 +368,11 @@ def main():
     model.coarse_matching.materialize_conf = not args.no_conf
     model.backbone_impl = args.backbone
     model.overlap_fine_branch = not args.no_overlap
-    B = args.batch
+    if args.scaling == "strong":
+        assert args.total_batch % world == 0, "--total-batch must be divisible by the number of ranks"
+        B = args.total_batch // world
+    else:
+        B = args.batch
     i0, i1 = make_images(1234 + rank, B, H_IMG, W_IMG)
     img0, img1 = torch.from_numpy(i0).to(dev), torch.from_numpy(i1).to(dev)
     last = {}
@@ -239,7 +381,7 @@ def main():
         data = {"image0": img0, "image1": img1}
         model(data)
         if world > 1:                                       # RCCL all-gather of the per-pair match counts
-            data["match_counts_global"] = all_gather_match_counts(data["_match_counts"][1:], world * B)
+            data["match_counts_global"] = all_gather_match_counts(data["_match_counts"][1:], world * B, rccl=rccl)
         last.clear()
         last.update(M=int(data["mconf"].shape[0]), data=data)
 
@@ -251,8 +393,12 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    if world > 1:                                            # the gathered counts must add up to the ranks' match totals
+        mt = torch.tensor([last["M"]], dtype=torch.int64, device=dev)
+        dist.all_reduce(mt)
+        assert int(last["data"]["match_counts_global"].sum().item()) == int(mt.item()), "count all-gather mismatch"
 
-    # ---- one extra untimed step with every kernel instrumented: breakdown + pick the dominant one
+    # ---- extra untimed steps with every kernel instrumented, streams serial: per-kernel breakdown
     lib.loftr_hip_timing_enable((1 << len(ids)) - 1)
     for kid in ids.values():
         read_timing(lib, kid)
@@ -278,39 +424,51 @@ def main():
     for name, kid in ids.items():
         ms, n = read_timing(lib, kid)
         if name in work and n:
-            kernels.append(roofline_entry(name, ms, n, work[name][0], work[name][1], NB))
+            e = roofline_entry(name, ms, n, work[name][0], work[name][1], NB)
+            if e:
+                e["traffic"] = pmc_traffic(name)
+                e["mfma_busy"] = pmc_mfma_busy(name)
+                kernels.append(e)
     model.overlap_fine_branch = not args.no_overlap
-    kernels = [k for k in kernels if k]
     kernels.sort(key=lambda k: -k["ms_per_step"])
-    dom = args.roofline_kernel if args.roofline_kernel != "auto" else (kernels[0]["kernel"] if kernels else None)
 
-    # ---- timed region: only the dominant kernel carries events
-    lib.loftr_hip_timing_enable(1 << ids[dom] if dom else 0)
-    if dom:
-        read_timing(lib, ids[dom])
+    # ---- timed region: the north_star kernels (score volume + encoder) carry events
+    timed_ids = [n for n in NORTH_STAR_TIMED if n in ids]
+    if args.match_type != "dual_softmax":
+        timed_ids = [n for n in timed_ids if not n.startswith("score_")]
+    mask = 0
+    for n in timed_ids:
+        mask |= 1 << ids[n]
+        read_timing(lib, ids[n])
+    lib.loftr_hip_timing_enable(mask)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     barrier()
-    elapsed = time.perf_counter() - t0
+    elapsed_local = time.perf_counter() - t0
     lib.loftr_hip_timing_enable(0)
+    timing = {}
+    for n in timed_ids:
+        ms, cnt = read_timing(lib, ids[n])
+        if cnt:
+            timing[n] = (ms, cnt)
     roof = None
-    if dom:
-        ms, n = read_timing(lib, ids[dom])
-        roof = roofline_entry(dom, ms, n, work[dom][0], work[dom][1], args.steps)
-        if roof:
-            roof["traffic"] = pmc_traffic(dom)
-            if not args.no_overlap and args.backbone == "hip":
-                solo = next((k for k in kernels if k["kernel"] == dom), None)
-                roof["note"] = ("timed region: the fine-branch launches of this kernel run on the side stream CONCURRENTLY with the "
-                                "coarse stage, so their durations (and this average) include time-slicing with other kernels; "
-                                "running alone (instrumented steps, `kernels`): avg %.1f us, frac %.3f"
-                                % ((solo["avg_launch_us"], solo["frac"]) if solo else (float("nan"), float("nan"))))
+    if "score_conf_kernel" in timing:
+        ms, cnt = timing["score_conf_kernel"]
+        roof = roofline_entry("score_conf_kernel", ms, cnt, work["score_conf_kernel"][0], work["score_conf_kernel"][1], args.steps)
+        roof["bound"], roof["achieved"], roof["peak"], roof["unit"], roof["frac"] = "hbm", roof["alg_GB_s"], HBM_PEAK_GBS, "GB/s", roof["hbm_frac"]
+        roof["traffic"] = pmc_traffic("score_conf_kernel")
+        roof["note"] = ("north_star score-volume kernel (dual-softmax pass B: recompute the score tile on MFMA, write conf_matrix "
+                        "once): algorithmic bytes = descriptors + conf_matrix (DESIGN.md §4) / in-region hipEvent launch time")
+    roof_enc = group_roofline([n for n in ENCODER_KERNELS if n in timing], timing, work, args.steps)
+    elapsed, per_rank_ms = elapsed_local, [round(elapsed_local / args.steps * 1e3, 3)]
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        t = torch.tensor([elapsed_local], dtype=torch.float64, device=dev)
+        allt = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(allt, t)
+        per_rank_ms = [round(float(x.item()) / args.steps * 1e3, 3) for x in allt]
+        elapsed = max(float(x.item()) for x in allt)
         mt = torch.tensor([last["M"]], dtype=torch.int64, device=dev)
         dist.all_reduce(mt)
         m_total = int(mt.item())
@@ -320,30 +478,39 @@ def main():
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = world * B * args.steps / elapsed
+        bb_desc = ("HIP implicit-GEMM / patch convolutions incl. the 7x7 stem" if args.backbone == "hip" else "PyTorch-ROCm / MIOpen fp32")
         out = {
             "metric": "image-pairs/sec @640x480 indoor-ds", "value": round(value, 3), "unit": "image-pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "dtype_note": "fp32 data everywhere; every GEMM / convolution evaluates each fp32 product as 3 fp16 MFMAs on a "
                           "(hi, lo) fp16 split with fp32 accumulation (fp32-class accuracy, csrc/gemm.h); --backbone torch = MIOpen fp32",
             "config": {"workload": f"batch={B} 640x480 synthetic grayscale pairs per GPU, indoor_ds dual-softmax "
-                                   f"(BASELINE configs[1]), full LoFTR.forward = ResNet-FPN backbone ({'HIP implicit-GEMM / patch convolutions incl. the 7x7 stem' if args.backbone == 'hip' else 'PyTorch-ROCm / MIOpen fp32'}) + HIP matching path",
+                                   f"({'BASELINE configs[1]' if args.scaling == 'weak' else 'BASELINE configs[2]: fixed total ' + str(world * B)}), "
+                                   f"full LoFTR.forward = ResNet-FPN backbone ({bb_desc}) + HIP matching path",
                        "weights": "seeded random init (no checkpoint on the box)", "thr": args.thr,
                        "thr_note": "stock thr 0.2 gives 0 matches with random weights; thr 0.0 keeps the fine stage loaded",
                        "conf_matrix_materialised": not args.no_conf, "match_type": args.match_type, "matches_per_pair": round(m_total / (world * B), 1),
-                       "global_batch": world * B, "parallelism": f"dp{world} (pairs sharded; RCCL all-gather of match counts)"},
+                       "global_batch": world * B, "parallelism": f"dp{world} (pairs sharded; RCCL all-gather of match counts)",
+                       "parity": "image-level goldens of the reference forward, both backbones: profiles/r02_parity_margins.txt"},
+            "per_rank_ms_per_step": per_rank_ms,
+            "collective": {"transport": transport, "ranks_in_communicator": (rccl.ranks_seen if rccl is not None else world) if world > 1 else 1},
             "stage_ms": {"backbone": round(backbone_ms, 3), "backbone_impl": args.backbone, "hot_path_hip": round(hot_ms, 3),
                          "note": "mean of 3 instrumented steps run WITHOUT the two-stream overlap (serial sum > ms_per_step when "
                                  "the timed region overlaps the FPN fine branch with the coarse stage); `kernels` likewise"},
             "fine_branch_overlapped_in_timed_region": not args.no_overlap,
             "hot_path_pairs_per_s": round(B / (hot_ms * 1e-3), 2),
-            "roofline": roof, "kernels": kernels,
+            "roofline": roof, "roofline_encoder": roof_enc, "kernels": kernels,
+            "pmc_source": ("profiles/pmc_traffic.json (rocprofv3 --pmc passes of this build, source hash " + source_hash() + ")")
+                          if pmc_table() else "no PMC passes for this build of the kernels: traffic / mfma_busy are null",
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(model, img0, img1)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
+        if rccl is not None:
+            rccl.close()
         dist.destroy_process_group()
 
 

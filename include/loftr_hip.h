@@ -31,10 +31,11 @@ typedef enum {
   LOFTR_ERR_UNSUPPORTED = -2,   /* shape outside what the kernels are built for (C, H, D, W)   */
   LOFTR_ERR_WORKSPACE = -3,     /* workspace smaller than *_workspace_bytes()                  */
   LOFTR_ERR_LAUNCH = -4,        /* HIP reported a launch error                                 */
-  LOFTR_ERR_NO_DEVICE = -5      /* no gfx950 device visible                                    */
+  LOFTR_ERR_NO_DEVICE = -5,     /* no gfx950 device visible                                    */
+  LOFTR_ERR_COMM = -6           /* RCCL unavailable or a collective / communicator call failed */
 } loftr_status;
 
-#define LOFTR_HIP_ABI_VERSION 11
+#define LOFTR_HIP_ABI_VERSION 12
 
 int loftr_hip_abi_version(void);
 const char* loftr_hip_status_string(int status);
@@ -248,6 +249,21 @@ int loftr_resize_linear_u8(const uint8_t* src, int sh, int sw, long src_pitch, u
                            long dst_pitch, void* stream);
 int loftr_pack_gray_u8(const uint8_t* src, long src_image_pitch, long src_row_pitch, const int* hw, int N, int PH,
                        int PW, float* image, uint8_t* mask, uint8_t* mask_c, int coarse_div, void* stream);
+
+/* ---- multi-GPU: the one data-path collective (SURVEY.md §8(b),(e)) -----------------------------------
+ * Replaces the reference's result merge across DDP ranks (test.py:65 + src/lightning/data.py:315 shard the pairs,
+ * src/utils/comm.py:113-219 gathers pickled results over gloo): pairs are independent, so all a rank needs from
+ * the others is how many matches each of THEIR pairs produced -- an RCCL all-gather of int32[n] per rank over xGMI
+ * on the caller's stream (latency bound; no host round trip).  counts_out[r*n + k] = counts_in[k] of rank r.
+ * The communicator is an opaque handle bound to the HIP device current at creation; the 128-byte unique id comes
+ * from loftr_rccl_unique_id on one rank and reaches the others through the caller's control plane.
+ * librccl is dlopen'ed on first use: LOFTR_ERR_COMM if it is missing or any RCCL call fails. */
+#define LOFTR_RCCL_ID_BYTES 128
+int loftr_rccl_unique_id(char* id_out, size_t id_bytes);
+int loftr_rccl_comm_create(const char* id, size_t id_bytes, int rank, int world, void** comm_out);
+int loftr_rccl_comm_info(void* comm, int* rank_out, int* world_out);
+int loftr_rccl_comm_destroy(void* comm);
+int loftr_rccl_allgather_counts(void* comm, const int32_t* counts_in, int32_t* counts_out, int n, void* stream);
 
 /* ---- per-kernel timing (profiling aid; the only process-global state of the library) ---------
  * When bit `id` of the mask is set, every launch of that kernel is bracketed by hipEvents

@@ -66,6 +66,11 @@ SIGNATURES = {
     "loftr_conv1x1_upsample_add": (_i, [_p, _i, _i, _i, _i, _p, C.POINTER(_l), _i, _p, _p, _p, _sz, _p]),
     "loftr_sp_from_f32": (_i, [_p, _p, _l, _i, _p]),
     "loftr_sp_to_f32": (_i, [_p, _p, _l, _i, _p]),
+    "loftr_rccl_unique_id": (_i, [C.c_char_p, _sz]),
+    "loftr_rccl_comm_create": (_i, [C.c_char_p, _sz, _i, _i, C.POINTER(_p)]),
+    "loftr_rccl_comm_info": (_i, [_p, C.POINTER(_i), C.POINTER(_i)]),
+    "loftr_rccl_comm_destroy": (_i, [_p]),
+    "loftr_rccl_allgather_counts": (_i, [_p, _p, _p, _i, _p]),
     "loftr_hip_timing_enable": (_i, [C.c_uint]),
     "loftr_hip_timing_kernel_count": (_i, []),
     "loftr_hip_timing_kernel_name": (C.c_char_p, [_i]),
@@ -74,7 +79,7 @@ SIGNATURES = {
     "loftr_linear_fwd": (_i, [_p, _p, _p, _i, _i, _i, _p, _sz, _p]),
 }
 
-ABI_VERSION = 11
+ABI_VERSION = 12
 _lib = None
 
 

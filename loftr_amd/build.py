@@ -15,7 +15,7 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ_DIR = os.path.join(CSRC, "build")
 LIB_PATH = os.path.join(HERE, "libloftr_hip.so")
 SOURCES = ["linear.hip", "attention.hip", "transformer.hip", "coarse_match.hip", "fine.hip", "misc.hip",
-           "sp_convert.hip", "conv.hip", "eval.hip", "input.hip"]
+           "sp_convert.hip", "conv.hip", "eval.hip", "input.hip", "comm.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-parameter"]
 
 
@@ -63,7 +63,7 @@ def _build(force, verbose, extra_flags):
 
     with ThreadPoolExecutor(max_workers=min(8, len(SOURCES))) as ex:
         objs = list(ex.map(compile_one, SOURCES))
-    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH, *objs],
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH, *objs, "-ldl"],
                        capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stderr}")

@@ -125,6 +125,7 @@ extern "C" const char* loftr_hip_status_string(int status) {
     case LOFTR_ERR_WORKSPACE: return "workspace too small";
     case LOFTR_ERR_LAUNCH: return "HIP kernel launch failed";
     case LOFTR_ERR_NO_DEVICE: return "no gfx950 (MI355X) device";
+    case LOFTR_ERR_COMM: return "RCCL unavailable or a communicator / collective call failed";
     default: return "unknown status";
   }
 }

@@ -15,7 +15,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .ops import _ptr, _stream, check
+from .ops import _ptr, _stream, check, _on_device
 
 
 def get_resized_wh(w, h, resize=None):
@@ -33,6 +33,7 @@ def get_divisible_wh(w, h, df=None):
     return w, h
 
 
+@_on_device
 def resize_linear_u8(img, dsize):
     """cv2.resize(img, dsize) (default INTER_LINEAR) for a uint8 grayscale DEVICE tensor [h, w] -> [h_new, w_new];
     dsize = (w_new, h_new).  Parity unpinned (see include/loftr_hip.h): OpenCV's algorithm restated, not verified against
@@ -97,6 +98,13 @@ def pack_gray(images, pad_hw=None, coarse_div=8, device="cuda", want_mask=True):
     if not torch.cuda.is_available():
         raise _lib.LoftrHipError("pack_gray needs a GPU (no CPU fallback)")
     dev = torch.device(device)
+    if dev.index is None:
+        dev = torch.device("cuda", torch.cuda.current_device())
+    with torch.cuda.device(dev):                     # copy, event and launch all on the target GPU's current stream
+        return _pack_gray_on(dev, arrs, N, hmax, wmax, PH, PW, masks, coarse_div)
+
+
+def _pack_gray_on(dev, arrs, N, hmax, wmax, PH, PW, masks, coarse_div):
     # staging: a slot of the persistent pinned ring (one row pitch for the batch, the (h, w) table behind the pixels),
     # filled with plain memcpys and uploaded by ONE asynchronous H2D copy of ~1 B / pixel
     pitch = (wmax + 3) // 4 * 4

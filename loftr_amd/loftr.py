@@ -221,8 +221,17 @@ class FineMatching(nn.Module):
         # reference quirk kept: scale1 is applied iff 'scale0' is in the batch (fine_matching.py:68)
         scale1 = data["scale1"] if "scale0" in data else None
         n = len(data["mconf"])
-        expec, mk1f = ops.fine_match(feat_f0, feat_f1, data["mkpts1_c"], data["b_ids"], scale, scale1)
-        data.update({"expec_f": expec, "mkpts0_f": data["mkpts0_c"], "mkpts1_f": mk1f[:n]})
+        if data["mkpts1_c"].shape[0] == M:
+            expec, mk1f = ops.fine_match(feat_f0, feat_f1, data["mkpts1_c"], data["b_ids"], scale, scale1)
+            mk1f = mk1f[:n]
+        else:
+            # thr < 0 only: CoarseMatching dropped the `mconf == 0` rows from mkpts*_c (coarse_matching.py:254-258)
+            # but not from b_ids, so there are M windows and n < M coarse points.  The reference then adds the
+            # refinement of the FIRST n windows to the n kept points (fine_matching.py:69, `[:len(mconf)]`): the
+            # kernel computes all M offsets from a zero base (one base point per window, never out of bounds).
+            expec, off = ops.fine_match(feat_f0, feat_f1, torch.zeros(M, 2, device=feat_f0.device), data["b_ids"], scale, scale1)
+            mk1f = data["mkpts1_c"] + off[:n]
+        data.update({"expec_f": expec, "mkpts0_f": data["mkpts0_c"], "mkpts1_f": mk1f})
 
 
 class LoFTR(nn.Module):
@@ -261,7 +270,7 @@ class LoFTR(nn.Module):
             x = cl(torch.cat([data["image0"], data["image1"]], dim=0))
             if use_hip and self.overlap_fine_branch:
                 feats_c, fine_fn = run(x, defer_fine=True)
-                main = torch.cuda.current_stream()
+                main = torch.cuda.current_stream(x.device)
                 if self._side_stream is None:
                     self._side_stream = torch.cuda.Stream(device=x.device)
                 side = self._side_stream
@@ -295,7 +304,7 @@ class LoFTR(nn.Module):
         feat_c0, feat_c1 = self.loftr_coarse(feat_c0, feat_c1, mask_c0, mask_c1, inplace=True)   # fresh pos-encoded copies
         self.coarse_matching(feat_c0, feat_c1, data, mask_c0=mask_c0, mask_c1=mask_c1)
         if getattr(self, "_fine_join", None) is not None:    # fine maps come from the side stream
-            torch.cuda.current_stream().wait_stream(self._fine_join)
+            torch.cuda.current_stream(feat_f0.device).wait_stream(self._fine_join)
             self._fine_join = None
         feat_f0_unfold, feat_f1_unfold = self.fine_preprocess(feat_f0, feat_f1, feat_c0, feat_c1, data)
         if feat_f0_unfold.size(0) != 0:
@@ -309,8 +318,15 @@ class LoFTR(nn.Module):
         data: image0, image1 [N,1,H,W] float; optional mask0/mask1 [N,H/8,W/8] ('0' = padded),
         scale0/scale1 [N,2].
         """
-        feat_c0, feat_c1, feat_f0, feat_f1 = self.run_backbone(data)
-        self.match_from_features(feat_c0, feat_c1, feat_f0, feat_f1, data)
+        dev = data["image0"].device
+        if data["image1"].device != dev:
+            raise ops._lib.LoftrHipError(f"image0 on {dev} but image1 on {data['image1'].device}")
+        if dev.type != "cuda":                       # CPU tensors: the ops raise (no fallback); keep their message
+            feat_c0, feat_c1, feat_f0, feat_f1 = self.run_backbone(data)
+            return self.match_from_features(feat_c0, feat_c1, feat_f0, feat_f1, data)
+        with torch.cuda.device(dev):                 # streams / workspaces / launches all on the tensors' GPU
+            feat_c0, feat_c1, feat_f0, feat_f1 = self.run_backbone(data)
+            self.match_from_features(feat_c0, feat_c1, feat_f0, feat_f1, data)
 
     def load_state_dict(self, state_dict, *args, **kwargs):
         for k in list(state_dict.keys()):

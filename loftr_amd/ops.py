@@ -5,6 +5,7 @@ path happens in the HIP kernels.  Every wrapper requires CUDA(ROCm) float32 cont
 and raises otherwise -- there is no CPU fallback.
 """
 import ctypes as C
+import functools
 
 import torch
 
@@ -17,6 +18,39 @@ LAYER_FIELDS = (("q_proj", "q_proj.weight"), ("k_proj", "k_proj.weight"), ("v_pr
                 ("merge", "merge.weight"), ("mlp0", "mlp.0.weight"), ("mlp2", "mlp.2.weight"),
                 ("norm1_w", "norm1.weight"), ("norm1_b", "norm1.bias"),
                 ("norm2_w", "norm2.weight"), ("norm2_b", "norm2.bias"))
+
+
+def _tensors_in(obj):
+    if isinstance(obj, torch.Tensor):
+        yield obj
+    elif isinstance(obj, (list, tuple)):
+        for o in obj:
+            yield from _tensors_in(o)
+    elif isinstance(obj, torch.nn.Module):
+        for prm in obj.parameters():
+            yield prm
+            break
+
+
+def _on_device(fn):
+    """Run a wrapper with the GPU of its tensor arguments current: the C entry points launch on the stream handle they
+    are given and never call hipSetDevice, so stream, workspace and pointers must all belong to ONE device -- the
+    tensors' device, not whatever device happens to be current (a model on cuda:1 without torch.cuda.set_device).
+    Tensors on different devices are rejected."""
+    @functools.wraps(fn)
+    def wrapped(*args, **kwargs):
+        dev = None
+        for t in _tensors_in(list(args) + list(kwargs.values())):
+            if t.is_cuda:
+                if dev is None:
+                    dev = t.device
+                elif t.device != dev:
+                    raise _lib.LoftrHipError(f"{fn.__name__}: tensors on different devices ({dev} and {t.device})")
+        if dev is None:
+            return fn(*args, **kwargs)            # no GPU tensor: the body raises its own 'expected a GPU tensor'
+        with torch.cuda.device(dev):
+            return fn(*args, **kwargs)
+    return wrapped
 
 
 def _need(t, name, dtype=torch.float32):
@@ -38,10 +72,10 @@ def _stream():
 
 
 def workspace(nbytes, device):
-    """Cached scratch buffer of at least nbytes on `device`, one per (device, current stream): calls on one
-    stream may share it (stream ordered), concurrent streams must not."""
+    """Cached scratch buffer of at least nbytes on `device`, one per (device, that device's current stream): calls
+    on one stream may share it (stream ordered), concurrent streams must not."""
     idx = (device.index if device.index is not None else torch.cuda.current_device(),
-           torch.cuda.current_stream().cuda_stream)
+           torch.cuda.current_stream(device).cuda_stream)
     buf = _WS.get(idx)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(int(nbytes * 1.25) + 4096, dtype=torch.uint8, device=device)
@@ -58,6 +92,7 @@ def _mask_u8(m, name):
 
 
 # ---------------------------------------------------------------------------------------------
+@_on_device
 def linear(a, w):
     """a [M,K] @ w[N,K]^T on the split-fp16 GEMM core (building block, exposed for tests)."""
     _need(a, "a"); _need(w, "w")
@@ -70,6 +105,7 @@ def linear(a, w):
     return out
 
 
+@_on_device
 def pos_encode_flatten(feat, pe):
     """feat [N,C,H,W] (any strides, e.g. channels-last) + pe[:, :H, :W], flattened to [N, H*W, C]."""
     if not feat.is_cuda or feat.dtype != torch.float32:
@@ -91,6 +127,7 @@ def layer_weights_struct(tensors):
     return lw
 
 
+@_on_device
 def encoder_layer(x, source, w_struct, nhead, x_mask=None, source_mask=None, out=None):
     """One LoFTREncoderLayer.  x [nb,L,C], source [nb,S,C] -> [nb,L,C]."""
     _need(x, "x"); _need(source, "source")
@@ -120,6 +157,7 @@ def stacked_halves(a, b):
     return torch.as_strided(a, (a.shape[0] + b.shape[0],) + tuple(a.shape[1:]), a.stride(), a.storage_offset())
 
 
+@_on_device
 def transformer(feat0, feat1, layer_structs, layer_names, nhead, mask0=None, mask1=None, inplace=False):
     """LocalFeatureTransformer.forward.  Returns new (feat0, feat1); inputs are not modified unless
     ``inplace`` (then, when feat0 / feat1 are the contiguous halves of one buffer, the layers run on
@@ -149,6 +187,7 @@ def transformer(feat0, feat1, layer_structs, layer_names, nhead, mask0=None, mas
     return f0, f1
 
 
+@_on_device
 def coarse_match(feat_c0, feat_c1, hw0_c, hw1_c, thr, border_rm, scale, match_type="dual_softmax",
                  temperature=0.1, bin_score=None, skh_iters=3, skh_prefilter=False, mask0=None, mask1=None,
                  scale0=None, scale1=None, want_conf=True, want_assign=False):
@@ -207,6 +246,7 @@ def _fmap(t):
     return FMap(t.data_ptr(), sn, sc, sh, sw, t.shape[2], t.shape[3])
 
 
+@_on_device
 def fine_preprocess(feat_f0, feat_f1, feat_c0, feat_c1, b_ids, i_ids, j_ids, hw0_c, hw1_c, W, stride,
                     down_w=None, down_b=None, merge_w=None, merge_b=None):
     """FinePreprocess.forward for M > 0.  Returns (feat_f0_unfold, feat_f1_unfold) [M, W*W, Cf]."""
@@ -233,6 +273,7 @@ def fine_preprocess(feat_f0, feat_f1, feat_c0, feat_c1, b_ids, i_ids, j_ids, hw0
     return out0, out1
 
 
+@_on_device
 def fine_match(feat_f0, feat_f1, mkpts1_c, b_ids, scale, scale1=None):
     """FineMatching for M > 0.  Returns (expec_f [M,3], mkpts1_f [M,2])."""
     _need(feat_f0, "feat_f0"); _need(feat_f1, "feat_f1")
@@ -254,6 +295,7 @@ def ceil32(c):
     return (c + 31) // 32 * 32
 
 
+@_on_device
 def sp_from_nhwc(x_nhwc):
     """fp32 [B,H,W,C] contiguous -> SP int32 [B,H,W,ceil32(C)]."""
     _need(x_nhwc, "x_nhwc")
@@ -263,6 +305,7 @@ def sp_from_nhwc(x_nhwc):
     return out
 
 
+@_on_device
 def sp_to_nhwc(x_sp, Cc):
     """SP int32 [B,H,W,Cp] -> fp32 [B,H,W,C]."""
     B, H, W, _ = x_sp.shape
@@ -300,6 +343,7 @@ def _prepared_conv(conv, bn):
 CONV_SHARED_GPU = 0x100      # include/loftr_hip.h: LOFTR_CONV_SHARED_GPU
 
 
+@_on_device
 def conv_bn_act(x_sp, Cin, conv, bn=None, act=0, residual=None, want_sp=True, want_f32=False, low_sp=None, shared_gpu=False):
     """nn.Conv2d(bias=False) [+ eval BatchNorm2d] [+ residual] [+ act] on an SP activation.
 
@@ -324,6 +368,7 @@ def conv_bn_act(x_sp, Cin, conv, bn=None, act=0, residual=None, want_sp=True, wa
     return y_sp, y_f32
 
 
+@_on_device
 def stem_conv_bn_relu(x, conv, bn):
     """conv1 (7x7, stride 2, one input channel) + eval bn1 + relu -> SP int32 [B,Ho,Wo,ceil32(C0)]."""
     if not x.is_cuda or x.dtype != torch.float32 or x.shape[1] != 1:
@@ -353,6 +398,7 @@ def conv1x1_upsample_add(x_sp, Cin, conv, low_sp):
     return conv_bn_act(x_sp, Cin, conv, low_sp=low_sp)[0]
 
 
+@_on_device
 def upsample2x_add(low_sp, lateral_sp, Cc):
     """lateral + bilinear x2 (align_corners=True) of low; SP in, SP out."""
     B, Hl, Wl, Cp = low_sp.shape
@@ -363,6 +409,7 @@ def upsample2x_add(low_sp, lateral_sp, Cc):
     return out
 
 
+@_on_device
 def epipolar_errors(mkpts0_f, mkpts1_f, m_bids, T_0to1, K0, K1):
     """Squared symmetric epipolar distance of every match (metrics.py:31-68) -> float32 [M], match order."""
     for name, t, dt in (("mkpts0_f", mkpts0_f, torch.float32), ("mkpts1_f", mkpts1_f, torch.float32), ("m_bids", m_bids, torch.int64),

@@ -1,7 +1,12 @@
 #!/usr/bin/env python
 """Per-kernel HBM traffic from two rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE, rocpd sqlite).
 
-    python tools/rocpd_pmc.py <fetch.db> <write.db> [--json profiles/pmc_traffic.json]
+    python tools/rocpd_pmc.py <fetch.db> <write.db> [--sq <sq.db>] [--json profiles/pmc_traffic.json]
+
+--sq: a third pass with `--pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE`: per kernel
+mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE * 1024 SIMDs)  (the gfx94x MfmaUtil formula; the counter
+advances 32 cycles per v_mfma_f32_32x32x16_f16, MI355X_MICROARCH.md).  The JSON is stamped with the hash of the kernel
+sources (bench.py:source_hash) so that bench.py only quotes PMC numbers collected on the build it is running.
 
 FETCH_SIZE / WRITE_SIZE are reported by rocprofv3 in KiB.  gfx950 correction (MI355X_MICROARCH.md
 §HBM): FETCH_SIZE counts the 128-B requests of a wide coalesced streaming read at 64 B, i.e. it
@@ -30,6 +35,10 @@ def short(name):
 
 def main():
     fetch, write = per_kernel(sys.argv[1], "FETCH_SIZE"), per_kernel(sys.argv[2], "WRITE_SIZE")
+    busy, active = {}, {}
+    if "--sq" in sys.argv:
+        sq = sys.argv[sys.argv.index("--sq") + 1]
+        busy, active = per_kernel(sq, "SQ_VALU_MFMA_BUSY_CYCLES"), per_kernel(sq, "GRBM_GUI_ACTIVE")
     out = {}
     print(f"{'kernel':44s} {'calls':>6} {'fetch_x2 MB':>12} {'write MB':>10} {'hbm MB/launch':>14}")
     for k in sorted(set(fetch) | set(write), key=lambda k: -(fetch.get(k, {}).get('avg_kib', 0) * fetch.get(k, {}).get('n', 0))):
@@ -42,7 +51,25 @@ def main():
         key = short(k)
         tag = key if key not in out else key + "#" + str(sum(1 for x in out if x.startswith(key)))
         out[tag] = dict(full_name=k[:160], launches=n, fetch_bytes_x2=f, write_bytes=w, hbm_bytes_per_launch=f + w)
-        print(f"{tag:44s} {n:6d} {f / 1e6:12.2f} {w / 1e6:10.2f} {(f + w) / 1e6:14.2f}")
+        extra = ""
+        if k in busy and k in active and active[k]["avg_kib"]:
+            # (per_kernel's "avg_kib" field is just the average counter value)
+            out[tag]["mfma_busy_cycles"] = busy[k]["avg_kib"]
+            out[tag]["gui_active_cycles"] = active[k]["avg_kib"]
+            out[tag]["mfma_busy"] = busy[k]["avg_kib"] / (active[k]["avg_kib"] * 1024.0)
+            extra = f"  mfma_busy {out[tag]['mfma_busy']:.3f}"
+        print(f"{tag:44s} {n:6d} {f / 1e6:12.2f} {w / 1e6:10.2f} {(f + w) / 1e6:14.2f}{extra}")
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    try:
+        b = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(b)
+        out["_meta"] = dict(source_hash=b.source_hash(), fetch_correction="FETCH_SIZE x2 (gfx950)", write_correction="none")
+        print("# source hash", out["_meta"]["source_hash"])
+    except Exception as e:      # noqa: BLE001
+        print("# could not stamp the source hash:", e)
     if "--json" in sys.argv:
         json.dump(out, open(sys.argv[sys.argv.index("--json") + 1], "w"), indent=1)
 
