@@ -230,14 +230,18 @@ __device__ __forceinline__ void conf_partials(f32x16 (&acc)[Cfg::TM][Cfg::TN], i
     half_max16(bv);                                  // maximum over the wave's 64-column strip
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      int bc = 0x7fffffff;                           // first column that attains it
+      int bc = 0x7fffffff, bl = 0x7fffffff;          // first column that attains it / minus the last one
 #pragma unroll
       for (int j = Cfg::TN - 1; j >= 0; --j)
         if (acc[i][j][r] == bv[r]) bc = n0 + e.lcol + j * 32;
+#pragma unroll
+      for (int j = 0; j < Cfg::TN; ++j)
+        if (acc[i][j][r] == bv[r]) bl = -(n0 + e.lcol + j * 32);
       bc = half_min_i32(bc);
+      bl = half_min_i32(bl);
       const int trow = e.lrow + e.rr(i, r);
-      if ((lane & 31) == 0 && (FULL || m0 + trow < g.L))
-        rp[trow] = make_float2(bv[r], __int_as_float(bc));
+      if ((lane & 31) == 0 && (FULL || m0 + trow < g.L))      // attained at two different columns: TIE_BIT (select_kernel)
+        rp[trow] = make_float2(bv[r], __int_as_float(bc | (bc != -bl ? (1 << 30) : 0)));
     }
   }
 #pragma unroll
@@ -312,6 +316,273 @@ __global__ __launch_bounds__(Cfg::THREADS, 2) void score_conf_kernel(
   }
 }
 
+// ==========================================================================================
+// Score-volume kernels, second generation (C == 256): a STATIONARY-OPERAND SWEEP instead of a tiled GEMM.
+//
+// A wave keeps the fp16 (hi, lo) MFMA fragments of 32 descriptors of image 0 for the whole K = 256 in
+// registers (128 VGPRs) and sweeps them over 32-column panels of image-1 descriptors that the workgroup's
+// EIGHT waves (256 rows, one workgroup per CU) share through LDS: 32 KB per panel, a four-stage ring filled by
+// global_load_lds two panels ahead.  Per panel and wave: 48 MFMAs from 32 ds_read_b128 -- no B-operand staging,
+// ONE s_barrier per panel (per 48 MFMAs; the tiled loop needs one per 24) and 85 B of DMA per MFMA (341 B
+// there): the global -> LDS path (~6.5 TB/s chip-wide) was what bounded a 4-wave version of this kernel.
+// The MFMA is issued with the image-1 panel as the A (row) operand and the image-0 fragments as the B (column)
+// operand, so in the accumulator layout a LANE owns one row i of the score matrix (lane & 31) and its 16
+// registers are 16 columns j = 8 (r >> 2) + 4 (lane >> 5) + (r & 3) of the panel:
+//   * row statistics (pass A: online max / sum exp; pass B: running max + first argmax of conf) are lane-private
+//     running values over the whole sweep -- no cross-lane reduction per tile, one half-wave exchange at the end;
+//   * each lane holds 4 consecutive columns per register quad -> conf_matrix leaves as 16-byte stores;
+//   * column statistics are a 32-lane DPP reduction per panel and wave, written as per-wave partials.
+// The two waves that share a SIMD (w and w + 4) run HALF A PERIOD APART: waves 0-3 do {MFMAs of panel p, epilogue
+// of panel p} between two barriers, waves 4-7 do {epilogue of panel p-1, MFMAs of panel p}, so one wave's VALU-only
+// epilogue (exp, DPP reductions, stores) always runs under its partner's MFMAs instead of next to its epilogue.
+// No LDS store and no VGPR-destination global load is issued inside the panel loop: either makes hipcc wait
+// vmcnt(0) and would drain the DMA ring every iteration.
+// Work unit = (pair, 256-row block, chunk of panels); the chunking depends on S only, so a pair's results do not
+// depend on the batch it is in.  Row partials: one per (row, chunk); column partials: one per (column, 32-row wave).
+namespace sweep {
+constexpr int W = 8, BR = 32 * W, PC = 32, KS = 16, STAGE = PC * 1024, NST = 4, MAXP = 32;
+constexpr int OFF_CSTAT = NST * STAGE;                    // float2 [MAXP * PC] column (max, 1/sum) of the chunk (pass B)
+constexpr int OFF_MASK = OFF_CSTAT + MAXP * PC * 8;       // uint8  [MAXP * PC] mask1 of the chunk
+constexpr int LDS_BYTES = OFF_MASK + MAXP * PC;
+static_assert(LDS_BYTES <= 160 * 1024, "one workgroup per CU");
+constexpr int DMA_PER_WAVE = PC * 8 / 8 / W;              // global_load_lds instructions per wave per panel (4)
+constexpr int TIE_BIT = 1 << 30;                          // set in the argmax word of a row partial: the maximum is attained twice
+
+struct Args {
+  const sp_t* f0; const sp_t* f1;
+  int N, L, S;
+  int RB, NCH, PPC, NP;             // row blocks, column chunks, panels per chunk, panels in total
+  float scale;
+  const uint8_t* mask0; const uint8_t* mask1;
+  float2* rowpart; float2* colpart;                 // pass A out: [N][NCH][L], [N][RB * W][S]
+  const float2* rowstat; const float2* colstat;     // pass B in
+  float* conf;                                      // pass B out or null
+  float2* rowmax_part; float* colmax_part;          // pass B out: [N][NCH][L] (max, argmax | TIE_BIT), [N][RB * W][S]
+};
+
+__device__ __forceinline__ int jr(int r, int g) { return 8 * (r >> 2) + 4 * g + (r & 3); }
+// the value of register (lane & 15) of a 16-register vector: lane l of a half-wave then owns column jr(l & 15, g)
+__device__ __forceinline__ float pick16(const f32x16& v, int sel) {
+  float x = v[0];
+#pragma unroll
+  for (int r = 1; r < 16; ++r) x = sel == r ? v[r] : x;
+  return x;
+}
+
+template <int PASS, bool HAS_MASK>
+__global__ __launch_bounds__(512, 2) void score_sweep_kernel(Args a) {
+  __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+  typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+  // ---- unit: groups (chunk, pair) are dealt to the XCDs; the row blocks of a group run back to back on it
+  const int id = blockIdx.x, xcd = id % NUM_XCD, slot = id / NUM_XCD;
+  const int grp = (slot / a.RB) * NUM_XCD + xcd, rb = slot % a.RB;
+  if (grp >= a.N * a.NCH) return;
+  const int n = grp % a.N, cc = grp / a.N;
+  const int p0 = cc * a.PPC, np = min(a.PPC, a.NP - p0);      // panels of this chunk (>= 1 by construction)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 5, li = lane & 31;
+  const bool late = wave >= W / 2;                             // this wave runs its epilogue half a period later
+  const int L = a.L, S = a.S;
+  const int row = rb * BR + wave * 32 + li;
+  const bool row_ok = row < L;
+  const bool rows_full = rb * BR + BR <= L;                    // block-uniform
+  const sp_t* f0n = a.f0 + (long)n * L * 256;
+  const sp_t* f1n = a.f1 + (long)n * S * 256;
+
+  // ---- stationary operand: this lane's 16-byte MFMA fragments of its row, all 16 k-steps, hi and lo
+  h16x8 bh[KS], bl[KS];
+  {
+    const u32x4* src = reinterpret_cast<const u32x4*>(f0n + (long)min(row, L - 1) * 256);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int c = (ks >> 1) * 8 + 2 * (ks & 1) + g;
+      bh[ks] = __builtin_bit_cast(h16x8, src[c]);
+      bl[ks] = __builtin_bit_cast(h16x8, src[c + 4]);
+    }
+  }
+  // ---- chunk tables -> LDS (ordinary loads and LDS stores happen only here, before any DMA is in flight)
+  float2* cstat_s = reinterpret_cast<float2*>(lds + OFF_CSTAT);
+  uint8_t* mask_s = reinterpret_cast<uint8_t*>(lds + OFF_MASK);
+  for (int t = threadIdx.x; t < np * PC; t += 512) {
+    const int col = min(p0 * PC + t, S - 1);
+    if (PASS == 1) cstat_s[t] = a.colstat[(long)n * S + col];
+    if (HAS_MASK) mask_s[t] = a.mask1[(long)n * S + col];
+  }
+  float rm = 0.f, rs = 0.f;                        // pass B: row (max, 1/sum)
+  if (PASS == 1) { const float2 t = a.rowstat[(long)n * L + min(row, L - 1)]; rm = t.x; rs = t.y; }
+  const bool mrow = HAS_MASK ? (a.mask0[(long)n * L + min(row, L - 1)] != 0) : true;
+
+  // ---- DMA of one panel: 32 rows x 8 k-groups x 128 B = 32 instructions, 4 per wave (k-group = wave)
+  // dword offset of this lane's 16 B inside a panel row set, per row octet: recomputed per issue (a few VALU per panel)
+  // rather than held in registers across the loop
+#define SWEEP_DOFF(oct_) ((oct_) * 8 * 256 + (lane >> 3) * 256 + (((lane & 7) ^ (((oct_) * 4 + (lane >> 4)) & 7)) << 2) + wave * 32)
+#define SWEEP_ISSUE(p_)                                                                                  \
+  {                                                                                                      \
+    const int col0__ = (p0 + (p_)) * PC;                                                                 \
+    char* st__ = lds + ((p_) & (NST - 1)) * STAGE + wave * 4096;                                         \
+    if (col0__ + PC <= S) {                                                                              \
+      const sp_t* base__ = f1n + (long)col0__ * 256;                                                     \
+      _Pragma("unroll") for (int oct__ = 0; oct__ < 4; ++oct__)                                          \
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(base__ + SWEEP_DOFF(oct__)), (lds_ptr_t)(st__ + oct__ * 1024), 16, 0, 0); \
+    } else {                  /* last panel of the matrix: rows beyond S re-read row S-1 (masked later) */ \
+      _Pragma("unroll") for (int oct__ = 0; oct__ < 4; ++oct__) {                                        \
+        const int r__ = oct__ * 8 + (lane >> 3);                                                         \
+        const int gc__ = min(col0__ + r__, S - 1);                                                       \
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(f1n + (long)gc__ * 256 + (SWEEP_DOFF(oct__) - r__ * 256)), \
+                                         (lds_ptr_t)(st__ + oct__ * 1024), 16, 0, 0);                    \
+      }                                                                                                  \
+    }                                                                                                    \
+  }
+
+  // ---- running row state (lane private)
+  float m_run = SENTINEL, s_run = 0.f;             // pass A
+  float best = -1.f; int bestj = 0; bool tie = false;   // pass B
+  const int a_off = lds_chunk_off(li, g);          // hi chunk of the even k-step; odd k-step: ^ 32, lo: ^ 64 (chunk + 2 / + 4)
+  const int sel = lane & 15;
+  const long part_row = ((long)n * a.RB * W + rb * W + wave) * S;          // this wave's row of the column partials
+
+  // Epilogue of panel p_ on the accumulators: statistics / conf_matrix.  A macro, not a lambda (captures of the register
+  // arrays by reference end up in scratch); expanded twice (early and late waves).
+#define SWEEP_EPILOGUE(p_)                                                                               \
+  {                                                                                                      \
+    const int col0 = (p0 + (p_)) * PC;                                                                   \
+    const bool fullp = col0 + PC <= S;             /* panel-uniform */                                   \
+    f32x16 v;                                                                                            \
+    _Pragma("unroll") for (int r = 0; r < 16; ++r) v[r] = (acc0[r] + acc1[r]) * a.scale;                 \
+    if (HAS_MASK) {                                                                                      \
+      _Pragma("unroll") for (int r = 0; r < 16; ++r)                                                     \
+        if (!(mrow && mask_s[(p_) * PC + jr(r, g)])) v[r] = LOFTR_NEG_INF;   /* masked_fill_(~(m0 x m1), -INF)  :115-118 */ \
+    }                                                                                                    \
+    if (!fullp) {                                                                                        \
+      _Pragma("unroll") for (int r = 0; r < 16; ++r) if (col0 + jr(r, g) >= S) v[r] = SENTINEL;          \
+    }                                                                                                    \
+    const int mycol = col0 + jr(sel, g);           /* the column this lane stores a partial for */       \
+    if (PASS == 0) {                                                                                     \
+      /* row: online (max, sum exp); exp(SENTINEL - x) == 0, so out-of-range columns drop out by themselves */ \
+      float tm = v[0];                                                                                   \
+      _Pragma("unroll") for (int r = 1; r < 16; ++r) tm = fmaxf(tm, v[r]);                               \
+      const float mn = fmaxf(m_run, tm);                                                                 \
+      float ssum = 0.f;                                                                                  \
+      _Pragma("unroll") for (int r = 0; r < 16; ++r) ssum += fexp(v[r] - mn);                            \
+      s_run = s_run * fexp(m_run - mn) + ssum;                                                           \
+      m_run = mn;                                                                                        \
+      /* columns: (max, sum exp) over the wave's 32 rows */                                              \
+      f32x16 cm;                                                                                         \
+      _Pragma("unroll") for (int r = 0; r < 16; ++r) cm[r] = (rows_full || row_ok) ? v[r] : SENTINEL;    \
+      f32x16 e = cm;                                                                                     \
+      half_max16(cm);                                                                                    \
+      _Pragma("unroll") for (int r = 0; r < 16; ++r) e[r] = fexp(e[r] - cm[r]);                          \
+      half_sum16(e);                                                                                     \
+      const float2 mine = make_float2(pick16(cm, sel), pick16(e, sel));                                  \
+      if (li < 16 && (fullp || mycol < S)) a.colpart[part_row + mycol] = mine;                           \
+    } else {                                                                                             \
+      /* conf = softmax(sim, dim=1) * softmax(sim, dim=2) = exp((v - rowmax) + (v - colmax)) / (rowsum * colsum)   :119 */ \
+      f32x16 c;                                                                                          \
+      _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                    \
+        const f32x4* cs4 = reinterpret_cast<const f32x4*>(cstat_s + (p_) * PC + 8 * q + 4 * g);   /* (max, 1/sum) x 4 columns */ \
+        const f32x4 c01 = cs4[0], c23 = cs4[1];                                                          \
+        const float cmx[4] = {c01.x, c01.z, c23.x, c23.z}, cis[4] = {c01.y, c01.w, c23.y, c23.w};        \
+        _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                  \
+          const float x = v[4 * q + e];                                                                  \
+          c[4 * q + e] = fexp((x - rm) + (x - cmx[e])) * (rs * cis[e]);                                  \
+        }                                                                                                \
+      }                                                                                                  \
+      if (!fullp) {                                                                                      \
+        _Pragma("unroll") for (int r = 0; r < 16; ++r) if (col0 + jr(r, g) >= S) c[r] = -1.f;            \
+      }                                                                                                  \
+      if (a.conf && (rows_full || row_ok)) {                                                             \
+        float* co = a.conf + ((long)n * L + row) * S + col0 + 4 * g;                                     \
+        if (fullp && (S & 3) == 0) {                                                                     \
+          _Pragma("unroll") for (int q = 0; q < 4; ++q)                                                  \
+            *reinterpret_cast<f32x4*>(co + 8 * q) = f32x4{c[4 * q], c[4 * q + 1], c[4 * q + 2], c[4 * q + 3]}; \
+        } else {                                                                                         \
+          _Pragma("unroll") for (int r = 0; r < 16; ++r) if (col0 + jr(r, g) < S) co[8 * (r >> 2) + (r & 3)] = c[r]; \
+        }                                                                                                \
+      }                                                                                                  \
+      /* row: running (max, FIRST argmax, attained-twice flag); registers ascend in column order for this half */ \
+      _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                   \
+        const bool gt = c[r] > best;                                                                     \
+        tie = gt ? false : (tie || c[r] == best);                                                        \
+        bestj = gt ? col0 + jr(r, g) : bestj;                                                            \
+        best = gt ? c[r] : best;                                                                         \
+      }                                                                                                  \
+      /* columns: max over the wave's rows */                                                            \
+      f32x16 cm;                                                                                         \
+      _Pragma("unroll") for (int r = 0; r < 16; ++r) cm[r] = (rows_full || row_ok) ? c[r] : -1.f;        \
+      half_max16(cm);                                                                                    \
+      const float mine = pick16(cm, sel);                                                                \
+      if (li < 16 && (fullp || mycol < S)) a.colmax_part[part_row + mycol] = mine;                       \
+    }                                                                                                    \
+  }
+
+  // Every ordinary load above must be COMPLETE before the first DMA is issued: hipcc waits vmcnt(0) at the first use
+  // of a VGPR-destination load, and a first use inside the panel loop would drain the in-flight DMA every iteration.
+  LOFTR_WAITCNT_VM(0);
+  __syncthreads();                                 // tables visible; no DMA in flight yet
+  SWEEP_ISSUE(0);
+  if (np > 1) SWEEP_ISSUE(1);
+  // Stores a wave issues between two DMA issues (they sit between the DMA of panel p+1 and the barrier of panel p+1
+  // in the in-order VMEM queue): pass A one partial store; pass B four conf stores + one partial store.  Panels that
+  // take the scalar-store tail path are followed by a full drain instead.
+  constexpr int ST = PASS == 0 ? 1 : 5;
+  f32x16 acc0, acc1;
+  bool drain = false;                              // block-uniform: the previous period issued an unknown number of stores
+  for (int p = 0; p < np; ++p) {
+    // panel p has landed once at most {DMA of panel p+1, the epilogue stores issued after it} are outstanding (VMEM
+    // operations retire in order).  The late waves have not stored anything before period 2, so the count only
+    // includes the stores from there on (conservative for the early waves at p = 1).
+    if (drain || p + 1 >= np) LOFTR_WAITCNT_VM(0);
+    else if (p < 2) LOFTR_WAITCNT_VM(DMA_PER_WAVE);
+    else LOFTR_WAITCNT_VM(DMA_PER_WAVE + ST);
+    __builtin_amdgcn_s_barrier();                  // ... for every wave; and every wave is past the MFMAs of panel p-2
+    if (p + 2 < np) SWEEP_ISSUE(p + 2);
+    drain = !((p0 + p) * PC + PC <= S && (S & 3) == 0) && PASS == 1;
+    if (late && p > 0) SWEEP_EPILOGUE(p - 1);
+    // ---- 48 MFMAs: two accumulators alternate so that no MFMA depends on its predecessor
+    const char* st = lds + (p & (NST - 1)) * STAGE;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const char* sk = st + (ks >> 1) * 4096;
+      const h16x8 ah = *reinterpret_cast<const h16x8*>(sk + (a_off ^ ((ks & 1) ? 32 : 0)));
+      const h16x8 al = *reinterpret_cast<const h16x8*>(sk + (a_off ^ ((ks & 1) ? 96 : 64)));
+      if (ks & 1) {
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[ks], acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[ks], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[ks], acc1, 0, 0, 0);
+      } else {
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[ks], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[ks], acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[ks], acc0, 0, 0, 0);
+      }
+    }
+    if (!late) SWEEP_EPILOGUE(p);
+  }
+  if (late) SWEEP_EPILOGUE(np - 1);
+#undef SWEEP_ISSUE
+#undef SWEEP_DOFF
+#undef SWEEP_EPILOGUE
+  // ---- row partials of this chunk: combine the two half-waves (they hold disjoint columns of the same row)
+  float2* rp = (PASS == 0 ? a.rowpart : a.rowmax_part) + ((long)n * a.NCH + cc) * L;
+  if (PASS == 0) {
+    const float mo = swap32(m_run), so = swap32(s_run);
+    const float M = fmaxf(m_run, mo);
+    const float Ssum = s_run * fexp(m_run - M) + so * fexp(mo - M);
+    if (g == 0 && row_ok) rp[row] = make_float2(M, Ssum);
+  } else {
+    const float bo = swap32(best);
+    const int jo = __float_as_int(swap32(__int_as_float(bestj)));
+    const bool to = swap32(tie ? 1.f : 0.f) != 0.f;
+    const bool other = bo > best || (bo == best && jo < bestj);
+    const bool t = (bo == best) || (bo > best ? to : (bo < best ? tie : false));
+    const float B = other ? bo : best;
+    const int J = other ? jo : bestj;
+    if (g == 0 && row_ok) rp[row] = make_float2(B, __int_as_float(J | (t ? TIE_BIT : 0)));
+  }
+}
+}  // namespace sweep
+
 __global__ void merge_colmax_kernel(const float* __restrict__ part, float* __restrict__ colmax, long cols, int P, int len) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= cols) return;
@@ -368,9 +639,37 @@ __device__ __forceinline__ int upper_limit(int hv, int bd, int hc) {
   return lim;
 }
 
+// The three tests of get_coarse_match on one (row, column) candidate whose confidence is the row maximum `bv`:
+//   1. confidence threshold (:172)  2. borders (:176-183)  3. mutual nearest neighbour (:187-189)
+__device__ __forceinline__ bool candidate_ok(const SelectParams& sp, const float* __restrict__ colmax, int n, int i, int j, float bv) {
+  const Geometry& g = sp.g;
+  if (!(bv > sp.thr)) return false;
+  if (sp.border > 0) {
+    const int y0 = i / g.w0c, x0 = i % g.w0c, y1 = j / g.w1c, x1 = j % g.w1c;
+    int l_h0, l_w0, l_h1, l_w1;
+    if (sp.valid) {
+      const int* v = sp.valid + n * 4;
+      l_h0 = upper_limit(v[0], sp.border, g.h0c); l_w0 = upper_limit(v[1], sp.border, g.w0c);
+      l_h1 = upper_limit(v[2], sp.border, g.h1c); l_w1 = upper_limit(v[3], sp.border, g.w1c);
+    } else {
+      l_h0 = g.h0c - sp.border; l_w0 = g.w0c - sp.border; l_h1 = g.h1c - sp.border; l_w1 = g.w1c - sp.border;
+    }
+    const int b = sp.border;
+    if (!(y0 >= b && x0 >= b && y1 >= b && x1 >= b && y0 < l_h0 && x0 < l_w0 && y1 < l_h1 && x1 < l_w1)) return false;
+  }
+  return bv == colmax[(long)n * g.S + j];
+}
+
 // one thread per row of the flattened [N*L] rows; 256 rows per block
+//
+// Exact ties.  The reference ANDs threshold, border and mutual-maximum masks over the whole row and takes the FIRST
+// surviving column (`mask.max(dim=2)`, coarse_matching.py:187-193): when the row maximum is attained more than once
+// and its first occurrence fails a test, a later tied column is still emitted.  The partials carry an "attained
+// twice" flag (TIE_BIT); only for such rows, and only if the first candidate fails, the thread walks the row of
+// conf_matrix for the first tied column that passes (needs the materialised conf_matrix; without it the row is
+// dropped like any row whose arg-max fails).
 __global__ __launch_bounds__(256) void select_kernel(SelectParams sp, const float2* __restrict__ rowmax_part,
-                                                     const float* __restrict__ colmax,
+                                                     const float* __restrict__ colmax, const float* __restrict__ conf,
                                                      int* __restrict__ cand_j, float* __restrict__ cand_conf,
                                                      int* __restrict__ cand_rank, int* __restrict__ block_count,
                                                      int* __restrict__ counts) {
@@ -384,32 +683,27 @@ __global__ __launch_bounds__(256) void select_kernel(SelectParams sp, const floa
     const int i = (int)(row - (long)n * g.L);
     const float2* p = rowmax_part + ((long)n * g.PJ) * g.L + i;
     bv = -1.f; bj = 0;
-    // eight partials in flight per thread (written as one dependent load -> compare chain the 75 strips cost 75 DRAM
-    // round trips: the grid is only rows / 256 workgroups).  The tail re-reads the last strip: `>` never replaces.
+    bool tie = false;
+    // eight partials in flight per thread (written as one dependent load -> compare chain the strips cost one DRAM
+    // round trip each: the grid is only rows / 256 workgroups).  The tail re-reads the last strip (k0 + u >= PJ: skipped).
     for (int k0 = 0; k0 < g.PJ; k0 += 8) {
       float2 e[8];
 #pragma unroll
       for (int u = 0; u < 8; ++u) e[u] = p[(long)min(k0 + u, g.PJ - 1) * g.L];
 #pragma unroll
-      for (int u = 0; u < 8; ++u)                      // ascending column chunks: > keeps the first
-        if (e[u].x > bv) { bv = e[u].x; bj = __float_as_int(e[u].y); }
-    }
-    // 1. confidence threshold (:172)  2. borders (:176-183)  3. mutual nearest (:187-189)
-    flag = bv > sp.thr;
-    if (flag && sp.border > 0) {
-      const int y0 = i / g.w0c, x0 = i % g.w0c, y1 = bj / g.w1c, x1 = bj % g.w1c;
-      int l_h0, l_w0, l_h1, l_w1;
-      if (sp.valid) {
-        const int* v = sp.valid + n * 4;
-        l_h0 = upper_limit(v[0], sp.border, g.h0c); l_w0 = upper_limit(v[1], sp.border, g.w0c);
-        l_h1 = upper_limit(v[2], sp.border, g.h1c); l_w1 = upper_limit(v[3], sp.border, g.w1c);
-      } else {
-        l_h0 = g.h0c - sp.border; l_w0 = g.w0c - sp.border; l_h1 = g.h1c - sp.border; l_w1 = g.w1c - sp.border;
+      for (int u = 0; u < 8; ++u) {                    // ascending column chunks: > keeps the first
+        if (k0 + u >= g.PJ) continue;
+        const int w = __float_as_int(e[u].y);
+        if (e[u].x > bv) { bv = e[u].x; bj = w & ~sweep::TIE_BIT; tie = (w & sweep::TIE_BIT) != 0; }
+        else if (e[u].x == bv) tie = true;
       }
-      const int b = sp.border;
-      flag = y0 >= b && x0 >= b && y1 >= b && x1 >= b && y0 < l_h0 && x0 < l_w0 && y1 < l_h1 && x1 < l_w1;
     }
-    if (flag) flag = bv == colmax[(long)n * g.S + bj];
+    flag = candidate_ok(sp, colmax, n, i, bj, bv);
+    if (!flag && tie && conf && bv > sp.thr) {          // rare: exact tie at the row maximum and the first one failed
+      const float* cr = conf + ((long)n * g.L + i) * g.S;
+      for (int j = bj + 1; j < g.S; ++j)
+        if (cr[j] == bv && candidate_ok(sp, colmax, n, i, j, bv)) { bj = j; flag = true; break; }
+    }
   }
   // block-local exclusive scan of the flags (ballot per wave + wave offsets through LDS)
   __shared__ int wave_tot[4];
@@ -425,16 +719,17 @@ __global__ __launch_bounds__(256) void select_kernel(SelectParams sp, const floa
     cand_conf[row] = bv;
     cand_rank[row] = flag ? off + within : -1;
   }
-  // per-pair match counts: one atomic per (wave, pair) instead of one per match (a wave's 64 consecutive rows span
-  // at most two pairs; with a low threshold the per-match atomics on N addresses were the whole kernel time)
+  // per-pair match counts: one atomic per (wave, pair) instead of one per match (with a low threshold the per-match
+  // atomics on N addresses were the whole kernel time).  A wave's 64 consecutive rows span one or two pairs when
+  // L >= 64 and up to 64 when the coarse grid is tiny: peel one pair per iteration.
   {
-    const int n_first = __builtin_amdgcn_readfirstlane(n);
-    const unsigned long long same = __ballot(flag && n == n_first), other = bal & ~same;
-    if (lane == 0 && same) atomicAdd(&counts[1 + n_first], __popcll(same));
-    if (other) {
-      const int src = __ffsll((long long)other) - 1;
-      const int n_other = __shfl(n, src);
-      if (lane == 0) atomicAdd(&counts[1 + n_other], __popcll(other));
+    unsigned long long rest = bal;
+    while (rest) {                                     // wave-uniform
+      const int src = __ffsll((long long)rest) - 1;
+      const int n_k = __shfl(n, src);
+      const unsigned long long same = __ballot(flag && n == n_k);
+      if (lane == 0) atomicAdd(&counts[1 + n_k], __popcll(same));
+      rest &= ~same;
     }
   }
   if (threadIdx.x == 0) block_count[blockIdx.x] = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
@@ -703,11 +998,12 @@ MatchWs carve(void* ws, size_t bytes, const Geometry& g) {
   MatchWs m;
   const size_t NL = (size_t)g.N * g.L, NS = (size_t)g.N * g.S;
   m.rowpart = wa.take<float2>(NL * g.PJ);
-  m.colpart = wa.take<float2>(NS * g.PI);
+  const size_t PIw = (size_t)ceil_div(g.L, 256) * 8;  // column partials per column: the sweep kernels write one per 32-row wave of every 256-row block
+  m.colpart = wa.take<float2>(NS * (PIw > (size_t)g.PI ? PIw : (size_t)g.PI));
   m.rowstat = wa.take<float2>(NL);
   m.colstat = wa.take<float2>(NS);
   m.rowmax_part = wa.take<float2>(NL * g.PJ);
-  m.colmax_part = wa.take<float>(NS * g.PI);
+  m.colmax_part = wa.take<float>(NS * (PIw > (size_t)g.PI ? PIw : (size_t)g.PI));
   m.colmax = wa.take<float>(NS);
   m.cand_conf = wa.take<float>(NL);
   m.cand_j = wa.take<int>(NL);
@@ -728,7 +1024,9 @@ MatchWs carve(void* ws, size_t bytes, const Geometry& g) {
 }
 
 size_t match_ws_bytes(int N, int L, int S, int C) {
-  const size_t PJ = (size_t)ceil_div(S, Cfg::BN) * Cfg::WN, PI = (size_t)ceil_div(L, Cfg::BM) * Cfg::WM;
+  const size_t PJ = (size_t)ceil_div(S, Cfg::BN) * Cfg::WN;
+  const size_t PIw = (size_t)ceil_div(L, 256) * 8, PIt = (size_t)ceil_div(L, Cfg::BM) * Cfg::WM;
+  const size_t PI = PIw > PIt ? PIw : PIt;
   const size_t NL = (size_t)N * L, NS = (size_t)N * S;
   size_t b = 0;
   b += NL * PJ * 8 * 2 + NS * PI * 8 + NS * PI * 4;
@@ -747,7 +1045,7 @@ bool params_ok(const loftr_coarse_params* p, const loftr_match_out* o) {
 
 // select -> scan -> scatter on the row/col max partials of conf
 int select_and_compact(const Geometry& g, const loftr_coarse_params& p, const loftr_match_out& out,
-                       const MatchWs& w, hipStream_t st) {
+                       const MatchWs& w, const float* conf, hipStream_t st) {
   const long NL = (long)g.N * g.L, NS = (long)g.N * g.S;
   hipLaunchKernelGGL(merge_colmax_kernel, dim3(ceil_div((int)NS, 256)), dim3(256), 0, st, w.colmax_part, w.colmax, NS, g.PI, g.S);
   const int* valid = nullptr;
@@ -758,7 +1056,7 @@ int select_and_compact(const Geometry& g, const loftr_coarse_params& p, const lo
   (void)hipMemsetAsync(out.counts, 0, sizeof(int32_t) * (1 + g.N), st);
   const int nblk = (int)((NL + 255) / 256);
   SelectParams sp{g, p.thr, p.border_rm, valid};
-  hipLaunchKernelGGL(select_kernel, dim3(nblk), dim3(256), 0, st, sp, w.rowmax_part, w.colmax, w.cand_j, w.cand_conf,
+  hipLaunchKernelGGL(select_kernel, dim3(nblk), dim3(256), 0, st, sp, w.rowmax_part, w.colmax, conf, w.cand_j, w.cand_conf,
                      w.cand_rank, w.block_count, out.counts);
   hipLaunchKernelGGL(scan_blocks_kernel, dim3(1), dim3(1024), 0, st, w.block_count, w.block_off, nblk, out.counts);
   ScatterParams sc{g, p.scale, p.scale0, p.scale1, out};
@@ -775,6 +1073,18 @@ extern "C" size_t loftr_coarse_match_workspace_bytes(int N, int L, int S, int C)
 }
 
 namespace {
+// Work decomposition of the sweep kernels: RB 256-row blocks x NCH column chunks of PPC 32-column panels per pair.
+// A function of (L, S) only -- never of N -- so that a pair's partial sums are merged in the same order whatever
+// batch it is in (bitwise batch invariance, tests/test_hip_parity.py::test_batch_consistency_full_size).
+void sweep_plan(const Geometry& g, sweep::Args& a) {
+  a.N = g.N; a.L = g.L; a.S = g.S;
+  a.RB = ceil_div(g.L, sweep::BR);
+  a.NP = ceil_div(g.S, sweep::PC);
+  a.NCH = ceil_div(a.NP, 30);                 // <= 30 panels per chunk (LDS tables hold 32); S = 4800: 5 chunks of 30,
+  a.PPC = ceil_div(a.NP, a.NCH);              //   8 pairs x 19 row blocks x 5 = 760 workgroups = 2.97 rounds of the 256 CUs
+  a.NCH = ceil_div(a.NP, a.PPC);
+}
+
 // descriptors -> SP (both images in one launch)
 int stage_descriptors(const float* f0, const float* f1, const Geometry& g, const MatchWs& w, hipStream_t st) {
   SpJobs j; j.n = 2;
@@ -799,8 +1109,34 @@ extern "C" int loftr_coarse_match_dual_softmax(const float* feat_c0, const float
   { int rc = stage_descriptors(feat_c0, feat_c1, g, w, st); if (rc) return rc; }
   // feat / sqrt(C) on both sides, then / temperature                 coarse_matching.py:108-114
   const float scale = 1.f / ((float)g.C * temperature);
-  const dim3 sgrid(score_grid(g)), block(Cfg::THREADS);
   const long NL = (long)g.N * g.L, NS = (long)g.N * g.S;
+  if (g.C == 256) {
+    // stationary-operand sweep (sweep:: above).  Partials: one per (row, column chunk) and per (column, row block).
+    Geometry gs = g;
+    sweep::Args a{};
+    sweep_plan(g, a);
+    gs.PJ = a.NCH; gs.PI = a.RB * sweep::W;
+    a.f0 = w.f0sp; a.f1 = w.f1sp; a.scale = scale; a.mask0 = p->mask0; a.mask1 = p->mask1;
+    a.rowpart = w.rowpart; a.colpart = w.colpart; a.rowstat = w.rowstat; a.colstat = w.colstat;
+    a.conf = conf_out; a.rowmax_part = w.rowmax_part; a.colmax_part = w.colmax_part;
+    const dim3 grid(NUM_XCD * ceil_div(g.N * a.NCH, NUM_XCD) * a.RB), block(512);
+    {
+      TimedLaunch tl(LOFTR_T_SCORE_STATS, st);
+      if (p->mask0) hipLaunchKernelGGL((sweep::score_sweep_kernel<0, true>), grid, block, 0, st, a);
+      else hipLaunchKernelGGL((sweep::score_sweep_kernel<0, false>), grid, block, 0, st, a);
+    }
+    hipLaunchKernelGGL(merge_stats_kernel, dim3(ceil_div((int)NL, 256)), dim3(256), 0, st, w.rowpart, w.rowstat, NL, gs.PJ, g.L);
+    hipLaunchKernelGGL(merge_stats_kernel, dim3(ceil_div((int)NS, 256)), dim3(256), 0, st, w.colpart, w.colstat, NS, gs.PI, g.S);
+    {
+      TimedLaunch tl(LOFTR_T_SCORE_CONF, st);
+      if (p->mask0) hipLaunchKernelGGL((sweep::score_sweep_kernel<1, true>), grid, block, 0, st, a);
+      else hipLaunchKernelGGL((sweep::score_sweep_kernel<1, false>), grid, block, 0, st, a);
+    }
+    LOFTR_CHECK_LAUNCH();
+    return select_and_compact(gs, *p, *out, w, conf_out, st);
+  }
+  // other descriptor widths: the tiled two-pass kernels
+  const dim3 sgrid(score_grid(g)), block(Cfg::THREADS);
   {
     TimedLaunch tl(LOFTR_T_SCORE_STATS, st);
     if (p->mask0)
@@ -818,7 +1154,7 @@ extern "C" int loftr_coarse_match_dual_softmax(const float* feat_c0, const float
       hipLaunchKernelGGL((score_conf_kernel<false>), sgrid, block, 0, st, w.f0sp, w.f1sp, g, scale, p->mask0, p->mask1, w.rowstat, w.colstat, conf_out, w.rowmax_part, w.colmax_part);
   }
   LOFTR_CHECK_LAUNCH();
-  return select_and_compact(g, *p, *out, w, st);
+  return select_and_compact(g, *p, *out, w, conf_out, st);
 }
 
 extern "C" int loftr_coarse_match_sinkhorn(const float* feat_c0, const float* feat_c1,
@@ -858,5 +1194,5 @@ extern "C" int loftr_coarse_match_sinkhorn(const float* feat_c0, const float* fe
     hipLaunchKernelGGL(ot_assign_bins_kernel, dim3(ceil_div((g.L > g.S ? g.L : g.S) + 1, 256), g.N), dim3(256), 0, st, g, bin_score, norm, w.ot_u, w.ot_v, assign_out);
   hipLaunchKernelGGL(ot_finalize_kernel, grid, block, 0, st, conf_out, g, norm, w.ot_u, w.ot_v, rk, ck, assign_out, w.rowmax_part, w.colmax_part);
   LOFTR_CHECK_LAUNCH();
-  return select_and_compact(g, *p, *out, w, st);
+  return select_and_compact(g, *p, *out, w, conf_out, st);
 }
