@@ -339,6 +339,18 @@ __global__ __launch_bounds__(Cfg::THREADS, 2) void score_conf_kernel(
 // vmcnt(0) and would drain the DMA ring every iteration.
 // Work unit = (pair, 256-row block, chunk of panels); the chunking depends on S only, so a pair's results do not
 // depend on the batch it is in.  Row partials: one per (row, chunk); column partials: one per (column, 32-row wave).
+#ifndef SWEEP_PROBE_EPI
+#define SWEEP_PROBE_EPI 1        // 0: skip the epilogues (timing probe only; wrong results)
+#endif
+#ifndef SWEEP_PROBE_LSE
+#define SWEEP_PROBE_LSE 1        // 0: pass B on (max, 1/sum) statistics instead of log-sum-exp biases
+#endif
+#ifndef SWEEP_PROBE_FAST
+#define SWEEP_PROBE_FAST 1       // 0: pass A exact variant only
+#endif
+#ifndef SWEEP_PROBE_SKEW
+#define SWEEP_PROBE_SKEW 1       // 0: all eight waves in phase
+#endif
 namespace sweep {
 constexpr int W = 8, BR = 32 * W, PC = 32, KS = 16, STAGE = PC * 1024, NST = 4, MAXP = 32;
 constexpr int OFF_CSTAT = NST * STAGE;                    // float2 [MAXP * PC] column (max, 1/sum) of the chunk (pass B)
@@ -358,6 +370,7 @@ struct Args {
   const float2* rowstat; const float2* colstat;     // pass B in
   float* conf;                                      // pass B out or null
   float2* rowmax_part; float* colmax_part;          // pass B out: [N][NCH][L] (max, argmax | TIE_BIT), [N][RB * W][S]
+  int* exact_flags;                                 // pass A: [N * NCH * RB] units the exact variant has to (re)do, or null = all
 };
 
 __device__ __forceinline__ int jr(int r, int g) { return 8 * (r >> 2) + 4 * g + (r & 3); }
@@ -369,8 +382,66 @@ __device__ __forceinline__ float pick16(const f32x16& v, int sel) {
   return x;
 }
 
-template <int PASS, bool HAS_MASK>
+// ---- transposed reductions over the 32 lanes of a half-wave --------------------------------------------------
+// A plain reduction of 16 registers across 32 lanes costs 16 x 5 cross-lane steps and leaves every lane with all 16
+// results.  Here every step HALVES the registers a lane carries (it keeps the half selected by one of its lane bits and
+// hands the other half to its partner, who keeps exactly that one): 8 + 4 + 2 + 1 + 1 steps, and lane l ends up with
+// the full reduction of register tr_reg(l) only -- which is all the column partials need (one lane stores one column).
+//   step partners: l ^ 7 (row_half_mirror), l ^ 1, l ^ 2 (quad_perm), l ^ 8 (row_ror:8), l ^ 16 (v_permlane16_swap);
+//   register kept by lane l:  8 * bit2(l) + 4 * bit0(l) + 2 * bit1(l) + bit3(l).
+__device__ __forceinline__ int tr_reg(int l) { return 8 * ((l >> 2) & 1) + 4 * (l & 1) + 2 * ((l >> 1) & 1) + ((l >> 3) & 1); }
+#define SWEEP_DPPF(v_, c_) __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v_), c_, 0xF, 0xF, true))
+#define SWEEP_DPPI(v_, c_) __builtin_amdgcn_update_dpp(0, v_, c_, 0xF, 0xF, true)
+// lane-dependent choice between two registers as ONE v_bfi_b32 on a precomputed all-ones / all-zeros lane mask
+// (a bool select costs a v_cmp + hazard nops + v_cndmask each time: hipcc re-materialises the comparison)
+__device__ __forceinline__ int bsel(int m, int a1, int a0) { return (a1 & m) | (a0 & ~m); }      // m ? a1 : a0
+__device__ __forceinline__ float bself(int m, float a1, float a0) { return __int_as_float(bsel(m, __float_as_int(a1), __float_as_int(a0))); }
+struct TrMasks { int m0, m1, m2, m3; };            // lane bit k set -> all ones
+__device__ __forceinline__ TrMasks tr_masks(int lane) { return TrMasks{-(lane & 1), -((lane >> 1) & 1), -((lane >> 2) & 1), -((lane >> 3) & 1)}; }
+__device__ __forceinline__ float treduce_add16(const f32x16& v, const TrMasks& t) {
+  float x8[8], x4[4], x2[2];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) x8[k] = bself(t.m2, v[8 + k], v[k]) + SWEEP_DPPF(bself(t.m2, v[k], v[8 + k]), 0x141);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) x4[k] = bself(t.m0, x8[4 + k], x8[k]) + SWEEP_DPPF(bself(t.m0, x8[k], x8[4 + k]), 0xB1);
+#pragma unroll
+  for (int k = 0; k < 2; ++k) x2[k] = bself(t.m1, x4[2 + k], x4[k]) + SWEEP_DPPF(bself(t.m1, x4[k], x4[2 + k]), 0x4E);
+  const float x1 = bself(t.m3, x2[1], x2[0]) + SWEEP_DPPF(bself(t.m3, x2[0], x2[1]), 0x128);
+  const auto q = __builtin_amdgcn_permlane16_swap(__float_as_int(x1), __float_as_int(x1), false, false);
+  return __int_as_float(q[0]) + __int_as_float(q[1]);
+}
+// the same with a signed-integer maximum: on the bit patterns of NON-NEGATIVE floats it is the float maximum (and any
+// negative float, the "invalid" marker -1, loses) -- without the canonicalisation fmaxf costs on cross-lane values
+__device__ __forceinline__ int treduce_imax16(const int (&v)[16], const TrMasks& t) {
+  int x8[8], x4[4], x2[2];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) x8[k] = max(bsel(t.m2, v[8 + k], v[k]), SWEEP_DPPI(bsel(t.m2, v[k], v[8 + k]), 0x141));
+#pragma unroll
+  for (int k = 0; k < 4; ++k) x4[k] = max(bsel(t.m0, x8[4 + k], x8[k]), SWEEP_DPPI(bsel(t.m0, x8[k], x8[4 + k]), 0xB1));
+#pragma unroll
+  for (int k = 0; k < 2; ++k) x2[k] = max(bsel(t.m1, x4[2 + k], x4[k]), SWEEP_DPPI(bsel(t.m1, x4[k], x4[2 + k]), 0x4E));
+  const int x1 = max(bsel(t.m3, x2[1], x2[0]), SWEEP_DPPI(bsel(t.m3, x2[0], x2[1]), 0x128));
+  const auto q = __builtin_amdgcn_permlane16_swap(x1, x1, false, false);
+  return max((int)q[0], (int)q[1]);
+}
+constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
+constexpr float FAST_SPREAD = 64.f;    // max - min of a wave's 32 x 32 score tile up to which one shared exp reference is exact enough
+
+// FASTA (pass A only): the lean epilogue with ONE shared exp reference per 32 x 32 wave tile.  It is exact only while
+// the tile's values span less than FAST_SPREAD and the tile is full, so this variant gives up on a unit the moment a
+// tile fails the test (or at once for units with a partial last panel): it raises the unit's flag and the
+// exact variant -- launched right behind it on the same grid, returning immediately for unflagged units -- redoes
+// that unit with per-row / per-column references.  Two kernels instead of one two-path kernel: together the paths
+// exceed the 256-VGPR budget of a 512-thread workgroup (30 spills measured).
+// TRACKJ (pass B): per-ELEMENT tracking of the first row arg-max (5 VALU per element).  Without it the sweep only tracks,
+// per lane, the maximum and the PANEL it first occurred in (11 VALU per panel) and select_kernel finds the column --
+// and any second occurrence -- by reading those 32 entries of conf_matrix back; that needs the materialised matrix.
+// The sweep is issue-bound (about five non-MFMA instructions fit under one 32-cycle MFMA), so this matters.
+template <int PASS, bool HAS_MASK, bool FASTA = false, bool TRACKJ = true>
 __global__ __launch_bounds__(512, 2) void score_sweep_kernel(Args a) {
+  static_assert(!(FASTA && (PASS != 0 || HAS_MASK)), "the shared-reference path is pass A without masks");
+  static_assert(TRACKJ || (PASS == 1 && !HAS_MASK), "panel-level tracking is the unmasked pass B");
+  constexpr bool LSE = SWEEP_PROBE_LSE && PASS == 1 && !HAS_MASK;      // pass B on log-sum-exp biases (one exp2(fma) per element)
   __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
   typedef __attribute__((address_space(3))) void* lds_ptr_t;
   typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
@@ -381,11 +452,17 @@ __global__ __launch_bounds__(512, 2) void score_sweep_kernel(Args a) {
   const int n = grp % a.N, cc = grp / a.N;
   const int p0 = cc * a.PPC, np = min(a.PPC, a.NP - p0);      // panels of this chunk (>= 1 by construction)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 5, li = lane & 31;
-  const bool late = wave >= W / 2;                             // this wave runs its epilogue half a period later
+  const bool late = SWEEP_PROBE_SKEW && wave >= W / 2;         // this wave runs its epilogue half a period later
   const int L = a.L, S = a.S;
   const int row = rb * BR + wave * 32 + li;
   const bool row_ok = row < L;
-  const bool rows_full = rb * BR + BR <= L;                    // block-uniform
+  const bool rows_full = FASTA || rb * BR + BR <= L;           // block-uniform (the fast variant only keeps full units)
+  int* const unit_flag = a.exact_flags ? a.exact_flags + (grp * a.RB + rb) : nullptr;
+  const bool rows_part = rb * BR + BR > L;                     // block-uniform: the last row block of the pair is partial
+  if (PASS == 0 && FASTA) {                                    // partial last panel: the exact variant's job
+    if ((p0 + np) * PC > S) { if (threadIdx.x == 0) *unit_flag = 1; return; }
+  }
+  if (PASS == 0 && !FASTA && unit_flag && *unit_flag == 0) return;   // the fast variant has done this unit
   const sp_t* f0n = a.f0 + (long)n * L * 256;
   const sp_t* f1n = a.f1 + (long)n * S * 256;
 
@@ -405,11 +482,20 @@ __global__ __launch_bounds__(512, 2) void score_sweep_kernel(Args a) {
   uint8_t* mask_s = reinterpret_cast<uint8_t*>(lds + OFF_MASK);
   for (int t = threadIdx.x; t < np * PC; t += 512) {
     const int col = min(p0 * PC + t, S - 1);
-    if (PASS == 1) cstat_s[t] = a.colstat[(long)n * S + col];
+    if (PASS == 1) {
+      const float2 cs = a.colstat[(long)n * S + col];
+      // LSE form: -log2 sum_i exp(v_ij) = -(max * log2 e) + log2(1 / sum): independent of which reference "max" was
+      if (LSE) reinterpret_cast<float*>(cstat_s)[t] = fmaf(-cs.x, LOG2E, __builtin_amdgcn_logf(cs.y));
+      else cstat_s[t] = cs;
+    }
     if (HAS_MASK) mask_s[t] = a.mask1[(long)n * S + col];
   }
-  float rm = 0.f, rs = 0.f;                        // pass B: row (max, 1/sum)
-  if (PASS == 1) { const float2 t = a.rowstat[(long)n * L + min(row, L - 1)]; rm = t.x; rs = t.y; }
+  float rm = 0.f, rs = 0.f;                        // pass B: row (max, 1/sum); LSE form: rm = -log2 sum_j exp(v_ij)
+  if (PASS == 1) {
+    const float2 t = a.rowstat[(long)n * L + min(row, L - 1)];
+    rm = LSE ? fmaf(-t.x, LOG2E, __builtin_amdgcn_logf(t.y)) : t.x; rs = t.y;
+  }
+  const float k2 = 2.f * a.scale * LOG2E;          // LSE form: conf = exp2(k2 * dot + rm + cb_j)
   const bool mrow = HAS_MASK ? (a.mask0[(long)n * L + min(row, L - 1)] != 0) : true;
 
   // ---- DMA of one panel: 32 rows x 8 k-groups x 128 B = 32 instructions, 4 per wave (k-group = wave)
@@ -435,8 +521,12 @@ __global__ __launch_bounds__(512, 2) void score_sweep_kernel(Args a) {
   }
 
   // ---- running row state (lane private)
-  float m_run = SENTINEL, s_run = 0.f;             // pass A
+  // pass A: sum of exp(v - ref_run) over the columns seen so far; ref_run >= every v seen is a running REFERENCE, not
+  // necessarily the maximum -- the merge kernels and pass B only ever use max-reference + log(sum) combinations
+  float ref_run = SENTINEL, s_run = 0.f;
   float best = -1.f; int bestj = 0; bool tie = false;   // pass B
+  const TrMasks trm = tr_masks(lane);
+  const int trcol = jr(tr_reg(lane & 15), g);       // panel column whose transposed reduction ends in this lane
   const int a_off = lds_chunk_off(li, g);          // hi chunk of the even k-step; odd k-step: ^ 32, lo: ^ 64 (chunk + 2 / + 4)
   const int sel = lane & 15;
   const long part_row = ((long)n * a.RB * W + rb * W + wave) * S;          // this wave's row of the column partials
@@ -446,7 +536,7 @@ __global__ __launch_bounds__(512, 2) void score_sweep_kernel(Args a) {
 #define SWEEP_EPILOGUE(p_)                                                                               \
   {                                                                                                      \
     const int col0 = (p0 + (p_)) * PC;                                                                   \
-    const bool fullp = col0 + PC <= S;             /* panel-uniform */                                   \
+    const bool fullp = FASTA || col0 + PC <= S;    /* panel-uniform */                                   \
     f32x16 v;                                                                                            \
     _Pragma("unroll") for (int r = 0; r < 16; ++r) v[r] = (acc0[r] + acc1[r]) * a.scale;                 \
     if (HAS_MASK) {                                                                                      \
@@ -458,26 +548,54 @@ __global__ __launch_bounds__(512, 2) void score_sweep_kernel(Args a) {
     }                                                                                                    \
     const int mycol = col0 + jr(sel, g);           /* the column this lane stores a partial for */       \
     if (PASS == 0) {                                                                                     \
-      /* row: online (max, sum exp); exp(SENTINEL - x) == 0, so out-of-range columns drop out by themselves */ \
-      float tm = v[0];                                                                                   \
-      _Pragma("unroll") for (int r = 1; r < 16; ++r) tm = fmaxf(tm, v[r]);                               \
-      const float mn = fmaxf(m_run, tm);                                                                 \
-      float ssum = 0.f;                                                                                  \
-      _Pragma("unroll") for (int r = 0; r < 16; ++r) ssum += fexp(v[r] - mn);                            \
-      s_run = s_run * fexp(m_run - mn) + ssum;                                                           \
-      m_run = mn;                                                                                        \
-      /* columns: (max, sum exp) over the wave's 32 rows */                                              \
-      f32x16 cm;                                                                                         \
-      _Pragma("unroll") for (int r = 0; r < 16; ++r) cm[r] = (rows_full || row_ok) ? v[r] : SENTINEL;    \
-      f32x16 e = cm;                                                                                     \
-      half_max16(cm);                                                                                    \
-      _Pragma("unroll") for (int r = 0; r < 16; ++r) e[r] = fexp(e[r] - cm[r]);                          \
-      half_sum16(e);                                                                                     \
-      const float2 mine = make_float2(pick16(cm, sel), pick16(e, sel));                                  \
-      if (li < 16 && (fullp || mycol < S)) a.colpart[part_row + mycol] = mine;                           \
+      float tm = v[0], tn = v[0];                                                                        \
+      _Pragma("unroll") for (int r = 1; r < 16; ++r) { tm = fmaxf(tm, v[r]); tn = fminf(tn, v[r]); }     \
+      if (FASTA) {                                                                                       \
+        float R = half_max(tm); R = fmaxf(R, swap32(R));           /* maximum / minimum of the wave's 32 x 32 tile */ \
+        float mnw = -half_max(-tn); mnw = fminf(mnw, swap32(mnw));                                       \
+        if (!(R - mnw <= FAST_SPREAD) && lane == 0) *unit_flag = 1;      /* (also catches NaN) -> redone exactly */ \
+        /* ONE exponential per element, relative to the tile maximum R, serves the row AND the column sums: every   \
+           element is within FAST_SPREAD of R, so nothing that matters to any row or column underflows */            \
+        const float nRk = -R * LOG2E;                                                                    \
+        f32x16 e;                                                                                        \
+        _Pragma("unroll") for (int r = 0; r < 16; ++r) e[r] = __builtin_amdgcn_exp2f(fmaf(v[r], LOG2E, nRk)); \
+        float ssum = 0.f;                                                                                \
+        _Pragma("unroll") for (int r = 0; r < 16; ++r) ssum += e[r];                                     \
+        const float Rn = fmaxf(ref_run, R);                                                              \
+        s_run = s_run * fexp(ref_run - Rn) + ssum * fexp(R - Rn);                                        \
+        ref_run = Rn;                                                                                    \
+        /* columns: sum of e over the wave's 32 rows, one column per lane, as (reference, sum); rows beyond L are      \
+           clamped copies of row L-1 (harmless for the tile extrema) and drop out here */                \
+        if (rows_part) { _Pragma("unroll") for (int r = 0; r < 16; ++r) e[r] = row_ok ? e[r] : 0.f; }    \
+        const float csum = treduce_add16(e, trm);                                                        \
+        if (li < 16) a.colpart[part_row + col0 + trcol] = make_float2(R, csum);                          \
+      } else {                                                                                           \
+        /* exact path: per-row reference = the running row maximum, per-column reference = the column maximum */    \
+        const float mn = fmaxf(ref_run, tm);                                                             \
+        float ssum = 0.f;                                                                                \
+        _Pragma("unroll") for (int r = 0; r < 16; ++r) ssum += fexp(v[r] - mn);    /* exp(SENTINEL - x) == 0 */ \
+        s_run = s_run * fexp(ref_run - mn) + ssum;                                                       \
+        ref_run = mn;                                                                                    \
+        f32x16 cm;                                                                                       \
+        _Pragma("unroll") for (int r = 0; r < 16; ++r) cm[r] = (rows_full || row_ok) ? v[r] : SENTINEL;  \
+        f32x16 e = cm;                                                                                   \
+        half_max16(cm);                                                                                  \
+        _Pragma("unroll") for (int r = 0; r < 16; ++r) e[r] = fexp(e[r] - cm[r]);                        \
+        half_sum16(e);                                                                                   \
+        const float2 mine = make_float2(pick16(cm, sel), pick16(e, sel));                                \
+        if (li < 16 && (fullp || mycol < S)) a.colpart[part_row + mycol] = mine;                         \
+      }                                                                                                  \
     } else {                                                                                             \
       /* conf = softmax(sim, dim=1) * softmax(sim, dim=2) = exp((v - rowmax) + (v - colmax)) / (rowsum * colsum)   :119 */ \
       f32x16 c;                                                                                          \
+      if (LSE) {                                                                                         \
+        /* = exp2(2 v log2e - LSE_row - LSE_col): the (acc0 + acc1) * scale above folds into the fma */  \
+        _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                  \
+          const f32x4 cb = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(cstat_s) + (p_) * PC + 8 * q + 4 * g); \
+          _Pragma("unroll") for (int e = 0; e < 4; ++e)                                                  \
+            c[4 * q + e] = __builtin_amdgcn_exp2f(fmaf(acc0[4 * q + e] + acc1[4 * q + e], k2, rm + cb[e])); \
+        }                                                                                                \
+      } else {                                                                                           \
       _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                    \
         const f32x4* cs4 = reinterpret_cast<const f32x4*>(cstat_s + (p_) * PC + 8 * q + 4 * g);   /* (max, 1/sum) x 4 columns */ \
         const f32x4 c01 = cs4[0], c23 = cs4[1];                                                          \
@@ -486,6 +604,7 @@ __global__ __launch_bounds__(512, 2) void score_sweep_kernel(Args a) {
           const float x = v[4 * q + e];                                                                  \
           c[4 * q + e] = fexp((x - rm) + (x - cmx[e])) * (rs * cis[e]);                                  \
         }                                                                                                \
+      }                                                                                                  \
       }                                                                                                  \
       if (!fullp) {                                                                                      \
         _Pragma("unroll") for (int r = 0; r < 16; ++r) if (col0 + jr(r, g) >= S) c[r] = -1.f;            \
@@ -499,19 +618,28 @@ __global__ __launch_bounds__(512, 2) void score_sweep_kernel(Args a) {
           _Pragma("unroll") for (int r = 0; r < 16; ++r) if (col0 + jr(r, g) < S) co[8 * (r >> 2) + (r & 3)] = c[r]; \
         }                                                                                                \
       }                                                                                                  \
-      /* row: running (max, FIRST argmax, attained-twice flag); registers ascend in column order for this half */ \
-      _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                   \
-        const bool gt = c[r] > best;                                                                     \
-        tie = gt ? false : (tie || c[r] == best);                                                        \
-        bestj = gt ? col0 + jr(r, g) : bestj;                                                            \
-        best = gt ? c[r] : best;                                                                         \
+      if (TRACKJ) {                                                                                      \
+        /* row: running (max, FIRST argmax, attained-twice flag); registers ascend in column order for this half */ \
+        _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                 \
+          const bool gt = c[r] > best;                                                                   \
+          tie = gt ? false : (tie || c[r] == best);                                                      \
+          bestj = gt ? col0 + jr(r, g) : bestj;                                                          \
+          best = gt ? c[r] : best;                                                                       \
+        }                                                                                                \
+      } else {                                                                                           \
+        /* row: running maximum and the FIRST panel that attains it (select_kernel finds the column) */  \
+        float pm = fmaxf(c[0], c[1]);                                                                    \
+        _Pragma("unroll") for (int r = 2; r < 16; r += 2) pm = fmaxf(pm, fmaxf(c[r], c[r + 1]));         \
+        const bool gt = pm > best;                                                                       \
+        tie = gt ? false : (tie || pm == best);                                                          \
+        bestj = gt ? (p0 + (p_)) : bestj;                                                                \
+        best = gt ? pm : best;                                                                           \
       }                                                                                                  \
-      /* columns: max over the wave's rows */                                                            \
-      f32x16 cm;                                                                                         \
-      _Pragma("unroll") for (int r = 0; r < 16; ++r) cm[r] = (rows_full || row_ok) ? c[r] : -1.f;        \
-      half_max16(cm);                                                                                    \
-      const float mine = pick16(cm, sel);                                                                \
-      if (li < 16 && (fullp || mycol < S)) a.colmax_part[part_row + mycol] = mine;                       \
+      /* columns: max over the wave's rows, one column per lane (conf >= 0: integer maximum of the bit patterns) */ \
+      int cb[16];                                                                                        \
+      _Pragma("unroll") for (int r = 0; r < 16; ++r) cb[r] = __float_as_int((rows_full || row_ok) ? c[r] : -1.f); \
+      const float cmine = __int_as_float(treduce_imax16(cb, trm));                            \
+      if (li < 16 && (fullp || col0 + trcol < S)) a.colmax_part[part_row + col0 + trcol] = cmine;        \
     }                                                                                                    \
   }
 
@@ -537,7 +665,7 @@ __global__ __launch_bounds__(512, 2) void score_sweep_kernel(Args a) {
     __builtin_amdgcn_s_barrier();                  // ... for every wave; and every wave is past the MFMAs of panel p-2
     if (p + 2 < np) SWEEP_ISSUE(p + 2);
     drain = !((p0 + p) * PC + PC <= S && (S & 3) == 0) && PASS == 1;
-    if (late && p > 0) SWEEP_EPILOGUE(p - 1);
+    if (SWEEP_PROBE_EPI && late && p > 0) SWEEP_EPILOGUE(p - 1);
     // ---- 48 MFMAs: two accumulators alternate so that no MFMA depends on its predecessor
     const char* st = lds + (p & (NST - 1)) * STAGE;
 #pragma unroll
@@ -557,18 +685,21 @@ __global__ __launch_bounds__(512, 2) void score_sweep_kernel(Args a) {
         acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[ks], acc0, 0, 0, 0);
       }
     }
-    if (!late) SWEEP_EPILOGUE(p);
+    if (SWEEP_PROBE_EPI && !late) SWEEP_EPILOGUE(p);
+    if (!SWEEP_PROBE_EPI) { s_run += acc0[0] + acc1[5]; best += acc0[3] + acc1[7]; }     // keep the MFMAs alive
   }
-  if (late) SWEEP_EPILOGUE(np - 1);
+  if (SWEEP_PROBE_EPI && late) SWEEP_EPILOGUE(np - 1);
 #undef SWEEP_ISSUE
 #undef SWEEP_DOFF
 #undef SWEEP_EPILOGUE
+#undef SWEEP_DPPF
+#undef SWEEP_DPPI
   // ---- row partials of this chunk: combine the two half-waves (they hold disjoint columns of the same row)
   float2* rp = (PASS == 0 ? a.rowpart : a.rowmax_part) + ((long)n * a.NCH + cc) * L;
   if (PASS == 0) {
-    const float mo = swap32(m_run), so = swap32(s_run);
-    const float M = fmaxf(m_run, mo);
-    const float Ssum = s_run * fexp(m_run - M) + so * fexp(mo - M);
+    const float ro = swap32(ref_run), so = swap32(s_run);
+    const float M = fmaxf(ref_run, ro);
+    const float Ssum = s_run * fexp(ref_run - M) + so * fexp(ro - M);
     if (g == 0 && row_ok) rp[row] = make_float2(M, Ssum);
   } else {
     const float bo = swap32(best);
@@ -630,6 +761,7 @@ struct SelectParams {
   Geometry g;
   float thr; int border;
   const int* valid;                 // [N,4] or null
+  int panel_mode;                   // row partials carry the 32-column PANEL of the maximum, not its column (sweep pass B)
 };
 
 // python slice semantics of `m[b, lim:] = False` with lim = hv - bd possibly negative
@@ -697,6 +829,14 @@ __global__ __launch_bounds__(256) void select_kernel(SelectParams sp, const floa
         if (e[u].x > bv) { bv = e[u].x; bj = w & ~sweep::TIE_BIT; tie = (w & sweep::TIE_BIT) != 0; }
         else if (e[u].x == bv) tie = true;
       }
+    }
+    if (sp.panel_mode) {        // the sweep tracked the first panel that attains the maximum: its first column, and whether
+      const float* cr = conf + ((long)n * g.L + i) * g.S;      // the maximum occurs again, come from those 32 entries of conf
+      const int c0 = bj * 32, c1 = min(g.S, c0 + 32);
+      int first = -1;
+      for (int j = c1 - 1; j >= c0; --j)
+        if (cr[j] == bv) { tie = tie || first >= 0; first = j; }
+      bj = first >= 0 ? first : c0;
     }
     flag = candidate_ok(sp, colmax, n, i, bj, bv);
     if (!flag && tie && conf && bv > sp.thr) {          // rare: exact tie at the row maximum and the first one failed
@@ -975,10 +1115,13 @@ __global__ void ot_assign_bins_kernel(Geometry g, float alpha, float norm, const
 }
 
 // ------------------------------------------------------------------------------------------
+// upper bound of the number of sweep work units (pair x column chunk x 256-row block)
+inline size_t sweep_flag_count(int N, int L, int S) { return (size_t)N * (ceil_div(S, 32 * 16) + 1) * ceil_div(L, 256); }
+
 struct MatchWs {
   float2 *rowpart, *colpart, *rowstat, *colstat, *rowmax_part;
   float *colmax_part, *colmax, *cand_conf;
-  int *cand_j, *cand_rank, *block_count, *block_off, *valid;
+  int *cand_j, *cand_rank, *block_count, *block_off, *valid, *sweep_flags;
   float *ot_u, *ot_v; float2* ot_part; uint8_t *rowkill, *colkill;
   sp_t *f0sp, *f1sp;             // SP copies of the descriptors (GEMM operands, gemm.h)
   bool ok;
@@ -1012,6 +1155,7 @@ MatchWs carve(void* ws, size_t bytes, const Geometry& g) {
   m.block_count = wa.take<int>(nblk);
   m.block_off = wa.take<int>(nblk);
   m.valid = wa.take<int>((size_t)g.N * 4);
+  m.sweep_flags = wa.take<int>(sweep_flag_count(g.N, g.L, g.S));
   m.ot_u = wa.take<float>((size_t)g.N * (g.L + 1));
   m.ot_v = wa.take<float>((size_t)g.N * (g.S + 1));
   m.ot_part = wa.take<float2>((size_t)g.N * (g.S + 1) * OT_RCH);
@@ -1033,7 +1177,8 @@ size_t match_ws_bytes(int N, int L, int S, int C) {
   b += NL * 8 + NS * 8 + NS * 4 + NL * 4 * 3 + ((NL + 255) / 256) * 8 + (size_t)N * 16;
   b += (size_t)N * (L + 1) * 4 + (size_t)N * (S + 1) * 4 + (size_t)N * (S + 1) * OT_RCH * 8 + NL + NS;
   b += (NL + NS) * (size_t)C * 4;
-  return b + 34 * 256;     // alignment slack of the bump allocator
+  b += sweep_flag_count(N, L, S) * 4;
+  return b + 36 * 256;     // alignment slack of the bump allocator
 }
 
 bool params_ok(const loftr_coarse_params* p, const loftr_match_out* o) {
@@ -1045,7 +1190,7 @@ bool params_ok(const loftr_coarse_params* p, const loftr_match_out* o) {
 
 // select -> scan -> scatter on the row/col max partials of conf
 int select_and_compact(const Geometry& g, const loftr_coarse_params& p, const loftr_match_out& out,
-                       const MatchWs& w, const float* conf, hipStream_t st) {
+                       const MatchWs& w, const float* conf, hipStream_t st, bool panel_mode = false) {
   const long NL = (long)g.N * g.L, NS = (long)g.N * g.S;
   hipLaunchKernelGGL(merge_colmax_kernel, dim3(ceil_div((int)NS, 256)), dim3(256), 0, st, w.colmax_part, w.colmax, NS, g.PI, g.S);
   const int* valid = nullptr;
@@ -1055,7 +1200,7 @@ int select_and_compact(const Geometry& g, const loftr_coarse_params& p, const lo
   }
   (void)hipMemsetAsync(out.counts, 0, sizeof(int32_t) * (1 + g.N), st);
   const int nblk = (int)((NL + 255) / 256);
-  SelectParams sp{g, p.thr, p.border_rm, valid};
+  SelectParams sp{g, p.thr, p.border_rm, valid, panel_mode ? 1 : 0};
   hipLaunchKernelGGL(select_kernel, dim3(nblk), dim3(256), 0, st, sp, w.rowmax_part, w.colmax, conf, w.cand_j, w.cand_conf,
                      w.cand_rank, w.block_count, out.counts);
   hipLaunchKernelGGL(scan_blocks_kernel, dim3(1), dim3(1024), 0, st, w.block_count, w.block_off, nblk, out.counts);
@@ -1122,18 +1267,28 @@ extern "C" int loftr_coarse_match_dual_softmax(const float* feat_c0, const float
     const dim3 grid(NUM_XCD * ceil_div(g.N * a.NCH, NUM_XCD) * a.RB), block(512);
     {
       TimedLaunch tl(LOFTR_T_SCORE_STATS, st);
-      if (p->mask0) hipLaunchKernelGGL((sweep::score_sweep_kernel<0, true>), grid, block, 0, st, a);
-      else hipLaunchKernelGGL((sweep::score_sweep_kernel<0, false>), grid, block, 0, st, a);
+      if (p->mask0 || !SWEEP_PROBE_FAST) {
+        a.exact_flags = nullptr;                       // padding masks (-1e9 fills): per-row / per-column references throughout
+        if (p->mask0) hipLaunchKernelGGL((sweep::score_sweep_kernel<0, true, false>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((sweep::score_sweep_kernel<0, false, false>), grid, block, 0, st, a);
+      } else {
+        a.exact_flags = w.sweep_flags;                 // shared-reference variant first, exact variant for the units it gave up on
+        (void)hipMemsetAsync(w.sweep_flags, 0, sizeof(int) * (size_t)g.N * a.NCH * a.RB, st);
+        hipLaunchKernelGGL((sweep::score_sweep_kernel<0, false, true>), grid, block, 0, st, a);
+        hipLaunchKernelGGL((sweep::score_sweep_kernel<0, false, false>), grid, block, 0, st, a);
+      }
     }
     hipLaunchKernelGGL(merge_stats_kernel, dim3(ceil_div((int)NL, 256)), dim3(256), 0, st, w.rowpart, w.rowstat, NL, gs.PJ, g.L);
     hipLaunchKernelGGL(merge_stats_kernel, dim3(ceil_div((int)NS, 256)), dim3(256), 0, st, w.colpart, w.colstat, NS, gs.PI, g.S);
     {
       TimedLaunch tl(LOFTR_T_SCORE_CONF, st);
-      if (p->mask0) hipLaunchKernelGGL((sweep::score_sweep_kernel<1, true>), grid, block, 0, st, a);
-      else hipLaunchKernelGGL((sweep::score_sweep_kernel<1, false>), grid, block, 0, st, a);
+      a.exact_flags = nullptr;
+      if (p->mask0) hipLaunchKernelGGL((sweep::score_sweep_kernel<1, true, false, true>), grid, block, 0, st, a);
+      else if (conf_out) hipLaunchKernelGGL((sweep::score_sweep_kernel<1, false, false, false>), grid, block, 0, st, a);
+      else hipLaunchKernelGGL((sweep::score_sweep_kernel<1, false, false, true>), grid, block, 0, st, a);
     }
     LOFTR_CHECK_LAUNCH();
-    return select_and_compact(gs, *p, *out, w, conf_out, st);
+    return select_and_compact(gs, *p, *out, w, conf_out, st, conf_out != nullptr && !p->mask0);
   }
   // other descriptor widths: the tiled two-pass kernels
   const dim3 sgrid(score_grid(g)), block(Cfg::THREADS);

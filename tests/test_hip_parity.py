@@ -142,7 +142,9 @@ def test_properties_full_size():
     out = run_hip(inp)
     conf = out["conf_matrix"]
     assert conf.shape == (2, 4800, 4800)
-    assert conf.min() >= 0 and conf.max() <= 1 + 1e-6
+    # conf = exp2(2 v log2e - LSE_row - LSE_col) (csrc/coarse_match.hip, sweep pass B): the two log-sum-exp biases are
+    # O(100) fp32 numbers, so a confidence of 1 carries ~1e-5 of rounding (the matching tolerance is 1e-4)
+    assert conf.min() >= 0 and conf.max() <= 1 + 3e-5
     assert conf.sum(2).max() <= 1 + 1e-4 and conf.sum(1).max() <= 1 + 1e-4
     b, i, j = out["b_ids"], out["i_ids"], out["j_ids"]
     assert np.array_equal(out["mconf"], conf[b, i, j])
