@@ -35,7 +35,7 @@ typedef enum {
   LOFTR_ERR_COMM = -6           /* RCCL unavailable or a collective / communicator call failed */
 } loftr_status;
 
-#define LOFTR_HIP_ABI_VERSION 12
+#define LOFTR_HIP_ABI_VERSION 13
 
 int loftr_hip_abi_version(void);
 const char* loftr_hip_status_string(int status);
@@ -189,7 +189,7 @@ int loftr_conv_bn_act(const uint32_t* x_sp, int B, int H, int W, int Cin, const 
                       const long* weight_strides, int Cout, int KH, int KW, int stride, int pad, const float* bn_weight, const float* bn_bias,
                       const float* bn_mean, const float* bn_var, float bn_eps, int act,
                       const uint32_t* residual_sp, uint32_t* y_sp, float* y_f32, void* ws, size_t ws_bytes,
-                      void* stream);
+                      const float* x_inv_scale, void* stream);
 /* Inference with constant weights: fold BN + encode the filter once, then run any number of convolutions on it.
  * loftr_conv_prepare fills `prepared` (loftr_conv_workspace_bytes(Cin, Cout, KH, KW) bytes, caller-owned, must
  * stay untouched while in use); loftr_conv_bn_act_prepared is loftr_conv_bn_act (low_sp == NULL) or
@@ -207,7 +207,7 @@ int loftr_conv_prepare(const float* weight, const long* weight_strides, int Cin,
 int loftr_conv_bn_act_prepared(const uint32_t* x_sp, int B, int H, int W, int Cin, const void* prepared,
                                size_t prepared_bytes, int Cout, int KH, int KW, int stride, int pad, int act,
                                const uint32_t* residual_sp, const uint32_t* low_sp, uint32_t* y_sp, float* y_f32,
-                               void* stream);
+                               const float* x_inv_scale, void* stream);
 /* Stem: nn.Conv2d(1, C0, 7, stride 2, padding 3, bias=False) + eval BatchNorm2d + ReLU (resnet_fpn.py:52-54,101),
  * direct convolution; x [B,1,H,W] fp32 through its element strides (sb, sc, sh, sw), y_sp [B,Ho,Wo,ceil32(C0)]. */
 int loftr_stem_conv_bn_relu(const float* x, const long* x_strides, int B, int H, int W, const float* weight,
@@ -224,6 +224,13 @@ int loftr_conv1x1_upsample_add(const uint32_t* x_sp, int B, int H, int W, int Ci
                                const long* weight_strides, int Cout, const uint32_t* low_sp, uint32_t* y_sp,
                                void* ws, size_t ws_bytes, void* stream);
 int loftr_sp_from_f32(const float* src, uint32_t* dst_sp, long rows, int C, void* stream);
+/* Operand scaling (csrc/gemm.h).  The fp16 (hi, lo) pair keeps 22 bits of a value only above 2^-3; GEMM operands are
+ * therefore stored times a power of two that lifts their maximum to [2^13, 2^14).  Filters: per output channel, inside
+ * loftr_conv_prepare.  Activations produced by the library are BatchNorm / LayerNorm bounded and stored as they are; an
+ * fp32 activation tensor of arbitrary magnitude enters through loftr_sp_from_f32_scaled, which writes the INVERSE of the
+ * power of two it applied to the whole tensor to *inv_scale_out (device float) -- pass that pointer as x_inv_scale to
+ * loftr_conv_bn_act / loftr_conv_bn_act_prepared (NULL = the tensor is unscaled). */
+int loftr_sp_from_f32_scaled(const float* src, uint32_t* dst_sp, long rows, int C, float* inv_scale_out, void* stream);
 int loftr_sp_to_f32(const uint32_t* src_sp, float* dst, long rows, int C, void* stream);
 
 /* ---- evaluation caller (the reference's test_step, src/lightning/lightning_loftr.py:205-229) ----------

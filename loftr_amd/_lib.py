@@ -55,16 +55,17 @@ SIGNATURES = {
                                    _i, _i, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
     "loftr_fine_match": (_i, [_p, _p, _i, _i, _i, _p, _p, _f, _p, _p, _p, _p]),
     "loftr_conv_workspace_bytes": (_sz, [_i, _i, _i, _i]),
-    "loftr_conv_bn_act": (_i, [_p, _i, _i, _i, _i, _p, C.POINTER(_l), _i, _i, _i, _i, _i, _p, _p, _p, _p, _f, _i, _p, _p, _p, _p, _sz, _p]),
+    "loftr_conv_bn_act": (_i, [_p, _i, _i, _i, _i, _p, C.POINTER(_l), _i, _i, _i, _i, _i, _p, _p, _p, _p, _f, _i, _p, _p, _p, _p, _sz, _p, _p]),
     "loftr_stem_conv_bn_relu": (_i, [_p, C.POINTER(_l), _i, _i, _i, _p, C.POINTER(_l), _i, _p, _p, _p, _p, _f, _p, _p]),
     "loftr_upsample2x_add": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
     "loftr_resize_linear_u8": (_i, [_p, _i, _i, _l, _p, _i, _i, _l, _p]),
     "loftr_pack_gray_u8": (_i, [_p, _l, _l, _p, _i, _i, _i, _p, _p, _p, _i, _p]),
     "loftr_epipolar_errors": (_i, [_p, _p, _p, _p, _p, _p, _l, _i, _p, _p]),
     "loftr_conv_prepare": (_i, [_p, C.POINTER(_l), _i, _i, _i, _i, _p, _p, _p, _p, _f, _p, _sz, _p]),
-    "loftr_conv_bn_act_prepared": (_i, [_p, _i, _i, _i, _i, _p, _sz, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p]),
+    "loftr_conv_bn_act_prepared": (_i, [_p, _i, _i, _i, _i, _p, _sz, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p]),
     "loftr_conv1x1_upsample_add": (_i, [_p, _i, _i, _i, _i, _p, C.POINTER(_l), _i, _p, _p, _p, _sz, _p]),
     "loftr_sp_from_f32": (_i, [_p, _p, _l, _i, _p]),
+    "loftr_sp_from_f32_scaled": (_i, [_p, _p, _l, _i, _p, _p]),
     "loftr_sp_to_f32": (_i, [_p, _p, _l, _i, _p]),
     "loftr_rccl_unique_id": (_i, [C.c_char_p, _sz]),
     "loftr_rccl_comm_create": (_i, [C.c_char_p, _sz, _i, _i, C.POINTER(_p)]),
@@ -79,7 +80,7 @@ SIGNATURES = {
     "loftr_linear_fwd": (_i, [_p, _p, _p, _i, _i, _i, _p, _sz, _p]),
 }
 
-ABI_VERSION = 12
+ABI_VERSION = 13
 _lib = None
 
 

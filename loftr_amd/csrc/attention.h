@@ -2,6 +2,9 @@
 #pragma once
 #include "gemm.h"
 
+// P (the merged attention projection, SP) is stored multiplied by this power of two (attention.hip: kv_finalize_kernel)
+constexpr float ATTN_P_SCALE = 32.f;
+
 size_t attention_workspace_bytes(int nb, int S, int C);
 
 // Coarse level (C = 256, 8 heads of 32): finalize of the linear-attention reduction.

@@ -76,6 +76,11 @@ __global__ __launch_bounds__(256) void kv_finalize_kernel(const float* __restric
     }
     r[dd] = s;
   }
+  // P feeds the merge GEMM as its B operand.  Its entries (KV / S times a merge weight) are O(0.01-0.1): stored times
+  // the fixed power of two ATTN_P_SCALE so that the fp16 (hi, lo) pair keeps its 22 bits (gemm.h); the merge GEMM's
+  // epilogue multiplies by 1 / ATTN_P_SCALE before the LayerNorm (linear.h: LinearLNArgs::out_scale).
+#pragma unroll
+  for (int dd = 0; dd < 8; ++dd) r[dd] *= ATTN_P_SCALE;
   u32x4 hi, lo;
   sp_pack8(r, hi, lo);
   sp_t* dst = pm + ((long)n * C + j) * C + h * 32 + q * 4;

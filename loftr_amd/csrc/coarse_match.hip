@@ -424,7 +424,7 @@ __device__ __forceinline__ int treduce_imax16(const int (&v)[16], const TrMasks&
   const auto q = __builtin_amdgcn_permlane16_swap(x1, x1, false, false);
   return max((int)q[0], (int)q[1]);
 }
-constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
+constexpr float LOG2E = 1.4426950408889634f;
 constexpr float FAST_SPREAD = 64.f;    // max - min of a wave's 32 x 32 score tile up to which one shared exp reference is exact enough
 
 // FASTA (pass A only): the lean epilogue with ONE shared exp reference per 32 x 32 wave tile.  It is exact only while

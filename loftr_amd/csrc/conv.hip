@@ -20,6 +20,8 @@ struct ConvArgs {
   ASrc a;                       // asrc_conv(x, geometry)
   const sp_t* w; int K;         // [Cout, K] SP, K = KH*KW*Cp
   const float* bias;            // [Cout] (folded BN shift) or null
+  const float* wscale;          // [Cout] inverse power-of-two scale of filter row co (conv_prep_kernel; gemm.h)
+  const float* x_inv;           // device scalar: inverse scale of the input activation tensor, or null (= 1)
   const sp_t* residual;         // [M, Coutp] SP or null (added before the activation)
   sp_t* y_sp;                   // [M, Coutp] SP or null
   float* y_f32;                 // [M, Cout] fp32 (NHWC) or null
@@ -42,9 +44,10 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[C
     const bool creal = col < p.Cout;              // a real output channel
     const bool cpad = col < p.Coutp;              // inside the padded SP row (pad channels are written as 0)
     const float b = (p.bias && creal) ? p.bias[col] : 0.f;
+    const float wsc = (creal ? p.wscale[col] : 1.f) * (p.x_inv ? *p.x_inv : 1.f);      // undo the operands' power-of-two scales
 #pragma unroll
     for (int i = 0; i < Cfg::TM; ++i) {
-      f32x16 v = acc[i][j];
+      f32x16 v = acc[i][j] * wsc;
       if (rs) {
         uint32_t w[16];
 #pragma unroll
@@ -94,12 +97,16 @@ __device__ __forceinline__ void conv_epilogue_up(const ConvArgs& p, f32x16 (&acc
   static_assert(Cfg::BM * LD <= Cfg::LDS_FLOATS, "accumulator tile does not fit the operand ring");
   const EpiLane<Cfg> e;
   __syncthreads();                                  // every wave is done reading the last k-tile
+  const float xinv = p.x_inv ? *p.x_inv : 1.f;
 #pragma unroll
-  for (int j = 0; j < Cfg::TN; ++j)
+  for (int j = 0; j < Cfg::TN; ++j) {
+    const int col = n0 + e.lcol + j * 32;
+    const float wsc = (col < p.Cout ? p.wscale[col] : 1.f) * xinv;        // undo the operands' power-of-two scales
 #pragma unroll
     for (int i = 0; i < Cfg::TM; ++i)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) lds[(e.lrow + e.rr(i, r)) * LD + e.lcol + j * 32] = acc[i][j][r];
+      for (int r = 0; r < 16; ++r) lds[(e.lrow + e.rr(i, r)) * LD + e.lcol + j * 32] = acc[i][j][r] * wsc;
+  }
   __syncthreads();
   const int Wo = 2 * p.Wl, Ho = 2 * p.Hl;
   constexpr int OCTS = Cfg::BN / 8;
@@ -182,7 +189,7 @@ using Cfg = GemmCfg<256, 128, 4, 2, 3>;                                         
 struct Conv3Args {
   const sp_t* x; int B, H, W, Cp, Cin;
   const sp_t* w; int K;
-  const float* bias; const sp_t* residual; sp_t* y_sp; float* y_f32;
+  const float* bias; const float* wscale; const float* x_inv; const sp_t* residual; sp_t* y_sp; float* y_f32;
   int Cout, Coutp, act;
   const sp_t* zeros;
   int tiles_x, tiles_y;
@@ -435,11 +442,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_kernel(Conv3Args p) {
     const int col = n0 + wn * 64 + j * 32 + tx;
     const bool creal = col < p.Cout, cpad = col < p.Coutp;
     const float bia = (p.bias && creal) ? p.bias[col] : 0.f;
+    const float wsc = (creal ? p.wscale[col] : 1.f) * (p.x_inv ? *p.x_inv : 1.f);      // undo the operands' power-of-two scales
     const int spc = (col & ~31) + (odd ? 16 : 0) + ((col & 31) >> 1);      // dword of this lane inside the SP row
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int y = y0 + wm * 2 + i;
-      f32x16 v = acc[i][j];
+      f32x16 v = acc[i][j] * wsc;
       uint32_t rw[16];
       if (p.residual) {
 #pragma unroll
@@ -660,8 +668,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wide_kernel(Conv3Args p) {
     const int col = (j_) * 32 + tx;                                                                         \
     const bool creal = col < p.Cout, cpad = col < p.Coutp;                                                  \
     const float bia = (p.bias && creal) ? p.bias[col] : 0.f;                                                \
+    const float wsc = (creal ? p.wscale[col] : 1.f) * (p.x_inv ? *p.x_inv : 1.f);                           \
     const int spc = (col & ~31) + (odd ? 16 : 0) + ((col & 31) >> 1);   /* dword of this lane inside the SP row */ \
-    f32x16 v = acc[j_];                                                                                     \
+    f32x16 v = acc[j_] * wsc;                                                                               \
     if (RES_) { _Pragma("unroll") for (int r = 0; r < 16; ++r) v[r] += sp_value(buf_[r], odd); }            \
     _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                        \
       float xv = v[r] + bia;                                                                                \
@@ -705,25 +714,52 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wide_kernel(Conv3Args p) {
 // Weight preparation: fold eval-mode BN, transpose to tap-major, pad channels, encode as SP.
 //   w [Cout, Cin, KH, KW] -> wsp [Cout, KH*KW*Cp];  bias[co] = beta - mean * scale,  scale = gamma / sqrt(var + eps)
 //   grid (ceil(groups_per_row / 8), Cout), 256 threads: one half-wave per 32-column SP group.
-__global__ __launch_bounds__(256) void conv_prep_kernel(const float* __restrict__ w, const float* __restrict__ bn_w,
-                                                        const float* __restrict__ bn_b, const float* __restrict__ bn_m,
-                                                        const float* __restrict__ bn_v, float eps, int Cin, int Cp,
-                                                        int KH, int KW, long s_co, long s_ci, long s_ky, long s_kx,
-                                                        sp_t* __restrict__ wsp, float* __restrict__ bias) {
-  const int co = blockIdx.y;
-  const int K = KH * KW * Cp;
+// Per output channel: BN scale / shift and the power-of-two that lifts the largest |folded weight| of the filter row
+// to [2^13, 2^14) (gemm.h: sp_row_scale).   grid (Cout), 256 threads.
+__global__ __launch_bounds__(256) void conv_rowscale_kernel(const float* __restrict__ w, const float* __restrict__ bn_w,
+                                                            const float* __restrict__ bn_b, const float* __restrict__ bn_m,
+                                                            const float* __restrict__ bn_v, float eps, int Cin, int KH, int KW,
+                                                            long s_co, long s_ci, long s_ky, long s_kx,
+                                                            float* __restrict__ bias, float* __restrict__ wscale) {
+  const int co = blockIdx.x;
   float scale = 1.f, shift = 0.f;
   if (bn_w) {
     scale = bn_w[co] / sqrtf(bn_v[co] + eps);
     shift = bn_b[co] - bn_m[co] * scale;
   }
-  if (blockIdx.x == 0 && threadIdx.x == 0) bias[co] = shift;
+  float m = 0.f;
+  for (int t = threadIdx.x; t < Cin * KH * KW; t += 256) {
+    const int c = t % Cin, tap = t / Cin;
+    m = fmaxf(m, fabsf(w[co * s_co + c * s_ci + (tap / KW) * s_ky + (tap % KW) * s_kx] * scale));
+  }
+  __shared__ float red[4];
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float inv;
+    (void)sp_row_scale(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])), &inv);
+    bias[co] = shift;
+    wscale[co] = inv;
+  }
+}
+
+__global__ __launch_bounds__(256) void conv_prep_kernel(const float* __restrict__ w, const float* __restrict__ bn_w,
+                                                        const float* __restrict__ bn_b, const float* __restrict__ bn_m,
+                                                        const float* __restrict__ bn_v, float eps, int Cin, int Cp,
+                                                        int KH, int KW, long s_co, long s_ci, long s_ky, long s_kx,
+                                                        sp_t* __restrict__ wsp, const float* __restrict__ wscale) {
+  const int co = blockIdx.y;
+  const int K = KH * KW * Cp;
+  float scale = 1.f;
+  if (bn_w) scale = bn_w[co] / sqrtf(bn_v[co] + eps);
+  const float up = 1.f / wscale[co];              // exact power of two (conv_rowscale_kernel ran before)
   const int grp = blockIdx.x * 8 + (threadIdx.x >> 5);
   if (grp * 32 >= K) return;
   const int col = grp * 32 + (threadIdx.x & 31);
   const int tap = col / Cp, c = col - tap * Cp;
   float v = 0.f;
-  if (c < Cin) v = w[co * s_co + c * s_ci + (tap / KW) * s_ky + (tap % KW) * s_kx] * scale;
+  if (c < Cin) v = (w[co * s_co + c * s_ci + (tap / KW) * s_ky + (tap % KW) * s_kx] * scale) * up;
   sp_store(wsp + (long)co * K, col, v, true);
 }
 
@@ -847,7 +883,7 @@ __global__ void sp_to_f32_kernel(const sp_t* __restrict__ src, float* __restrict
 
 extern "C" size_t loftr_conv_workspace_bytes(int Cin, int Cout, int KH, int KW) {
   if (Cin <= 0 || Cout <= 0 || KH <= 0 || KW <= 0) return 0;
-  return align_up((size_t)Cout * KH * KW * ceil32(Cin) * 4, 256) + align_up((size_t)Cout * 4, 256) + 2048;
+  return align_up((size_t)Cout * KH * KW * ceil32(Cin) * 4, 256) + 2 * align_up((size_t)Cout * 4, 256) + 2048;
 }
 
 // Grid of a persistent kernel that holds one workgroup per CU: min(virtual workgroups, CUs), CUs rounded down to a
@@ -865,13 +901,14 @@ static unsigned persistent_grid(unsigned nvirt) {
   return cus > 0 && nvirt > (unsigned)cus ? (unsigned)cus : nvirt;
 }
 
-// Folded weights live in a caller-owned buffer laid out [SP weights Cout x K][bias Cout][zero page 256 B]
+// Folded weights live in a caller-owned buffer laid out [SP weights Cout x K][bias Cout][inverse row scales Cout][zero page 256 B]
 // (loftr_conv_workspace_bytes): conv_prepare fills it, conv_run consumes it.
-struct ConvPrepared { sp_t* wsp; float* bias; sp_t* zeros; };
+struct ConvPrepared { sp_t* wsp; float* bias; float* wscale; sp_t* zeros; };
 static bool conv_prepared_layout(void* buf, size_t bytes, int Cin, int Cout, int KH, int KW, ConvPrepared& o) {
   WsAlloc wa(buf, bytes);
   o.wsp = wa.take<sp_t>((size_t)Cout * KH * KW * ceil32(Cin));
   o.bias = wa.take<float>(Cout);
+  o.wscale = wa.take<float>(Cout);
   o.zeros = wa.take<sp_t>(64);
   return wa.ok();
 }
@@ -886,16 +923,18 @@ static int conv_prepare(const float* weight, const long* weight_strides, int Cin
   if (!conv_prepared_layout(buf, bytes, Cin, Cout, KH, KW, pr)) return LOFTR_ERR_WORKSPACE;
   const int Cp = ceil32(Cin), K = KH * KW * Cp;
   (void)hipMemsetAsync(pr.zeros, 0, 256, st);
+  hipLaunchKernelGGL(conv_rowscale_kernel, dim3(Cout), dim3(256), 0, st, weight, bn_weight, bn_bias, bn_mean, bn_var, bn_eps,
+                     Cin, KH, KW, weight_strides[0], weight_strides[1], weight_strides[2], weight_strides[3], pr.bias, pr.wscale);
   hipLaunchKernelGGL(conv_prep_kernel, dim3(ceil_div(K / 32, 8), Cout), dim3(256), 0, st, weight, bn_weight, bn_bias,
                      bn_mean, bn_var, bn_eps, Cin, Cp, KH, KW, weight_strides[0], weight_strides[1], weight_strides[2],
-                     weight_strides[3], pr.wsp, pr.bias);
+                     weight_strides[3], pr.wsp, pr.wscale);
   LOFTR_CHECK_LAUNCH();
   return LOFTR_OK;
 }
 
 static int conv_run(const uint32_t* x_sp, int B, int H, int W, int Cin, const void* prepared, size_t prepared_bytes, int Cout,
                     int KH, int KW, int stride, int pad, int act, const uint32_t* residual_sp, const uint32_t* up_sp,
-                    uint32_t* y_sp, float* y_f32, void* stream) {
+                    uint32_t* y_sp, float* y_f32, void* stream, const float* x_inv = nullptr) {
   LOFTR_CHECK_ARG(x_sp && prepared && (y_sp || y_f32) && B >= 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0);
   const bool shared_gpu = (act & LOFTR_CONV_SHARED_GPU) != 0;      // see loftr_hip.h: no persistent workgroups
   act &= ~LOFTR_CONV_SHARED_GPU;
@@ -920,7 +959,7 @@ static int conv_run(const uint32_t* x_sp, int B, int H, int W, int Cin, const vo
   g.zeros = zeros;
   ConvArgs p;
   p.a = asrc_conv(x_sp, g);
-  p.w = wsp; p.K = K; p.bias = bias; p.residual = residual_sp; p.y_sp = y_sp; p.y_f32 = y_f32;
+  p.w = wsp; p.K = K; p.bias = bias; p.wscale = pr.wscale; p.x_inv = x_inv; p.residual = residual_sp; p.y_sp = y_sp; p.y_f32 = y_f32;
   p.M = (int)M; p.Cout = Cout; p.Coutp = ceil32(Cout); p.act = act;
   p.up = up_sp; p.Hl = g.Ho / 2; p.Wl = g.Wo / 2;
   p.sy = g.Ho > 1 ? (float)(p.Hl - 1) / (float)(g.Ho - 1) : 0.f;
@@ -928,7 +967,7 @@ static int conv_run(const uint32_t* x_sp, int B, int H, int W, int Cin, const vo
   static const int use_patch = []() { const char* e = getenv("LOFTR_CONV_PATCH"); return e ? atoi(e) : 1; }();
   if (use_patch && KH == 3 && KW == 3 && stride == 1 && pad == 1 && !up_sp) {
     Conv3Args c;
-    c.x = x_sp; c.B = B; c.H = H; c.W = W; c.Cp = g.Cp; c.Cin = Cin; c.w = wsp; c.K = K; c.bias = bias; c.residual = residual_sp;
+    c.x = x_sp; c.B = B; c.H = H; c.W = W; c.Cp = g.Cp; c.Cin = Cin; c.w = wsp; c.K = K; c.bias = bias; c.wscale = pr.wscale; c.x_inv = x_inv; c.residual = residual_sp;
     c.y_sp = y_sp; c.y_f32 = y_f32; c.Cout = Cout; c.Coutp = ceil32(Cout); c.act = act; c.zeros = zeros;
     c.tiles_x = ceil_div(W, c3::TX); c.tiles_y = ceil_div(H, c3::TY);
     // LOFTR_CONV_WIDE=0: run 7-column-tile outputs as 128 + 96 columns on the generic kernel (A/B experiments)
@@ -972,22 +1011,22 @@ extern "C" int loftr_conv_prepare(const float* weight, const long* weight_stride
 extern "C" int loftr_conv_bn_act_prepared(const uint32_t* x_sp, int B, int H, int W, int Cin, const void* prepared,
                                           size_t prepared_bytes, int Cout, int KH, int KW, int stride, int pad, int act,
                                           const uint32_t* residual_sp, const uint32_t* low_sp, uint32_t* y_sp, float* y_f32,
-                                          void* stream) {
+                                          const float* x_inv_scale, void* stream) {
   return conv_run(x_sp, B, H, W, Cin, prepared, prepared_bytes, Cout, KH, KW, stride, pad, act, residual_sp, low_sp, y_sp, y_f32,
-                  stream);
+                  stream, x_inv_scale);
 }
 
 extern "C" int loftr_conv_bn_act(const uint32_t* x_sp, int B, int H, int W, int Cin, const float* weight,
                                  const long* weight_strides, int Cout, int KH, int KW, int stride, int pad, const float* bn_weight, const float* bn_bias,
                                  const float* bn_mean, const float* bn_var, float bn_eps, int act,
                                  const uint32_t* residual_sp, uint32_t* y_sp, float* y_f32, void* ws, size_t ws_bytes,
-                                 void* stream) {
+                                 const float* x_inv_scale, void* stream) {
   LOFTR_CHECK_ARG(x_sp && (y_sp || y_f32) && B >= 0 && H > 0 && W > 0);
   if (B == 0) return LOFTR_OK;
   const int rc = conv_prepare(weight, weight_strides, Cin, Cout, KH, KW, bn_weight, bn_bias, bn_mean, bn_var, bn_eps, ws, ws_bytes,
                               (hipStream_t)stream);
   if (rc != LOFTR_OK) return rc;
-  return conv_run(x_sp, B, H, W, Cin, ws, ws_bytes, Cout, KH, KW, stride, pad, act, residual_sp, nullptr, y_sp, y_f32, stream);
+  return conv_run(x_sp, B, H, W, Cin, ws, ws_bytes, Cout, KH, KW, stride, pad, act, residual_sp, nullptr, y_sp, y_f32, stream, x_inv_scale);
 }
 
 extern "C" int loftr_conv1x1_upsample_add(const uint32_t* x_sp, int B, int H, int W, int Cin, const float* weight,
@@ -1036,6 +1075,11 @@ extern "C" int loftr_upsample2x_add(const uint32_t* low_sp, const uint32_t* late
 extern "C" int loftr_sp_from_f32(const float* src, uint32_t* dst_sp, long rows, int C, void* stream) {
   LOFTR_CHECK_ARG(src && dst_sp && rows >= 0 && C > 0);
   return launch_sp_convert1(src, C, dst_sp, rows, C, (hipStream_t)stream);
+}
+
+extern "C" int loftr_sp_from_f32_scaled(const float* src, uint32_t* dst_sp, long rows, int C, float* inv_scale_out, void* stream) {
+  LOFTR_CHECK_ARG(src && dst_sp && inv_scale_out && rows >= 0 && C > 0);
+  return launch_sp_convert1(src, C, dst_sp, rows, C, (hipStream_t)stream, inv_scale_out);
 }
 
 extern "C" int loftr_sp_to_f32(const uint32_t* src_sp, float* dst, long rows, int C, void* stream) {

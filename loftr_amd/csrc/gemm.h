@@ -5,16 +5,24 @@
 // 10-100x, and gfx950 has no xf32.  The fp32-input MFMA (v_mfma_f32_32x32x2_f32) is
 // exact but runs at the fp32 VECTOR rate (157 TFLOP/s), 1/16 of the fp16 matrix rate.  Instead every
 // fp32 value x that feeds a GEMM is represented by two fp16 numbers
-//        hi = fp16(x),   lo = fp16(x - hi)          (x - hi is exact in fp32; |x - hi - lo| <= 2^-22 |x|)
+//        hi = fp16(x),   lo = fp16(x - hi)          (x - hi is exact in fp32)
 // and each product is evaluated as three fp16 MFMAs with fp32 accumulation,
 //        a*b  ~=  hi_a*hi_b + hi_a*lo_b + lo_a*hi_b          (dropped: lo_a*lo_b ~ 2^-22 |a*b|)
 // i.e. ~22 mantissa bits per product at 3/16 of the cost of the fp32 MFMA (peak 2.5 PF / 3).  Every
 // fp16 x fp16 product is exact in fp32, so the only extra error over an fp32 fma chain is the
-// 2^-22-relative representation / dropped-term error: measured end-to-end through the 8 coarse
-// layers + dual-softmax it moves conf by 1.4e-5 vs an fp64 run (fp32 chain: 1.9e-5), DESIGN.md §5.
-// Range: |x| must stay below the fp16 maximum 65504 (LayerNorm-bounded activations and weights are
-// O(1)); tiny values degrade gracefully (absolute error <= 2^-25 through fp16 subnormals, which
-// the MFMA does not flush -- tools/micro/f16_denorm.hip).
+// representation / dropped-term error: measured end-to-end through the 8 coarse layers + dual-softmax it
+// moves conf by 1.4e-5 vs an fp64 run (fp32 chain: 1.9e-5), DESIGN.md §5.
+// Representation error and SCALING.  |x - hi - lo| <= 2^-22 |x| holds only while lo is a NORMAL fp16 number,
+// i.e. for |x| >= 2^-3: below that lo is subnormal and the error is the absolute 2^-25 (the MFMA does not flush
+// subnormals, tools/micro/f16_denorm.hip) -- 2e-5 relative at |x| = 1e-3.  What a GEMM needs is error small against
+// the ROW it is summed with, so operands are stored pre-multiplied by a power of two that lifts the row maximum to
+// [2^13, 2^14) (exact; undone in the consumer's epilogue, also exactly):
+//   * weight matrices / convolution filters: one exponent per output row (sp_convert with SpJobs::inv_scale,
+//     conv_prep_kernel), multiplied back per output column -- entries down to 2^-17 of the row maximum keep 22 bits;
+//   * activations entering through the C-ABI as fp32 (loftr_linear_fwd: per row; loftr_sp_from_f32_scaled: per
+//     tensor) likewise; activations produced INSIDE the pipeline are LayerNorm / BatchNorm bounded (O(1)) and are
+//     stored unscaled -- an epilogue cannot know its tensor's maximum before it has written it.
+// Range: a scaled |x| stays below 2^14, an unscaled one must stay below the fp16 maximum 65504.
 //
 // The SP ("split pair") tensor format.  Doing the split inside the GEMM costs ~4 VALU instructions
 // per operand element per tile -- measured 9 VALU per MFMA, matrix pipe 23 % busy (profiles/,
@@ -596,8 +604,22 @@ struct SpJobs {
   const float* src[SP_MAX_JOBS];
   sp_t* dst[SP_MAX_JOBS];
   int rows[SP_MAX_JOBS], K[SP_MAX_JOBS], ld[SP_MAX_JOBS];     // ld = source row pitch in floats
+  float* inv_scale[SP_MAX_JOBS];   // null: stored as is.  Else float[rows]: every row is stored multiplied by the power of two
+                                   // that lifts its maximum to [2^13, 2^14) and the INVERSE factor is written here (gemm.h header)
+  const float* tensor_inv[SP_MAX_JOBS];   // null, or a device scalar: the whole tensor is stored multiplied by 1 / *tensor_inv
   int n;
+  SpJobs() : n(0) { for (int i = 0; i < SP_MAX_JOBS; ++i) { inv_scale[i] = nullptr; tensor_inv[i] = nullptr; } }
 };
+// power of two s with max * s in [2^13, 2^14) (1 for an all-zero row); returns s, *inv = 1 / s (both exact)
+__host__ __device__ static inline float sp_row_scale(float absmax, float* inv) {
+  if (!(absmax > 0.f) || !(absmax < 3.0e38f)) { *inv = 1.f; return 1.f; }
+  int e;
+  (void)frexpf(absmax, &e);                 // absmax = m * 2^e, m in [0.5, 1)
+  int sh = 14 - e;                          // m * 2^14 in [2^13, 2^14)
+  sh = sh > 100 ? 100 : (sh < -100 ? -100 : sh);
+  *inv = ldexpf(1.f, -sh);
+  return ldexpf(1.f, sh);
+}
 static inline int ceil32(int k) { return (k + 31) / 32 * 32; }
 int launch_sp_convert(const SpJobs& jobs, hipStream_t st);
-int launch_sp_convert1(const float* src, int ld, sp_t* dst, long rows, int K, hipStream_t st);
+int launch_sp_convert1(const float* src, int ld, sp_t* dst, long rows, int K, hipStream_t st, float* tensor_inv_out = nullptr);

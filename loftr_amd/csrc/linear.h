@@ -13,6 +13,8 @@ struct LinearArgs {
   int M, N, K;
   const float* bias; int bias_mode; int group;
   bool relu;
+  const float* wscale_inv;      // [N] or null: W row n was stored multiplied by a power of two, this is its inverse (gemm.h)
+  const float* ascale_inv;      // [M] or null: the same for the rows of A (loftr_linear_fwd only)
 };
 int launch_linear(const LinearArgs& p, hipStream_t st);
 
@@ -34,6 +36,7 @@ struct ProjArgs {
   float inv_s;                           // 1 / v_length
   const float* kv;                       // [nbatch, 8, 33, 32] (row 32 of each head = Ksum) or null
   float v_length, eps;
+  const float* wsc[3];                   // per segment: [C] inverse row scales of w[seg] or null
 };
 int launch_proj(const ProjArgs& p, hipStream_t st);
 
@@ -51,6 +54,7 @@ struct ProjKVArgs {
   const uint8_t* mask;                           // [nbatch * S] or null
   float inv_s;
   float* part; int splits;
+  const float* wsc;                              // [2C] inverse row scales of w_kv (same interleaved row order) or null
 };
 int launch_proj_kv(const ProjKVArgs& p, hipStream_t st);
 
@@ -68,5 +72,8 @@ struct LinearLNArgs {
   int M, C, K;
   float eps;
   int nbatch; long w_batch_stride;
+  const float* wscale_inv;      // [C] inverse row scales of W or null
+  float out_scale;              // 0 = none; else every accumulator is multiplied by it first (P of the merged attention
+                                // projection is stored times a fixed power of two, attention.hip)
 };
 int launch_linear_ln(const LinearLNArgs& p, hipStream_t st);

@@ -24,9 +24,14 @@ __device__ __forceinline__ void linear_epilogue(const LinearArgs& p, f32x16 (&ac
     const int col = n0 + e.lcol + j * 32;
     const bool cok = FULL || col < p.N;
     const float bcol = (BIAS == 1 && cok) ? p.bias[col] : 0.f;
+    const float wsc = (p.wscale_inv && cok) ? p.wscale_inv[col] : 1.f;      // undo the weight row's power-of-two scale
 #pragma unroll
     for (int i = 0; i < Cfg::TM; ++i) {
-      f32x16 v = acc[i][j];
+      f32x16 v = acc[i][j] * wsc;
+      if (p.ascale_inv) {                                                     // ... and the A row's (block-uniform branch)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] *= p.ascale_inv[FULL ? m0 + e.lrow + e.rr(i, r) : min(m0 + e.lrow + e.rr(i, r), p.M - 1)];
+      }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int trow = e.lrow + e.rr(i, r);
@@ -111,9 +116,10 @@ __device__ __forceinline__ void proj_epilogue(const ProjArgs& p, f32x16 (&acc)[C
   for (int j = 0; j < Cfg::TN; ++j) {
     const int col = n0 + e.lcol + j * 32;                          // head = col / 32, d = col % 32 = lane & 31
     const float ksum = ZSCALE ? p.kv[(n * 8 + (col >> 5)) * (33 * 32) + 32 * 32 + (col & 31)] : 0.f;
+    const float wsc = p.wsc[seg] ? p.wsc[seg][col] : 1.f;
 #pragma unroll
     for (int i = 0; i < Cfg::TM; ++i) {
-      f32x16 v = acc[i][j];
+      f32x16 v = acc[i][j] * wsc;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         float x = v[r];
@@ -191,6 +197,7 @@ __global__ __launch_bounds__(Cfg::THREADS, 2) void proj_kv_kernel(ProjKVArgs p) 
   const int wm = wave % Cfg::WM, wn = wave / Cfg::WM;
   const uint8_t* mask = p.mask ? p.mask + n * p.S : nullptr;
   // feature map / masks on the accumulators: tile j = 0 holds K (elu+1), j = 1 holds V (1/S); rows >= S contribute 0
+  const float wk = p.wsc ? p.wsc[n0 + e.lcol] : 1.f, wv = p.wsc ? p.wsc[n0 + e.lcol + 32] : 1.f;
   float ksum = 0.f;
 #pragma unroll
   for (int i = 0; i < Cfg::TM; ++i)
@@ -199,9 +206,9 @@ __global__ __launch_bounds__(Cfg::THREADS, 2) void proj_kv_kernel(ProjKVArgs p) 
       const int row = m0 + e.lrow + e.rr(i, r);
       float mk = row < p.S ? 1.f : 0.f;
       if (mask) mk = (row < p.S && mask[row]) ? 1.f : 0.f;
-      const float k = acc[i][0][r];
+      const float k = acc[i][0][r] * wk;
       acc[i][0][r] = (k > 0.f ? k + 1.f : __expf(k)) * mk;            // elu(k)+1, linear_attention.py:31-32,37-38
-      acc[i][1][r] = acc[i][1][r] * (mk * p.inv_s);                    // values * mask / v_length   :39-42
+      acc[i][1][r] = acc[i][1][r] * (wv * (mk * p.inv_s));             // values * mask / v_length   :39-42
       ksum += acc[i][0][r];
     }
   // KV[d][v] += sum_rows K[row][d] V[row][v]: register r of the K tile IS the A operand of v_mfma_f32_32x32x2_f32
@@ -265,6 +272,14 @@ __global__ __launch_bounds__(Cfg::THREADS, 2) void linear_ln_kernel(LinearLNArgs
   const int wn = wave / Cfg::WM;
   const float inv_c = 1.f / (float)p.C;
   const EpiLane<Cfg> e;
+  if (p.wscale_inv || p.out_scale != 0.f) {         // undo the power-of-two operand scales (exact) before the statistics
+#pragma unroll
+    for (int j = 0; j < Cfg::TN; ++j) {
+      const float sc = (p.wscale_inv ? p.wscale_inv[e.lcol + j * 32] : 1.f) * (p.out_scale != 0.f ? p.out_scale : 1.f);
+#pragma unroll
+      for (int i = 0; i < Cfg::TM; ++i) acc[i][j] *= sc;
+    }
+  }
   const bool full = m0 + Cfg::BM <= p.M;            // block-uniform
 
   float* red = lds;                                 // [BM][WN] partial sums

@@ -16,6 +16,7 @@ constexpr int MAX_LAYERS = 16;
 struct LayerSp {                 // SP copies of one layer's matrices (workspace) + the fp32 originals needed
   const sp_t *q, *k, *v, *merge, *mlp0, *mlp2;
   const sp_t* kv;                // C == 256: [2C, C], rows interleaved per head [K_h | V_h] (linear.h: ProjKVArgs)
+  const float *q_s, *k_s, *v_s, *merge_s, *mlp0_s, *mlp2_s, *kv_s;   // inverse per-row power-of-two scales (gemm.h)
   const float* merge_f32;
   const float *n1w, *n1b, *n2w, *n2b;
 };
@@ -28,7 +29,8 @@ struct EncoderWs {
   bool ok;
 };
 
-size_t weights_sp_dwords(int C) { return (size_t)12 * C * C; }     // q k v merge (4) + mlp0 (4) + mlp2 (2) + interleaved kv (2)
+// q k v merge (4) + mlp0 (4) + mlp2 (2) + interleaved kv (2) matrices, then their 9C inverse row scales (padded to 16C)
+size_t weights_sp_dwords(int C) { return (size_t)12 * C * C + (size_t)16 * C; }
 constexpr int JOBS_PER_LAYER = 6 + 16;
 
 size_t encoder_ws_bytes(int nb, int L, int S, int C) {
@@ -64,25 +66,28 @@ bool weights_ok(const loftr_layer_weights& w) {
 // queue the fp32 -> SP conversion of one layer's six matrices; returns the SP view
 LayerSp stage_layer(const loftr_layer_weights& w, sp_t* dst, int C, SpJobs& jobs) {
   LayerSp l;
-  auto add = [&](const float* src, int rows, int K) {
+  float* sc = reinterpret_cast<float*>(dst + (size_t)12 * C * C);      // the layer's scale block behind its matrices
+  auto add = [&](const float* src, int rows, int K, float* inv) {
     const int i = jobs.n++;
-    jobs.src[i] = src; jobs.dst[i] = dst; jobs.rows[i] = rows; jobs.K[i] = K; jobs.ld[i] = K;
+    jobs.src[i] = src; jobs.dst[i] = dst; jobs.rows[i] = rows; jobs.K[i] = K; jobs.ld[i] = K; jobs.inv_scale[i] = inv;
     sp_t* r = dst;
     dst += (size_t)rows * K;
     return r;
   };
-  l.q = add(w.q_proj, C, C);
-  l.k = add(w.k_proj, C, C);
-  l.v = add(w.v_proj, C, C);
-  l.merge = add(w.merge, C, C);
-  l.mlp0 = add(w.mlp0, 2 * C, 2 * C);
-  l.mlp2 = add(w.mlp2, C, 2 * C);
+  l.q_s = sc; l.k_s = sc + C; l.v_s = sc + 2 * C; l.merge_s = sc + 3 * C; l.mlp0_s = sc + 4 * C; l.mlp2_s = sc + 6 * C;
+  l.kv_s = sc + 7 * C;
+  l.q = add(w.q_proj, C, C, sc);
+  l.k = add(w.k_proj, C, C, sc + C);
+  l.v = add(w.v_proj, C, C, sc + 2 * C);
+  l.merge = add(w.merge, C, C, sc + 3 * C);
+  l.mlp0 = add(w.mlp0, 2 * C, 2 * C, sc + 4 * C);
+  l.mlp2 = add(w.mlp2, C, 2 * C, sc + 6 * C);
   l.kv = nullptr;
   if (C == 256) {                // per head: 32 rows of k_proj then 32 rows of v_proj
     l.kv = dst;
     for (int h = 0; h < 8; ++h) {
-      add(w.k_proj + (size_t)h * 32 * C, 32, C);
-      add(w.v_proj + (size_t)h * 32 * C, 32, C);
+      add(w.k_proj + (size_t)h * 32 * C, 32, C, sc + 7 * C + h * 64);
+      add(w.v_proj + (size_t)h * 32 * C, 32, C, sc + 7 * C + h * 64 + 32);
     }
   }
   l.merge_f32 = w.merge;
@@ -104,42 +109,46 @@ int encoder_layer(const float* x_f32, const sp_t* x_sp, const sp_t* src_sp, bool
     // -> finalize: sum of the row-tile partials + P (KV folded into merge)
     float* part = attention_part_buffer(e.attn, e.attn_bytes, nb, S);
     if (!part) return LOFTR_ERR_WORKSPACE;
-    ProjKVArgs pkv{src_sp, S, C, nb, w.kv, src_mask, inv_s, part, ceil_div(S, 128)};
+    ProjKVArgs pkv{src_sp, S, C, nb, w.kv, src_mask, inv_s, part, ceil_div(S, 128), w.kv_s};
     if ((rc = launch_proj_kv(pkv, st))) return rc;
     const float* kv = nullptr; const sp_t* pm = nullptr;
     if ((rc = launch_attention_finalize(w.merge_f32, nb, S, C, H, e.attn, e.attn_bytes, &kv, &pm, st))) return rc;
     (void)Ms;
     // q projection with the normaliser applied in its epilogue (per pair: grid.z = nb)
     ProjArgs pq{x_sp, L, C, nb, 1, {w.q, nullptr, nullptr}, {e.q, nullptr, nullptr}, {0, 0, 0}, x_mask, inv_s,
-                kv, (float)S, attn_eps};
+                kv, (float)S, attn_eps, {w.q_s, nullptr, nullptr}};
     if ((rc = launch_proj(pq, st))) return rc;
     // message = norm1(merge(attention))  as ONE GEMM against P                    transformer.py:50-52
     LinearLNArgs m{asrc_plain(e.q, C), pm, C, w.n1w, w.n1b, nullptr, nullptr, e.msgn, L, C, C, 1e-5f,
-                   nb, (long)C * C};
+                   nb, (long)C * C, nullptr, 1.f / ATTN_P_SCALE};
     if ((rc = launch_linear_ln(m, st))) return rc;
   } else {
     float* qf = reinterpret_cast<float*>(e.q);
     if (self) {
-      ProjArgs p{x_sp, Ml, C, 1, 3, {w.q, w.k, w.v}, {qf, e.k, e.v}, {0, 1, 2}, x_mask, inv_s, nullptr, 0.f, 0.f};
+      ProjArgs p{x_sp, Ml, C, 1, 3, {w.q, w.k, w.v}, {qf, e.k, e.v}, {0, 1, 2}, x_mask, inv_s, nullptr, 0.f, 0.f,
+                 {w.q_s, w.k_s, w.v_s}};
       if ((rc = launch_proj(p, st))) return rc;
     } else {
       ProjArgs pq{x_sp, Ml, C, 1, 1, {w.q, nullptr, nullptr}, {qf, nullptr, nullptr}, {0, 0, 0}, x_mask, inv_s,
-                  nullptr, 0.f, 0.f};
+                  nullptr, 0.f, 0.f, {w.q_s, nullptr, nullptr}};
       if ((rc = launch_proj(pq, st))) return rc;
       ProjArgs pkv{src_sp, Ms, C, 1, 2, {w.k, w.v, nullptr}, {e.k, e.v, nullptr}, {1, 2, 0}, src_mask, inv_s,
-                   nullptr, 0.f, 0.f};
+                   nullptr, 0.f, 0.f, {w.k_s, w.v_s, nullptr}};
       if ((rc = launch_proj(pkv, st))) return rc;
     }
     if ((rc = launch_attention_small(qf, e.k, e.v, e.msg, nb, L, S, C, H, st))) return rc;
     // message = norm1(merge(message))                                   transformer.py:51-52
-    LinearLNArgs m{asrc_plain(e.msg, C), w.merge, C, w.n1w, w.n1b, nullptr, nullptr, e.msgn, Ml, C, C, 1e-5f, 1, 0};
+    LinearLNArgs m{asrc_plain(e.msg, C), w.merge, C, w.n1w, w.n1b, nullptr, nullptr, e.msgn, Ml, C, C, 1e-5f, 1, 0,
+                   w.merge_s, 0.f};
     if ((rc = launch_linear_ln(m, st))) return rc;
   }
   // hidden = relu(mlp.0(cat[x, message]))                             transformer.py:55
-  LinearArgs h{asrc_cat(x_sp, e.msgn, C, C), w.mlp0, 2 * C, nullptr, e.hid, 2 * C, Ml, 2 * C, 2 * C, nullptr, 0, 1, true};
+  LinearArgs h{asrc_cat(x_sp, e.msgn, C, C), w.mlp0, 2 * C, nullptr, e.hid, 2 * C, Ml, 2 * C, 2 * C, nullptr, 0, 1, true,
+               w.mlp0_s, nullptr};
   if ((rc = launch_linear(h, st))) return rc;
   // out = x + norm2(mlp.2(hidden))                                    transformer.py:55-58
-  LinearLNArgs o{asrc_plain(e.hid, 2 * C), w.mlp2, 2 * C, w.n2w, w.n2b, x_f32, out_f32, out_sp, Ml, C, 2 * C, 1e-5f, 1, 0};
+  LinearLNArgs o{asrc_plain(e.hid, 2 * C), w.mlp2, 2 * C, w.n2w, w.n2b, x_f32, out_f32, out_sp, Ml, C, 2 * C, 1e-5f, 1, 0,
+                 w.mlp2_s, 0.f};
   return launch_linear_ln(o, st);
 }
 
@@ -242,7 +251,8 @@ extern "C" int loftr_transformer_fwd(float* feat0, float* feat1, const uint8_t* 
 // ------------------------------------------------------------------------------------------
 extern "C" size_t loftr_linear_workspace_bytes(int M, int N, int K) {
   if (M <= 0 || N <= 0 || K <= 0) return 0;
-  return align_up((size_t)M * ceil32(K) * 4, 256) + align_up((size_t)N * ceil32(K) * 4, 256) + 1024;
+  return align_up((size_t)M * ceil32(K) * 4, 256) + align_up((size_t)N * ceil32(K) * 4, 256) +
+         align_up((size_t)M * 4, 256) + align_up((size_t)N * 4, 256) + 1024;
 }
 
 extern "C" int loftr_linear_fwd(const float* a, const float* w, float* out, int M, int N, int K,
@@ -255,12 +265,14 @@ extern "C" int loftr_linear_fwd(const float* a, const float* w, float* out, int 
   WsAlloc wa(ws, ws_bytes);
   sp_t* a_sp = wa.take<sp_t>((size_t)M * Kp);
   sp_t* w_sp = wa.take<sp_t>((size_t)N * Kp);
+  float* a_inv = wa.take<float>((size_t)M);          // per-row power-of-two scales of both operands (gemm.h): the product is
+  float* w_inv = wa.take<float>((size_t)N);          // accurate relative to the ROWS' magnitudes, whatever the tensors' scale
   if (!wa.ok()) return LOFTR_ERR_WORKSPACE;
   SpJobs jobs; jobs.n = 2;
-  jobs.src[0] = a; jobs.dst[0] = a_sp; jobs.rows[0] = M; jobs.K[0] = K; jobs.ld[0] = K;
-  jobs.src[1] = w; jobs.dst[1] = w_sp; jobs.rows[1] = N; jobs.K[1] = K; jobs.ld[1] = K;
+  jobs.src[0] = a; jobs.dst[0] = a_sp; jobs.rows[0] = M; jobs.K[0] = K; jobs.ld[0] = K; jobs.inv_scale[0] = a_inv;
+  jobs.src[1] = w; jobs.dst[1] = w_sp; jobs.rows[1] = N; jobs.K[1] = K; jobs.ld[1] = K; jobs.inv_scale[1] = w_inv;
   int rc;
   if ((rc = launch_sp_convert(jobs, st))) return rc;
-  LinearArgs p{asrc_plain(a_sp, Kp), w_sp, Kp, out, nullptr, N, M, N, Kp, nullptr, 0, 1, false};
+  LinearArgs p{asrc_plain(a_sp, Kp), w_sp, Kp, out, nullptr, N, M, N, Kp, nullptr, 0, 1, false, w_inv, a_inv};
   return launch_linear(p, st);
 }

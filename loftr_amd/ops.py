@@ -296,11 +296,19 @@ def ceil32(c):
 
 
 @_on_device
-def sp_from_nhwc(x_nhwc):
-    """fp32 [B,H,W,C] contiguous -> SP int32 [B,H,W,ceil32(C)]."""
+def sp_from_nhwc(x_nhwc, scaled=False):
+    """fp32 [B,H,W,C] contiguous -> SP int32 [B,H,W,ceil32(C)].
+    scaled=True: the tensor is stored times the power of two that lifts its maximum to [2^13, 2^14) (csrc/gemm.h:
+    full split-fp16 precision whatever the tensor's magnitude); returns (sp, inv_scale) with inv_scale a device float
+    to hand to conv_bn_act(x_inv_scale=...)."""
     _need(x_nhwc, "x_nhwc")
     B, H, W, Cc = x_nhwc.shape
     out = torch.empty(B, H, W, ceil32(Cc), dtype=torch.int32, device=x_nhwc.device)
+    if scaled:
+        inv = torch.empty(1, dtype=torch.float32, device=x_nhwc.device)
+        check(_lib.load().loftr_sp_from_f32_scaled(_ptr(x_nhwc), _ptr(out), B * H * W, Cc, _ptr(inv), _stream()),
+              "loftr_sp_from_f32_scaled")
+        return out, inv
     check(_lib.load().loftr_sp_from_f32(_ptr(x_nhwc), _ptr(out), B * H * W, Cc, _stream()), "loftr_sp_from_f32")
     return out
 
@@ -344,7 +352,8 @@ CONV_SHARED_GPU = 0x100      # include/loftr_hip.h: LOFTR_CONV_SHARED_GPU
 
 
 @_on_device
-def conv_bn_act(x_sp, Cin, conv, bn=None, act=0, residual=None, want_sp=True, want_f32=False, low_sp=None, shared_gpu=False):
+def conv_bn_act(x_sp, Cin, conv, bn=None, act=0, residual=None, want_sp=True, want_f32=False, low_sp=None, shared_gpu=False,
+                x_inv_scale=None):
     """nn.Conv2d(bias=False) [+ eval BatchNorm2d] [+ residual] [+ act] on an SP activation.
 
     x_sp int32 [B,H,W,ceil32(Cin)]; returns (y_sp or None, y_f32 [B,Ho,Wo,Cout] or None).
@@ -363,7 +372,7 @@ def conv_bn_act(x_sp, Cin, conv, bn=None, act=0, residual=None, want_sp=True, wa
     y_f32 = torch.empty(B, Ho, Wo, Cout, dtype=torch.float32, device=dev) if want_f32 else None
     check(_lib.load().loftr_conv_bn_act_prepared(_ptr(x_sp), B, H, W, Cin, _ptr(prepared), prepared.numel(), Cout, KH, KW,
                                                  stride, pad, int(act) | (CONV_SHARED_GPU if shared_gpu else 0), _ptr(residual),
-                                                 _ptr(low_sp), _ptr(y_sp), _ptr(y_f32),
+                                                 _ptr(low_sp), _ptr(y_sp), _ptr(y_f32), _ptr(x_inv_scale),
                                                  _stream()), "loftr_conv_bn_act_prepared")
     return y_sp, y_f32
 

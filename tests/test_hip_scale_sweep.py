@@ -1,0 +1,93 @@
+"""The split-fp16 GEMM core must be accurate whatever the MAGNITUDE of its operands (VERDICT r1 "what's weak" #2).
+
+An fp32 value x is carried as hi = fp16(x), lo = fp16(x - hi); lo keeps its bits only while it is a normal fp16 number,
+i.e. for |x| >= 2^-3 -- at |x| ~ 1e-3 the pair is good to 2e-5 only.  Operands are therefore stored times a power of two
+(csrc/gemm.h): weight rows / filter rows always, fp32 activations entering through the C-ABI per row (loftr_linear_fwd)
+or per tensor (loftr_sp_from_f32_scaled).  Sweep: operand scales {1, 1e-2, 1e-3, 1e-4} x {1, 1e-3}; error against fp64
+relative to the output's magnitude must stay <= 2e-6 (plain fp32 sits at 2-7e-7 on these shapes)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+TOL = 2e-6
+A_SCALES = [1.0, 1e-2, 1e-3, 1e-4]
+W_SCALES = [1.0, 1e-3]
+
+
+@pytest.mark.parametrize("sa", A_SCALES)
+@pytest.mark.parametrize("sw", W_SCALES)
+def test_linear_fwd_scale_invariant(sa, sw):
+    from loftr_amd import ops
+    g = torch.Generator().manual_seed(17)
+    M, N, K = 1000, 256, 256
+    a = torch.randn(M, K, generator=g) * sa
+    w = torch.randn(N, K, generator=g) * sw
+    a[:, 5] *= 30.0                      # rows with a wide dynamic range
+    w[7] *= 1e-2                         # and weight rows of very different size
+    ref = a.double() @ w.double().t()
+    out = ops.linear(a.cuda(), w.cuda()).cpu().double()
+    err = (out - ref).abs().max() / ref.abs().max()
+    f32 = ((a @ w.t()).double() - ref).abs().max() / ref.abs().max()
+    assert err <= TOL, (sa, sw, float(err), float(f32))
+    # per-ROW accuracy too: the tiny weight row is not drowned by the others
+    row = 7
+    err7 = (out[:, row] - ref[:, row]).abs().max() / ref[:, row].abs().max()
+    assert err7 <= 4 * TOL, (sa, sw, float(err7))
+
+
+@pytest.mark.parametrize("sa", A_SCALES)
+@pytest.mark.parametrize("sw", W_SCALES)
+@pytest.mark.parametrize("k,cin,cout", [(3, 128, 128), (1, 196, 256), (3, 196, 196)])
+def test_conv_bn_act_scale_invariant(sa, sw, k, cin, cout):
+    from loftr_amd import ops
+    g = torch.Generator().manual_seed(k * 100 + cin)
+    B, H, W = 2, 24, 32
+    conv = nn.Conv2d(cin, cout, k, stride=1, padding=k // 2, bias=False)
+    conv.weight.data = torch.randn(conv.weight.shape, generator=g) * (2.0 / (cin * k * k)) ** 0.5 * sw
+    conv.weight.data[3] *= 1e-2
+    bn = nn.BatchNorm2d(cout).eval()
+    bn.weight.data = 1.0 + 0.2 * torch.randn(cout, generator=g)
+    bn.bias.data = 0.1 * torch.randn(cout, generator=g) * sa * sw
+    bn.running_mean.data = 0.1 * torch.randn(cout, generator=g) * sa * sw
+    bn.running_var.data = (0.5 + torch.rand(cout, generator=g)) * (sa * sw) ** 2      # BN statistics at the data's scale
+    x = torch.randn(B, cin, H, W, generator=g) * sa
+    y = F.conv2d(x.double(), conv.weight.double(), padding=k // 2)
+    y = F.batch_norm(y, bn.running_mean.double(), bn.running_var.double(), bn.weight.double(), bn.bias.double(), False, 0.0, bn.eps)
+    y = F.relu(y)
+    dev = "cuda:0"
+    conv, bn = conv.to(dev), bn.to(dev)
+    x_sp, inv = ops.sp_from_nhwc(x.permute(0, 2, 3, 1).contiguous().to(dev), scaled=True)
+    _, out = ops.conv_bn_act(x_sp, cin, conv, bn, act=1, want_sp=False, want_f32=True, x_inv_scale=inv)
+    out = out.permute(0, 3, 1, 2).cpu().double()
+    err = (out - y).abs().max() / y.abs().max()
+    assert err <= TOL, (sa, sw, float(err))
+
+
+def test_transformer_layer_with_small_weights_and_gammas():
+    """One coarse encoder layer whose matrices are 1e-3 x xavier and whose LayerNorm gammas are small (the trained-
+    checkpoint regime the verdict names): still fp32-class against an fp64 evaluation of the oracle."""
+    from loftr_amd import ops
+    from loftr_amd.synth import make_weights
+    from oracle import loftr_oracle as O
+    from loftr_amd.config import get_cfg
+    cfg = get_cfg()
+    w = make_weights(3, cfg)
+    pre = "loftr_coarse.layers.0."
+    rng = np.random.default_rng(0)
+    for name in ("q_proj", "k_proj", "v_proj", "merge", "mlp.0", "mlp.2"):
+        w[pre + name + ".weight"] = (w[pre + name + ".weight"] * 1e-3).astype(np.float32)
+    w[pre + "norm1.weight"] = (0.02 * rng.standard_normal(256)).astype(np.float32)
+    w[pre + "norm2.weight"] = (0.02 * rng.standard_normal(256)).astype(np.float32)
+    x = rng.standard_normal((2, 300, 256)).astype(np.float32)
+    src = rng.standard_normal((2, 280, 256)).astype(np.float32)
+    w64 = {k: np.asarray(v, np.float64) for k, v in w.items()}
+    ref = O.encoder_layer(x.astype(np.float64), src.astype(np.float64), w64, pre, 8)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    sd = {f: t(w[pre + n]) for f, n in ops.LAYER_FIELDS}
+    out = ops.encoder_layer(t(x), t(src), ops.layer_weights_struct(sd), 8).cpu().numpy()
+    upd = np.abs(ref - x).max()                      # size of the layer's update (the residual x itself is exact)
+    err = np.abs(out - ref).max()
+    assert err <= 2e-5 * max(upd, 1e-3) + 1e-7, (float(err), float(upd))
