@@ -320,6 +320,11 @@ def main():
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(self_spawn(sys.argv[1:], args.gpus))
+    # stdout carries exactly ONE line, the JSON: libraries that print banners to fd 1 (RCCL prints its version block at
+    # communicator creation) are pointed at stderr for the duration of the run
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
@@ -329,7 +334,10 @@ def main():
     dev = torch.device("cuda", local_rank)
     dist = None
     rccl, transport = None, "none"
-    if world > 1:
+    # LOFTR_BENCH_FORCE_DIST=1: take the multi-rank code path (process group, C-ABI communicator, collectives, timing
+    # gathers) even with ONE rank -- the only way to exercise it on a 1-GPU box (tools/gpu/dist1.sh)
+    multi = world > 1 or os.environ.get("LOFTR_BENCH_FORCE_DIST") == "1"
+    if multi:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
@@ -380,20 +388,20 @@ def main():
     def step():
         data = {"image0": img0, "image1": img1}
         model(data)
-        if world > 1:                                       # RCCL all-gather of the per-pair match counts
+        if multi:                                           # RCCL all-gather of the per-pair match counts
             data["match_counts_global"] = all_gather_match_counts(data["_match_counts"][1:], world * B, rccl=rccl)
         last.clear()
         last.update(M=int(data["mconf"].shape[0]), data=data)
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         step()
-    if world > 1:                                            # the gathered counts must add up to the ranks' match totals
+    if multi:                                                # the gathered counts must add up to the ranks' match totals
         mt = torch.tensor([last["M"]], dtype=torch.int64, device=dev)
         dist.all_reduce(mt)
         assert int(last["data"]["match_counts_global"].sum().item()) == int(mt.item()), "count all-gather mismatch"
@@ -463,7 +471,7 @@ def main():
                         "once): algorithmic bytes = descriptors + conf_matrix (DESIGN.md §4) / in-region hipEvent launch time")
     roof_enc = group_roofline([n for n in ENCODER_KERNELS if n in timing], timing, work, args.steps)
     elapsed, per_rank_ms = elapsed_local, [round(elapsed_local / args.steps * 1e3, 3)]
-    if world > 1:
+    if multi:
         t = torch.tensor([elapsed_local], dtype=torch.float64, device=dev)
         allt = [torch.zeros_like(t) for _ in range(world)]
         dist.all_gather(allt, t)
@@ -494,7 +502,7 @@ def main():
                        "global_batch": world * B, "parallelism": f"dp{world} (pairs sharded; RCCL all-gather of match counts)",
                        "parity": "image-level goldens of the reference forward, both backbones: profiles/r02_parity_margins.txt"},
             "per_rank_ms_per_step": per_rank_ms,
-            "collective": {"transport": transport, "ranks_in_communicator": (rccl.ranks_seen if rccl is not None else world) if world > 1 else 1},
+            "collective": {"transport": transport, "ranks_in_communicator": (rccl.ranks_seen if rccl is not None else world) if multi else 1},
             "stage_ms": {"backbone": round(backbone_ms, 3), "backbone_impl": args.backbone, "hot_path_hip": round(hot_ms, 3),
                          "note": "mean of 3 instrumented steps run WITHOUT the two-stream overlap (serial sum > ms_per_step when "
                                  "the timed region overlaps the FPN fine branch with the coarse stage); `kernels` likewise"},
@@ -506,8 +514,11 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(model, img0, img1)
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
         print(json.dumps(out), flush=True)
-    if world > 1:
+        os.dup2(2, 1)
+    if multi:
         dist.barrier()
         if rccl is not None:
             rccl.close()

@@ -94,8 +94,15 @@ int loftr_encoder_layer_fwd(const float* x, const float* source, const uint8_t* 
  *   layer run as one batch of 2N sequences. */
 int loftr_transformer_fwd(float* feat0, float* feat1, const uint8_t* mask0, const uint8_t* mask1,
                           const loftr_layer_weights* layers, const int* layer_is_cross,
-                          int n_layers, int N, int L, int S, int C, int H, void* ws,
-                          size_t ws_bytes, void* stream);
+                          int n_layers, int N, int L, int S, int C, int H, const void* prepared,
+                          size_t prepared_bytes, void* ws, size_t ws_bytes, void* stream);
+/* Inference with constant weights: every layer matrix is re-encoded once (row-scaled split-fp16 operand format,
+ * csrc/gemm.h) into a caller-owned buffer of loftr_transformer_prepared_bytes(n_layers, C) bytes; hand it to
+ * loftr_transformer_fwd as `prepared` (NULL there = convert on every call into the workspace).  The LayerNorm vectors
+ * are always read from `layers`.  The buffer must be rebuilt when a weight changes. */
+size_t loftr_transformer_prepared_bytes(int n_layers, int C);
+int loftr_transformer_prepare(const loftr_layer_weights* layers, int n_layers, int C, void* prepared,
+                              size_t prepared_bytes, void* stream);
 
 /* ---- CoarseMatching ------------------------------------------------------------------------
  * Geometry + selection parameters shared by the two match types. */

@@ -45,7 +45,9 @@ SIGNATURES = {
     "loftr_encoder_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "loftr_encoder_layer_fwd": (_i, [_p, _p, _p, _p, C.POINTER(LayerWeights), _p, _i, _i, _i, _i, _i, _p, _sz, _p]),
     "loftr_transformer_fwd": (_i, [_p, _p, _p, _p, C.POINTER(LayerWeights), C.POINTER(_i), _i, _i, _i, _i, _i, _i,
-                                   _p, _sz, _p]),
+                                   _p, _sz, _p, _sz, _p]),
+    "loftr_transformer_prepared_bytes": (_sz, [_i, _i]),
+    "loftr_transformer_prepare": (_i, [C.POINTER(LayerWeights), _i, _i, _p, _sz, _p]),
     "loftr_coarse_match_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "loftr_coarse_match_dual_softmax": (_i, [_p, _p, C.POINTER(CoarseParams), _f, _p, C.POINTER(MatchOut), _p, _sz, _p]),
     "loftr_coarse_match_sinkhorn": (_i, [_p, _p, C.POINTER(CoarseParams), _f, _i, _i, _p, _p, C.POINTER(MatchOut),

@@ -190,15 +190,55 @@ extern "C" int loftr_encoder_layer_fwd(const float* x, const float* source, cons
   return encoder_layer(x, x_sp, self ? x_sp : s_sp, self, x_mask, source_mask, lw, out, nullptr, nb, L, S, C, H, e, st);
 }
 
+namespace {
+// fp32 -> SP (row-scaled) conversion of every matrix of `n_layers` layers into `w_sp`, batched in launches of <= SP_MAX_JOBS
+int convert_layers(const loftr_layer_weights* layers, int n_layers, int C, sp_t* w_sp, SpJobs& jobs, LayerSp* lw, hipStream_t st) {
+  int rc;
+  for (int i = 0; i < n_layers; ++i) {
+    if (jobs.n + JOBS_PER_LAYER > SP_MAX_JOBS) {
+      if ((rc = launch_sp_convert(jobs, st))) return rc;
+      jobs = SpJobs();
+    }
+    lw[i] = stage_layer(layers[i], w_sp + weights_sp_dwords(C) * i, C, jobs);
+  }
+  return launch_sp_convert(jobs, st);
+}
+// the SP views of an already converted block (same layout as convert_layers produces)
+void view_layers(const loftr_layer_weights* layers, int n_layers, int C, sp_t* w_sp, LayerSp* lw) {
+  for (int i = 0; i < n_layers; ++i) {
+    SpJobs scratch;
+    lw[i] = stage_layer(layers[i], w_sp + weights_sp_dwords(C) * i, C, scratch);     // pointer arithmetic only; nothing launched
+  }
+}
+}  // namespace
+
+extern "C" size_t loftr_transformer_prepared_bytes(int n_layers, int C) {
+  if (n_layers <= 0 || C <= 0) return 0;
+  return align_up(weights_sp_dwords(C) * 4 * (size_t)n_layers, 256) + 256;
+}
+
+extern "C" int loftr_transformer_prepare(const loftr_layer_weights* layers, int n_layers, int C, void* prepared,
+                                         size_t prepared_bytes, void* stream) {
+  LOFTR_CHECK_ARG(layers && prepared && n_layers > 0);
+  if (!(C == 256 || C == 128) || n_layers > MAX_LAYERS) return LOFTR_ERR_UNSUPPORTED;
+  for (int i = 0; i < n_layers; ++i) LOFTR_CHECK_ARG(weights_ok(layers[i]));
+  if (prepared_bytes < loftr_transformer_prepared_bytes(n_layers, C)) return LOFTR_ERR_WORKSPACE;
+  LayerSp lw[MAX_LAYERS];
+  SpJobs jobs;
+  return convert_layers(layers, n_layers, C, reinterpret_cast<sp_t*>(prepared), jobs, lw, (hipStream_t)stream);
+}
+
 extern "C" int loftr_transformer_fwd(float* feat0, float* feat1, const uint8_t* mask0,
                                      const uint8_t* mask1, const loftr_layer_weights* layers,
                                      const int* layer_is_cross, int n_layers, int N, int L, int S,
-                                     int C, int H, void* ws, size_t ws_bytes, void* stream) {
+                                     int C, int H, const void* prepared, size_t prepared_bytes, void* ws, size_t ws_bytes,
+                                     void* stream) {
   LOFTR_CHECK_ARG(feat0 && feat1 && layers && layer_is_cross && n_layers >= 0 && N >= 0 && L > 0 && S > 0);
   LOFTR_CHECK_ARG((mask0 == nullptr) == (mask1 == nullptr));
   if (!((C == 256 || C == 128) && H == 8) || n_layers > MAX_LAYERS) return LOFTR_ERR_UNSUPPORTED;
   if (N == 0 || n_layers == 0) return LOFTR_OK;
   LOFTR_CHECK_ARG(ws != nullptr);
+  if (prepared && prepared_bytes < loftr_transformer_prepared_bytes(n_layers, C)) return LOFTR_ERR_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
   for (int i = 0; i < n_layers; ++i) LOFTR_CHECK_ARG(weights_ok(layers[i]));
   // The two self-attention calls of a layer are independent (transformer.py:92-94): when the two
@@ -214,22 +254,19 @@ extern "C" int loftr_transformer_fwd(float* feat0, float* feat1, const uint8_t* 
   int rc;
   LayerSp lw[MAX_LAYERS];
   {
-    // residual stream -> SP mirror, all layer matrices -> SP: batched in launches of <= SP_MAX_JOBS tensors
-    SpJobs jobs; jobs.n = 0;
+    // residual stream -> SP mirror; layer matrices -> SP (unless the caller hands in the block loftr_transformer_prepare
+    // built once for these weights: inference weights are constant)
+    SpJobs jobs;
     auto add = [&](const float* src, sp_t* dst, long rows) {
       const int i = jobs.n++;
       jobs.src[i] = src; jobs.dst[i] = dst; jobs.rows[i] = (int)rows; jobs.K[i] = C; jobs.ld[i] = C;
     };
     add(feat0, sp0, (long)N * L);
     add(feat1, sp1, (long)N * S);
-    for (int i = 0; i < n_layers; ++i) {
-      if (jobs.n + JOBS_PER_LAYER > SP_MAX_JOBS) {
-        if ((rc = launch_sp_convert(jobs, st))) return rc;
-        jobs.n = 0;
-      }
-      lw[i] = stage_layer(layers[i], w_sp + weights_sp_dwords(C) * i, C, jobs);
-    }
-    if ((rc = launch_sp_convert(jobs, st))) return rc;
+    if (prepared) {
+      view_layers(layers, n_layers, C, reinterpret_cast<sp_t*>(const_cast<void*>(prepared)), lw);
+      if ((rc = launch_sp_convert(jobs, st))) return rc;
+    } else if ((rc = convert_layers(layers, n_layers, C, w_sp, jobs, lw, st))) return rc;
   }
   for (int i = 0; i < n_layers; ++i) {
     if (!layer_is_cross[i]) {

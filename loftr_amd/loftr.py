@@ -116,7 +116,22 @@ class LocalFeatureTransformer(nn.Module):
                 raise KeyError
         structs = [layer.weight_struct() for layer in self.layers]
         return ops.transformer(feat0.contiguous(), feat1.contiguous(), structs, self.layer_names, self.nhead,
-                               mask0, mask1, inplace=inplace)
+                               mask0, mask1, inplace=inplace, prepared=self._prepared(structs, feat0.device))
+
+    def _prepared(self, structs, device):
+        """The layers' matrices in the library's GEMM operand format, rebuilt only when a weight tensor is modified in
+        place (tensor._version), replaced (data_ptr) or moved -- inference weights are constant, so the per-call
+        re-encoding (a launch over 11 M weights per transformer) runs once."""
+        if self.training or not str(device).startswith("cuda"):
+            return None
+        mats = [getattr(getattr(layer, n) if "." not in n else layer.mlp[int(n.split(".")[1])], "weight")
+                for layer in self.layers for n in ("q_proj", "k_proj", "v_proj", "merge", "mlp.0", "mlp.2")]
+        key = tuple((t.data_ptr(), t._version) for t in mats) + (str(device),)
+        cached = getattr(self, "_loftr_prepared", None)
+        if cached is None or cached[0] != key:
+            cached = (key, ops.transformer_prepare(structs, self.d_model, device))
+            self._loftr_prepared = cached
+        return cached[1]
 
 
 class CoarseMatching(nn.Module):

@@ -158,7 +158,19 @@ def stacked_halves(a, b):
 
 
 @_on_device
-def transformer(feat0, feat1, layer_structs, layer_names, nhead, mask0=None, mask1=None, inplace=False):
+def transformer_prepare(layer_structs, Cc, device):
+    """All layer matrices re-encoded once into the library's GEMM operand format (loftr_transformer_prepare)."""
+    n_layers = len(layer_structs)
+    lib = _lib.load()
+    buf = torch.empty(lib.loftr_transformer_prepared_bytes(n_layers, Cc), dtype=torch.uint8, device=device)
+    arr = (LayerWeights * n_layers)(*layer_structs)
+    with torch.cuda.device(device):
+        check(lib.loftr_transformer_prepare(arr, n_layers, Cc, _ptr(buf), buf.numel(), _stream()), "loftr_transformer_prepare")
+    return buf
+
+
+@_on_device
+def transformer(feat0, feat1, layer_structs, layer_names, nhead, mask0=None, mask1=None, inplace=False, prepared=None):
     """LocalFeatureTransformer.forward.  Returns new (feat0, feat1); inputs are not modified unless
     ``inplace`` (then, when feat0 / feat1 are the contiguous halves of one buffer, the layers run on
     that buffer directly instead of on a torch.cat copy of it)."""
@@ -183,6 +195,7 @@ def transformer(feat0, feat1, layer_structs, layer_names, nhead, mask0=None, mas
     nbytes = lib.loftr_encoder_workspace_bytes(2 * N, L, S, Cc)
     ws = workspace(nbytes, feat0.device)
     check(lib.loftr_transformer_fwd(_ptr(f0), _ptr(f1), _ptr(m0), _ptr(m1), arr, kinds, n_layers, N, L, S, Cc, nhead,
+                                    _ptr(prepared), prepared.numel() if prepared is not None else 0,
                                     _ptr(ws), ws.numel(), _stream()), "loftr_transformer_fwd")
     return f0, f1
 
