@@ -285,7 +285,7 @@ def group_roofline(names, timing, work, steps):
          "alg_GB_s": round(by / t / 1e9, 1), "hbm_frac": round(by / t / 1e9 / HBM_PEAK_GBS, 4),
          "traffic": None, "mfma_busy": None,
          "note": "executed rate = 3 fp16 MFMAs per fp32 product (csrc/gemm.h) against the 2.5 PF dense fp16 peak; "
-                 "mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE * 1024 SIMDs), time-weighted over the kernels"}
+                 "mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs * 1024 SIMDs), time-weighted over the kernels"}
     if all(x is not None for x in traffic) and traffic:
         # bytes per STEP: per-launch PMC bytes x launches per step of each kernel
         e["traffic"] = round(sum(pmc_traffic(n) * timing[n][1] / steps for n in names if n in timing))

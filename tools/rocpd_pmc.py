@@ -4,7 +4,7 @@
     python tools/rocpd_pmc.py <fetch.db> <write.db> [--sq <sq.db>] [--json profiles/pmc_traffic.json]
 
 --sq: a third pass with `--pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE`: per kernel
-mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE * 1024 SIMDs)  (the gfx94x MfmaUtil formula; the counter
+mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 * 1024 SIMDs)  (GUI_ACTIVE is reported summed over the 8 XCDs; the counter
 advances 32 cycles per v_mfma_f32_32x32x16_f16, MI355X_MICROARCH.md).  The JSON is stamped with the hash of the kernel
 sources (bench.py:source_hash) so that bench.py only quotes PMC numbers collected on the build it is running.
 
@@ -33,32 +33,48 @@ def short(name):
     return re.split(r"[<(]", name)[0]
 
 
+def bench_name(full):
+    """Kernel name as bench.py's timing table knows it (one entry per kernel FAMILY: template variants are pooled)."""
+    if "score_sweep_kernel<1" in full:
+        return "score_conf_kernel"          # dual-softmax pass B (writes conf_matrix)
+    if "score_sweep_kernel<0" in full:
+        return "score_stats_kernel"         # pass A: shared-reference variant + exact variant
+    return short(full)
+
+
 def main():
     fetch, write = per_kernel(sys.argv[1], "FETCH_SIZE"), per_kernel(sys.argv[2], "WRITE_SIZE")
     busy, active = {}, {}
     if "--sq" in sys.argv:
         sq = sys.argv[sys.argv.index("--sq") + 1]
         busy, active = per_kernel(sq, "SQ_VALU_MFMA_BUSY_CYCLES"), per_kernel(sq, "GRBM_GUI_ACTIVE")
-    out = {}
-    print(f"{'kernel':44s} {'calls':>6} {'fetch_x2 MB':>12} {'write MB':>10} {'hbm MB/launch':>14}")
-    for k in sorted(set(fetch) | set(write), key=lambda k: -(fetch.get(k, {}).get('avg_kib', 0) * fetch.get(k, {}).get('n', 0))):
+    pool = {}
+    for k in set(fetch) | set(write):
         if not ("kernel" in k and ("loftr" in k or "Geometry" in k or "Args" in k or "anonymous" in k or "attn" in k or "kv_" in k
                                   or "gather" in k or "fine_match" in k or "pos_encode" in k)):
             continue
-        f = fetch.get(k, {}).get("avg_kib", 0.0) * 1024 * 2
-        w = write.get(k, {}).get("avg_kib", 0.0) * 1024
         n = fetch.get(k, write.get(k))["n"]
-        key = short(k)
-        tag = key if key not in out else key + "#" + str(sum(1 for x in out if x.startswith(key)))
-        out[tag] = dict(full_name=k[:160], launches=n, fetch_bytes_x2=f, write_bytes=w, hbm_bytes_per_launch=f + w)
-        extra = ""
-        if k in busy and k in active and active[k]["avg_kib"]:
-            # (per_kernel's "avg_kib" field is just the average counter value)
-            out[tag]["mfma_busy_cycles"] = busy[k]["avg_kib"]
-            out[tag]["gui_active_cycles"] = active[k]["avg_kib"]
-            out[tag]["mfma_busy"] = busy[k]["avg_kib"] / (active[k]["avg_kib"] * 1024.0)
-            extra = f"  mfma_busy {out[tag]['mfma_busy']:.3f}"
-        print(f"{tag:44s} {n:6d} {f / 1e6:12.2f} {w / 1e6:10.2f} {(f + w) / 1e6:14.2f}{extra}")
+        e = pool.setdefault(bench_name(k), dict(launches=0, fetch=0.0, write=0.0, busy=0.0, active=0.0, variants=[]))
+        e["launches"] += n
+        e["fetch"] += fetch.get(k, {}).get("avg_kib", 0.0) * 1024 * 2 * n          # gfx950: FETCH_SIZE counts 128-B requests at 64 B
+        e["write"] += write.get(k, {}).get("avg_kib", 0.0) * 1024 * n
+        if k in busy and k in active:
+            e["busy"] += busy[k]["avg_kib"] * busy[k]["n"]                          # (per_kernel's "avg_kib" is the plain average)
+            e["active"] += active[k]["avg_kib"] * active[k]["n"]
+        e["variants"].append(k[:140])
+    out = {}
+    print(f"{'kernel (template variants pooled)':44s} {'calls':>6} {'fetch_x2 MB':>12} {'write MB':>10} {'hbm MB/launch':>14} {'mfma_busy':>10}")
+    for name, e in sorted(pool.items(), key=lambda kv: -(kv[1]["fetch"] + kv[1]["write"])):
+        n = e["launches"]
+        f, w = e["fetch"] / n, e["write"] / n
+        out[name] = dict(launches=n, fetch_bytes_x2=f, write_bytes=w, hbm_bytes_per_launch=f + w, variants=e["variants"])
+        mb = ""
+        if e["active"] > 0:
+            # GRBM_GUI_ACTIVE comes back summed over the 8 XCDs (checked against kernel durations x clock), the SQ counter over
+            # all 1024 SIMDs: busy fraction of a SIMD's matrix pipe = busy / (active / 8 * 1024)
+            out[name]["mfma_busy"] = e["busy"] / (e["active"] / 8.0 * 1024.0)
+            mb = f"{out[name]['mfma_busy']:10.3f}"
+        print(f"{name:44s} {n:6d} {f / 1e6:12.2f} {w / 1e6:10.2f} {(f + w) / 1e6:14.2f} {mb}")
     import importlib.util
     import os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
