@@ -202,6 +202,22 @@ __device__ __forceinline__ void sp_store(sp_t* row_ptr, int col, float v, bool p
   if (pred) row_ptr[sp_index(col)] = w;
 }
 
+// Epilogue addressing.  `base[idx]` with a 32-bit index still costs a 64-bit multiply-add per access (the scale by
+// sizeof(T) may carry into bit 32): hipcc emits v_mad_u64_u32 / v_lshl_add_u64 per store.  A 32-bit BYTE offset added to
+// a block-uniform base pointer maps onto the global_load / global_store "SGPR base + 32-bit VGPR offset" form: one
+// v_add_u32 (or none, if the compiler folds constants) per access.  Tiles are < 4 GB, so byte offsets fit 32 bits.
+#ifdef LOFTR_EPI_OLD      // A/B switch (tools/gpu/ab_lib.sh): element indexing as before
+template <typename T> __device__ __forceinline__ void st_off(T* base, unsigned byte_off, T v) { base[byte_off / (unsigned)sizeof(T)] = v; }
+template <typename T> __device__ __forceinline__ T ld_off(const T* base, unsigned byte_off) { return base[byte_off / (unsigned)sizeof(T)]; }
+#else
+template <typename T> __device__ __forceinline__ void st_off(T* base, unsigned byte_off, T v) {
+  *reinterpret_cast<T*>(reinterpret_cast<char*>(base) + byte_off) = v;
+}
+template <typename T> __device__ __forceinline__ T ld_off(const T* base, unsigned byte_off) {
+  return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+#endif
+
 // Wave w of a workgroup owns sub-tile (wm, wn) = (w % WM, w / WM): consecutive waves -- which the
 // hardware spreads over the four SIMDs -- walk down the M direction first, so the two waves sharing a SIMD
 // in an 8-wave workgroup sit in different column strips (balances the matrix pipes when the last

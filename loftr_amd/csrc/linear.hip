@@ -39,20 +39,33 @@ __device__ __forceinline__ void linear_epilogue(const LinearArgs& p, f32x16 (&ac
         if (BIAS == 2) { if (FULL || (m0 + trow < p.M && cok)) v[r] += p.bias[(unsigned)(((m0 + trow) / p.group) * p.N + col)]; }
         if (RELU) v[r] = fmaxf(v[r], 0.f);
       }
+      const unsigned rowb = (unsigned)p.ldo * 4u;
       if (OUT_F32) {
+        if (FULL) {                                  // 32-bit byte offsets from the block-uniform tile base (gemm.h: st_off)
+          const unsigned off = (unsigned)(e.lrow * p.ldo + e.lcol + j * 32) * 4u;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int trow = e.lrow + e.rr(i, r);
-          if (FULL || (m0 + trow < p.M && cok)) of[(unsigned)(trow * p.ldo + e.lcol + j * 32)] = v[r];
+          for (int r = 0; r < 16; ++r) st_off(of, off + (unsigned)e.rr(i, r) * rowb, v[r]);
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int trow = e.lrow + e.rr(i, r);
+            if (m0 + trow < p.M && cok) of[(unsigned)(trow * p.ldo + e.lcol + j * 32)] = v[r];
+          }
         }
       }
       if (OUT_SP) {
         uint32_t w[16];
         sp_words16(v, e.odd, w);
+        if (FULL) {
+          const unsigned off = (unsigned)(e.lrow * p.ldo + e.spcol + j * 32) * 4u;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int trow = e.lrow + e.rr(i, r);
-          if (FULL || (m0 + trow < p.M && cok)) os[(unsigned)(trow * p.ldo + e.spcol + j * 32)] = w[r];
+          for (int r = 0; r < 16; ++r) st_off(os, off + (unsigned)e.rr(i, r) * rowb, w[r]);
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int trow = e.lrow + e.rr(i, r);
+            if (m0 + trow < p.M && cok) os[(unsigned)(trow * p.ldo + e.spcol + j * 32)] = w[r];
+          }
         }
       }
     }
@@ -131,21 +144,37 @@ __device__ __forceinline__ void proj_epilogue(const ProjArgs& p, f32x16 (&acc)[C
         f32x16 den = v * ksum;
         half_sum16(den);
 #pragma unroll
+#ifdef LOFTR_EPI_OLD
         for (int r = 0; r < 16; ++r) v[r] *= p.v_length / (den[r] + p.eps);
+#else
+        for (int r = 0; r < 16; ++r) v[r] *= p.v_length * __builtin_amdgcn_rcpf(den[r] + p.eps);   // 1 / (Q . Ksum + eps), :44 -- v_rcp_f32 (1 ulp) instead of the ten-instruction IEEE division
+#endif
         uint32_t w[16];
         sp_words16(v, e.odd, w);
         sp_t* os = reinterpret_cast<sp_t*>(p.out[seg]) + (row_base + m0) * p.C + n0;
+        if (FULL) {                                  // 32-bit byte offsets from the block-uniform tile base (gemm.h: st_off)
+          const unsigned rowb = (unsigned)p.C * 4u, off = (unsigned)(e.lrow * p.C + e.spcol + j * 32) * 4u;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int trow = e.lrow + e.rr(i, r);
-          if (FULL || m0 + trow < p.M) os[(unsigned)(trow * p.C + e.spcol + j * 32)] = w[r];
+          for (int r = 0; r < 16; ++r) st_off(os, off + (unsigned)e.rr(i, r) * rowb, w[r]);
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int trow = e.lrow + e.rr(i, r);
+            if (m0 + trow < p.M) os[(unsigned)(trow * p.C + e.spcol + j * 32)] = w[r];
+          }
         }
       } else {
         float* of = reinterpret_cast<float*>(p.out[seg]) + (row_base + m0) * p.C + n0;
+        if (FULL) {
+          const unsigned rowb = (unsigned)p.C * 4u, off = (unsigned)(e.lrow * p.C + e.lcol + j * 32) * 4u;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int trow = e.lrow + e.rr(i, r);
-          if (FULL || m0 + trow < p.M) of[(unsigned)(trow * p.C + e.lcol + j * 32)] = v[r];
+          for (int r = 0; r < 16; ++r) st_off(of, off + (unsigned)e.rr(i, r) * rowb, v[r]);
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int trow = e.lrow + e.rr(i, r);
+            if (m0 + trow < p.M) of[(unsigned)(trow * p.C + e.lcol + j * 32)] = v[r];
+          }
         }
       }
     }
@@ -338,33 +367,53 @@ __global__ __launch_bounds__(Cfg::THREADS, 2) void linear_ln_kernel(LinearLNArgs
   for (int i = 0; i < Cfg::TM; ++i)
 #pragma unroll
     for (int r = 0; r < 16; ++r) rs[i][r] = rstd_s[e.lrow + e.rr(i, r)];
+  constexpr unsigned CB = Cfg::BN * 4;              // bytes per row (the block spans the row: C == BN)
+  const unsigned off_f = (unsigned)(e.lrow * Cfg::BN + e.lcol) * 4u, off_s = (unsigned)(e.lrow * Cfg::BN + e.spcol) * 4u;
 #pragma unroll
   for (int j = 0; j < Cfg::TN; ++j) {
     const float gam = p.gamma[e.lcol + j * 32], bet = p.beta[e.lcol + j * 32];
 #pragma unroll
     for (int i = 0; i < Cfg::TM; ++i) {
       f32x16 v;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int trow = e.lrow + e.rr(i, r);
-        const unsigned ro = (unsigned)((full ? trow : min(trow, p.M - 1 - m0)) * p.C);
-        v[r] = (acc[i][j][r] - mu[i][r]) * rs[i][r] * gam + bet;
-        if (HAS_RES) v[r] += res[ro + e.lcol + j * 32];
-      }
-      if (OUT_F32) {
+      if (full) {                                   // block-uniform: 32-bit byte offsets from the tile base (gemm.h: st_off)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int trow = e.lrow + e.rr(i, r);
-          if (full || m0 + trow < p.M) of[(unsigned)(trow * p.C) + e.lcol + j * 32] = v[r];
+          v[r] = (acc[i][j][r] - mu[i][r]) * rs[i][r] * gam + bet;
+          if (HAS_RES) v[r] += ld_off(res, off_f + (unsigned)(e.rr(i, r) * CB + j * 128));
         }
-      }
-      if (OUT_SP) {
-        uint32_t w[16];
-        sp_words16(v, e.odd, w);
+        if (OUT_F32) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) st_off(of, off_f + (unsigned)(e.rr(i, r) * CB + j * 128), v[r]);
+        }
+        if (OUT_SP) {
+          uint32_t w[16];
+          sp_words16(v, e.odd, w);
+#pragma unroll
+          for (int r = 0; r < 16; ++r) st_off(os, off_s + (unsigned)(e.rr(i, r) * CB + j * 128), w[r]);
+        }
+      } else {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int trow = e.lrow + e.rr(i, r);
-          if (full || m0 + trow < p.M) os[(unsigned)(trow * p.C) + e.spcol + j * 32] = w[r];
+          const unsigned ro = (unsigned)(min(trow, p.M - 1 - m0) * p.C);
+          v[r] = (acc[i][j][r] - mu[i][r]) * rs[i][r] * gam + bet;
+          if (HAS_RES) v[r] += res[ro + e.lcol + j * 32];
+        }
+        if (OUT_F32) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int trow = e.lrow + e.rr(i, r);
+            if (m0 + trow < p.M) of[(unsigned)(trow * p.C) + e.lcol + j * 32] = v[r];
+          }
+        }
+        if (OUT_SP) {
+          uint32_t w[16];
+          sp_words16(v, e.odd, w);
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int trow = e.lrow + e.rr(i, r);
+            if (m0 + trow < p.M) os[(unsigned)(trow * p.C) + e.spcol + j * 32] = w[r];
+          }
         }
       }
     }
