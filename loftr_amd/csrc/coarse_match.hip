@@ -1036,6 +1036,131 @@ __global__ void ot_col_merge_kernel(const float2* __restrict__ part, Geometry g,
   v[idx] = log_nu - (m + logf(s));
 }
 
+// ---- one Sinkhorn iteration in ONE pass over Z ------------------------------------------------------------------
+// u = log_mu - LSE_j(Z + v) needs whole rows, v' = log_nu - LSE_i(Z + u) needs whole columns: two sweeps over the
+// 92 MB-per-pair volume per iteration when done as separate kernels (plus 32 column-partial rows).  Here a workgroup
+// owns a contiguous range of rows and thread t owns the columns {t, t + 256, ...} for the whole kernel: it loads its
+// CPT entries of a row ONCE (coalesced: the block reads 1 KB per instruction), keeps them in registers through the
+// block-wide row reduction (-> u_i) and then folds them, now with u_i, into its private running column statistics --
+// every element of Z crosses HBM once per iteration.  R rows are processed per round so that one pair of block
+// reductions (max, sum) serves R rows.  The dustbin column (j = S) is an extra lane-private term of every row; the
+// dustbin row (i = L, constant alpha) only needs u_L = log(S) + norm - LSE_j(alpha + v_j), computed by the first
+// workgroup of the pair and added analytically by the merge kernel.
+//   grid (WGP, N), 256 threads;  part [N][WGP][S + 1] (max, sum exp) of Z[i][j] + u[i] over the workgroup's rows.
+template <int CPT, int R>
+__global__ __launch_bounds__(256) void ot_iter_kernel(const float* __restrict__ z, Geometry g, float alpha, float norm,
+                                                      const float* __restrict__ v, float* __restrict__ u,
+                                                      float2* __restrict__ part, int rows_per_wg) {
+  __shared__ float red[R][4];
+  __shared__ float bc[R];
+  const int n = blockIdx.y, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int S = g.S, L = g.L;
+  const float* vn = v + (long)n * (S + 1);
+  float vk[CPT], cm[CPT], cs[CPT];
+#pragma unroll
+  for (int k = 0; k < CPT; ++k) {
+    const int j = t + 256 * k;
+    vk[k] = j <= S ? vn[j] : 0.f;
+    cm[k] = SENTINEL; cs[k] = 0.f;
+  }
+  const int r0 = blockIdx.x * rows_per_wg, r1 = min(r0 + rows_per_wg, L);
+  for (int rb = r0; rb < r1; rb += R) {
+    float zz[R][CPT], tm[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int i = min(rb + r, L - 1);
+      const float* zr = z + ((long)n * L + i) * S;
+      tm[r] = SENTINEL;
+#pragma unroll
+      for (int k = 0; k < CPT; ++k) {
+        const int j = t + 256 * k;
+        zz[r][k] = j < S ? zr[j] : (j == S ? alpha : SENTINEL);       // dustbin column; beyond it: never contributes
+        tm[r] = fmaxf(tm[r], zz[r][k] + vk[k]);
+      }
+    }
+    // block-wide row maxima, then sums of exp
+#pragma unroll
+    for (int r = 0; r < R; ++r) { const float m = wave_max(tm[r]); if (lane == 0) red[r][wave] = m; }
+    __syncthreads();
+    float rmax[R], ts[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      rmax[r] = fmaxf(fmaxf(red[r][0], red[r][1]), fmaxf(red[r][2], red[r][3]));
+      ts[r] = 0.f;
+#pragma unroll
+      for (int k = 0; k < CPT; ++k) ts[r] += expf(zz[r][k] + vk[k] - rmax[r]);        // exp(SENTINEL - x) == 0
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < R; ++r) { const float sm = wave_sum(ts[r]); if (lane == 0) red[r][wave] = sm; }
+    __syncthreads();
+    if (t < R) {
+      const float ssum = (red[t][0] + red[t][1]) + (red[t][2] + red[t][3]);
+      const float ui = norm - (rmax[t] + logf(ssum));                  // log_mu = norm for the real rows
+      bc[t] = ui;
+      if (rb + t < r1) u[(long)n * (L + 1) + rb + t] = ui;
+    }
+    __syncthreads();
+    // fold the rows, now with their u, into the thread's column statistics
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      if (rb + r >= r1) break;                                         // block-uniform
+      const float ui = bc[r];
+#pragma unroll
+      for (int k = 0; k < CPT; ++k) {
+        const float y = zz[r][k] + ui;
+        const float mn = fmaxf(cm[k], y);
+        cs[k] = cs[k] * expf(cm[k] - mn) + expf(y - mn);
+        cm[k] = mn;
+      }
+    }
+    __syncthreads();                                                   // red / bc are reused by the next round
+  }
+  float2* pn = part + ((long)n * gridDim.x + blockIdx.x) * (S + 1);
+#pragma unroll
+  for (int k = 0; k < CPT; ++k) {
+    const int j = t + 256 * k;
+    if (j <= S) pn[j] = make_float2(cm[k], cs[k]);
+  }
+  if (blockIdx.x == 0) {               // u of the dustbin row: log(S) + norm - LSE_j(alpha + v_j), j = 0 .. S
+    float m = SENTINEL;
+#pragma unroll
+    for (int k = 0; k < CPT; ++k) if (t + 256 * k <= S) m = fmaxf(m, alpha + vk[k]);
+    m = wave_max(m);
+    if (lane == 0) red[0][wave] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red[0][0], red[0][1]), fmaxf(red[0][2], red[0][3]));
+    float sm = 0.f;
+#pragma unroll
+    for (int k = 0; k < CPT; ++k) if (t + 256 * k <= S) sm += expf(alpha + vk[k] - m);
+    __syncthreads();
+    sm = wave_sum(sm);
+    if (lane == 0) red[0][wave] = sm;
+    __syncthreads();
+    if (t == 0) u[(long)n * (L + 1) + L] = logf((float)S) + norm - (m + logf((red[0][0] + red[0][1]) + (red[0][2] + red[0][3])));
+  }
+}
+
+// v[n][j] = log_nu[j] - LSE over {the P workgroup partials of column j, the dustbin-row term alpha + u[n][L]}
+__global__ void ot_col_merge2_kernel(const float2* __restrict__ part, Geometry g, float alpha, float norm, int P,
+                                     const float* __restrict__ u, float* __restrict__ v) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long cols = (long)g.N * (g.S + 1);
+  if (idx >= cols) return;
+  const int n = (int)(idx / (g.S + 1)), j = (int)(idx - (long)n * (g.S + 1));
+  const float2* p = part + (long)n * P * (g.S + 1) + j;
+  const float bin = alpha + u[(long)n * (g.L + 1) + g.L];
+  float m = bin;
+  for (int k = 0; k < P; ++k) m = fmaxf(m, p[(long)k * (g.S + 1)].x);
+  float s = expf(bin - m);
+  for (int k = 0; k < P; ++k) {
+    const float2 e = p[(long)k * (g.S + 1)];
+    s += in_range(e.x) ? e.y * expf(e.x - m) : 0.f;
+  }
+  const float log_nu = j == g.S ? logf((float)g.L) + norm : norm;
+  v[idx] = log_nu - (m + logf(s));
+}
+
 // dustbin prefilter (coarse_matching.py:136-140): row i is dropped when the argmax of its
 // assignment row (dustbin column included) is the dustbin; same for columns.
 //   rowkill[n][i], colkill[n][j].  Ties resolve to the first index like torch.max.
@@ -1334,7 +1459,22 @@ extern "C" int loftr_coarse_match_sinkhorn(const float* feat_c0, const float* fe
   (void)hipMemsetAsync(w.ot_u, 0, sizeof(float) * g.N * (g.L + 1), st);
   (void)hipMemsetAsync(w.ot_v, 0, sizeof(float) * g.N * (g.S + 1), st);
   const long cols = (long)g.N * (g.S + 1);
+  // fused iteration (one pass over Z): up to 19 x 256 (indoor) / 44 x 256 (outdoor 840 x 840) columns incl. the dustbin
+  const int cpt = ceil_div(g.S + 1, 256);
+  const bool fused = cpt <= 44;
+  int wgp = 512 / (g.N > 0 ? g.N : 1);                     // ~2 workgroups per CU over the batch
+  wgp = wgp < 1 ? 1 : (wgp > OT_RCH ? OT_RCH : wgp);       // the partial buffer holds OT_RCH rows per column
+  if (wgp > ceil_div(g.L, 4)) wgp = ceil_div(g.L, 4);
+  int rpw = ceil_div(g.L, wgp);
+  rpw = ceil_div(rpw, 4) * 4;
+  wgp = ceil_div(g.L, rpw);
   for (int it = 0; it < iters; ++it) {
+    if (fused) {
+      if (cpt <= 19) hipLaunchKernelGGL((ot_iter_kernel<19, 4>), dim3(wgp, g.N), dim3(256), 0, st, conf_out, g, bin_score, norm, w.ot_v, w.ot_u, w.ot_part, rpw);
+      else hipLaunchKernelGGL((ot_iter_kernel<44, 2>), dim3(wgp, g.N), dim3(256), 0, st, conf_out, g, bin_score, norm, w.ot_v, w.ot_u, w.ot_part, rpw);
+      hipLaunchKernelGGL(ot_col_merge2_kernel, dim3(ceil_div((int)cols, 256)), dim3(256), 0, st, w.ot_part, g, bin_score, norm, wgp, w.ot_u, w.ot_v);
+      continue;
+    }
     hipLaunchKernelGGL(ot_row_lse_kernel, dim3(ceil_div(g.L + 1, 4), g.N), dim3(256), 0, st, conf_out, g, bin_score, norm, w.ot_v, w.ot_u);
     hipLaunchKernelGGL(ot_col_part_kernel, dim3(ceil_div(g.S + 1, 64), OT_RCH, g.N), dim3(256), 0, st, conf_out, g, bin_score, w.ot_u, w.ot_part);
     hipLaunchKernelGGL(ot_col_merge_kernel, dim3(ceil_div((int)cols, 256)), dim3(256), 0, st, w.ot_part, g, norm, w.ot_v);
