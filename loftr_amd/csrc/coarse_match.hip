@@ -348,6 +348,12 @@ __global__ __launch_bounds__(Cfg::THREADS, 2) void score_conf_kernel(
 #ifndef SWEEP_PROBE_FAST
 #define SWEEP_PROBE_FAST 1       // 0: pass A exact variant only
 #endif
+#ifndef SWEEP_PROBE_ACC1
+#define SWEEP_PROBE_ACC1 0       // 1: a single accumulator chain (probe)
+#endif
+#ifndef SWEEP_PROBE_PRIO
+#define SWEEP_PROBE_PRIO 0       // 1: s_setprio 1 around the MFMA block (probe)
+#endif
 #ifndef SWEEP_PROBE_SKEW
 #define SWEEP_PROBE_SKEW 1       // 0: all eight waves in phase
 #endif
@@ -667,6 +673,7 @@ __global__ __launch_bounds__(512, 2) void score_sweep_kernel(Args a) {
     drain = !((p0 + p) * PC + PC <= S && (S & 3) == 0) && PASS == 1;
     if (SWEEP_PROBE_EPI && late && p > 0) SWEEP_EPILOGUE(p - 1);
     // ---- 48 MFMAs: two accumulators alternate so that no MFMA depends on its predecessor
+    if (SWEEP_PROBE_PRIO) __builtin_amdgcn_s_setprio(1);
     const char* st = lds + (p & (NST - 1)) * STAGE;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
@@ -675,7 +682,11 @@ __global__ __launch_bounds__(512, 2) void score_sweep_kernel(Args a) {
       const char* sk = st + (ks >> 1) * 4096;
       const h16x8 ah = *reinterpret_cast<const h16x8*>(sk + (a_off ^ ((ks & 1) ? 32 : 0)));
       const h16x8 al = *reinterpret_cast<const h16x8*>(sk + (a_off ^ ((ks & 1) ? 96 : 64)));
-      if (ks & 1) {
+      if (SWEEP_PROBE_ACC1) {
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[ks], acc0, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[ks], acc0, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[ks], acc0, 0, 0, 0);
+      } else if (ks & 1) {
         acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[ks], acc1, 0, 0, 0);
         acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[ks], acc0, 0, 0, 0);
         acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[ks], acc1, 0, 0, 0);
@@ -685,6 +696,7 @@ __global__ __launch_bounds__(512, 2) void score_sweep_kernel(Args a) {
         acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[ks], acc0, 0, 0, 0);
       }
     }
+    if (SWEEP_PROBE_PRIO) __builtin_amdgcn_s_setprio(0);
     if (SWEEP_PROBE_EPI && !late) SWEEP_EPILOGUE(p);
     if (!SWEEP_PROBE_EPI) { s_run += acc0[0] + acc1[5]; best += acc0[3] + acc1[7]; }     // keep the MFMAs alive
   }
