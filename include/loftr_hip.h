@@ -249,6 +249,20 @@ int loftr_sp_to_f32(const uint32_t* src_sp, float* dst, long rows, int C, void* 
 int loftr_epipolar_errors(const float* mkpts0_f, const float* mkpts1_f, const long* m_bids, const float* T_0to1,
                           const float* K0, const float* K1, long M, int N, float* epi_errs, void* stream);
 
+/* Replaces estimate_pose (src/utils/metrics.py:72-98: cv2.findEssentialMat(RANSAC) + cv2.recoverPose on intrinsics-
+ * normalised key points), the pose step of compute_pose_errors (:101-136).  HOST function (cv2 is a CPU library too):
+ * all pointers are host memory, the call is synchronous.  kpts0 / kpts1 [M,2] pixels, K0 / K1 [3,3] row-major,
+ * thresh_px = RANSAC_PIXEL_THR (0.5), conf = RANSAC_CONF (0.99999), seed for the sampler.
+ * Outputs: R [3,3], t [3] (unit norm), inliers [M] (RANSAC inliers that are in front of both cameras), *n_inliers =
+ * their number, or -1 when the reference would return None (M < 5, no model, no point passes the cheirality test).
+ * PARITY UNPINNED against OpenCV (absent from this image): published algorithms restated (five-point solver of Nister
+ * 2004, Sampson-distance RANSAC with OpenCV's documented parameters), own sampling sequence -- csrc/pose.hip.
+ * loftr_five_point exposes the minimal / least-squares solver: q0 / q1 [n,2] normalised points (double), up to 10
+ * essential matrices (row-major, unit Frobenius norm) in E_out [10,9]. */
+int loftr_estimate_pose(const float* kpts0, const float* kpts1, long M, const float* K0, const float* K1, float thresh_px,
+                        float conf, unsigned seed, float* R_out, float* t_out, uint8_t* inliers_out, long* n_inliers);
+int loftr_five_point(const double* q0, const double* q1, int n, double* E_out, int* n_solutions);
+
 /* ---- input wire format (the step before the path; src/utils/dataset.py:78-89,111-118,149, megadepth.py:116-121) ----
  * From resized uint8 grayscale images to the tensors LoFTR.forward consumes: zero padding to [PH,PW] at the
  * bottom / right (pad_bottom_right), `float / 255`, the padding mask and its coarse version

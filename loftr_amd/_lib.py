@@ -63,6 +63,8 @@ SIGNATURES = {
     "loftr_resize_linear_u8": (_i, [_p, _i, _i, _l, _p, _i, _i, _l, _p]),
     "loftr_pack_gray_u8": (_i, [_p, _l, _l, _p, _i, _i, _i, _p, _p, _p, _i, _p]),
     "loftr_epipolar_errors": (_i, [_p, _p, _p, _p, _p, _p, _l, _i, _p, _p]),
+    "loftr_estimate_pose": (_i, [_p, _p, _l, _p, _p, _f, _f, C.c_uint, _p, _p, _p, C.POINTER(_l)]),
+    "loftr_five_point": (_i, [_p, _p, _i, _p, C.POINTER(_i)]),
     "loftr_conv_prepare": (_i, [_p, C.POINTER(_l), _i, _i, _i, _i, _p, _p, _p, _p, _f, _p, _sz, _p]),
     "loftr_conv_bn_act_prepared": (_i, [_p, _i, _i, _i, _i, _p, _sz, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p]),
     "loftr_conv1x1_upsample_add": (_i, [_p, _i, _i, _i, _i, _p, C.POINTER(_l), _i, _p, _p, _p, _sz, _p]),

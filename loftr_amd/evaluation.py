@@ -12,10 +12,11 @@ for ``from loftr_amd.evaluation import ...``.
   tensor out -- no host round trip between the matcher and its first consumer;
 * aggregation (AUC / precision over a dataset: a few thousand scalars, once per dataset) is host-side numpy like
   the reference's;
-* pose estimation (metrics.py:71-140) is OpenCV (`cv2.findEssentialMat` RANSAC + `cv2.recoverPose`): used when
-  cv2 is importable, otherwise `compute_pose_errors` raises unless an `estimator` is supplied or
-  ``on_missing="inf"`` asks for the reference's own failure values (R_err = t_err = inf, no inliers,
-  metrics.py:128-131).  Not re-implemented here: without the library its RANSAC cannot be pinned.
+* pose estimation (metrics.py:71-140) is OpenCV in the reference (`cv2.findEssentialMat` RANSAC + `cv2.recoverPose`):
+  used when cv2 is importable; otherwise `estimate_pose_native` -- the library's own five-point RANSAC + cheirality
+  (csrc/pose.hip: Nister's solver, Sampson distance, OpenCV's documented parameters; host code like cv2's).  PARITY
+  UNPINNED against OpenCV (absent from this image; its sampling sequence cannot be reproduced): tests/test_pose.py
+  checks the solver on exact data and the recovered pose on synthetic scenes with known ground truth.
 """
 import os
 
@@ -85,12 +86,33 @@ def _cfg_get(config, path, default):
     return default if node is None else node
 
 
+def estimate_pose_native(kpts0, kpts1, K0, K1, thresh, conf=0.99999, seed=0):
+    """estimate_pose (metrics.py:72-98) on the library's own five-point RANSAC + cheirality (csrc/pose.hip, host code;
+    parity against cv2 unpinned).  Returns (R [3,3], t [3], inlier mask [M] bool) or None like the reference."""
+    import ctypes as C
+    from . import _lib
+    k0 = np.ascontiguousarray(kpts0, np.float32).reshape(-1, 2)
+    k1 = np.ascontiguousarray(kpts1, np.float32).reshape(-1, 2)
+    M = k0.shape[0]
+    if M < 5:
+        return None
+    K0c, K1c = np.ascontiguousarray(K0, np.float32), np.ascontiguousarray(K1, np.float32)
+    R, t = np.empty((3, 3), np.float32), np.empty(3, np.float32)
+    inl = np.zeros(M, np.uint8)
+    n = C.c_long(-1)
+    ptr = lambda a: a.ctypes.data_as(C.c_void_p)
+    _lib.check(_lib.load().loftr_estimate_pose(ptr(k0), ptr(k1), M, ptr(K0c), ptr(K1c), float(thresh), float(conf), int(seed),
+                                               ptr(R), ptr(t), ptr(inl), C.byref(n)), "loftr_estimate_pose")
+    if n.value < 0:
+        return None
+    return R.astype(np.float64), t.astype(np.float64), inl.astype(bool)
+
+
 def compute_pose_errors(data, config=None, estimator=None, on_missing="raise"):
     """metrics.py:103-140.  Update: data['R_errs'], ['t_errs'] (lists of float), ['inliers'] (list of bool arrays).
 
     estimator(kpts0, kpts1, K0, K1, pixel_thr, conf=) -> (R, t, inlier_mask) | None; default: OpenCV as in the
-    reference.  on_missing: 'raise' (default) or 'inf' = record the reference's failure values when no estimator
-    is available."""
+    reference when importable, else estimate_pose_native.  (on_missing is kept for callers of the round-1 signature.)"""
     pixel_thr = _cfg_get(config, ("TRAINER", "RANSAC_PIXEL_THR"), 0.5)
     conf = _cfg_get(config, ("TRAINER", "RANSAC_CONF"), 0.99999)
     if estimator is None:
@@ -98,9 +120,7 @@ def compute_pose_errors(data, config=None, estimator=None, on_missing="raise"):
             import cv2  # noqa: F401
             estimator = estimate_pose_cv2
         except ImportError:
-            if on_missing != "inf":
-                raise ImportError("compute_pose_errors needs OpenCV (cv2.findEssentialMat / recoverPose, as the reference) "
-                                  "or an explicit estimator=; pass on_missing='inf' to record failed poses instead")
+            estimator = estimate_pose_native       # OpenCV absent: the library's five-point RANSAC (parity unpinned)
     data.update({"R_errs": [], "t_errs": [], "inliers": []})
     m_bids = data["m_bids"].cpu().numpy()
     pts0, pts1 = data["mkpts0_f"].cpu().numpy(), data["mkpts1_f"].cpu().numpy()

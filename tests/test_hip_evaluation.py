@@ -52,7 +52,8 @@ def test_epipolar_errors_large_and_edge_cases():
 
 def test_test_step_loop_and_dump(tmp_path):
     """matcher -> metrics -> dumps -> aggregate, with the LoFTR drop-in on synthetic pairs and synthetic geometry
-    (pose estimation needs OpenCV: absent here -> on_missing='inf' records the reference's failure values)."""
+    (pose estimation: OpenCV is absent here -> the library's own five-point RANSAC, csrc/pose.hip; the matches of a
+    random-weight matcher on random images carry no geometry, so the pose errors are large but well-formed)."""
     from loftr_amd import LoFTR, default_cfg, evaluation
     from _scenes import make_scene
     import copy
@@ -69,7 +70,7 @@ def test_test_step_loop_and_dump(tmp_path):
                  "T_0to1": torch.from_numpy(sc["T_0to1"]).to(DEV), "K0": torch.from_numpy(sc["K0"]).to(DEV),
                  "K1": torch.from_numpy(sc["K1"]).to(DEV),
                  "pair_names": [[f"s{step}/a{b}.jpg" for b in range(N)], [f"s{step}/b{b}.jpg" for b in range(N)]]}
-        out = evaluation.test_step(matcher, batch, dump=True, on_missing="inf")
+        out = evaluation.test_step(matcher, batch, dump=True)
         outputs.append(out)
         M = batch["mkpts0_f"].shape[0]
         assert M > 0 and batch["epi_errs"].shape == (M,)
@@ -78,13 +79,13 @@ def test_test_step_loop_and_dump(tmp_path):
         assert epi_close(batch["epi_errs"].cpu().numpy(), ref)
         m = out["metrics"]
         assert m["identifiers"] == [f"s{step}/a{b}.jpg#s{step}/b{b}.jpg" for b in range(N)]
-        assert sum(len(e) for e in m["epi_errs"]) == M and len(m["R_errs"]) == N and all(np.isinf(m["R_errs"]))
+        assert sum(len(e) for e in m["epi_errs"]) == M and len(m["R_errs"]) == N and all(np.isinf(r) or 0 <= r <= 180 for r in m["R_errs"])
         d = out["dumps"]
         assert len(d) == N and set(d[0]) == {"pair_names", "identifier", "mkpts0_f", "mkpts1_f", "mconf", "epi_errs", "R_errs", "t_errs", "inliers"}
         assert d[1]["mkpts0_f"].shape == (int((batch["m_bids"] == 1).sum()), 2)
     res = evaluation.test_epoch_end(outputs, dump_dir=str(tmp_path))
-    assert set(res) == {"auc@5", "auc@10", "auc@20", "prec@5e-04"} and res["auc@5"] == 0.0        # every pose failed
+    assert set(res) == {"auc@5", "auc@10", "auc@20", "prec@5e-04"} and 0.0 <= res["auc@5"] <= res["auc@20"] <= 1.0
     dumped = np.load(os.path.join(str(tmp_path), "LoFTR_pred_eval.npy"), allow_pickle=True)
     assert len(dumped) == 4 and dumped[0]["identifier"] == "s0/a0.jpg#s0/b0.jpg"
-    with pytest.raises(ImportError):
-        evaluation.compute_pose_errors(batch)                                                      # no cv2, no estimator
+    evaluation.compute_pose_errors(batch)                                                          # no cv2: native estimator
+    assert len(batch["R_errs"]) == N and len(batch["inliers"]) == N
