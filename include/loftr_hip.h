@@ -249,6 +249,41 @@ int loftr_sp_to_f32(const uint32_t* src_sp, float* dst, long rows, int C, void* 
 int loftr_epipolar_errors(const float* mkpts0_f, const float* mkpts1_f, const long* m_bids, const float* T_0to1,
                           const float* K0, const float* K1, long M, int N, float* epi_errs, void* stream);
 
+/* ---- training-side consumers of the path's outputs, FORWARD VALUES ONLY --------------------
+ * loftr_spvs_coarse replaces spvs_coarse (src/loftr/utils/supervision.py:22-109, with warp_kpts of
+ * src/loftr/utils/geometry.py:5-54): both coarse grids are warped into the other image through the depth maps and the
+ * relative pose, rounded to the nearest coarse cell, and the mutual-nearest pairs become the ground-truth matches.
+ *   depth0 [N,dh0,dw0], depth1 [N,dh1,dw1] f32; T_0to1, T_1to0 [N,4,4]; K0, K1 [N,3,3]; scale0/1 [N,2] or NULL (both);
+ *   mask0 [N,L], mask1 [N,S] uint8 coarse masks or NULL (both); H*, W* = image sizes, scale = RESOLUTION[0] (8).
+ *   Outputs: w_pt0_i [N,L,2], pt1_i [N,S,2] (data['spv_w_pt0_i'], ['spv_pt1_i']); spv_b/i/j [capacity N*L] in ascending
+ *   (b, i), *count = their number (device int32; 0 -> the caller substitutes the reference's single (0,0,0), :94-99);
+ *   conf_gt [N,L,S] or NULL (data['conf_matrix_gt']; the losses below work from the id lists and do not need it).
+ * loftr_spvs_fine replaces spvs_fine (:124-142): expec_f_gt = (w_pt0_i[b,i] - pt1_i[b,j]) / scale / radius, scale
+ *   multiplied by scale1[b] when given (the reference applies it iff 'scale0' is in the batch).
+ * loftr_coarse_loss_sums / loftr_fine_loss_sums produce the reduction sums of LoFTRLoss (src/losses/loftr_loss.py:22-157)
+ *   in fp64, one pass each (see csrc/train.hip for the layout of `sums`); the means, weights and corner cases are
+ *   finished by the caller (loftr_amd/training.py).  Backward passes are not provided. */
+typedef struct {
+  int N, H0, W0, H1, W1, scale;
+  int dh0, dw0, dh1, dw1;
+  const float* depth0; const float* depth1;
+  const float* T_0to1; const float* T_1to0;
+  const float* K0; const float* K1;
+  const float* scale0; const float* scale1;
+  const uint8_t* mask0; const uint8_t* mask1;
+} loftr_spvs_params;
+size_t loftr_spvs_coarse_workspace_bytes(int N, int L, int S);
+int loftr_spvs_coarse(const loftr_spvs_params* p, float* w_pt0_i, float* pt1_i, int64_t* spv_b, int64_t* spv_i, int64_t* spv_j,
+                      int32_t* count, float* conf_gt, void* ws, size_t ws_bytes, void* stream);
+int loftr_spvs_fine(const float* w_pt0_i, const float* pt1_i, int L, int S, const int64_t* b_ids, const int64_t* i_ids,
+                    const int64_t* j_ids, long M, float scale, float radius, const float* scale1, float* expec_f_gt, void* stream);
+size_t loftr_loss_workspace_bytes(int N, int L, int S);
+int loftr_coarse_loss_sums(const float* conf, int N, int L, int S, int kind, const int64_t* gt_b, const int64_t* gt_i,
+                           const int64_t* gt_j, long M, const uint8_t* mask0, const uint8_t* mask1, float alpha, float gamma,
+                           double* sums, void* ws, size_t ws_bytes, void* stream);
+int loftr_fine_loss_sums(const float* expec_f, int ld, const float* expec_f_gt, long M, int with_std, float correct_thr,
+                         double* sums, void* ws, size_t ws_bytes, void* stream);
+
 /* Replaces estimate_pose (src/utils/metrics.py:72-98: cv2.findEssentialMat(RANSAC) + cv2.recoverPose on intrinsics-
  * normalised key points), the pose step of compute_pose_errors (:101-136).  HOST function (cv2 is a CPU library too):
  * all pointers are host memory, the call is synchronous.  kpts0 / kpts1 [M,2] pixels, K0 / K1 [3,3] row-major,

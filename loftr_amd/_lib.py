@@ -32,6 +32,11 @@ class MatchOut(C.Structure):
     _fields_ = [(n, _p) for n in ("b_ids", "i_ids", "j_ids", "mconf", "mkpts0_c", "mkpts1_c", "counts")]
 
 
+class SpvsParams(C.Structure):
+    _fields_ = [(n, _i) for n in ("N", "H0", "W0", "H1", "W1", "scale", "dh0", "dw0", "dh1", "dw1")] + \
+               [(n, _p) for n in ("depth0", "depth1", "T_0to1", "T_1to0", "K0", "K1", "scale0", "scale1", "mask0", "mask1")]
+
+
 class FMap(C.Structure):
     _fields_ = [("data", _p), ("sn", _l), ("sc", _l), ("sh", _l), ("sw", _l), ("H", _i), ("W", _i)]
 
@@ -63,6 +68,12 @@ SIGNATURES = {
     "loftr_resize_linear_u8": (_i, [_p, _i, _i, _l, _p, _i, _i, _l, _p]),
     "loftr_pack_gray_u8": (_i, [_p, _l, _l, _p, _i, _i, _i, _p, _p, _p, _i, _p]),
     "loftr_epipolar_errors": (_i, [_p, _p, _p, _p, _p, _p, _l, _i, _p, _p]),
+    "loftr_spvs_coarse_workspace_bytes": (_sz, [_i, _i, _i]),
+    "loftr_spvs_coarse": (_i, [C.POINTER(SpvsParams), _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
+    "loftr_spvs_fine": (_i, [_p, _p, _i, _i, _p, _p, _p, _l, _f, _f, _p, _p, _p]),
+    "loftr_loss_workspace_bytes": (_sz, [_i, _i, _i]),
+    "loftr_coarse_loss_sums": (_i, [_p, _i, _i, _i, _i, _p, _p, _p, _l, _p, _p, _f, _f, _p, _p, _sz, _p]),
+    "loftr_fine_loss_sums": (_i, [_p, _i, _p, _l, _i, _f, _p, _p, _sz, _p]),
     "loftr_estimate_pose": (_i, [_p, _p, _l, _p, _p, _f, _f, C.c_uint, _p, _p, _p, C.POINTER(_l)]),
     "loftr_five_point": (_i, [_p, _p, _i, _p, C.POINTER(_i)]),
     "loftr_conv_prepare": (_i, [_p, C.POINTER(_l), _i, _i, _i, _i, _p, _p, _p, _p, _f, _p, _sz, _p]),

@@ -188,3 +188,28 @@ def import_reference_dataset_utils():
         sys.path.insert(0, REFERENCE_ROOT)
     import importlib
     return importlib.import_module("src.utils.dataset")
+
+
+# ---- training-side consumers (src/loftr/utils/supervision.py, src/losses/loftr_loss.py): SURVEY.md §8(f) rank 4 ----
+def import_reference_training():
+    """(supervision module, LoFTRLoss class) of the real reference.  loguru is stubbed (logger only); kornia's
+    create_meshgrid is the restatement above (published semantics)."""
+    if not reference_available():
+        raise RuntimeError(f"reference not found at {REFERENCE_ROOT}")
+    _install_stubs()
+
+    class _Logger:
+        def __getattr__(self, name):
+            return lambda *a, **k: None
+
+    if "loguru" not in sys.modules:
+        m = types.ModuleType("loguru")
+        m.logger = _Logger()
+        sys.modules["loguru"] = m
+    sys.modules["kornia.utils"].create_meshgrid = _create_meshgrid
+    if REFERENCE_ROOT not in sys.path:
+        sys.path.insert(0, REFERENCE_ROOT)
+    import importlib
+    sup = importlib.import_module("src.loftr.utils.supervision")
+    loss = importlib.import_module("src.losses.loftr_loss")
+    return sup, loss.LoFTRLoss

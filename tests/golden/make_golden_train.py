@@ -1,0 +1,134 @@
+"""Goldens of the training-side consumers (forward values): the reference's own spvs_coarse / spvs_fine
+(src/loftr/utils/supervision.py) and LoFTRLoss (src/losses/loftr_loss.py) on synthetic two-view geometry.
+
+    python tests/golden/make_golden_train.py       # authoring container only (needs /root/reference)
+
+Scene: a plane Z = Z0(x, y) seen by two cameras with a small relative motion; depth1 is the true depth of that
+surface from camera 1 (ray / plane intersection), so that the bidirectional warp of spvs_coarse finds mutual nearest
+cells; some depth holes (0) exercise the "warped to the corner" edge case.  Case `train_md` adds MegaDepth-style
+padding masks and scale0 / scale1."""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+CASES = {"train_sc": dict(N=2, H=96, W=128, masks=False, seed=1),
+         "train_md": dict(N=2, H=96, W=96, masks=True, seed=2)}
+
+
+def _rot(axis, ang):
+    axis = axis / np.linalg.norm(axis)
+    K = np.array([[0, -axis[2], axis[1]], [axis[2], 0, -axis[0]], [-axis[1], axis[0], 0]])
+    return np.eye(3) + np.sin(ang) * K + (1 - np.cos(ang)) * K @ K
+
+
+def make_inputs(rc):
+    rng = np.random.default_rng(rc["seed"])
+    N, H, W = rc["N"], rc["H"], rc["W"]
+    K0 = np.stack([np.array([[90.0 + 5 * n, 0, W / 2 - 1.5], [0, 92.0, H / 2 + 0.5], [0, 0, 1]]) for n in range(N)]).astype(np.float32)
+    K1 = np.stack([np.array([[88.0, 0, W / 2 + 1.0], [0, 91.0 + 3 * n, H / 2 - 1.0], [0, 0, 1]]) for n in range(N)]).astype(np.float32)
+    T01, T10, d0s, d1s = [], [], [], []
+    for n in range(N):
+        R = _rot(rng.standard_normal(3), 0.05 + 0.05 * rng.random())
+        t = 0.15 * rng.standard_normal(3)
+        T = np.eye(4); T[:3, :3], T[:3, 3] = R, t
+        T01.append(T); T10.append(np.linalg.inv(T))
+        Z0 = 3.0 + 0.3 * n
+        d0 = np.full((H, W), Z0, np.float32)                     # fronto-parallel plane in camera 0
+        nrm = R @ np.array([0, 0, 1.0])
+        v, u = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
+        rays = np.linalg.inv(K1[n].astype(np.float64)) @ np.stack([u.ravel(), v.ravel(), np.ones(H * W)])
+        d1 = ((Z0 + nrm @ t) / (nrm @ rays)).reshape(H, W).astype(np.float32)
+        holes = rng.random((H, W)) < 0.03
+        d0[holes] = 0
+        d1[rng.random((H, W)) < 0.03] = 0
+        d0s.append(d0); d1s.append(d1)
+    inp = dict(depth0=np.stack(d0s), depth1=np.stack(d1s), T_0to1=np.stack(T01).astype(np.float32),
+               T_1to0=np.stack(T10).astype(np.float32), K0=K0, K1=K1)
+    if rc["masks"]:
+        h, w = H // 8, W // 8
+        m0, m1 = np.zeros((N, h, w), bool), np.zeros((N, h, w), bool)
+        m0[0, :9, :], m0[1, :, :10] = True, True
+        m1[0, :, :11], m1[1, :10, :] = True, True
+        inp.update(mask0=m0, mask1=m1, scale0=np.array([[1.9, 1.9], [1.25, 1.5]], np.float32),
+                   scale1=np.array([[1.0, 2.0], [1.6, 1.6]], np.float32))
+        # the depth maps / intrinsics live at ORIGINAL resolution = resized * scale: keep it simple and scale K accordingly
+        for k, sc in (("K0", inp["scale0"]), ("K1", inp["scale1"])):
+            Kk = inp[k].copy(); Kk[:, 0, :] *= sc[:, :1]; Kk[:, 1, :] *= sc[:, 1:]; inp[k] = Kk
+        big = lambda d, sc: np.stack([np.kron(d[n], np.ones((2, 2), np.float32)) for n in range(N)])     # 2x depth maps cover scale <= 2
+        inp["depth0"], inp["depth1"] = big(inp["depth0"], None), big(inp["depth1"], None)
+    return inp
+
+
+def replay_matcher_outputs(rc, gt_b, gt_i, gt_j):
+    """conf_matrix / conf_matrix_with_bin of a case, regenerated from the seed exactly as make() drew them."""
+    rng = np.random.default_rng(rc["seed"] + 100)
+    N, L = rc["N"], (rc["H"] // 8) * (rc["W"] // 8)
+    S = L
+    rng.random(len(gt_b)); rng.integers(0, N, 6); rng.integers(1, L, 6); rng.integers(0, S, 6)
+    conf = rng.random((N, L, S)).astype(np.float32) ** 4
+    conf[gt_b, gt_i, gt_j] = 0.3 + 0.69 * rng.random(len(gt_b)).astype(np.float32)
+    conf_bin = rng.random((N, L + 1, S + 1)).astype(np.float32) ** 3
+    return conf, conf_bin
+
+
+def make(name):
+    from oracle.ref_shim import import_reference_training
+    sup, LoFTRLoss = import_reference_training()
+    rc = CASES[name]
+    inp = make_inputs(rc)
+    N, H, W = rc["N"], rc["H"], rc["W"]
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+    data = {"image0": torch.zeros(N, 1, H, W), "image1": torch.zeros(N, 1, H, W), "dataset_name": ["scannet"] * N,
+            "pair_names": [["a"] * N, ["b"] * N], **{k: t(v) for k, v in inp.items()}}
+    cfg = {"LOFTR": {"RESOLUTION": (8, 2), "FINE_WINDOW_SIZE": 5}}
+    sup.spvs_coarse(data, cfg)
+    store = {k: data[k].numpy() for k in ("spv_b_ids", "spv_i_ids", "spv_j_ids", "spv_w_pt0_i", "spv_pt1_i")}
+    store["conf_gt_sum"] = data["conf_matrix_gt"].sum((1, 2)).numpy()
+    # a plausible matcher output: the GT matches minus a few, plus a few wrong ones; conf / expec_f synthetic
+    rng = np.random.default_rng(rc["seed"] + 100)
+    L, S = (H // 8) * (W // 8), (H // 8) * (W // 8)
+    gt_b, gt_i, gt_j = store["spv_b_ids"], store["spv_i_ids"], store["spv_j_ids"]
+    keep = rng.random(len(gt_b)) < 0.8
+    b = np.concatenate([gt_b[keep], rng.integers(0, N, 6)]); i = np.concatenate([gt_i[keep], rng.integers(1, L, 6)])
+    j = np.concatenate([gt_j[keep], rng.integers(0, S, 6)])
+    o = np.lexsort((i, b)); b, i, j = b[o], i[o], j[o]
+    data.update(b_ids=t(b), i_ids=t(i), j_ids=t(j))
+    sup.spvs_fine(data, cfg)
+    store.update(b_ids=b, i_ids=i, j_ids=j, expec_f_gt=data["expec_f_gt"].numpy())
+    conf = rng.random((N, L, S)).astype(np.float32) ** 4
+    conf[gt_b, gt_i, gt_j] = 0.3 + 0.69 * rng.random(len(gt_b)).astype(np.float32)
+    conf_bin = rng.random((N, L + 1, S + 1)).astype(np.float32) ** 3
+    expec_f = np.concatenate([data["expec_f_gt"].numpy() + 0.1 * rng.standard_normal((len(b), 2)).astype(np.float32),
+                              0.05 + rng.random((len(b), 1)).astype(np.float32)], 1).astype(np.float32)
+    store.update(conf_seed=np.int64(rc["seed"] + 100), expec_f=expec_f)
+    data.update(conf_matrix=t(conf), conf_matrix_with_bin=t(conf_bin), expec_f=t(expec_f))
+    losses = {}
+    for tag, (ctype, sparse, mtype, ftype) in {"focal_sparse_ds": ("focal", True, "dual_softmax", "l2_with_std"),
+                                                 "focal_sparse_ot": ("focal", True, "sinkhorn", "l2_with_std"),
+                                                 "focal_dense_ds": ("focal", False, "dual_softmax", "l2"),
+                                                 "ce_dense_ds": ("cross_entropy", False, "dual_softmax", "l2_with_std")}.items():
+        lcfg = {"loftr": {"loss": dict(coarse_type=ctype, coarse_weight=1.0, focal_alpha=0.25, focal_gamma=2.0, pos_weight=1.0,
+                                       neg_weight=1.0, fine_type=ftype, fine_weight=1.0, fine_correct_thr=1.0),
+                          "match_coarse": dict(match_type=mtype, sparse_spvs=sparse)}}
+        crit = LoFTRLoss(lcfg).eval()
+        d2 = dict(data)
+        if ftype == "l2":                   # the reference's plain-l2 path takes [M,2] (loftr_loss.py:110-121)
+            d2["expec_f"] = t(expec_f[:, :2].copy())
+        crit(d2)
+        losses[tag] = {k: float(v) for k, v in d2["loss_scalars"].items()}
+    store["losses"] = np.array(json.dumps(losses))
+    store["recipe"] = np.array(json.dumps(rc))
+    np.savez_compressed(os.path.join(HERE, f"{name}.npz"), **store)
+    print(name, "GT matches", len(gt_b), "predictions", len(b), losses)
+
+
+if __name__ == "__main__":
+    for nm in sys.argv[1:] or list(CASES):
+        make(nm)

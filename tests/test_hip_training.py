@@ -1,0 +1,114 @@
+"""GPU parity of the training-side consumers (forward values): loftr_amd.training through the
+C-ABI (csrc/train.hip) against the goldens produced by the reference's own spvs_coarse / spvs_fine / LoFTRLoss
+(tests/golden/train_*.npz, generator: make_golden_train.py) and the numpy oracle for the corner cases."""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from test_train_oracle import CASES, LOSS_CFGS, MG, check_spvs, load
+
+pytestmark = pytest.mark.gpu
+CFG = {"LOFTR": {"RESOLUTION": (8, 2), "FINE_WINDOW_SIZE": 5}}
+
+
+def batch(rc, inp, dev):
+    N, H, W = rc["N"], rc["H"], rc["W"]
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    return {"image0": torch.zeros(N, 1, H, W, device=dev), "image1": torch.zeros(N, 1, H, W, device=dev),
+            "dataset_name": ["scannet"] * N, **{k: t(v) for k, v in inp.items()}}
+
+
+def loss_cfg(ctype, sparse, mtype, ftype):
+    return {"loftr": {"loss": dict(coarse_type=ctype, coarse_weight=1.0, focal_alpha=0.25, focal_gamma=2.0, pos_weight=1.0, neg_weight=1.0,
+                                   fine_type=ftype, fine_weight=1.0, fine_correct_thr=1.0),
+                      "match_coarse": dict(match_type=mtype, sparse_spvs=sparse)}}
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_supervision_against_reference_golden(name):
+    from loftr_amd.training import compute_supervision_coarse, compute_supervision_fine
+    dev = torch.device("cuda", 0)
+    rc, inp, g = load(name)
+    data = batch(rc, inp, dev)
+    compute_supervision_coarse(data, CFG)
+    out = {k: data[k].cpu().numpy() for k in ("spv_b_ids", "spv_i_ids", "spv_j_ids", "spv_w_pt0_i", "spv_pt1_i")}
+    check_spvs(out, g)
+    key = out["spv_b_ids"] * 10**6 + out["spv_i_ids"]
+    assert np.all(np.diff(key) > 0)                                    # torch.where order: ascending (b, i)
+    gt = data["conf_matrix_gt"]
+    assert gt.sum().item() == len(out["spv_b_ids"]) and gt[data["spv_b_ids"], data["spv_i_ids"], data["spv_j_ids"]].min().item() == 1
+    # fine supervision on the reference's own coarse supervision and predictions
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    data.update(spv_w_pt0_i=t(g["spv_w_pt0_i"]), spv_pt1_i=t(g["spv_pt1_i"]), b_ids=t(g["b_ids"]), i_ids=t(g["i_ids"]), j_ids=t(g["j_ids"]))
+    compute_supervision_fine(data, CFG)
+    ef = data["expec_f_gt"].cpu().numpy()
+    assert np.abs(ef - g["expec_f_gt"]).max() <= 1e-5 * max(1.0, np.abs(g["expec_f_gt"]).max())
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_losses_against_reference_golden(name):
+    from loftr_amd.training import LoFTRLoss
+    dev = torch.device("cuda", 0)
+    rc, inp, g = load(name)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    conf, conf_bin = MG.replay_matcher_outputs(rc, g["spv_b_ids"], g["spv_i_ids"], g["spv_j_ids"])
+    data = {"conf_matrix": t(conf), "conf_matrix_with_bin": t(conf_bin), "expec_f_gt": t(g["expec_f_gt"]),
+            **{k: t(g[k]) for k in ("spv_b_ids", "spv_i_ids", "spv_j_ids")}}
+    if "mask0" in inp:
+        data.update(mask0=t(inp["mask0"]), mask1=t(inp["mask1"]))
+    want = json.loads(str(g["losses"]))
+    for tag, (ctype, sparse, mtype, ftype) in LOSS_CFGS.items():
+        d = dict(data)
+        d["expec_f"] = t(g["expec_f"][:, :2].copy() if ftype == "l2" else g["expec_f"])
+        LoFTRLoss(loss_cfg(ctype, sparse, mtype, ftype)).eval()(d)
+        got = {k: float(v) for k, v in d["loss_scalars"].items()}
+        for k in ("loss_c", "loss_f", "loss"):
+            assert abs(got[k] - want[tag][k]) <= 2e-6 * max(1.0, abs(want[tag][k])), (tag, k, got, want[tag])
+        assert d["loss"].is_cuda
+
+
+def test_corner_cases_against_oracle():
+    """No ground truth at all (supervision.py:94-99, loftr_loss.py:32-36), no correct fine entry (:113-117, :138-143),
+    empty prediction list."""
+    from oracle import train_oracle as T
+    from loftr_amd.training import LoFTRLoss, compute_supervision_coarse, compute_supervision_fine
+    dev = torch.device("cuda", 0)
+    rc, inp, g = load("train_sc")
+    inp = dict(inp)
+    inp["depth0"] = np.zeros_like(inp["depth0"])                        # every cell of image 0 warps to the corner
+    data = batch(rc, inp, dev)
+    compute_supervision_coarse(data, CFG)
+    assert data["_spv_count"] == 0 and data["spv_b_ids"].tolist() == [0] and data["spv_i_ids"].tolist() == [0]
+    assert data["conf_matrix_gt"].sum().item() == 0
+    N, L = rc["N"], (rc["H"] // 8) * (rc["W"] // 8)
+    rng = np.random.default_rng(5)
+    conf = rng.random((N, L, L)).astype(np.float32) ** 4
+    gt0 = np.zeros((N, L, L), np.float32)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    data.update(conf_matrix=t(conf), b_ids=torch.zeros(0, dtype=torch.int64, device=dev), i_ids=torch.zeros(0, dtype=torch.int64, device=dev),
+                j_ids=torch.zeros(0, dtype=torch.int64, device=dev))
+    compute_supervision_fine(data, CFG)
+    assert tuple(data["expec_f_gt"].shape) == (0, 2)
+    for ctype, sparse in (("focal", True), ("focal", False), ("cross_entropy", False)):
+        crit = LoFTRLoss(loss_cfg(ctype, sparse, "dual_softmax", "l2_with_std")).eval()
+        lc = float(crit.compute_coarse_loss(data["conf_matrix"], data))
+        want = T.coarse_loss(conf, gt0, None, ctype, sparse, "dual_softmax")
+        assert abs(lc - want) <= 2e-6 * max(1.0, abs(want)), (ctype, sparse, lc, want)
+    # fine loss without a correct entry
+    ef = t(np.array([[0.1, 0.2, 0.5], [0.3, -0.1, 0.7]], np.float32))
+    egt = t(np.array([[1.5, 0.0], [0.2, -2.0]], np.float32))
+    for ftype in ("l2", "l2_with_std"):
+        crit = LoFTRLoss(loss_cfg("focal", True, "dual_softmax", ftype))
+        assert crit.eval().compute_fine_loss(ef, egt) is None
+        lf = float(crit.train().compute_fine_loss(ef, egt))
+        assert abs(lf - (0.0 if ftype == "l2_with_std" else (1.4 ** 2 + 0.2 ** 2))) <= 1e-6
+
+
+def test_rejects_cpu_tensors():
+    from loftr_amd import _lib
+    from loftr_amd.training import compute_supervision_coarse
+    rc, inp, g = load("train_sc")
+    with pytest.raises((_lib.LoftrHipError, RuntimeError)):
+        compute_supervision_coarse(batch(rc, inp, torch.device("cpu")), CFG)
