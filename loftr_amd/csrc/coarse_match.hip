@@ -354,6 +354,22 @@ __global__ __launch_bounds__(Cfg::THREADS, 2) void score_conf_kernel(
 #ifndef SWEEP_PROBE_PRIO
 #define SWEEP_PROBE_PRIO 0       // 1: s_setprio 1 around the MFMA block (probe)
 #endif
+#ifndef SWEEP_PIPE
+#define SWEEP_PIPE 0             // 0: compiler-visible ds_reads in the panel loop, order and waits left to hipcc (A/B)
+#endif
+#ifndef PIPE_DEP
+#define PIPE_DEP 1               // phases of fragment prefetch
+#endif
+#define PIPE_NBUF (PIPE_DEP + 1)
+#ifndef SWEEP_PROBE_NODMA
+#define SWEEP_PROBE_NODMA 0      // 1: no LDS-DMA (timing probes only; wrong results)
+#endif
+#ifndef SWEEP_PROBE_NOLDS
+#define SWEEP_PROBE_NOLDS 0      // 1: no panel fragment reads
+#endif
+#ifndef SWEEP_PROBE_NOBAR
+#define SWEEP_PROBE_NOBAR 0      // 1: no per-panel barrier
+#endif
 #ifndef SWEEP_PROBE_SKEW
 #define SWEEP_PROBE_SKEW 1       // 0: all eight waves in phase
 #endif
@@ -533,6 +549,7 @@ __global__ __launch_bounds__(512, 2) void score_sweep_kernel(Args a) {
   float best = -1.f; int bestj = 0; bool tie = false;   // pass B
   const TrMasks trm = tr_masks(lane);
   const int trcol = jr(tr_reg(lane & 15), g);       // panel column whose transposed reduction ends in this lane
+  const unsigned lds_base = (unsigned)(size_t)(lds_ptr_t)lds;
   const int a_off = lds_chunk_off(li, g);          // hi chunk of the even k-step; odd k-step: ^ 32, lo: ^ 64 (chunk + 2 / + 4)
   const int sel = lane & 15;
   const long part_row = ((long)n * a.RB * W + rb * W + wave) * S;          // this wave's row of the column partials
@@ -668,13 +685,69 @@ __global__ __launch_bounds__(512, 2) void score_sweep_kernel(Args a) {
     if (drain || p + 1 >= np) LOFTR_WAITCNT_VM(0);
     else if (p < 2) LOFTR_WAITCNT_VM(DMA_PER_WAVE);
     else LOFTR_WAITCNT_VM(DMA_PER_WAVE + ST);
-    __builtin_amdgcn_s_barrier();                  // ... for every wave; and every wave is past the MFMAs of panel p-2
-    if (p + 2 < np) SWEEP_ISSUE(p + 2);
+    if (!SWEEP_PROBE_NOBAR) __builtin_amdgcn_s_barrier();   // ... for every wave; and every wave is past the MFMAs of panel p-2
+    if (p + 2 < np && !SWEEP_PROBE_NODMA) SWEEP_ISSUE(p + 2);
     drain = !((p0 + p) * PC + PC <= S && (S & 3) == 0) && PASS == 1;
+    const char* st = lds + (p & (NST - 1)) * STAGE;
+#if SWEEP_PIPE
+    // ---- 48 MFMAs in eight phases of two k-steps (one 4 KB k-group of the panel: hi / lo fragments of an even and an
+    // odd k-step = four ds_read_b128), the fragments of phase ph + PIPE_DEP in flight while phase ph multiplies.
+    // The reads are inline asm with COUNTED lgkmcnt waits: while LDS-DMA is in flight hipcc's wait insertion degrades
+    // every LDS dependency to lgkmcnt(0) (the DMA counts as a pending flat access), so with compiler-visible reads a
+    // wave exposes the full LDS latency once per ds_read group and cannot keep the matrix pipe busy on its own --
+    // which is what the half-period skew of the two waves of a SIMD relies on.  LDS reads return in order, so
+    // "phase ph has landed" is lgkmcnt(4 PIPE_DEP) right after the reads of phase ph + PIPE_DEP were issued; the wait
+    // statement names the fragments it releases ("+v"), which is what keeps their MFMAs below it.
+    h16x8 fr[PIPE_NBUF][4];
+    const unsigned stb = lds_base + (p & (NST - 1)) * STAGE;
+    const unsigned ad0 = stb + a_off, ad1 = stb + (a_off ^ 64), ad2 = stb + (a_off ^ 32), ad3 = stb + (a_off ^ 96);
+#define SWEEP_LOADPH(ph_)                                                                                \
+    asm volatile("ds_read_b128 %0, %4 offset:%8\n\tds_read_b128 %1, %5 offset:%8\n\t"                  \
+                 "ds_read_b128 %2, %6 offset:%8\n\tds_read_b128 %3, %7 offset:%8"                       \
+                 : "=&v"(fr[(ph_) % PIPE_NBUF][0]), "=&v"(fr[(ph_) % PIPE_NBUF][1]), "=&v"(fr[(ph_) % PIPE_NBUF][2]),  \
+                   "=&v"(fr[(ph_) % PIPE_NBUF][3])                                                       \
+                 : "v"(ad0), "v"(ad1), "v"(ad2), "v"(ad3), "i"((ph_) * 4096));
+#define SWEEP_WAITPH(ph_, n_)                                                                            \
+    asm volatile("s_waitcnt lgkmcnt(%4)"                                                                 \
+                 : "+v"(fr[(ph_) % PIPE_NBUF][0]), "+v"(fr[(ph_) % PIPE_NBUF][1]), "+v"(fr[(ph_) % PIPE_NBUF][2]),    \
+                   "+v"(fr[(ph_) % PIPE_NBUF][3])                                                        \
+                 : "i"(n_));
+#define SWEEP_PHASE(ph_)                                                                                 \
+    if ((ph_) + PIPE_DEP < 8) SWEEP_LOADPH((ph_) + PIPE_DEP)                                             \
+    SWEEP_WAITPH(ph_, 4 * ((ph_) + PIPE_DEP < 8 ? PIPE_DEP : 7 - (ph_)))                                 \
+    {                                                                                                    \
+      const h16x8 ah0 = fr[(ph_) % PIPE_NBUF][0], al0 = fr[(ph_) % PIPE_NBUF][1];                        \
+      const h16x8 ah1 = fr[(ph_) % PIPE_NBUF][2], al1 = fr[(ph_) % PIPE_NBUF][3];                        \
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al0, bh[2 * (ph_)], acc0, 0, 0, 0);                  \
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0, bl[2 * (ph_)], acc1, 0, 0, 0);                  \
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0, bh[2 * (ph_)], acc0, 0, 0, 0);                  \
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al1, bh[2 * (ph_) + 1], acc1, 0, 0, 0);              \
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1, bl[2 * (ph_) + 1], acc0, 0, 0, 0);              \
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1, bh[2 * (ph_) + 1], acc1, 0, 0, 0);              \
+    }                                                                                                    \
+    __builtin_amdgcn_sched_barrier(0);
+#if SWEEP_PROBE_NOLDS
+#undef SWEEP_LOADPH
+#undef SWEEP_WAITPH
+#define SWEEP_LOADPH(ph_)
+#define SWEEP_WAITPH(ph_, n_)
+#pragma unroll
+    for (int b_ = 0; b_ < PIPE_NBUF; ++b_) { fr[b_][0] = bh[b_]; fr[b_][1] = bl[b_]; fr[b_][2] = bh[b_ + 4]; fr[b_][3] = bl[b_ + 4]; }
+#endif
+    SWEEP_LOADPH(0)
+    if (PIPE_DEP > 1) SWEEP_LOADPH(1)
+    if (SWEEP_PROBE_EPI && late && p > 0) SWEEP_EPILOGUE(p - 1);      // (its VALU work covers the latency of the first fragments)
+    if (SWEEP_PROBE_PRIO) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+    SWEEP_PHASE(0) SWEEP_PHASE(1) SWEEP_PHASE(2) SWEEP_PHASE(3) SWEEP_PHASE(4) SWEEP_PHASE(5) SWEEP_PHASE(6) SWEEP_PHASE(7)
+#undef SWEEP_LOADPH
+#undef SWEEP_WAITPH
+#undef SWEEP_PHASE
+#else
     if (SWEEP_PROBE_EPI && late && p > 0) SWEEP_EPILOGUE(p - 1);
     // ---- 48 MFMAs: two accumulators alternate so that no MFMA depends on its predecessor
     if (SWEEP_PROBE_PRIO) __builtin_amdgcn_s_setprio(1);
-    const char* st = lds + (p & (NST - 1)) * STAGE;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
 #pragma unroll
@@ -696,6 +769,7 @@ __global__ __launch_bounds__(512, 2) void score_sweep_kernel(Args a) {
         acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[ks], acc0, 0, 0, 0);
       }
     }
+#endif
     if (SWEEP_PROBE_PRIO) __builtin_amdgcn_s_setprio(0);
     if (SWEEP_PROBE_EPI && !late) SWEEP_EPILOGUE(p);
     if (!SWEEP_PROBE_EPI) { s_run += acc0[0] + acc1[5]; best += acc0[3] + acc1[7]; }     // keep the MFMAs alive

@@ -7,8 +7,10 @@ exceptions.  Every sub-module after the backbone holds parameters only; its arit
 call into ``libloftr_hip.so`` (``loftr_amd/ops.py``).  There is no PyTorch fallback: on a box
 without the built extension or without a GPU the forward raises.
 
-Scope: inference (``.eval()``).  The training-only branches of the reference (GT padding /
-random sampling in ``coarse_matching.py:200-236``) are outside the hot path and raise.
+Scope: forward values.  In ``.train()`` mode CoarseMatching also performs the reference's random
+sampling / ground-truth padding of the coarse matches (``coarse_matching.py:200-236``, host-side
+index arithmetic on the kernels' outputs); no sub-module builds an autograd graph -- backward
+passes are not provided (forward only).
 """
 import math
 
@@ -134,8 +136,15 @@ class LocalFeatureTransformer(nn.Module):
         return cached[1]
 
 
+def compute_max_candidates(p_m0, p_m1):
+    """coarse_matching.py:44-54: sum over the batch of min(valid area of image 0, of image 1) in coarse cells."""
+    h0s, w0s = p_m0.sum(1).max(-1)[0], p_m0.sum(-1).max(-1)[0]
+    h1s, w1s = p_m1.sum(1).max(-1)[0], p_m1.sum(-1).max(-1)[0]
+    return torch.sum(torch.min(torch.stack([h0s * w0s, h1s * w1s], -1), -1)[0])
+
+
 class CoarseMatching(nn.Module):
-    """coarse_matching.py:61-261 (inference branch)."""
+    """coarse_matching.py:61-261."""
 
     def __init__(self, config):
         super().__init__()
@@ -158,9 +167,6 @@ class CoarseMatching(nn.Module):
             raise NotImplementedError()
 
     def forward(self, feat_c0, feat_c1, data, mask_c0=None, mask_c1=None):
-        if self.training:
-            raise NotImplementedError("CoarseMatching: the training branch (GT padding / sampling, "
-                                      "coarse_matching.py:200-236) is outside the HIP hot path; call .eval()")
         scale = data["hw0_i"][0] / data["hw0_c"][0]
         kw = dict(thr=self.thr, border_rm=self.border_rm, scale=scale, match_type=self.match_type,
                   mask0=mask_c0, mask1=mask_c1, scale0=data.get("scale0"), scale1=data.get("scale1"))
@@ -169,12 +175,16 @@ class CoarseMatching(nn.Module):
         else:
             sparse = self.config["sparse_spvs"]          # KeyError with cvpr default_cfg, like the reference (:142)
             kw.update(bin_score=float(self.bin_score.detach()), skh_iters=self.skh_iters,
-                      skh_prefilter=self.skh_prefilter, want_assign=bool(sparse))
+                      skh_prefilter=self.skh_prefilter and not self.training,      # "if not self.training and ..." (:136)
+                      want_assign=bool(sparse))
         r = ops.coarse_match(feat_c0, feat_c1, tuple(data["hw0_c"]), tuple(data["hw1_c"]), **kw)
         if "conf_matrix_with_bin" in r:
             data.update({"conf_matrix_with_bin": r["conf_matrix_with_bin"]})
         data.update({"conf_matrix": r["conf_matrix"]})
         mconf = r["mconf"]
+        if self.training:
+            data["_match_counts"] = r["counts"]
+            return data.update(**self._train_sample(r, data, scale))
         out = {"b_ids": r["b_ids"], "i_ids": r["i_ids"], "j_ids": r["j_ids"]}
         if self.thr >= 0:
             # conf > thr >= 0  =>  mconf != 0 everywhere: the `mconf != 0` filter of :254-258 is a no-op
@@ -186,6 +196,41 @@ class CoarseMatching(nn.Module):
                         "mkpts1_c": r["mkpts1_c"][keep], "mconf": mconf[keep]})
         data.update(**out)
         data["_match_counts"] = r["counts"]               # [1+N] int32: total, per pair (extra key)
+
+
+    def _train_sample(self, r, data, scale):
+        """coarse_matching.py:200-259 on the kernels' match list: sample / pad the fine-level training set with
+        ground-truth matches (mconf = 0 marks the padding), then the coordinate bookkeeping for the padded list.
+        Same torch.randint calls as the reference, in the same order."""
+        if data["conf_matrix"] is None:
+            raise ops._lib.LoftrHipError("CoarseMatching.train(): materialize_conf must stay True (the losses read conf_matrix)")
+        b_ids, i_ids, j_ids, mconf = r["b_ids"], r["i_ids"], r["j_ids"], r["mconf"]
+        dev = mconf.device
+        N, L, S = data["conf_matrix"].shape
+        if "mask0" not in data:
+            num_candidates_max = N * max(L, S)
+        else:
+            num_candidates_max = compute_max_candidates(data["mask0"], data["mask1"])
+        num_matches_train = int(num_candidates_max * self.train_coarse_percent)
+        num_matches_pred = len(b_ids)
+        assert self.train_pad_num_gt_min < num_matches_train, "min-num-gt-pad should be less than num-train-matches"
+        if num_matches_pred <= num_matches_train - self.train_pad_num_gt_min:
+            pred_indices = torch.arange(num_matches_pred, device=dev)
+        else:
+            pred_indices = torch.randint(num_matches_pred, (num_matches_train - self.train_pad_num_gt_min,), device=dev)
+        gt_pad_indices = torch.randint(len(data["spv_b_ids"]),
+                                       (max(num_matches_train - num_matches_pred, self.train_pad_num_gt_min),), device=dev)
+        mconf_gt = torch.zeros(len(data["spv_b_ids"]), device=dev)
+        b_ids, i_ids, j_ids, mconf = (torch.cat([x[pred_indices], y[gt_pad_indices]], dim=0) for x, y in
+                                      ((b_ids, data["spv_b_ids"]), (i_ids, data["spv_i_ids"]), (j_ids, data["spv_j_ids"]),
+                                       (mconf, mconf_gt)))
+        scale0 = scale * data["scale0"][b_ids] if "scale0" in data else scale
+        scale1 = scale * data["scale1"][b_ids] if "scale1" in data else scale
+        mkpts0_c = torch.stack([i_ids % data["hw0_c"][1], i_ids // data["hw0_c"][1]], dim=1) * scale0
+        mkpts1_c = torch.stack([j_ids % data["hw1_c"][1], j_ids // data["hw1_c"][1]], dim=1) * scale1
+        keep = mconf != 0
+        return {"b_ids": b_ids, "i_ids": i_ids, "j_ids": j_ids, "gt_mask": mconf == 0, "m_bids": b_ids[keep],
+                "mkpts0_c": mkpts0_c[keep], "mkpts1_c": mkpts1_c[keep], "mconf": mconf[keep]}
 
 
 class FinePreprocess(nn.Module):
@@ -240,7 +285,7 @@ class FineMatching(nn.Module):
             expec, mk1f = ops.fine_match(feat_f0, feat_f1, data["mkpts1_c"], data["b_ids"], scale, scale1)
             mk1f = mk1f[:n]
         else:
-            # thr < 0 only: CoarseMatching dropped the `mconf == 0` rows from mkpts*_c (coarse_matching.py:254-258)
+            # thr < 0 or .train(): CoarseMatching dropped the `mconf == 0` rows from mkpts*_c (coarse_matching.py:254-258)
             # but not from b_ids, so there are M windows and n < M coarse points.  The reference then adds the
             # refinement of the FIRST n windows to the n kept points (fine_matching.py:69, `[:len(mconf)]`): the
             # kernel computes all M offsets from a zero base (one base point per window, never out of bounds).

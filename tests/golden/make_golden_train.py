@@ -129,6 +129,66 @@ def make(name):
     print(name, "GT matches", len(gt_b), "predictions", len(b), losses)
 
 
+# ---- CoarseMatching.train(): random sampling / ground-truth padding (coarse_matching.py:200-259) ------------------
+COARSE_TRAIN = {"ctrain_pad": dict(N=2, h=12, w=16, C=256, seed=11, percent=0.4, pad_min=20, masks=False, thr=0.0),      # few predictions: arange + GT padding
+                "ctrain_sample": dict(N=2, h=12, w=16, C=256, seed=12, percent=0.12, pad_min=8, masks=True, thr=0.0)}    # more than the budget: sampled
+
+
+def det_randint(high, size, device=None, **kw):
+    """Deterministic stand-in for torch.randint in BOTH implementations (their RNG streams differ by device)."""
+    n = size[0]
+    return ((torch.arange(n, dtype=torch.int64) * 7919 + 13) % max(int(high), 1)).to(device)
+
+
+def coarse_train_inputs(rc):
+    rng = np.random.default_rng(rc["seed"])
+    N, L, C = rc["N"], rc["h"] * rc["w"], rc["C"]
+    f0 = rng.standard_normal((N, L, C)).astype(np.float32)
+    perm = np.stack([rng.permutation(L) for _ in range(N)])
+    f1 = np.stack([f0[n][perm[n]] for n in range(N)]) * 0.9 + 0.45 * rng.standard_normal((N, L, C)).astype(np.float32)
+    f0, f1 = f0 * 4, f1.astype(np.float32) * 4           # peaked dual-softmax: a few hundred mutual matches
+    G = 60
+    spv = dict(spv_b_ids=rng.integers(0, N, G), spv_i_ids=rng.integers(1, L, G), spv_j_ids=rng.integers(0, L, G))
+    inp = dict(feat_c0=f0, feat_c1=f1, **spv)
+    if rc["masks"]:
+        m0, m1 = np.zeros((N, rc["h"], rc["w"]), bool), np.zeros((N, rc["h"], rc["w"]), bool)
+        m0[0, :10, :], m0[1, :, :13] = True, True
+        m1[0, :, :14], m1[1, :11, :] = True, True
+        inp.update(mask0=m0, mask1=m1, scale0=np.array([[1.5, 1.5], [1.0, 2.0]], np.float32), scale1=np.array([[2.0, 1.25], [1.1, 1.1]], np.float32))
+    return inp
+
+
+def coarse_train_config(rc):
+    return dict(thr=rc["thr"], border_rm=1, train_coarse_percent=rc["percent"], train_pad_num_gt_min=rc["pad_min"], match_type="dual_softmax",
+                dsmax_temperature=0.1, skh_init_bin_score=1.0, skh_iters=3, skh_prefilter=False, sparse_spvs=True)
+
+
+def make_coarse_train(name):
+    from oracle.ref_shim import import_reference
+    import_reference()
+    import importlib
+    cm = importlib.import_module("src.loftr.utils.coarse_matching")
+    rc = COARSE_TRAIN[name]
+    inp = coarse_train_inputs(rc)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+    H, W = rc["h"] * 8, rc["w"] * 8
+    data = {"hw0_i": torch.Size([H, W]), "hw1_i": torch.Size([H, W]), "hw0_c": torch.Size([rc["h"], rc["w"]]), "hw1_c": torch.Size([rc["h"], rc["w"]]),
+            **{k: t(v) for k, v in inp.items() if not k.startswith("feat")}}
+    mod = cm.CoarseMatching(coarse_train_config(rc)).train()
+    real = torch.randint
+    torch.randint = det_randint
+    try:
+        m0 = data["mask0"].flatten(-2) if rc["masks"] else None
+        m1 = data["mask1"].flatten(-2) if rc["masks"] else None
+        with torch.no_grad():
+            mod(t(inp["feat_c0"]), t(inp["feat_c1"]), data, mask_c0=m0, mask_c1=m1)
+    finally:
+        torch.randint = real
+    keys = ("b_ids", "i_ids", "j_ids", "gt_mask", "m_bids", "mkpts0_c", "mkpts1_c", "mconf")
+    np.savez_compressed(os.path.join(HERE, f"{name}.npz"), recipe=np.array(json.dumps(rc)), **{k: data[k].numpy() for k in keys})
+    print(name, "fine-level training set", len(data["b_ids"]), "of which predictions", int((~data["gt_mask"]).sum()))
+
+
 if __name__ == "__main__":
-    for nm in sys.argv[1:] or list(CASES):
-        make(nm)
+    for nm in sys.argv[1:] or list(CASES) + list(COARSE_TRAIN):
+        (make if nm in CASES else make_coarse_train)(nm)

@@ -112,3 +112,32 @@ def test_rejects_cpu_tensors():
     rc, inp, g = load("train_sc")
     with pytest.raises((_lib.LoftrHipError, RuntimeError)):
         compute_supervision_coarse(batch(rc, inp, torch.device("cpu")), CFG)
+
+
+@pytest.mark.parametrize("name", list(MG.COARSE_TRAIN))
+def test_coarse_matching_train_branch(name, monkeypatch):
+    """CoarseMatching.train(): the sampled / ground-truth-padded fine-level training set of the reference module
+    (coarse_matching.py:200-259), torch.randint replaced by the same deterministic sequence on both sides."""
+    import os
+    from _cases import GOLDEN_DIR
+    from loftr_amd.loftr import CoarseMatching
+    dev = torch.device("cuda", 0)
+    g = dict(np.load(os.path.join(GOLDEN_DIR, f"{name}.npz")))
+    rc = json.loads(str(g["recipe"]))
+    inp = MG.coarse_train_inputs(rc)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    H, W = rc["h"] * 8, rc["w"] * 8
+    data = {"hw0_i": torch.Size([H, W]), "hw1_i": torch.Size([H, W]), "hw0_c": torch.Size([rc["h"], rc["w"]]),
+            "hw1_c": torch.Size([rc["h"], rc["w"]]), **{k: t(v) for k, v in inp.items() if not k.startswith("feat")}}
+    mod = CoarseMatching(MG.coarse_train_config(rc)).to(dev).train()
+    monkeypatch.setattr(torch, "randint", MG.det_randint)
+    m0 = data["mask0"].flatten(-2) if rc["masks"] else None
+    m1 = data["mask1"].flatten(-2) if rc["masks"] else None
+    mod(t(inp["feat_c0"]), t(inp["feat_c1"]), data, mask_c0=m0, mask_c1=m1)
+    for k in ("b_ids", "i_ids", "j_ids", "gt_mask", "m_bids"):
+        assert np.array_equal(data[k].cpu().numpy(), g[k]), k
+    for k in ("mkpts0_c", "mkpts1_c"):
+        assert np.array_equal(data[k].cpu().numpy(), g[k]), k
+    # the contract's bar; these logits are O(200) (features x 4), where the log-sum-exp form rounds conf = 1 by up to 3e-5
+    assert np.abs(data["mconf"].cpu().numpy() - g["mconf"]).max() <= 1e-4
+    assert data["gt_mask"].sum().item() >= rc["pad_min"]
