@@ -343,13 +343,36 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
         transport = "torch.distributed (nccl = RCCL)"
         if args.collective in ("auto", "cabi"):
-            try:
-                rccl = RcclCounts(dev)
+            # The communicator is created and proven (one collective, checked) on a watchdog thread: in-round boxes have one
+            # GPU, so ranks > 1 of this path first run under the driver -- a hang there must cost a fallback, not the run.
+            import threading
+            box = {}
+
+            def _setup():
+                try:
+                    with torch.cuda.device(dev):
+                        rc = RcclCounts(dev)
+                        probe = torch.full((2,), rank + 1, dtype=torch.int32, device=dev)
+                        got = rc.all_gather(probe)
+                        torch.cuda.current_stream(dev).synchronize()
+                        want = [r + 1 for r in range(world) for _ in range(2)]
+                        if got.tolist() != want:
+                            raise RuntimeError(f"probe all-gather returned {got.tolist()}, expected {want}")
+                    box["rccl"] = rc
+                except Exception as e:                       # noqa: BLE001
+                    box["err"] = e
+
+            th = threading.Thread(target=_setup, daemon=True)
+            th.start()
+            th.join(float(os.environ.get("LOFTR_BENCH_RCCL_TIMEOUT", 120)))
+            if "rccl" in box:
+                rccl = box["rccl"]
                 transport = "C-ABI loftr_rccl_allgather_counts (RCCL over xGMI)"
-            except Exception as e:                           # noqa: BLE001
+            else:
+                err = box.get("err", "timed out")
                 if args.collective == "cabi":
-                    raise
-                print(f"[bench] rank {rank}: C-ABI RCCL communicator unavailable ({e}); using torch.distributed", file=sys.stderr)
+                    raise RuntimeError(f"C-ABI RCCL communicator unavailable: {err}")
+                print(f"[bench] rank {rank}: C-ABI RCCL communicator unavailable ({err}); using torch.distributed", file=sys.stderr)
             # every rank must take the same path: agree on it
             ok = torch.tensor([1 if rccl is not None else 0], device=dev)
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)

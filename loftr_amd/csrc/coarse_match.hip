@@ -349,7 +349,7 @@ __global__ __launch_bounds__(Cfg::THREADS, 2) void score_conf_kernel(
 #define SWEEP_PROBE_FAST 1       // 0: pass A exact variant only
 #endif
 #ifndef SWEEP_PROBE_ACC1
-#define SWEEP_PROBE_ACC1 0       // 1: a single accumulator chain (probe)
+#define SWEEP_PROBE_ACC1 (PASS == 0) // ONE accumulator chain (no acc0 + acc1 in the epilogue) where it measured faster: pass A -2.5 %, pass B +1.5 %
 #endif
 #ifndef SWEEP_PROBE_PRIO
 #define SWEEP_PROBE_PRIO 0       // 1: s_setprio 1 around the MFMA block (probe)
@@ -361,6 +361,12 @@ __global__ __launch_bounds__(Cfg::THREADS, 2) void score_conf_kernel(
 #define PIPE_DEP 1               // phases of fragment prefetch
 #endif
 #define PIPE_NBUF (PIPE_DEP + 1)
+#ifndef SWEEP_PROBE_NOSTORE
+#define SWEEP_PROBE_NOSTORE 0    // 1: pass B without the conf_matrix stores (timing probe)
+#endif
+#ifndef SWEEP_PROBE_COAL
+#define SWEEP_PROBE_COAL 0       // 1: pass B stores in the pattern of a lane = column layout: 16 x 4 B, 128 B contiguous per half-wave
+#endif
 #ifndef SWEEP_PROBE_NODMA
 #define SWEEP_PROBE_NODMA 0      // 1: no LDS-DMA (timing probes only; wrong results)
 #endif
@@ -556,12 +562,13 @@ __global__ __launch_bounds__(512, 2) void score_sweep_kernel(Args a) {
 
   // Epilogue of panel p_ on the accumulators: statistics / conf_matrix.  A macro, not a lambda (captures of the register
   // arrays by reference end up in scratch); expanded twice (early and late waves).
+#define SWEEP_ACC(r_) (SWEEP_PROBE_ACC1 ? acc0[r_] : acc0[r_] + acc1[r_])
 #define SWEEP_EPILOGUE(p_)                                                                               \
   {                                                                                                      \
     const int col0 = (p0 + (p_)) * PC;                                                                   \
     const bool fullp = FASTA || col0 + PC <= S;    /* panel-uniform */                                   \
     f32x16 v;                                                                                            \
-    _Pragma("unroll") for (int r = 0; r < 16; ++r) v[r] = (acc0[r] + acc1[r]) * a.scale;                 \
+    _Pragma("unroll") for (int r = 0; r < 16; ++r) v[r] = SWEEP_ACC(r) * a.scale;                        \
     if (HAS_MASK) {                                                                                      \
       _Pragma("unroll") for (int r = 0; r < 16; ++r)                                                     \
         if (!(mrow && mask_s[(p_) * PC + jr(r, g)])) v[r] = LOFTR_NEG_INF;   /* masked_fill_(~(m0 x m1), -INF)  :115-118 */ \
@@ -571,19 +578,29 @@ __global__ __launch_bounds__(512, 2) void score_sweep_kernel(Args a) {
     }                                                                                                    \
     const int mycol = col0 + jr(sel, g);           /* the column this lane stores a partial for */       \
     if (PASS == 0) {                                                                                     \
-      float tm = v[0], tn = v[0];                                                                        \
-      _Pragma("unroll") for (int r = 1; r < 16; ++r) { tm = fmaxf(tm, v[r]); tn = fminf(tn, v[r]); }     \
+      float tm = FASTA ? SWEEP_ACC(0) : v[0], tn = tm;      /* FASTA: extrema of the RAW dot products (scale > 0) */ \
+      _Pragma("unroll") for (int r = 1; r < 16; r += 2) {                                                \
+        const float x0 = FASTA ? SWEEP_ACC(r) : v[r], x1 = r + 1 < 16 ? (FASTA ? SWEEP_ACC(r + 1) : v[r + 1]) : x0; \
+        tm = fmaxf(fmaxf(tm, x0), x1); tn = fminf(fminf(tn, x0), x1);            /* v_max3 / v_min3 */  \
+      }                                                                                                  \
       if (FASTA) {                                                                                       \
         float R = half_max(tm); R = fmaxf(R, swap32(R));           /* maximum / minimum of the wave's 32 x 32 tile */ \
         float mnw = -half_max(-tn); mnw = fminf(mnw, swap32(mnw));                                       \
+        R *= a.scale; mnw *= a.scale;                                                                    \
         if (!(R - mnw <= FAST_SPREAD) && lane == 0) *unit_flag = 1;      /* (also catches NaN) -> redone exactly */ \
         /* ONE exponential per element, relative to the tile maximum R, serves the row AND the column sums: every   \
-           element is within FAST_SPREAD of R, so nothing that matters to any row or column underflows */            \
-        const float nRk = -R * LOG2E;                                                                    \
+           element is within FAST_SPREAD of R, so nothing that matters to any row or column underflows.  Packed     \
+           fp32 arithmetic (v_pk_fma_f32 / v_pk_add_f32: two elements per instruction) on the raw accumulators,     \
+           exponent = dot * (scale log2 e) - R log2 e with the same scale log2 e = k2 / 2 pass B uses */            \
+        const f32x2 sl2 = {0.5f * k2, 0.5f * k2}, nrk2 = {-R * LOG2E, -R * LOG2E};                       \
         f32x16 e;                                                                                        \
-        _Pragma("unroll") for (int r = 0; r < 16; ++r) e[r] = __builtin_amdgcn_exp2f(fmaf(v[r], LOG2E, nRk)); \
-        float ssum = 0.f;                                                                                \
-        _Pragma("unroll") for (int r = 0; r < 16; ++r) ssum += e[r];                                     \
+        f32x2 ss2 = {0.f, 0.f};                                                                          \
+        _Pragma("unroll") for (int r = 0; r < 16; r += 2) {                                              \
+          const f32x2 x2 = __builtin_elementwise_fma(f32x2{SWEEP_ACC(r), SWEEP_ACC(r + 1)}, sl2, nrk2);  \
+          e[r] = __builtin_amdgcn_exp2f(x2.x); e[r + 1] = __builtin_amdgcn_exp2f(x2.y);                  \
+          ss2 += f32x2{e[r], e[r + 1]};                                                                  \
+        }                                                                                                \
+        const float ssum = ss2.x + ss2.y;                                                                \
         const float Rn = fmaxf(ref_run, R);                                                              \
         s_run = s_run * fexp(ref_run - Rn) + ssum * fexp(R - Rn);                                        \
         ref_run = Rn;                                                                                    \
@@ -613,10 +630,14 @@ __global__ __launch_bounds__(512, 2) void score_sweep_kernel(Args a) {
       f32x16 c;                                                                                          \
       if (LSE) {                                                                                         \
         /* = exp2(2 v log2e - LSE_row - LSE_col): the (acc0 + acc1) * scale above folds into the fma */  \
+        const f32x2 k22 = {k2, k2}, rm2 = {rm, rm};                                                      \
         _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                  \
           const f32x4 cb = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(cstat_s) + (p_) * PC + 8 * q + 4 * g); \
-          _Pragma("unroll") for (int e = 0; e < 4; ++e)                                                  \
-            c[4 * q + e] = __builtin_amdgcn_exp2f(fmaf(acc0[4 * q + e] + acc1[4 * q + e], k2, rm + cb[e])); \
+          _Pragma("unroll") for (int e = 0; e < 4; e += 2) {            /* two elements per v_pk_add / v_pk_fma */ \
+            const f32x2 x2 = __builtin_elementwise_fma(f32x2{SWEEP_ACC(4 * q + e), SWEEP_ACC(4 * q + e + 1)}, k22, \
+                                                       rm2 + f32x2{cb[e], cb[e + 1]});                   \
+            c[4 * q + e] = __builtin_amdgcn_exp2f(x2.x); c[4 * q + e + 1] = __builtin_amdgcn_exp2f(x2.y); \
+          }                                                                                              \
         }                                                                                                \
       } else {                                                                                           \
       _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                    \
@@ -634,7 +655,11 @@ __global__ __launch_bounds__(512, 2) void score_sweep_kernel(Args a) {
       }                                                                                                  \
       if (a.conf && (rows_full || row_ok)) {                                                             \
         float* co = a.conf + ((long)n * L + row) * S + col0 + 4 * g;                                     \
-        if (fullp && (S & 3) == 0) {                                                                     \
+        if (SWEEP_PROBE_NOSTORE) {                                                                       \
+        } else if (SWEEP_PROBE_COAL) {      /* timing probe: the store pattern of a lane = column layout (wrong data) */ \
+          float* cq = a.conf + ((long)n * L + rb * BR + wave * 32) * S + col0 + li;                      \
+          _Pragma("unroll") for (int r = 0; r < 16; ++r) cq[(long)jr(r, g) * S] = c[r];                  \
+        } else if (fullp && (S & 3) == 0) {                                                              \
           _Pragma("unroll") for (int q = 0; q < 4; ++q)                                                  \
             *reinterpret_cast<f32x4*>(co + 8 * q) = f32x4{c[4 * q], c[4 * q + 1], c[4 * q + 2], c[4 * q + 3]}; \
         } else {                                                                                         \
@@ -651,8 +676,8 @@ __global__ __launch_bounds__(512, 2) void score_sweep_kernel(Args a) {
         }                                                                                                \
       } else {                                                                                           \
         /* row: running maximum and the FIRST panel that attains it (select_kernel finds the column) */  \
-        float pm = fmaxf(c[0], c[1]);                                                                    \
-        _Pragma("unroll") for (int r = 2; r < 16; r += 2) pm = fmaxf(pm, fmaxf(c[r], c[r + 1]));         \
+        float pm = c[0];                                                                                 \
+        _Pragma("unroll") for (int r = 1; r < 16; r += 2) pm = fmaxf(fmaxf(pm, c[r]), r + 1 < 16 ? c[r + 1] : c[r]);   /* v_max3 */ \
         const bool gt = pm > best;                                                                       \
         tie = gt ? false : (tie || pm == best);                                                          \
         bestj = gt ? (p0 + (p_)) : bestj;                                                                \
@@ -675,7 +700,7 @@ __global__ __launch_bounds__(512, 2) void score_sweep_kernel(Args a) {
   // Stores a wave issues between two DMA issues (they sit between the DMA of panel p+1 and the barrier of panel p+1
   // in the in-order VMEM queue): pass A one partial store; pass B four conf stores + one partial store.  Panels that
   // take the scalar-store tail path are followed by a full drain instead.
-  constexpr int ST = PASS == 0 ? 1 : 5;
+  constexpr int ST = PASS == 0 ? 1 : (SWEEP_PROBE_NOSTORE ? 1 : SWEEP_PROBE_COAL ? 17 : 5);
   f32x16 acc0, acc1;
   bool drain = false;                              // block-uniform: the previous period issued an unknown number of stores
   for (int p = 0; p < np; ++p) {
@@ -718,12 +743,21 @@ __global__ __launch_bounds__(512, 2) void score_sweep_kernel(Args a) {
     {                                                                                                    \
       const h16x8 ah0 = fr[(ph_) % PIPE_NBUF][0], al0 = fr[(ph_) % PIPE_NBUF][1];                        \
       const h16x8 ah1 = fr[(ph_) % PIPE_NBUF][2], al1 = fr[(ph_) % PIPE_NBUF][3];                        \
-      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al0, bh[2 * (ph_)], acc0, 0, 0, 0);                  \
-      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0, bl[2 * (ph_)], acc1, 0, 0, 0);                  \
-      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0, bh[2 * (ph_)], acc0, 0, 0, 0);                  \
-      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al1, bh[2 * (ph_) + 1], acc1, 0, 0, 0);              \
-      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1, bl[2 * (ph_) + 1], acc0, 0, 0, 0);              \
-      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1, bh[2 * (ph_) + 1], acc1, 0, 0, 0);              \
+      if (SWEEP_PROBE_ACC1) {                                                                            \
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al0, bh[2 * (ph_)], acc0, 0, 0, 0);                \
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0, bl[2 * (ph_)], acc0, 0, 0, 0);                \
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0, bh[2 * (ph_)], acc0, 0, 0, 0);                \
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al1, bh[2 * (ph_) + 1], acc0, 0, 0, 0);            \
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1, bl[2 * (ph_) + 1], acc0, 0, 0, 0);            \
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1, bh[2 * (ph_) + 1], acc0, 0, 0, 0);            \
+      } else {                                                                                           \
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al0, bh[2 * (ph_)], acc0, 0, 0, 0);                \
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0, bl[2 * (ph_)], acc1, 0, 0, 0);                \
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0, bh[2 * (ph_)], acc0, 0, 0, 0);                \
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al1, bh[2 * (ph_) + 1], acc1, 0, 0, 0);            \
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1, bl[2 * (ph_) + 1], acc0, 0, 0, 0);            \
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1, bh[2 * (ph_) + 1], acc1, 0, 0, 0);            \
+      }                                                                                                  \
     }                                                                                                    \
     __builtin_amdgcn_sched_barrier(0);
 #if SWEEP_PROBE_NOLDS
@@ -772,12 +806,13 @@ __global__ __launch_bounds__(512, 2) void score_sweep_kernel(Args a) {
 #endif
     if (SWEEP_PROBE_PRIO) __builtin_amdgcn_s_setprio(0);
     if (SWEEP_PROBE_EPI && !late) SWEEP_EPILOGUE(p);
-    if (!SWEEP_PROBE_EPI) { s_run += acc0[0] + acc1[5]; best += acc0[3] + acc1[7]; }     // keep the MFMAs alive
+    if (!SWEEP_PROBE_EPI) { s_run += acc0[0] + (SWEEP_PROBE_ACC1 ? 0.f : acc1[5]); best += acc0[3] + (SWEEP_PROBE_ACC1 ? 0.f : acc1[7]); }     // keep the MFMAs alive
   }
   if (SWEEP_PROBE_EPI && late) SWEEP_EPILOGUE(np - 1);
 #undef SWEEP_ISSUE
 #undef SWEEP_DOFF
 #undef SWEEP_EPILOGUE
+#undef SWEEP_ACC
 #undef SWEEP_DPPF
 #undef SWEEP_DPPI
   // ---- row partials of this chunk: combine the two half-waves (they hold disjoint columns of the same row)

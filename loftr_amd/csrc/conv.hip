@@ -890,14 +890,23 @@ extern "C" size_t loftr_conv_workspace_bytes(int Cin, int Cout, int KH, int KW) 
 // multiple of the XCD count so that the grid stride keeps every workgroup on its XCD (LOFTR_CONV_PERSIST=0: one
 // workgroup per tile, the non-persistent schedule, for A/B runs; LOFTR_CONV_PERSIST=n >= 8: cap the grid at n).
 static unsigned persistent_grid(unsigned nvirt) {
-  static const int cus = []() {
+  static const int forced = []() {                      // -1: ask the device
     const char* e = getenv("LOFTR_CONV_PERSIST");
     if (e && atoi(e) == 0) return 0;
     if (e && atoi(e) >= NUM_XCD) return atoi(e) / NUM_XCD * NUM_XCD;      // explicit workgroup cap (tests: many tiles per workgroup)
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
-    return n / NUM_XCD * NUM_XCD;
+    return -1;
   }();
+  int cus = forced;
+  if (cus < 0) {                                        // per CURRENT device (a process may drive several GPUs)
+    static int per_dev[64];                             // 0 = not asked yet; benign race: every thread computes the same value
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nvirt;
+    if (per_dev[dev] == 0) {
+      if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return nvirt;
+      per_dev[dev] = n / NUM_XCD * NUM_XCD;
+    }
+    cus = per_dev[dev];
+  }
   return cus > 0 && nvirt > (unsigned)cus ? (unsigned)cus : nvirt;
 }
 

@@ -13,6 +13,7 @@ index arithmetic on the kernels' outputs); no sub-module builds an autograd grap
 passes are not provided (forward only).
 """
 import math
+import weakref
 
 import torch
 import torch.nn as nn
@@ -130,8 +131,8 @@ class LocalFeatureTransformer(nn.Module):
                 for layer in self.layers for n in ("q_proj", "k_proj", "v_proj", "merge", "mlp.0", "mlp.2")]
         key = tuple((t.data_ptr(), t._version) for t in mats) + (str(device),)
         cached = getattr(self, "_loftr_prepared", None)
-        if cached is None or cached[0] != key:
-            cached = (key, ops.transformer_prepare(structs, self.d_model, device))
+        if cached is None or cached[0] != key or not all(r() is t for r, t in zip(cached[2], mats)):
+            cached = (key, ops.transformer_prepare(structs, self.d_model, device), [weakref.ref(t) for t in mats])
             self._loftr_prepared = cached
         return cached[1]
 

@@ -5,6 +5,7 @@ path happens in the HIP kernels.  Every wrapper requires CUDA(ROCm) float32 cont
 and raises otherwise -- there is no CPU fallback.
 """
 import ctypes as C
+import weakref
 import functools
 
 import torch
@@ -348,7 +349,8 @@ def _prepared_conv(conv, bn):
     bnp = [] if bn is None else [bn.weight, bn.bias, bn.running_mean, bn.running_var]
     key = tuple((t.data_ptr(), t._version, tuple(t.stride())) for t in [w] + bnp) + (None if bn is None else float(bn.eps), str(w.device))
     cached = getattr(conv, "_loftr_prepared", None)
-    if cached is not None and cached[0] == key:
+    # ... or replaced by a NEW tensor object the allocator put at the same address (weak references to the originals)
+    if cached is not None and cached[0] == key and all(r() is t for r, t in zip(cached[2], [w] + bnp)):
         return cached[1]
     Cout, Cin, KH, KW = w.shape
     lib = _lib.load()
@@ -357,7 +359,7 @@ def _prepared_conv(conv, bn):
     ptrs = [_ptr(t) for t in bnp] if bnp else [None] * 4
     check(lib.loftr_conv_prepare(_ptr(w), wst, Cin, Cout, KH, KW, *ptrs, float(bn.eps) if bn is not None else 0.0, _ptr(buf),
                                  buf.numel(), _stream()), "loftr_conv_prepare")
-    conv._loftr_prepared = (key, buf)
+    conv._loftr_prepared = (key, buf, [weakref.ref(t) for t in [w] + bnp])
     return buf
 
 

@@ -100,6 +100,19 @@ def test_prepared_weights_follow_inplace_updates():
         assert (run() - ref()).abs().max().item() < 1e-4
 
 
+def test_prepared_weights_follow_tensor_identity():
+    """A parameter REPLACED by a new tensor object at the same address with the same version counter (what the caching
+    allocator can hand back after the old one is freed) must not hit the cached folded weights."""
+    from loftr_amd import ops
+    conv = nn.Conv2d(32, 32, 3, padding=1, bias=False).cuda()
+    buf1 = ops._prepared_conv(conv, None)
+    assert ops._prepared_conv(conv, None) is buf1
+    old = conv.weight
+    conv.weight = nn.Parameter(old.detach())             # same storage, same data_ptr, same _version: a different object
+    assert conv.weight.data_ptr() == old.data_ptr() and conv.weight._version == old._version
+    assert ops._prepared_conv(conv, None) is not buf1
+
+
 def test_stem_vs_torch():
     from loftr_amd import ops
     g = torch.Generator().manual_seed(9)
