@@ -349,7 +349,9 @@ __global__ __launch_bounds__(Cfg::THREADS, 2) void score_conf_kernel(
 #define SWEEP_PROBE_FAST 1       // 0: pass A exact variant only
 #endif
 #ifndef SWEEP_PROBE_ACC1
-#define SWEEP_PROBE_ACC1 (PASS == 0) // ONE accumulator chain (no acc0 + acc1 in the epilogue) where it measured faster: pass A -2.5 %, pass B +1.5 %
+#define SWEEP_PROBE_ACC1 0       // 1: ONE accumulator chain (no acc0 + acc1 in the epilogue): pass A -2.5 %, pass B +1.5 %, net 0.
+                                 // MUST be the same in both passes: conf = exp2(2 v - LSE) near 1 relies on pass B reproducing
+                                 // pass A's v bit for bit (a different summation order costs 1e-4 at logits of a few hundred)
 #endif
 #ifndef SWEEP_PROBE_PRIO
 #define SWEEP_PROBE_PRIO 0       // 1: s_setprio 1 around the MFMA block (probe)
