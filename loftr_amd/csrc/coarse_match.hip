@@ -1115,7 +1115,7 @@ __global__ __launch_bounds__(256) void ot_row_lse_kernel(const float* __restrict
 
 // column partial (max, sum exp) of Zfull[i][j] + u[i] over a chunk of rows.
 //   grid (ceil((S+1)/64), RCH, N), 256 threads = 64 columns x 4 row lanes
-constexpr int OT_RCH = 32;
+constexpr int OT_RCH = 128;      // rows of the column partial buffer per pair (>= workgroups per pair of the fused passes)
 __global__ __launch_bounds__(256) void ot_col_part_kernel(const float* __restrict__ z, Geometry g, float alpha,
                                                           const float* __restrict__ u,
                                                           float2* __restrict__ part) {
@@ -1350,6 +1350,242 @@ __global__ __launch_bounds__(Cfg::THREADS, 2) void ot_finalize_kernel(float* __r
   conf_partials<false>(acc, m0, n0, n, g, blockIdx.x, blockIdx.y, rowmax_part, colmax_part);
 }
 
+// ---- round 2: the Sinkhorn passes as ONE row-streaming kernel -------------------------------------------------------
+// ot_iter_kernel above issues CPT scalar loads per row and consumes them at once (no load is in flight while the block
+// reduces and exponentiates: 1.35 TB/s measured), pays three expf per element, and its grid was capped at 32 workgroups
+// per pair (4 waves per CU at N = 8).  ot_pass_kernel keeps the ownership scheme (a workgroup owns a contiguous range of
+// rows, a thread owns columns for the whole kernel) and changes the rest:
+//   * a thread owns G4 groups of FOUR consecutive columns: one 16-byte load per group and row (S % 4 == 0: rows aligned);
+//   * the rows of round k + 1 are loaded into a second register set before round k is processed;
+//   * exponentials are v_exp_f32(x log2e); the running column statistics take ONE reference update
+//     per column and round (R + 1 exponentials per R elements instead of 2 R); every thread derives u_i itself from the
+//     block sums (no broadcast round trip) and the reduction buffers alternate by round parity: two barriers per round;
+//   * FINAL = true is the last pass (ot_finalize_kernel's job) on the same skeleton: conf = exp(Z + u + v - norm) written
+//     over Z (and into assign_matrix), per-row (max, FIRST arg-max, attained-twice flag) by a block reduction -- one
+//     partial per row, PJ = 1 -- and per-workgroup column maxima (P = workgroups per pair partial rows).
+//   grid (WGP, N), 256 threads.
+namespace otp {
+constexpr float L2E = 1.4426950408889634f;
+
+// exp(x) as v_exp_f32(x log2 e).  The DIFFERENCE is formed first, never folded into an fma with a prescaled offset: with
+// padding masks the potentials u, v of masked rows / columns are ~ +-1e9 (they cancel the -1e9 fill), and
+// fma(y, log2e, -m log2e) would carry the rounding error of the 1.4e9-sized offset (+-64) into the exponent, where
+// y - m is exact.  For the same reason conf is evaluated in the reference's order ((Z + u) + v) - norm: on masked
+// entries the result IS rounding noise of that order, and the mutual-nearest test sees it.
+__device__ __forceinline__ float ex(float x) { return __builtin_amdgcn_exp2f(x * L2E); }
+
+// (value, first index | TIE) pairs: the better of two; equal values keep the smaller index and raise the flag
+__device__ __forceinline__ void best_merge(float& b, int& w, float ob, int ow) {
+  const int jb = w & ~sweep::TIE_BIT, jo = ow & ~sweep::TIE_BIT;
+  const bool take = ob > b || (ob == b && jo < jb);
+  const int tie = ob == b ? sweep::TIE_BIT : (take ? (ow & sweep::TIE_BIT) : (w & sweep::TIE_BIT));
+  b = take ? ob : b;
+  w = (take ? jo : jb) | tie;
+}
+
+#ifndef OTP_PREFETCH
+#define OTP_PREFETCH 0           // 1: second register set for the next round's rows (256 VGPRs, 2 workgroups / SIMD set) -- A/B
+#endif
+template <int G4, int R, bool FINAL>
+__global__ __launch_bounds__(256, OTP_PREFETCH ? 2 : 3) void ot_pass_kernel(float* __restrict__ z, Geometry g, float alpha, float norm,
+                                                      const float* __restrict__ v, float* __restrict__ u,
+                                                      float2* __restrict__ part, int rows_per_wg,
+                                                      const uint8_t* __restrict__ rowkill, const uint8_t* __restrict__ colkill,
+                                                      float* __restrict__ assign, float2* __restrict__ rowmax_part,
+                                                      float* __restrict__ colmax_part) {
+  __shared__ float red_a[2][R][4], red_b[2][R][4];
+  __shared__ int red_w[2][R][4];
+  const int n = blockIdx.y, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int S = g.S, L = g.L, S4 = S >> 2;
+  const float* vn = v + (long)n * (S + 1);
+  f32x4 vk[G4], ca[G4], cb[G4];         // column constants; ITER: running (reference, sum);  FINAL: ca = running column maximum
+  unsigned kill = 0;                    // FINAL: bit 4 k + e set: the prefilter zeroes this column
+#pragma unroll
+  for (int k = 0; k < G4; ++k) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int j = 4 * (t + 256 * k) + e;
+      const float x = j <= S ? vn[j] : 0.f;
+      vk[k][e] = x;
+      if (FINAL && colkill && j < S && colkill[(long)n * S + j]) kill |= 1u << (4 * k + e);
+      ca[k][e] = FINAL ? -1.f : SENTINEL; cb[k][e] = 0.f;
+    }
+  }
+  const int r0 = blockIdx.x * rows_per_wg, r1 = min(r0 + rows_per_wg, L);
+  if (r0 >= r1) return;                 // (never: the host sizes the grid to the rows)
+  f32x4 zc[R][G4];
+#if OTP_PREFETCH
+  f32x4 zn[R][G4];
+#endif
+#define OTP_LOAD(dst_, rb_)                                                                              \
+  _Pragma("unroll") for (int r = 0; r < R; ++r) {                                                        \
+    const float* zr__ = z + ((long)n * L + min((rb_) + r, L - 1)) * S;                                   \
+    _Pragma("unroll") for (int k = 0; k < G4; ++k) {                                                     \
+      const int q__ = t + 256 * k;                                                                       \
+      dst_[r][k] = q__ < S4 ? *reinterpret_cast<const f32x4*>(zr__ + 4 * q__)                            \
+                            : (q__ == S4 ? f32x4{alpha, SENTINEL, SENTINEL, SENTINEL} : f32x4{SENTINEL, SENTINEL, SENTINEL, SENTINEL}); \
+    }                                                                                                    \
+  }
+#if OTP_PREFETCH
+  OTP_LOAD(zc, r0)
+#endif
+  int par = 0;
+  for (int rb = r0; rb < r1; rb += R, par ^= 1) {
+#if OTP_PREFETCH
+    const bool more = rb + R < r1;                       // block-uniform
+    if (more) OTP_LOAD(zn, rb + R)
+#else
+    OTP_LOAD(zc, rb)                                     // latency is hidden by the other workgroups of the CU (3 x 4 waves)
+#endif
+    if (!FINAL) {
+      // ---- u_i = log_mu - LSE_j(Z_ij + v_j): block maximum, then block sum of exponentials
+      float rmx[R], ui[R];
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        float m = SENTINEL;
+#pragma unroll
+        for (int k = 0; k < G4; ++k) {
+          const f32x4 a = zc[r][k] + vk[k];
+          m = fmaxf(fmaxf(m, a[0]), a[1]); m = fmaxf(fmaxf(m, a[2]), a[3]);
+        }
+        m = wave_max(m);
+        if (lane == 0) red_a[par][r][wave] = m;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        rmx[r] = fmaxf(fmaxf(red_a[par][r][0], red_a[par][r][1]), fmaxf(red_a[par][r][2], red_a[par][r][3]));
+        float sm = 0.f;
+#pragma unroll
+        for (int k = 0; k < G4; ++k) {
+          const f32x4 a = zc[r][k] + vk[k];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) sm += ex(a[e] - rmx[r]);                       // exp(-huge) == 0 for the padding
+        }
+        sm = wave_sum(sm);
+        if (lane == 0) red_b[par][r][wave] = sm;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const float ssum = (red_b[par][r][0] + red_b[par][r][1]) + (red_b[par][r][2] + red_b[par][r][3]);
+        ui[r] = norm - (rmx[r] + logf(ssum));            // log_mu = norm for the real rows
+        if (t == 0 && rb + r < r1) u[(long)n * (L + 1) + rb + r] = ui[r];
+        if (rb + r >= r1) ui[r] = SENTINEL;              // rows beyond the range: y = SENTINEL below, contribute nothing
+      }
+      // ---- fold the R rows, now with their u, into the thread's column statistics: one reference update per round
+#pragma unroll
+      for (int k = 0; k < G4; ++k) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float y[R], m = ca[k][e];
+#pragma unroll
+          for (int r = 0; r < R; ++r) { y[r] = ui[r] > SENTINEL ? zc[r][k][e] + ui[r] : SENTINEL; m = fmaxf(m, y[r]); }
+          float acc = cb[k][e] * ex(ca[k][e] - m);
+#pragma unroll
+          for (int r = 0; r < R; ++r) acc += ex(y[r] - m);
+          ca[k][e] = m; cb[k][e] = acc;
+        }
+      }
+    } else {
+      // ---- conf_ij = exp(((Z_ij + u_i) + v_j) - norm), in the reference's association (see ex() above)
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const int i = rb + r;
+        const bool valid = i < r1;                       // block-uniform
+        const int ic = min(i, L - 1);
+        const float ub = u[(long)n * (L + 1) + ic];
+        const bool rk = rowkill && rowkill[(long)n * L + ic];
+        float* zr = z + ((long)n * L + ic) * S;
+        float* ar = assign ? assign + ((long)n * (L + 1) + ic) * (S + 1) : nullptr;
+        float best = -1.f; int bw = 0;
+#pragma unroll
+        for (int k = 0; k < G4; ++k) {
+          const int q = t + 256 * k;
+          f32x4 c;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float x = ex(((zc[r][k][e] + ub) + vk[k][e]) - norm);
+            if (rk || ((kill >> (4 * k + e)) & 1u)) x = 0.f;       // skh_prefilter: coarse_matching.py:136-140
+            c[e] = (q < S4 && valid) ? x : -1.f;
+          }
+          if (q < S4 && valid) {
+            *reinterpret_cast<f32x4*>(zr + 4 * q) = c;
+            // conf_matrix is a VIEW of assign_matrix in the reference (:133): the prefilter zeroing is visible there too
+            if (ar) { ar[4 * q] = c[0]; ar[4 * q + 1] = c[1]; ar[4 * q + 2] = c[2]; ar[4 * q + 3] = c[3]; }
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {                  // this thread's columns ascend with (k, e): > keeps the first
+            if (c[e] > best) { best = c[e]; bw = 4 * q + e; }
+            else if (c[e] == best) bw |= sweep::TIE_BIT;
+            ca[k][e] = fmaxf(ca[k][e], c[e]);
+          }
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+          const float ob = __shfl_xor(best, o, 64);
+          const int ow = __shfl_xor(bw, o, 64);
+          best_merge(best, bw, ob, ow);
+        }
+        if (lane == 0) { red_a[par][r][wave] = best; red_w[par][r][wave] = bw; }
+      }
+      __syncthreads();
+      if (t < R && rb + t < r1) {
+        float b = red_a[par][t][0]; int w = red_w[par][t][0];
+#pragma unroll
+        for (int k = 1; k < 4; ++k) best_merge(b, w, red_a[par][t][k], red_w[par][t][k]);
+        rowmax_part[(long)n * L + rb + t] = make_float2(b, __int_as_float(w));       // PJ = 1
+      }
+    }
+#if OTP_PREFETCH
+    if (more) {
+#pragma unroll
+      for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int k = 0; k < G4; ++k) zc[r][k] = zn[r][k];
+    }
+#endif
+  }
+#undef OTP_LOAD
+  if (FINAL) {
+    float* cp = colmax_part + ((long)n * gridDim.x + blockIdx.x) * S;
+#pragma unroll
+    for (int k = 0; k < G4; ++k) if (t + 256 * k < S4) *reinterpret_cast<f32x4*>(cp + 4 * (t + 256 * k)) = ca[k];
+    return;
+  }
+  float2* pn = part + ((long)n * gridDim.x + blockIdx.x) * (S + 1);
+#pragma unroll
+  for (int k = 0; k < G4; ++k)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int j = 4 * (t + 256 * k) + e;
+      if (j <= S) pn[j] = make_float2(ca[k][e], cb[k][e]);
+    }
+  if (blockIdx.x == 0) {               // u of the dustbin row: log(S) + norm - LSE_j(alpha + v_j), j = 0 .. S
+    __syncthreads();
+    float m = SENTINEL;
+#pragma unroll
+    for (int k = 0; k < G4; ++k)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) if (4 * (t + 256 * k) + e <= S) m = fmaxf(m, alpha + vk[k][e]);
+    m = wave_max(m);
+    if (lane == 0) red_a[0][0][wave] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red_a[0][0][0], red_a[0][0][1]), fmaxf(red_a[0][0][2], red_a[0][0][3]));
+    float sm = 0.f;
+#pragma unroll
+    for (int k = 0; k < G4; ++k)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) if (4 * (t + 256 * k) + e <= S) sm += expf(alpha + vk[k][e] - m);
+    sm = wave_sum(sm);
+    if (lane == 0) red_b[0][0][wave] = sm;
+    __syncthreads();
+    if (t == 0)
+      u[(long)n * (L + 1) + L] = logf((float)S) + norm - (m + logf((red_b[0][0][0] + red_b[0][0][1]) + (red_b[0][0][2] + red_b[0][0][3])));
+  }
+}
+}  // namespace otp
+
 // dustbin column / row / corner of the assignment matrix
 __global__ void ot_assign_bins_kernel(Geometry g, float alpha, float norm, const float* __restrict__ u,
                                       const float* __restrict__ v, float* __restrict__ assign) {
@@ -1582,6 +1818,19 @@ extern "C" int loftr_coarse_match_sinkhorn(const float* feat_c0, const float* fe
   (void)hipMemsetAsync(w.ot_u, 0, sizeof(float) * g.N * (g.L + 1), st);
   (void)hipMemsetAsync(w.ot_v, 0, sizeof(float) * g.N * (g.S + 1), st);
   const long cols = (long)g.N * (g.S + 1);
+  // row-streaming passes (otp::ot_pass_kernel): aligned rows and at most 5 x 1024 columns incl. the dustbin (indoor)
+  const bool rowstream = (g.S & 3) == 0 && g.S + 1 <= 4 * 256 * 5;
+  int wgs = 0;                                             // workgroups per pair of the row-streaming passes
+  int rpws = 0;
+  if (rowstream) {
+    constexpr int R = 2;
+    const int capP = [&] { const int a = ceil_div(g.L, 256) * 8; const int c = a > g.PI ? a : g.PI; return c < OT_RCH ? c : OT_RCH; }();
+    wgs = 768 / g.N;                                       // ~3 workgroups (of 4 waves) per CU over the batch
+    wgs = wgs < 1 ? 1 : (wgs > capP ? capP : wgs);
+    if (wgs > ceil_div(g.L, R)) wgs = ceil_div(g.L, R);
+    rpws = ceil_div(ceil_div(g.L, wgs), R) * R;
+    wgs = ceil_div(g.L, rpws);
+  }
   // fused iteration (one pass over Z): up to 19 x 256 (indoor) / 44 x 256 (outdoor 840 x 840) columns incl. the dustbin
   const int cpt = ceil_div(g.S + 1, 256);
   const bool fused = cpt <= 44;
@@ -1592,6 +1841,12 @@ extern "C" int loftr_coarse_match_sinkhorn(const float* feat_c0, const float* fe
   rpw = ceil_div(rpw, 4) * 4;
   wgp = ceil_div(g.L, rpw);
   for (int it = 0; it < iters; ++it) {
+    if (rowstream) {
+      hipLaunchKernelGGL((otp::ot_pass_kernel<5, 2, false>), dim3(wgs, g.N), dim3(256), 0, st, conf_out, g, bin_score, norm, w.ot_v, w.ot_u,
+                         w.ot_part, rpws, nullptr, nullptr, nullptr, nullptr, nullptr);
+      hipLaunchKernelGGL(ot_col_merge2_kernel, dim3(ceil_div((int)cols, 256)), dim3(256), 0, st, w.ot_part, g, bin_score, norm, wgs, w.ot_u, w.ot_v);
+      continue;
+    }
     if (fused) {
       if (cpt <= 19) hipLaunchKernelGGL((ot_iter_kernel<19, 4>), dim3(wgp, g.N), dim3(256), 0, st, conf_out, g, bin_score, norm, w.ot_v, w.ot_u, w.ot_part, rpw);
       else hipLaunchKernelGGL((ot_iter_kernel<44, 2>), dim3(wgp, g.N), dim3(256), 0, st, conf_out, g, bin_score, norm, w.ot_v, w.ot_u, w.ot_part, rpw);
@@ -1610,6 +1865,14 @@ extern "C" int loftr_coarse_match_sinkhorn(const float* feat_c0, const float* fe
   }
   if (assign_out)
     hipLaunchKernelGGL(ot_assign_bins_kernel, dim3(ceil_div((g.L > g.S ? g.L : g.S) + 1, 256), g.N), dim3(256), 0, st, g, bin_score, norm, w.ot_u, w.ot_v, assign_out);
+  if (rowstream) {
+    hipLaunchKernelGGL((otp::ot_pass_kernel<5, 2, true>), dim3(wgs, g.N), dim3(256), 0, st, conf_out, g, bin_score, norm, w.ot_v, w.ot_u,
+                       nullptr, rpws, rk, ck, assign_out, w.rowmax_part, w.colmax_part);
+    LOFTR_CHECK_LAUNCH();
+    Geometry gs = g;
+    gs.PJ = 1; gs.PI = wgs;                                // one row partial per row, one column-maximum partial per workgroup
+    return select_and_compact(gs, *p, *out, w, conf_out, st);
+  }
   hipLaunchKernelGGL(ot_finalize_kernel, grid, block, 0, st, conf_out, g, norm, w.ot_u, w.ot_v, rk, ck, assign_out, w.rowmax_part, w.colmax_part);
   LOFTR_CHECK_LAUNCH();
   return select_and_compact(g, *p, *out, w, conf_out, st);
