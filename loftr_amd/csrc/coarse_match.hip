@@ -557,7 +557,7 @@ __global__ __launch_bounds__(512, 2) void score_sweep_kernel(Args a) {
   float best = -1.f; int bestj = 0; bool tie = false;   // pass B
   const TrMasks trm = tr_masks(lane);
   const int trcol = jr(tr_reg(lane & 15), g);       // panel column whose transposed reduction ends in this lane
-  const unsigned lds_base = (unsigned)(size_t)(lds_ptr_t)lds;
+  [[maybe_unused]] const unsigned lds_base = (unsigned)(size_t)(lds_ptr_t)lds;     // SWEEP_PIPE: LDS address of the panel ring
   const int a_off = lds_chunk_off(li, g);          // hi chunk of the even k-step; odd k-step: ^ 32, lo: ^ 64 (chunk + 2 / + 4)
   const int sel = lane & 15;
   const long part_row = ((long)n * a.RB * W + rb * W + wave) * S;          // this wave's row of the column partials
@@ -579,7 +579,17 @@ __global__ __launch_bounds__(512, 2) void score_sweep_kernel(Args a) {
       _Pragma("unroll") for (int r = 0; r < 16; ++r) if (col0 + jr(r, g) >= S) v[r] = SENTINEL;          \
     }                                                                                                    \
     const int mycol = col0 + jr(sel, g);           /* the column this lane stores a partial for */       \
-    if (PASS == 0) {                                                                                     \
+    if (PASS == 2) {                               /* Sinkhorn: the scaled, mask-filled score itself (coarse_matching.py:123-126) */ \
+      if (rows_full || row_ok) {                                                                         \
+        float* co = a.conf + ((long)n * L + row) * S + col0 + 4 * g;                                     \
+        if (fullp && (S & 3) == 0) {                                                                     \
+          _Pragma("unroll") for (int q = 0; q < 4; ++q)                                                  \
+            *reinterpret_cast<f32x4*>(co + 8 * q) = f32x4{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]}; \
+        } else {                                                                                         \
+          _Pragma("unroll") for (int r = 0; r < 16; ++r) if (col0 + jr(r, g) < S) co[8 * (r >> 2) + (r & 3)] = v[r]; \
+        }                                                                                                \
+      }                                                                                                  \
+    } else if (PASS == 0) {                                                                                     \
       float tm = FASTA ? SWEEP_ACC(0) : v[0], tn = tm;      /* FASTA: extrema of the RAW dot products (scale > 0) */ \
       _Pragma("unroll") for (int r = 1; r < 16; r += 2) {                                                \
         const float x0 = FASTA ? SWEEP_ACC(r) : v[r], x1 = r + 1 < 16 ? (FASTA ? SWEEP_ACC(r + 1) : v[r + 1]) : x0; \
@@ -702,7 +712,7 @@ __global__ __launch_bounds__(512, 2) void score_sweep_kernel(Args a) {
   // Stores a wave issues between two DMA issues (they sit between the DMA of panel p+1 and the barrier of panel p+1
   // in the in-order VMEM queue): pass A one partial store; pass B four conf stores + one partial store.  Panels that
   // take the scalar-store tail path are followed by a full drain instead.
-  constexpr int ST = PASS == 0 ? 1 : (SWEEP_PROBE_NOSTORE ? 1 : SWEEP_PROBE_COAL ? 17 : 5);
+  constexpr int ST = PASS == 0 ? 1 : PASS == 2 ? 4 : (SWEEP_PROBE_NOSTORE ? 1 : SWEEP_PROBE_COAL ? 17 : 5);
   f32x16 acc0, acc1;
   bool drain = false;                              // block-uniform: the previous period issued an unknown number of stores
   for (int p = 0; p < np; ++p) {
@@ -714,7 +724,7 @@ __global__ __launch_bounds__(512, 2) void score_sweep_kernel(Args a) {
     else LOFTR_WAITCNT_VM(DMA_PER_WAVE + ST);
     if (!SWEEP_PROBE_NOBAR) __builtin_amdgcn_s_barrier();   // ... for every wave; and every wave is past the MFMAs of panel p-2
     if (p + 2 < np && !SWEEP_PROBE_NODMA) SWEEP_ISSUE(p + 2);
-    drain = !((p0 + p) * PC + PC <= S && (S & 3) == 0) && PASS == 1;
+    drain = !((p0 + p) * PC + PC <= S && (S & 3) == 0) && PASS >= 1;
     const char* st = lds + (p & (NST - 1)) * STAGE;
 #if SWEEP_PIPE
     // ---- 48 MFMAs in eight phases of two k-steps (one 4 KB k-group of the panel: hi / lo fragments of an even and an
@@ -818,6 +828,7 @@ __global__ __launch_bounds__(512, 2) void score_sweep_kernel(Args a) {
 #undef SWEEP_DPPF
 #undef SWEEP_DPPI
   // ---- row partials of this chunk: combine the two half-waves (they hold disjoint columns of the same row)
+  if (PASS == 2) return;
   float2* rp = (PASS == 0 ? a.rowpart : a.rowmax_part) + ((long)n * a.NCH + cc) * L;
   if (PASS == 0) {
     const float ro = swap32(ref_run), so = swap32(s_run);
@@ -1273,12 +1284,23 @@ __global__ void ot_col_merge2_kernel(const float2* __restrict__ part, Geometry g
   const int n = (int)(idx / (g.S + 1)), j = (int)(idx - (long)n * (g.S + 1));
   const float2* p = part + (long)n * P * (g.S + 1) + j;
   const float bin = alpha + u[(long)n * (g.L + 1) + g.L];
+  // eight partials in flight per thread (as a dependent load -> compare chain the P partial rows cost one DRAM round
+  // trip each: 48 us at P = 96); same reference and summation order as the plain loops
   float m = bin;
-  for (int k = 0; k < P; ++k) m = fmaxf(m, p[(long)k * (g.S + 1)].x);
+  for (int k0 = 0; k0 < P; k0 += 8) {
+    float e[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) e[q] = p[(long)min(k0 + q, P - 1) * (g.S + 1)].x;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) m = fmaxf(m, e[q]);
+  }
   float s = expf(bin - m);
-  for (int k = 0; k < P; ++k) {
-    const float2 e = p[(long)k * (g.S + 1)];
-    s += in_range(e.x) ? e.y * expf(e.x - m) : 0.f;
+  for (int k0 = 0; k0 < P; k0 += 8) {
+    float2 e[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) e[q] = p[(long)min(k0 + q, P - 1) * (g.S + 1)];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) s += (k0 + q < P && in_range(e[q].x)) ? e[q].y * expf(e[q].x - m) : 0.f;
   }
   const float log_nu = j == g.S ? logf((float)g.L) + norm : norm;
   v[idx] = log_nu - (m + logf(s));
@@ -1814,7 +1836,17 @@ extern "C" int loftr_coarse_match_sinkhorn(const float* feat_c0, const float* fe
   const float norm = -logf((float)(g.L + g.S));            // SuperGlue: norm = -log(m + n)
   const dim3 grid(ceil_div(g.S, Cfg::BN), ceil_div(g.L, Cfg::BM), g.N), sgrid(score_grid(g)), block(Cfg::THREADS);
   { TimedLaunch tl(LOFTR_T_OT_STORE, st);
-    hipLaunchKernelGGL(score_store_kernel, sgrid, block, 0, st, w.f0sp, w.f1sp, g, scale, p->mask0, p->mask1, conf_out); }
+    if (g.C == 256) {                                      // the stationary-operand sweep with a store-only epilogue
+      sweep::Args a{};
+      sweep_plan(g, a);
+      a.f0 = w.f0sp; a.f1 = w.f1sp; a.scale = scale; a.mask0 = p->mask0; a.mask1 = p->mask1; a.conf = conf_out;
+      const dim3 swgrid(NUM_XCD * ceil_div(g.N * a.NCH, NUM_XCD) * a.RB);
+      if (p->mask0) hipLaunchKernelGGL((sweep::score_sweep_kernel<2, true>), swgrid, dim3(512), 0, st, a);
+      else hipLaunchKernelGGL((sweep::score_sweep_kernel<2, false>), swgrid, dim3(512), 0, st, a);
+    } else {
+      hipLaunchKernelGGL(score_store_kernel, sgrid, block, 0, st, w.f0sp, w.f1sp, g, scale, p->mask0, p->mask1, conf_out);
+    }
+  }
   (void)hipMemsetAsync(w.ot_u, 0, sizeof(float) * g.N * (g.L + 1), st);
   (void)hipMemsetAsync(w.ot_v, 0, sizeof(float) * g.N * (g.S + 1), st);
   const long cols = (long)g.N * (g.S + 1);
