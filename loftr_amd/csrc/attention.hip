@@ -38,6 +38,7 @@ __global__ __launch_bounds__(256) void kv_finalize_kernel(const float* __restric
     f32x4 a[5];
 #pragma unroll
     for (int u = 0; u < 5; ++u) a[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4                     // the loads of four partials in flight (same summation order): the loop is a DRAM-latency chain otherwise
     for (int k = w; k < splits; k += 4) {
       const f32x4* pk = reinterpret_cast<const f32x4*>(p + (long)k * (33 * 32));
 #pragma unroll
