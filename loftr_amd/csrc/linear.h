@@ -77,3 +77,8 @@ struct LinearLNArgs {
                                 // projection is stored times a fixed power of two, attention.hip)
 };
 int launch_linear_ln(const LinearLNArgs& p, hipStream_t st);
+
+// Stationary-weight sweep variants of the two K = 256 layers of the coarse level (rowsweep.hip).  They return
+// LOFTR_ERR_UNSUPPORTED for any other shape / option; the caller then uses launch_proj / launch_linear_ln.
+int launch_rowsweep_q(const ProjArgs& p, hipStream_t st);
+int launch_rowsweep_ln(const LinearLNArgs& p, hipStream_t st);

@@ -93,8 +93,16 @@ int launch_linear(const LinearArgs& p, hipStream_t st) {
   // the combinations the matching path uses
   if (f && !s && p.bias_mode == 0 && !p.relu)
     hipLaunchKernelGGL((linear_kernel<CfgGen, true, false, 0, false>), grid, block, 0, st, p);       // loftr_linear_fwd
-  else if (!f && s && p.bias_mode == 0 && p.relu)
+  else if (!f && s && p.bias_mode == 0 && p.relu) {
+#ifdef LOFTR_LINEAR_DMA                              // A/B: 256 x 128 tiles on the LDS-DMA ring (as the convolutions) for the big mlp.0
+    using CfgBig = GemmCfg<256, 128, 4, 2, 3>;
+    if (p.M >= 8192 && p.N % CfgBig::BN == 0)
+      hipLaunchKernelGGL((linear_kernel<CfgBig, false, true, 0, true>), dim3(xcd_grid(ceil_div(p.M, CfgBig::BM), p.N / CfgBig::BN)),
+                         dim3(CfgBig::THREADS), 0, st, p);
+    else
+#endif
     hipLaunchKernelGGL((linear_kernel<CfgGen, false, true, 0, true>), grid, block, 0, st, p);        // mlp.0 + ReLU
+  }
   else if (!f && s && p.bias_mode == 1 && !p.relu)
     hipLaunchKernelGGL((linear_kernel<CfgGen, false, true, 1, false>), grid, block, 0, st, p);       // down_proj
   else if (f && !s && p.bias_mode == 1 && !p.relu)

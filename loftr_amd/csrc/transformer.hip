@@ -117,11 +117,13 @@ int encoder_layer(const float* x_f32, const sp_t* x_sp, const sp_t* src_sp, bool
     // q projection with the normaliser applied in its epilogue (per pair: grid.z = nb)
     ProjArgs pq{x_sp, L, C, nb, 1, {w.q, nullptr, nullptr}, {e.q, nullptr, nullptr}, {0, 0, 0}, x_mask, inv_s,
                 kv, (float)S, attn_eps, {w.q_s, nullptr, nullptr}};
-    if ((rc = launch_proj(pq, st))) return rc;
+    if ((rc = launch_rowsweep_q(pq, st)) == LOFTR_ERR_UNSUPPORTED) rc = launch_proj(pq, st);
+    if (rc) return rc;
     // message = norm1(merge(attention))  as ONE GEMM against P                    transformer.py:50-52
     LinearLNArgs m{asrc_plain(e.q, C), pm, C, w.n1w, w.n1b, nullptr, nullptr, e.msgn, L, C, C, 1e-5f,
                    nb, (long)C * C, nullptr, 1.f / ATTN_P_SCALE};
-    if ((rc = launch_linear_ln(m, st))) return rc;
+    if ((rc = launch_rowsweep_ln(m, st)) == LOFTR_ERR_UNSUPPORTED) rc = launch_linear_ln(m, st);
+    if (rc) return rc;
   } else {
     float* qf = reinterpret_cast<float*>(e.q);
     if (self) {
