@@ -39,6 +39,12 @@ def bench_name(full):
         return "score_conf_kernel"          # dual-softmax pass B (writes conf_matrix)
     if "score_sweep_kernel<0" in full:
         return "score_stats_kernel"         # pass A: shared-reference variant + exact variant
+    if "score_sweep_kernel<2" in full:
+        return "score_store_kernel"         # Sinkhorn: score store on the sweep
+    if "rowsweep_kernel<0" in full:
+        return "proj_kernel"                # coarse q projection (timed under LOFTR_T_PROJ)
+    if "rowsweep_kernel<1" in full:
+        return "linear_ln_kernel"           # coarse merge + LayerNorm (LOFTR_T_LINEAR_LN)
     return short(full)
 
 
