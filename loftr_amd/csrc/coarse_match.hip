@@ -1534,6 +1534,7 @@ __global__ __launch_bounds__(256, OTP_PREFETCH ? 2 : 3) void ot_pass_kernel(floa
           if (q < S4 && valid) {
             *reinterpret_cast<f32x4*>(zr + 4 * q) = c;
             // conf_matrix is a VIEW of assign_matrix in the reference (:133): the prefilter zeroing is visible there too
+            // (row pitch S + 1: only 4-byte aligned.  Scalar stores: one unaligned dwordx4 per group measured 40 % slower)
             if (ar) { ar[4 * q] = c[0]; ar[4 * q + 1] = c[1]; ar[4 * q + 2] = c[2]; ar[4 * q + 3] = c[3]; }
           }
 #pragma unroll
