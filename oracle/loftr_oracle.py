@@ -209,13 +209,13 @@ def sinkhorn_conf(feat_c0, feat_c1, bin_score, iters=3, mask_c0=None, mask_c1=No
         valid = mask_c0[:, :, None].astype(bool) & mask_c1[:, None, :].astype(bool)
         sim = np.where(valid, sim, dt.type(-INF))
     assign = np.exp(log_optimal_transport(sim, bin_score, iters))       # :130-132
-    conf = assign[:, :-1, :-1].copy()                                   # :133
+    conf = assign[:, :-1, :-1]                                          # :133 -- a VIEW: the prefilter below zeroes assign too (:143 clones it later)
     if prefilter:                                                       # :136-140 (eval only)
         filter0 = (assign.argmax(axis=2) == S)[:, :-1]
         filter1 = (assign.argmax(axis=1) == L)[:, :-1]
         conf[np.broadcast_to(filter0[:, :, None], conf.shape)] = 0
         conf[np.broadcast_to(filter1[:, None, :], conf.shape)] = 0
-    return conf.astype(dt), assign.astype(dt)
+    return conf.astype(dt).copy(), assign.astype(dt)
 
 
 def coarse_match_select(conf, thr, border_rm, hw0_c, hw1_c, hw0_i, mask0=None, mask1=None,

@@ -218,3 +218,42 @@ def test_single_encoder_layer_vs_oracle(C, L, S, masked):
             got = layer(t(x), t(src), t(xm), t(sm)).cpu().numpy()
             ref = O.encoder_layer(x, src, w, "l.", 8, xm, sm)
         assert np.abs(got - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max()), (self_attn, np.abs(got - ref).max())
+
+
+@pytest.mark.parametrize("hw0,hw1,C,masked,prefilter", [((7, 9), (9, 7), 256, False, False), ((7, 9), (5, 7), 256, True, True),
+                                                         ((6, 8), (8, 6), 128, False, False), ((9, 12), (12, 9), 256, True, False)])
+def test_sinkhorn_paths_vs_oracle(hw0, hw1, C, masked, prefilter):
+    """Sinkhorn coarse matching against the numpy oracle on the shapes the goldens do not reach: rows that are not
+    16-byte aligned (S % 4 != 0: the round-1 iteration / finalize kernels), another descriptor width (tiled score store),
+    and the row-streaming passes (S % 4 == 0) with masks on unequal grids."""
+    import torch
+    from oracle import loftr_oracle as O
+    from loftr_amd import ops
+    rng = np.random.default_rng(hw0[0] * 100 + hw1[1] + C)
+    N, L, S = 3, hw0[0] * hw0[1], hw1[0] * hw1[1]
+    f0 = rng.standard_normal((N, L, C)).astype(np.float32) * 2
+    f1 = rng.standard_normal((N, S, C)).astype(np.float32) * 2
+    k = min(L, S)
+    f1[:, :k] += 1.5 * f0[:, rng.permutation(L)[:k]]
+    m0 = m1 = None
+    if masked:
+        m0 = np.ones((N,) + hw0, bool); m0[1, hw0[0] - 2:] = False
+        m1 = np.ones((N,) + hw1, bool); m1[2, :, hw1[1] - 3:] = False
+    conf_ref, assign_ref = O.sinkhorn_conf(f0, f1, np.float32(1.0), 3, None if m0 is None else m0.reshape(N, -1),
+                                           None if m1 is None else m1.reshape(N, -1), prefilter=prefilter)
+    sel = O.coarse_match_select(conf_ref, 0.0, 1, hw0, hw1, (hw0[0] * 8, hw0[1] * 8), m0, m1)
+    t = lambda a: None if a is None else torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    r = ops.coarse_match(t(f0), t(f1), hw0, hw1, thr=0.0, border_rm=1, scale=8.0, match_type="sinkhorn", bin_score=1.0, skh_iters=3,
+                         skh_prefilter=prefilter, mask0=None if m0 is None else t(m0).flatten(-2),
+                         mask1=None if m1 is None else t(m1).flatten(-2), want_assign=True)
+    conf, assign = r["conf_matrix"].cpu().numpy(), r["conf_matrix_with_bin"].cpu().numpy()
+    valid = np.ones((N, L, S), bool) if m0 is None else (m0.reshape(N, -1)[:, :, None] & m1.reshape(N, -1)[:, None, :])
+    # masked entries are rounding noise of ((Z + u) + v) - norm with |u|, |v| ~ 1e9 (DESIGN 9.2): compared where valid
+    assert np.abs(conf - conf_ref)[valid].max() <= TOL_CONF
+    assert np.abs(assign[:, :-1, :-1] - assign_ref[:, :-1, :-1])[valid].max() <= TOL_CONF
+    if m0 is None:
+        assert np.abs(assign[:, -1, :] - assign_ref[:, -1, :]).max() <= TOL_CONF and np.abs(assign[:, :, -1] - assign_ref[:, :, -1]).max() <= TOL_CONF
+    got = set(zip(r["b_ids"].tolist(), r["i_ids"].tolist(), r["j_ids"].tolist()))
+    want = set(zip(sel["b_ids"].tolist(), sel["i_ids"].tolist(), sel["j_ids"].tolist()))
+    assert len(got ^ want) <= 1, sorted(got ^ want)            # (a near-tie between two fp32 roundings may flip one)
+    assert len(want) > 0 or prefilter
