@@ -257,3 +257,31 @@ def test_sinkhorn_paths_vs_oracle(hw0, hw1, C, masked, prefilter):
     want = set(zip(sel["b_ids"].tolist(), sel["i_ids"].tolist(), sel["j_ids"].tolist()))
     assert len(got ^ want) <= 1, sorted(got ^ want)            # (a near-tie between two fp32 roundings may flip one)
     assert len(want) > 0 or prefilter
+
+
+@pytest.mark.parametrize("hw0,hw1,C,masked", [((7, 9), (9, 7), 128, False), ((6, 8), (5, 7), 64, True), ((9, 11), (7, 5), 256, True)])
+def test_dual_softmax_paths_vs_oracle(hw0, hw1, C, masked):
+    """Dual-softmax coarse matching against the numpy oracle off the goldens' shapes: descriptor widths other than 256
+    (the tiled two-pass kernels) and odd, unequal grids with masks on the sweep (partial panels / row blocks)."""
+    import torch
+    from oracle import loftr_oracle as O
+    from loftr_amd import ops
+    rng = np.random.default_rng(hw0[0] * 10 + hw1[1] + C)
+    N, L, S = 3, hw0[0] * hw0[1], hw1[0] * hw1[1]
+    f0 = rng.standard_normal((N, L, C)).astype(np.float32)
+    f1 = rng.standard_normal((N, S, C)).astype(np.float32)
+    k = min(L, S)
+    f1[:, :k] += 1.5 * f0[:, rng.permutation(L)[:k]]
+    m0 = m1 = None
+    if masked:
+        m0 = np.ones((N,) + hw0, bool); m0[1, hw0[0] - 2:] = False
+        m1 = np.ones((N,) + hw1, bool); m1[2, :, hw1[1] - 2:] = False
+    conf_ref = O.dual_softmax_conf(f0, f1, 0.1, None if m0 is None else m0.reshape(N, -1), None if m1 is None else m1.reshape(N, -1))
+    sel = O.coarse_match_select(conf_ref, 0.0, 1, hw0, hw1, (hw0[0] * 8, hw0[1] * 8), m0, m1)
+    t = lambda a: None if a is None else torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    r = ops.coarse_match(t(f0), t(f1), hw0, hw1, thr=0.0, border_rm=1, scale=8.0, temperature=0.1,
+                         mask0=None if m0 is None else t(m0).flatten(-2), mask1=None if m1 is None else t(m1).flatten(-2))
+    assert np.abs(r["conf_matrix"].cpu().numpy() - conf_ref).max() <= TOL_CONF
+    got = set(zip(r["b_ids"].tolist(), r["i_ids"].tolist(), r["j_ids"].tolist()))
+    want = set(zip(sel["b_ids"].tolist(), sel["i_ids"].tolist(), sel["j_ids"].tolist()))
+    assert len(got ^ want) <= 1 and len(want) > 10, sorted(got ^ want)
