@@ -95,7 +95,10 @@ int launch_linear(const LinearArgs& p, hipStream_t st) {
     hipLaunchKernelGGL((linear_kernel<CfgGen, true, false, 0, false>), grid, block, 0, st, p);       // loftr_linear_fwd
   else if (!f && s && p.bias_mode == 0 && p.relu) {
 #ifdef LOFTR_LINEAR_DMA                              // A/B: 256 x 128 tiles on the LDS-DMA ring (as the convolutions) for the big mlp.0
-    using CfgBig = GemmCfg<256, 128, 4, 2, 3>;
+#ifndef LOFTR_LINEAR_BIG
+#define LOFTR_LINEAR_BIG 256, 128, 4, 2, 3
+#endif
+    using CfgBig = GemmCfg<LOFTR_LINEAR_BIG>;
     if (p.M >= 8192 && p.N % CfgBig::BN == 0)
       hipLaunchKernelGGL((linear_kernel<CfgBig, false, true, 0, true>), dim3(xcd_grid(ceil_div(p.M, CfgBig::BM), p.N / CfgBig::BN)),
                          dim3(CfgBig::THREADS), 0, st, p);
