@@ -35,7 +35,9 @@ typedef enum {
   LOFTR_ERR_COMM = -6           /* RCCL unavailable or a collective / communicator call failed */
 } loftr_status;
 
-#define LOFTR_HIP_ABI_VERSION 13
+/* 13: prepared transformer weights, RCCL entry points, scaled activations, pose estimation;
+ * 14: training-side consumers (loftr_spvs_coarse / _fine, loftr_coarse_loss_sums, loftr_fine_loss_sums) */
+#define LOFTR_HIP_ABI_VERSION 14
 
 int loftr_hip_abi_version(void);
 const char* loftr_hip_status_string(int status);

@@ -95,7 +95,7 @@ SIGNATURES = {
     "loftr_linear_fwd": (_i, [_p, _p, _p, _i, _i, _i, _p, _sz, _p]),
 }
 
-ABI_VERSION = 13
+ABI_VERSION = 14
 _lib = None
 
 
