@@ -19,7 +19,9 @@ sys.path.insert(0, ROOT)
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 CASES = {"train_sc": dict(N=2, H=96, W=128, masks=False, seed=1),
-         "train_md": dict(N=2, H=96, W=96, masks=True, seed=2)}
+         "train_md": dict(N=2, H=96, W=96, masks=True, seed=2),
+         # corner cases of supervision.py:94-99 / loftr_loss.py:32-36,113-117,138-143: no ground truth at all (depth maps = 0)
+         "train_nogt": dict(N=2, H=64, W=64, masks=False, seed=3, no_gt=True)}
 
 
 def _rot(axis, ang):
@@ -49,6 +51,14 @@ def make_inputs(rc):
         d0[holes] = 0
         d1[rng.random((H, W)) < 0.03] = 0
         d0s.append(d0); d1s.append(d1)
+    if rc.get("no_gt"):
+        # zero depth alone is not "no ground truth" for the reference: spvs_coarse ignores warp_kpts' valid mask, every cell then
+        # warps to the projection of the translation, and one spurious mutual pair appears.  Put that projection far outside
+        # the image in both directions: every nearest index is 0 and cell 0 is excluded (supervision.py:76-81).
+        d0s = [np.zeros_like(d) for d in d0s]
+        d1s = [np.zeros_like(d) for d in d1s]
+        for T in T01 + T10:
+            T[:3, 3] = (5.0, 0.0, 0.01)
     inp = dict(depth0=np.stack(d0s), depth1=np.stack(d1s), T_0to1=np.stack(T01).astype(np.float32),
                T_1to0=np.stack(T10).astype(np.float32), K0=K0, K1=K1)
     if rc["masks"]:

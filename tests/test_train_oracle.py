@@ -50,7 +50,8 @@ def test_oracle_supervision_and_losses(name):
     # losses on the reference's own GT
     N, L = rc["N"], (rc["H"] // 8) * (rc["W"] // 8)
     gt = np.zeros((N, L, L), np.float32)
-    gt[g["spv_b_ids"], g["spv_i_ids"], g["spv_j_ids"]] = 1
+    if g["conf_gt_sum"].sum() > 0:                        # else: the reference's placeholder ids (0, 0, 0), conf_matrix_gt all zero
+        gt[g["spv_b_ids"], g["spv_i_ids"], g["spv_j_ids"]] = 1
     conf, conf_bin = MG.replay_matcher_outputs(rc, g["spv_b_ids"], g["spv_i_ids"], g["spv_j_ids"])
     weight = None
     if "mask0" in inp:
@@ -61,4 +62,7 @@ def test_oracle_supervision_and_losses(name):
         lc = T.coarse_loss(c, gt, weight, ctype, sparse, mtype)
         lf = T.fine_loss(g["expec_f"], g["expec_f_gt"], ftype)
         assert abs(lc - want[tag]["loss_c"]) <= 2e-6 * max(1, abs(want[tag]["loss_c"])), (tag, lc, want[tag])
-        assert abs(lf - want[tag]["loss_f"]) <= 2e-6, (tag, lf, want[tag])
+        if lf is None:                                     # eval mode, no correct coarse match: loss_scalars carry 1.0 (loftr_loss.py:186-188)
+            assert want[tag]["loss_f"] == 1.0 and abs(want[tag]["loss"] - want[tag]["loss_c"]) <= 1e-7
+        else:
+            assert abs(lf - want[tag]["loss_f"]) <= 2e-6, (tag, lf, want[tag])
