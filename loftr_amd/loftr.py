@@ -329,7 +329,13 @@ class LoFTR(nn.Module):
         self._fine_join = None
         if data["hw0_i"] == data["hw1_i"]:
             x = cl(torch.cat([data["image0"], data["image1"]], dim=0))
-            if use_hip and self.overlap_fine_branch:
+            # the convolution kernels index an activation tensor with 32 bits (conv.hip: images * pixels * channels < 2^31 at the
+            # widest 1/2-resolution map): larger batches go through the backbone in chunks (> 62 pairs at 640 x 480)
+            cap = getattr(self, "_backbone_chunk_images", None) or max(1, (2 ** 31 - 1) // ((x.shape[2] // 2) * (x.shape[3] // 2) * 256))
+            if use_hip and x.shape[0] > cap:
+                outs = [run(x[i:i + cap]) for i in range(0, x.shape[0], cap)]
+                feats_c, feats_f = torch.cat([o[0] for o in outs]), torch.cat([o[1] for o in outs])
+            elif use_hip and self.overlap_fine_branch:
                 feats_c, fine_fn = run(x, defer_fine=True)
                 main = torch.cuda.current_stream(x.device)
                 if self._side_stream is None:

@@ -311,3 +311,19 @@ def test_conv3x3_many_tiles_per_workgroup():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, "-c", code], env=env, cwd=root, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]
+
+
+def test_backbone_chunking_is_bitwise_identical():
+    """Batches whose activation tensors would exceed the kernels' 32-bit indexing go through the backbone in chunks
+    (loftr.py:run_backbone); forced here with a tiny chunk size: same bytes as the single pass."""
+    from loftr_amd import LoFTR
+    from loftr_amd.config import get_cfg
+    torch.manual_seed(3)
+    model = LoFTR(get_cfg(thr=0.0)).eval().cuda()
+    g = torch.Generator().manual_seed(5)
+    data = lambda: {"image0": torch.rand(3, 1, 64, 96, generator=g.manual_seed(5)).cuda(), "image1": torch.rand(3, 1, 64, 96, generator=g.manual_seed(6)).cuda()}
+    a = data(); model(a)
+    model._backbone_chunk_images = 4                          # 6 images -> chunks of 4 + 2
+    b = data(); model(b)
+    for k in ("conf_matrix", "mkpts0_f", "mkpts1_f", "mconf", "b_ids"):
+        assert torch.equal(a[k], b[k]), k
