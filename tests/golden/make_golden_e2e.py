@@ -61,7 +61,9 @@ def e2e_cfg(thr):
 
 CASES = {"e2e_scannet": dict(images="scannet", bn_strength=0.3),
          "e2e_synth": dict(images="synth", bn_strength=0.3),
-         "e2e_synth_bn06": dict(images="synth", bn_strength=0.6)}
+         "e2e_synth_bn06": dict(images="synth", bn_strength=0.6),
+         # images of DIFFERENT sizes: the reference runs its backbone once per image (loftr.py:48-49) and L != S everywhere after
+         "e2e_unequal": dict(images="synth", bn_strength=0.3, crop0=(384, 512), crop1=(320, 448))}
 
 
 def e2e_state_dict(module_with_backbone, cfg, bn_strength):
@@ -82,7 +84,12 @@ def load_images(name):
         imgs = [(a.astype(np.float32) / np.float32(255.0))[None, None] for a in u8]
         return imgs[0], imgs[1], dict(image0_u8=u8[0], image1_u8=u8[1])
     i0, i1 = make_images(1234, 8, H_IMG, W_IMG)          # the bench's rank-0 batch; pair 0
-    return i0[:1].copy(), i1[:1].copy(), dict(image_checksums=np.array([checksum(i0[:1]), checksum(i1[:1])]))
+    i0, i1 = _crop(i0[:1], CASES[name].get("crop0")), _crop(i1[:1], CASES[name].get("crop1"))
+    return i0, i1, dict(image_checksums=np.array([checksum(i0), checksum(i1)]))
+
+
+def _crop(img, hw):
+    return np.ascontiguousarray(img if hw is None else img[:, :, :hw[0], :hw[1]])
 
 
 def images_from_golden(g):
@@ -90,7 +97,8 @@ def images_from_golden(g):
     if "image0_u8" in g:
         return tuple((np.asarray(g[k]).astype(np.float32) / np.float32(255.0))[None, None] for k in ("image0_u8", "image1_u8"))
     i0, i1 = make_images(1234, 8, H_IMG, W_IMG)
-    i0, i1 = i0[:1].copy(), i1[:1].copy()
+    rc = json.loads(str(g["recipe"]))
+    i0, i1 = _crop(i0[:1], rc.get("crop0")), _crop(i1[:1], rc.get("crop1"))
     want = np.asarray(g["image_checksums"])
     assert np.allclose([checksum(i0), checksum(i1)], want, rtol=1e-12), "synthetic images drifted"
     return i0, i1
