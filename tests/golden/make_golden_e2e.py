@@ -63,7 +63,11 @@ CASES = {"e2e_scannet": dict(images="scannet", bn_strength=0.3),
          "e2e_synth": dict(images="synth", bn_strength=0.3),
          "e2e_synth_bn06": dict(images="synth", bn_strength=0.6),
          # images of DIFFERENT sizes: the reference runs its backbone once per image (loftr.py:48-49) and L != S everywhere after
-         "e2e_unequal": dict(images="synth", bn_strength=0.3, crop0=(384, 512), crop1=(320, 448))}
+         "e2e_unequal": dict(images="synth", bn_strength=0.3, crop0=(384, 512), crop1=(320, 448)),
+         # MegaDepth-style batch: zero-padded bottom / right, coarse padding masks, scale0 / scale1 (dataset.py:72-118; exercises
+         # coarse_matching.py:28-43,115-118,243-244, linear_attention.py:35-39, fine_matching.py:68 from images)
+         "e2e_masked": dict(images="synth", bn_strength=0.3, crop0=(384, 512), crop1=(384, 512), valid0=(320, 512), valid1=(384, 400),
+                            scale0=(1.9, 1.9), scale1=(1.25, 1.5))}
 
 
 def e2e_state_dict(module_with_backbone, cfg, bn_strength):
@@ -92,6 +96,23 @@ def _crop(img, hw):
     return np.ascontiguousarray(img if hw is None else img[:, :, :hw[0], :hw[1]])
 
 
+def extras(rc, img0, img1):
+    """mask0 / mask1 [1, H/8, W/8] bool and scale0 / scale1 [1, 2] of a masked case (numpy), images zeroed outside the valid
+    rectangle like pad_bottom_right does (dataset.py:72-89); {} for the other cases."""
+    if "valid0" not in rc:
+        return {}
+    out = {}
+    for tag, img in (("0", img0), ("1", img1)):
+        vh, vw = rc["valid" + tag]
+        img[:, :, vh:, :] = 0
+        img[:, :, :, vw:] = 0
+        m = np.zeros((1, img.shape[2] // 8, img.shape[3] // 8), bool)
+        m[:, :vh // 8, :vw // 8] = True
+        out["mask" + tag] = m
+        out["scale" + tag] = np.asarray([rc["scale" + tag]], np.float32)
+    return out
+
+
 def images_from_golden(g):
     """Inverse of the storage above (used by the tests on boxes without the reference / the JPEGs)."""
     if "image0_u8" in g:
@@ -104,7 +125,7 @@ def images_from_golden(g):
     return i0, i1
 
 
-def run_reference(img0, img1, thr, bn_strength, timing=False, dtype=torch.float32):
+def run_reference(img0, img1, thr, bn_strength, timing=False, dtype=torch.float32, extra=None):
     from oracle.ref_shim import import_reference
     from tests.golden.make_golden import conf_digest
     RefLoFTR, _ = import_reference()
@@ -117,6 +138,8 @@ def run_reference(img0, img1, thr, bn_strength, timing=False, dtype=torch.float3
     secs = []
     for _ in range(3 if timing else 1):
         data = {"image0": torch.from_numpy(img0).to(dtype), "image1": torch.from_numpy(img1).to(dtype)}
+        for k, v in (extra or {}).items():
+            data[k] = torch.from_numpy(v) if v.dtype == bool else torch.from_numpy(v).to(dtype)
         t0 = time.perf_counter()
         with torch.no_grad():
             model(data)
@@ -133,15 +156,16 @@ def run_reference(img0, img1, thr, bn_strength, timing=False, dtype=torch.float3
 
 def make(name):
     img0, img1, store = load_images(name)
+    ex = extras(CASES[name], img0, img1)
     for tag, thr in (("thr0", 0.0), ("thr02", 0.2)):
-        out = run_reference(img0, img1, thr, CASES[name]["bn_strength"], timing=(tag == "thr0"))
+        out = run_reference(img0, img1, thr, CASES[name]["bn_strength"], timing=(tag == "thr0"), extra=ex)
         for k, v in out.items():
             if tag == "thr02" and (k.startswith("conf_") or k.startswith("feat_") or k == "ref_cpu_seconds"):
                 continue          # conf_matrix / features do not depend on the threshold
             store[f"{tag}/{k}" if k in KEEP else k] = v
         print(f"{name} {tag}: M={len(out['mconf'])} conf.max={out['conf_row_max'].max():.4f} "
               f"|feat_c|max={out['feat_c_absmax']:.2f} ref CPU {np.median(out['ref_cpu_seconds']):.1f}s on {os.cpu_count()} vCPU")
-    out64 = run_reference(img0, img1, 0.0, CASES[name]["bn_strength"], dtype=torch.float64)
+    out64 = run_reference(img0, img1, 0.0, CASES[name]["bn_strength"], dtype=torch.float64, extra=ex)
     for k in KEEP:
         store[f"ref64/{k}"] = out64[k]
     k32 = list(zip(store["thr0/i_ids"].tolist(), store["thr0/j_ids"].tolist()))
