@@ -53,9 +53,12 @@ SCANNET = ("assets/scannet_sample_images/scene0711_00_frame-001680.jpg",
 KEEP = ("b_ids", "i_ids", "j_ids", "mkpts0_c", "mkpts1_c", "mconf", "expec_f", "mkpts0_f", "mkpts1_f")
 
 
-def e2e_cfg(thr):
+def e2e_cfg(thr, rc=None):
     cfg = get_cfg(thr=thr)
     cfg["coarse"]["temp_bug_fix"] = True
+    if rc and rc.get("resolution"):                      # ResNetFPN_16_4: coarse map at 1/16, fine at 1/4 (resnet_fpn.py:121-199)
+        cfg["resolution"] = tuple(rc["resolution"])
+        cfg["resnetfpn"] = {"initial_dim": 128, "block_dims": list(rc["block_dims"])}
     return cfg
 
 
@@ -67,7 +70,10 @@ CASES = {"e2e_scannet": dict(images="scannet", bn_strength=0.3),
          # MegaDepth-style batch: zero-padded bottom / right, coarse padding masks, scale0 / scale1 (dataset.py:72-118; exercises
          # coarse_matching.py:28-43,115-118,243-244, linear_attention.py:35-39, fine_matching.py:68 from images)
          "e2e_masked": dict(images="synth", bn_strength=0.3, crop0=(384, 512), crop1=(384, 512), valid0=(320, 512), valid1=(384, 400),
-                            scale0=(1.9, 1.9), scale1=(1.25, 1.5))}
+                            scale0=(1.9, 1.9), scale1=(1.25, 1.5)),
+         # the other backbone the reference ships: ResNetFPN_16_4 (coarse 1/16 = 24 x 32 cells, fine 1/4)
+         "e2e_r16_4": dict(images="synth", bn_strength=0.3, crop0=(384, 512), crop1=(384, 512), resolution=(16, 4),
+                           block_dims=(128, 128, 196, 256))}
 
 
 def e2e_state_dict(module_with_backbone, cfg, bn_strength):
@@ -125,11 +131,11 @@ def images_from_golden(g):
     return i0, i1
 
 
-def run_reference(img0, img1, thr, bn_strength, timing=False, dtype=torch.float32, extra=None):
+def run_reference(img0, img1, thr, bn_strength, timing=False, dtype=torch.float32, extra=None, rc=None):
     from oracle.ref_shim import import_reference
     from tests.golden.make_golden import conf_digest
     RefLoFTR, _ = import_reference()
-    cfg = e2e_cfg(thr)
+    cfg = e2e_cfg(thr, rc)
     model = RefLoFTR(copy.deepcopy(cfg)).eval()
     model.load_state_dict(e2e_state_dict(model, cfg, bn_strength), strict=True)
     model = model.to(dtype)
@@ -158,14 +164,14 @@ def make(name):
     img0, img1, store = load_images(name)
     ex = extras(CASES[name], img0, img1)
     for tag, thr in (("thr0", 0.0), ("thr02", 0.2)):
-        out = run_reference(img0, img1, thr, CASES[name]["bn_strength"], timing=(tag == "thr0"), extra=ex)
+        out = run_reference(img0, img1, thr, CASES[name]["bn_strength"], timing=(tag == "thr0"), extra=ex, rc=CASES[name])
         for k, v in out.items():
             if tag == "thr02" and (k.startswith("conf_") or k.startswith("feat_") or k == "ref_cpu_seconds"):
                 continue          # conf_matrix / features do not depend on the threshold
             store[f"{tag}/{k}" if k in KEEP else k] = v
         print(f"{name} {tag}: M={len(out['mconf'])} conf.max={out['conf_row_max'].max():.4f} "
               f"|feat_c|max={out['feat_c_absmax']:.2f} ref CPU {np.median(out['ref_cpu_seconds']):.1f}s on {os.cpu_count()} vCPU")
-    out64 = run_reference(img0, img1, 0.0, CASES[name]["bn_strength"], dtype=torch.float64, extra=ex)
+    out64 = run_reference(img0, img1, 0.0, CASES[name]["bn_strength"], dtype=torch.float64, extra=ex, rc=CASES[name])
     for k in KEEP:
         store[f"ref64/{k}"] = out64[k]
     k32 = list(zip(store["thr0/i_ids"].tolist(), store["thr0/j_ids"].tolist()))
