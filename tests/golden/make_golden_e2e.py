@@ -56,6 +56,8 @@ KEEP = ("b_ids", "i_ids", "j_ids", "mkpts0_c", "mkpts1_c", "mconf", "expec_f", "
 def e2e_cfg(thr, rc=None):
     cfg = get_cfg(thr=thr)
     cfg["coarse"]["temp_bug_fix"] = True
+    if rc and rc.get("match_type") == "sinkhorn":        # configs/loftr/indoor/loftr_ot.py + default.py:29-36 (BASELINE configs[4])
+        cfg["match_coarse"].update(match_type="sinkhorn", skh_prefilter=False, sparse_spvs=True)
     if rc and rc.get("resolution"):                      # ResNetFPN_16_4: coarse map at 1/16, fine at 1/4 (resnet_fpn.py:121-199)
         cfg["resolution"] = tuple(rc["resolution"])
         cfg["resnetfpn"] = {"initial_dim": 128, "block_dims": list(rc["block_dims"])}
@@ -72,6 +74,8 @@ CASES = {"e2e_scannet": dict(images="scannet", bn_strength=0.3),
          "e2e_masked": dict(images="synth", bn_strength=0.3, crop0=(384, 512), crop1=(384, 512), valid0=(320, 512), valid1=(384, 400),
                             scale0=(1.9, 1.9), scale1=(1.25, 1.5)),
          # the other backbone the reference ships: ResNetFPN_16_4 (coarse 1/16 = 24 x 32 cells, fine 1/4)
+         # Sinkhorn matching from images (conf_matrix_with_bin is produced as well: sparse_spvs)
+         "e2e_ot": dict(images="synth", bn_strength=0.3, crop0=(384, 512), crop1=(384, 512), match_type="sinkhorn"),
          "e2e_r16_4": dict(images="synth", bn_strength=0.3, crop0=(384, 512), crop1=(384, 512), resolution=(16, 4),
                            block_dims=(128, 128, 196, 256))}
 
