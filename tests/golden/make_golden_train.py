@@ -199,6 +199,71 @@ def make_coarse_train(name):
     print(name, "fine-level training set", len(data["b_ids"]), "of which predictions", int((~data["gt_mask"]).sum()))
 
 
+# ---- the whole training-step forward: PL_LoFTR._trainval_inference (lightning_loftr.py:82-93) --------------------------
+# compute_supervision_coarse -> matcher(batch) in .train() mode -> compute_supervision_fine -> LoFTRLoss, on images + depth +
+# poses; matcher weights seeded like the e2e goldens, torch.randint replaced by det_randint.
+STEP_CASES = {"tstep_ds": dict(geometry="train_sc", thr=0.0, percent=0.4, pad_min=20, match_type="dual_softmax"),
+              "tstep_ot": dict(geometry="train_sc", thr=0.0, percent=0.4, pad_min=20, match_type="sinkhorn")}
+STEP_KEYS = ("spv_b_ids", "spv_i_ids", "spv_j_ids", "b_ids", "i_ids", "j_ids", "gt_mask", "m_bids", "mconf", "mkpts0_c", "mkpts1_c",
+             "mkpts0_f", "mkpts1_f", "expec_f", "expec_f_gt")
+
+
+def step_matcher_cfg(rc):
+    from loftr_amd.config import full_default_cfg
+    cfg = full_default_cfg()                               # src/config/default.py: temp_bug_fix True, sparse_spvs True
+    cfg["match_coarse"].update(thr=rc["thr"], train_coarse_percent=rc["percent"], train_pad_num_gt_min=rc["pad_min"],
+                               match_type=rc["match_type"])
+    return cfg
+
+
+def step_loss_cfg(rc):
+    return {"loftr": {"loss": dict(coarse_type="focal", coarse_weight=1.0, focal_alpha=0.25, focal_gamma=2.0, pos_weight=1.0, neg_weight=1.0,
+                                   fine_type="l2_with_std", fine_weight=1.0, fine_correct_thr=1.0),
+                      "match_coarse": dict(match_type=rc["match_type"], sparse_spvs=True)}}
+
+
+def step_batch(rc):
+    """numpy inputs of a training step: images (seeded, correlated) + the two-view geometry of CASES[rc['geometry']]."""
+    from loftr_amd.synth import make_images
+    geo = CASES[rc["geometry"]]
+    inp = make_inputs(geo)
+    i0, i1 = make_images(4321, geo["N"], geo["H"], geo["W"])
+    return dict(image0=i0, image1=i1, **inp), geo
+
+
+def make_step(name):
+    import copy
+    from oracle.ref_shim import import_reference
+    from tests.golden.make_golden_e2e import e2e_state_dict
+    RefLoFTR, _ = import_reference()
+    sup, LoFTRLoss = __import__("oracle.ref_shim", fromlist=["x"]).import_reference_training()
+    rc = STEP_CASES[name]
+    batch, geo = step_batch(rc)
+    cfg = step_matcher_cfg(rc)
+    model = RefLoFTR(copy.deepcopy(cfg))
+    model.load_state_dict(e2e_state_dict(model, cfg, 0.3), strict=True)
+    model.train()                                          # BatchNorm on batch statistics, CoarseMatching samples / pads
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+    data = {"dataset_name": ["scannet"] * geo["N"], "pair_names": [["a"] * geo["N"], ["b"] * geo["N"]], **{k: t(v) for k, v in batch.items()}}
+    real = torch.randint
+    torch.randint = det_randint
+    try:
+        with torch.no_grad():
+            sup.compute_supervision_coarse(data, {"LOFTR": {"RESOLUTION": (8, 2), "FINE_WINDOW_SIZE": 5}}) if False else sup.spvs_coarse(
+                data, {"LOFTR": {"RESOLUTION": (8, 2), "FINE_WINDOW_SIZE": 5}})
+            model(data)
+            sup.spvs_fine(data, {"LOFTR": {"RESOLUTION": (8, 2), "FINE_WINDOW_SIZE": 5}})
+            LoFTRLoss(step_loss_cfg(rc)).train()(data)
+    finally:
+        torch.randint = real
+    store = {k: data[k].numpy() for k in STEP_KEYS}
+    store["losses"] = np.array(json.dumps({k: float(v) for k, v in data["loss_scalars"].items()}))
+    store["recipe"] = np.array(json.dumps(rc))
+    np.savez_compressed(os.path.join(HERE, f"{name}.npz"), **store)
+    print(name, "training set", len(data["b_ids"]), "predictions", int((~data["gt_mask"]).sum()), "GT", len(data["spv_b_ids"]),
+          {k: float(v) for k, v in data["loss_scalars"].items()})
+
+
 if __name__ == "__main__":
-    for nm in sys.argv[1:] or list(CASES) + list(COARSE_TRAIN):
-        (make if nm in CASES else make_coarse_train)(nm)
+    for nm in sys.argv[1:] or list(CASES) + list(COARSE_TRAIN) + list(STEP_CASES):
+        (make if nm in CASES else make_coarse_train if nm in COARSE_TRAIN else make_step)(nm)

@@ -144,3 +144,53 @@ def test_coarse_matching_train_branch(name, monkeypatch):
     # the contract's bar; these logits are O(200) (features x 4), where the log-sum-exp form rounds conf = 1 by up to 3e-5
     assert np.abs(data["mconf"].cpu().numpy() - g["mconf"]).max() <= 1e-4
     assert data["gt_mask"].sum().item() >= rc["pad_min"]
+
+
+@pytest.mark.parametrize("name", list(MG.STEP_CASES))
+def test_training_step_chain_against_reference(name, monkeypatch):
+    """PL_LoFTR._trainval_inference (lightning_loftr.py:82-93) end to end: coarse supervision -> matcher in .train() mode
+    (sampling / ground-truth padding, FineMatching's [:len(mconf)] slice) -> fine supervision -> losses, against the same
+    chain of the reference (tests/golden/tstep_*.npz).  The backbone runs as the PyTorch mirror on the CPU in train mode
+    (BatchNorm on batch statistics: the reference's own arithmetic, no MIOpen noise); everything after it is the HIP path."""
+    import copy
+    import importlib.util
+    import os
+    from _cases import GOLDEN_DIR
+    from loftr_amd import LoFTR
+    from loftr_amd.training import LoFTRLoss, compute_supervision_coarse, compute_supervision_fine
+    spec = importlib.util.spec_from_file_location("make_golden_e2e", os.path.join(GOLDEN_DIR, "make_golden_e2e.py"))
+    E2E = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(E2E)
+    dev = torch.device("cuda", 0)
+    g = dict(np.load(os.path.join(GOLDEN_DIR, f"{name}.npz")))
+    rc = json.loads(str(g["recipe"]))
+    batch, geo = MG.step_batch(rc)
+    N = geo["N"]
+    cfg = MG.step_matcher_cfg(rc)
+    cpu = LoFTR(copy.deepcopy(cfg))
+    sd = E2E.e2e_state_dict(cpu, cfg, 0.3)
+    cpu.load_state_dict(sd, strict=True)
+    cpu.train()
+    with torch.no_grad():
+        fc, ff = cpu.backbone(torch.from_numpy(np.concatenate([batch["image0"], batch["image1"]], 0)))
+    model = LoFTR(copy.deepcopy(cfg))
+    model.load_state_dict(sd, strict=True)
+    model = model.to(dev).train()
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    data = {"dataset_name": ["scannet"] * N, **{k: t(v) for k, v in batch.items()}}
+    monkeypatch.setattr(torch, "randint", MG.det_randint)
+    compute_supervision_coarse(data, CFG)
+    data.update({"bs": N, "hw0_i": data["image0"].shape[2:], "hw1_i": data["image1"].shape[2:]})
+    with torch.no_grad():
+        model.match_from_features(fc[:N].to(dev), fc[N:].to(dev), ff[:N].to(dev), ff[N:].to(dev), data)
+    compute_supervision_fine(data, CFG)
+    LoFTRLoss(MG.step_loss_cfg(rc)).train()(data)
+    for k in ("spv_b_ids", "spv_i_ids", "spv_j_ids", "b_ids", "i_ids", "j_ids", "gt_mask", "m_bids"):
+        assert np.array_equal(data[k].cpu().numpy(), g[k]), k
+    for k, tol in (("mconf", 1e-4), ("mkpts0_c", 0.0), ("mkpts1_c", 0.0), ("mkpts0_f", 1e-3), ("mkpts1_f", 1e-3), ("expec_f", 3e-4), ("expec_f_gt", 1e-5)):
+        d = np.abs(data[k].cpu().numpy().astype(np.float64) - g[k]).max() if len(g[k]) else 0.0
+        assert d <= tol * max(1.0, np.abs(g[k]).max() if k == "expec_f_gt" else 1.0), (k, d)
+    want = json.loads(str(g["losses"]))
+    got = {k: float(v) for k, v in data["loss_scalars"].items()}
+    for k in ("loss_c", "loss_f", "loss"):
+        assert abs(got[k] - want[k]) <= 2e-4 * max(1.0, abs(want[k])), (k, got, want)
