@@ -194,3 +194,30 @@ def test_training_step_chain_against_reference(name, monkeypatch):
     got = {k: float(v) for k, v in data["loss_scalars"].items()}
     for k in ("loss_c", "loss_f", "loss"):
         assert abs(got[k] - want[k]) <= 2e-4 * max(1.0, abs(want[k])), (k, got, want)
+
+
+def test_train_mode_forward_from_images_runs(monkeypatch):
+    """LoFTR.forward in .train() mode straight from images: the backbone goes through PyTorch (BatchNorm on batch statistics),
+    CoarseMatching samples / pads with the ground truth, the fine stage runs on the padded list.  MIOpen's arithmetic is not
+    the reference's bit for bit, so this checks structure, not the golden ids (test_training_step_chain_* pins those)."""
+    import copy
+    from loftr_amd import LoFTR
+    from loftr_amd.training import compute_supervision_coarse
+    dev = torch.device("cuda", 0)
+    rc = MG.STEP_CASES["tstep_ds"]
+    batch, geo = MG.step_batch(rc)
+    cfg = MG.step_matcher_cfg(rc)
+    torch.manual_seed(0)
+    model = LoFTR(copy.deepcopy(cfg)).to(dev).train()
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    data = {"dataset_name": ["scannet"] * geo["N"], **{k: t(v) for k, v in batch.items()}}
+    monkeypatch.setattr(torch, "randint", MG.det_randint)
+    compute_supervision_coarse(data, CFG)
+    model(data)
+    n_train = int(geo["N"] * (geo["H"] // 8) * (geo["W"] // 8) * rc["percent"])
+    assert data["b_ids"].shape[0] == n_train == data["expec_f"].shape[0]
+    assert int(data["gt_mask"].sum()) >= rc["pad_min"]
+    n = int((~data["gt_mask"]).sum())
+    assert data["mkpts0_f"].shape == data["mkpts1_f"].shape == (n, 2) == tuple(data["mkpts1_c"].shape)
+    assert torch.isfinite(data["expec_f"]).all() and torch.isfinite(data["mkpts1_f"]).all()
+    assert model.backbone.bn1.num_batches_tracked.item() == 1          # BatchNorm really ran in training mode
