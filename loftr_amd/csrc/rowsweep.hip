@@ -4,7 +4,7 @@
 // The tiled GEMM core (gemm.h) gives a 128 x 128 tile of a K = 256 product eight k-tiles of work between a DMA prologue
 // and an epilogue that touches every accumulator: the q projection (30 GFLOP executed) took 111 us and merge + LayerNorm
 // 158 us at B = 8 -- 0.2-0.3 PF of the ~1.1 PF the same loop sustains on long k.  Here the loop is turned inside out, as
-// for the score volume (coarse_match.hip, namespace sweep): the WEIGHT matrix [256 out, 256 in] is the stationary operand
+// for the score volume (score_sweep.h, namespace sweep): the WEIGHT matrix [256 out, 256 in] is the stationary operand
 // -- wave w of eight keeps the (hi, lo) MFMA fragments of its 32 output features for the whole K in 128 VGPRs -- and the
 // workgroup sweeps it over 32-token panels of the activation (32 KB each) that the eight waves share through a four-stage
 // LDS ring filled by global_load_lds two panels ahead (counted s_waitcnt vmcnt, one s_barrier per panel = per 48 MFMAs).
@@ -153,7 +153,7 @@ __global__ __launch_bounds__(512, 2) void rowsweep_kernel(Args a) {
     RSW_STORE(y__, (p0 + (pp_)) * PT + li)                                                               \
   }
 
-  // Every ordinary load above must be COMPLETE before the first DMA is issued (see coarse_match.hip: a first use inside
+  // Every ordinary load above must be COMPLETE before the first DMA is issued (see score_sweep.h: a first use inside
   // the panel loop would make hipcc drain the in-flight DMA every iteration).
   LOFTR_WAITCNT_VM(0);
   __syncthreads();                                 // tables visible; no DMA in flight yet

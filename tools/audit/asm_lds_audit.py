@@ -1,4 +1,4 @@
-"""Audit of the inline-asm LDS reads (coarse_match.hip, namespace sweep): hipcc does not know that the destination
+"""Audit of the inline-asm LDS reads (score_sweep.h, compiled as part of coarse_match.hip; namespace sweep): hipcc does not know that the destination
 registers of an asm `ds_read` are not valid until the matching `s_waitcnt lgkmcnt`, so a compiler-generated copy /
 spill / use of them in between would read stale data (cdna_hip_programming.md §5.7 item 1).  This script compiles the
 file to ISA and checks, for every asm block of ds_reads, that no instruction names a destination register before the
