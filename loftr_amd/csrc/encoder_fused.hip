@@ -1,0 +1,436 @@
+// The x side of a coarse LoFTREncoderLayer as ONE kernel with the tokens stationary in registers (round 3).
+//   reference: src/loftr/loftr_module/transformer.py:47-58 (q_proj, merge, norm1, mlp, norm2, residual),
+//              linear_attention.py:31-36,44-45 (feature map, mask, normaliser)
+//
+//   Q' = z (.) (elu(x Wq^T) + 1) (.) mask      message = LayerNorm1(Q' P^T)        (P = KV folded into merge, attention.hip)
+//   hidden = relu([x, message] W0^T)           out = x + LayerNorm2(hidden W2^T)
+//
+// Until round 2 these were four launches (q projection, merge + LN, mlp.0, mlp.2 + LN) that moved 14 tensor-sized
+// streams through HBM per layer call (Q', message, the 512-wide hidden tensor written and read back).  Activations do not
+// fit the LDS next to a weight stream (a 128-token tile of one SP tensor is 128 KB of the 160), but they fit the REGISTER
+// file, which is three times the LDS: 32 tokens x 256 features as MFMA B-operand fragments are 128 VGPRs per lane.
+//
+// Design.  A workgroup is four waves, one per SIMD (up to 512 registers each); a wave owns 32 tokens for the whole layer:
+//   * its tokens' activations are the MFMA's B operand (lane = token, 8 consecutive features per lane and k-step, hi and lo
+//     halves), the weights are the A operand and stream through a three-stage LDS ring that the four waves share: panels
+//     of 32 KB = 8 blocks of (32 rows x 128 B), filled by global_load_lds two panels ahead, ONE barrier per panel
+//     (48 MFMAs per wave);
+//   * with D[feature][token] the lane that owns a token RECEIVES that token's outputs (16 features per 32-feature panel,
+//     the other 16 in lane ^ 32): an output panel becomes the next GEMM's B fragments by a (hi, lo) split and eight
+//     v_permlane32_swap -- activations never leave the wave, no LDS round trip, no cross-wave exchange, and LayerNorm is a
+//     lane-private sum plus one half-wave exchange;
+//   * two panel shapes cover all four GEMMs.  "R" = 32 output features x 256 k (Wq rows with x; W0 rows with x, then with
+//     the message): one output panel, 16 k-steps.  "K" = 256 output features x 32 k (P with one head of Q'; W2 with one
+//     32-wide slice of the hidden layer): all eight output panels advance by two k-steps.  So Q' and the hidden layer are
+//     consumed 32 features at a time as they are produced and never exist as a whole (Q': 16 registers, hidden: 16).
+//   Live state per lane: x 128 + message accumulators / message fragments 128 + output accumulators 128 + ~70.
+// HBM traffic per call: x (SP) and x (fp32, residual) in, out (fp32 + SP) in place: 4 tensor streams instead of 13.
+// Weights: 2 MB per workgroup (128 tokens) from the XCD's L2 -- one sequence's workgroups run on one XCD.
+#include "linear.h"
+
+namespace {
+namespace efx {
+constexpr int W = 4, PT = 32, STAGE = 32 * 1024, NST = 3, BLK = 4096;
+constexpr int NPANEL = 16 + 48;                         // 8 x (Wq_h, P_h) + 16 x (W0a, W0b, W2_k)
+constexpr int DMA_PER_WAVE = 8;                         // global_load_lds per wave and panel: 2 blocks x 4 row octets
+// per-feature tables (floats) behind the ring
+constexpr int T_WQS = 0, T_KSUM = 256, T_G1 = 512, T_B1 = 768, T_W0S = 1024, T_W2S = 1536, T_G2 = 1792, T_B2 = 2048, T_N = 2304;
+constexpr int OFF_TAB = NST * STAGE;
+constexpr int LDS_BYTES = OFF_TAB + T_N * 4;
+static_assert(LDS_BYTES <= 160 * 1024, "one workgroup per CU");
+
+struct Args {
+  const sp_t* x_sp; const float* x_f32;                 // [nseq][T][256]
+  float* out_f32; sp_t* out_sp;                         // may alias x (a wave touches only its own tokens)
+  const sp_t* wq; const sp_t* pm; long pm_seq_stride;   // [256][256] SP; [nseq][256][256] SP (row j, column (h, d))
+  const sp_t* w0; const sp_t* w2;                       // [512][512], [256][512] SP
+  const float *wq_s, *w0_s, *w2_s;                      // inverse power-of-two row scales (gemm.h)
+  const float* kv;                                      // [nseq][8][33][32], row 32 of a head = Ksum
+  const uint8_t* mask;                                  // [nseq * T] or null
+  const float *g1, *b1, *g2, *b2;
+  float v_length, attn_eps, p_out_scale, ln_eps;
+  int nseq, T, groups;                                  // groups of W token blocks per sequence
+};
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+
+// exchange with lane ^ 32: afterwards lanes 0..31 hold (own a, partner's a), lanes 32..63 (partner's b, own b)
+__device__ __forceinline__ void swap_halves(uint32_t& a, uint32_t& b) {
+  const auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+  a = r[0]; b = r[1];
+}
+__device__ __forceinline__ void sp_pack4(float x0, float x1, float x2, float x3, uint2& hi, uint2& lo) {
+  const uint32_t a = sp_pack(x0), b = sp_pack(x1), c = sp_pack(x2), d = sp_pack(x3);
+  hi = make_uint2((a & 0xffffu) | (b << 16), (c & 0xffffu) | (d << 16));
+  lo = make_uint2((a >> 16) | (b & 0xffff0000u), (c >> 16) | (d & 0xffff0000u));
+}
+// 16 outputs of one 32-feature panel (register r of a lane in half-wave g = feature 8 (r >> 2) + 4 g + (r & 3) of the lane's
+// token) -> the lane's B-operand fragments of the panel's two k-steps (k-step s, element e = feature 16 s + 8 g + e).
+// g = 0 keeps its quads 0 / 2 and receives the partner's (features +4), g = 1 keeps 1 / 3 and receives the partner's.
+__device__ __forceinline__ void pack_panel(const float (&v)[16], h16x8 (&fh)[2], h16x8 (&fl)[2]) {
+  uint2 H[4], L[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) sp_pack4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3], H[q], L[q]);
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    swap_halves(H[2 * s].x, H[2 * s + 1].x); swap_halves(H[2 * s].y, H[2 * s + 1].y);
+    swap_halves(L[2 * s].x, L[2 * s + 1].x); swap_halves(L[2 * s].y, L[2 * s + 1].y);
+    fh[s] = __builtin_bit_cast(h16x8, u32x4{H[2 * s].x, H[2 * s].y, H[2 * s + 1].x, H[2 * s + 1].y});
+    fl[s] = __builtin_bit_cast(h16x8, u32x4{L[2 * s].x, L[2 * s].y, L[2 * s + 1].x, L[2 * s + 1].y});
+  }
+}
+
+__global__ __launch_bounds__(W * 64, 1) void encoder_x_kernel(Args a) {
+  __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
+  // ---- workgroup -> (sequence, group of token blocks): a sequence's groups run back to back on one XCD (weights, P in its L2)
+  const int id = blockIdx.x, xcd = id % NUM_XCD, slot = id / NUM_XCD;
+  const int seq = (slot / a.groups) * NUM_XCD + xcd, grp = slot % a.groups;
+  if (seq >= a.nseq) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 5, li = lane & 31;
+  const int T = a.T;
+  const int tok = (grp * W + wave) * PT + li;
+  const bool live = (grp * W + wave) * PT < T;          // wave-uniform: a wave beyond the sequence only feeds the ring
+  const long row = (long)seq * T + min(tok, T - 1);
+  float* tab = reinterpret_cast<float*>(lds + OFF_TAB);
+
+  // ---- per-feature tables -> LDS, this lane's token -> registers (ordinary loads / LDS stores: all BEFORE the first DMA)
+  for (int f = threadIdx.x; f < 256; f += W * 64) {
+    tab[T_WQS + f] = a.wq_s[f];
+    tab[T_KSUM + f] = a.kv[((long)seq * 8 + (f >> 5)) * (33 * 32) + 32 * 32 + (f & 31)];
+    tab[T_G1 + f] = a.g1[f]; tab[T_B1 + f] = a.b1[f];
+    tab[T_W0S + f] = a.w0_s[f]; tab[T_W0S + 256 + f] = a.w0_s[256 + f];
+    tab[T_W2S + f] = a.w2_s[f];
+    tab[T_G2 + f] = a.g2[f]; tab[T_B2 + f] = a.b2[f];
+  }
+  h16x8 xh[16], xl[16];                                 // B fragments of x: k-step ks, element e = feature 16 ks + 8 g + e
+  {
+    const u32x4* src = reinterpret_cast<const u32x4*>(a.x_sp + row * 256);
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) {
+      const int c = (ks >> 1) * 8 + 2 * (ks & 1) + g;
+      xh[ks] = __builtin_bit_cast(h16x8, src[c]);
+      xl[ks] = __builtin_bit_cast(h16x8, src[c + 4]);
+    }
+  }
+  const float mk = (a.mask && !a.mask[row]) ? 0.f : 1.f;
+
+  // ---- the weight stream.  Panel p of NPANEL lives in ring stage p % 3.
+  //   block b (4 KB) of a stage = 32 rows x 128 B (one 32-k group), 16-B chunk c of row r at slot c ^ ((r >> 1) & 7).
+  //   R panel: block b = k-group b of the panel's 32 rows;  K panel: block b = rows 32 b .. + 31 of the panel's k-group.
+  //   One DMA instruction = 8 rows x 128 B; wave w issues blocks w and w + 4.
+  const sp_t* pm = a.pm + (long)seq * a.pm_seq_stride;
+  int dro[4];                                           // row-octet part of the source offset (rows; dwords of the chunk)
+  int dch[4];
+#pragma unroll
+  for (int oct = 0; oct < 4; ++oct) {
+    dro[oct] = oct * 8 + (lane >> 3);
+    dch[oct] = ((lane & 7) ^ ((oct * 4 + (lane >> 4)) & 7)) << 2;
+  }
+#define EFX_ISSUE(p_)                                                                                      \
+  {                                                                                                        \
+    const int p__ = (p_);                                                                                  \
+    const sp_t* base__; int pitch__; bool kt__;                                                            \
+    if (p__ < 16) {                                                                                        \
+      const int h__ = p__ >> 1;                                                                            \
+      if (p__ & 1) { base__ = pm + h__ * 32; pitch__ = 256; kt__ = true; }                                 \
+      else { base__ = a.wq + (long)h__ * 32 * 256; pitch__ = 256; kt__ = false; }                          \
+    } else {                                                                                               \
+      const int q__ = p__ - 16, hp__ = q__ / 3, i__ = q__ - 3 * hp__;                                      \
+      if (i__ == 2) { base__ = a.w2 + hp__ * 32; pitch__ = 512; kt__ = true; }                             \
+      else { base__ = a.w0 + (long)hp__ * 32 * 512 + i__ * 256; pitch__ = 512; kt__ = false; }             \
+    }                                                                                                      \
+    char* st__ = lds + (p__ % NST) * STAGE;                                                                \
+    _Pragma("unroll") for (int bi__ = 0; bi__ < 2; ++bi__) {                                               \
+      const int b__ = wave + 4 * bi__;                                                                     \
+      const sp_t* bb__ = kt__ ? base__ + (long)b__ * 32 * pitch__ : base__ + b__ * 32;                     \
+      _Pragma("unroll") for (int oct__ = 0; oct__ < 4; ++oct__)                                            \
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(bb__ + dro[oct__] * pitch__ + dch[oct__]),            \
+                                         (lds_ptr_t)(st__ + b__ * BLK + oct__ * 1024), 16, 0, 0);          \
+    }                                                                                                      \
+  }
+  // panel p has landed once at most the DMAs of panel p + 1 are outstanding (VMEM operations retire in order); the barrier
+  // makes every wave's share visible and proves every wave is past panel p - 1, whose stage panel p + 2 then overwrites
+#define EFX_BEGIN(p_)                                                                                      \
+  {                                                                                                        \
+    if ((p_) + 1 < NPANEL) LOFTR_WAITCNT_VM(DMA_PER_WAVE); else LOFTR_WAITCNT_VM(0);                       \
+    __builtin_amdgcn_s_barrier();                                                                          \
+    if ((p_) + 2 < NPANEL) EFX_ISSUE((p_) + 2);                                                            \
+  }
+  const int a_off = lds_chunk_off(li, g);               // hi chunk of the even k-step; odd k-step: ^ 32, lo: ^ 64
+  // LDS fragment reads run one UNIT (four 16-B fragments, six MFMAs = 192 matrix-pipe cycles) ahead of the MFMAs that
+  // consume them -- one wave per SIMD: nobody else hides the ds_read latency.  With LDS-DMA in flight hipcc turns every
+  // LDS wait into lgkmcnt(0); EFX_USE (an empty asm that names the current fragments) pins that wait BEFORE the next
+  // unit's reads are issued, so it only ever waits for reads issued a whole unit earlier.
+#define EFX_RD(st_, blk_, odd_, lo_) (*reinterpret_cast<const h16x8*>((st_) + (blk_) * BLK + (a_off ^ (((odd_) ? 32 : 0) | ((lo_) ? 64 : 0)))))
+#define EFX_USE(a_, b_, c_, d_) asm volatile("" :: "v"(a_), "v"(b_), "v"(c_), "v"(d_))
+  // R panel: acc0 / acc1 (two chains) += W[32 rows][256 k] . B fragments bh / bl; unit u = k-group u = k-steps 2u, 2u + 1
+#define EFX_RPANEL(st_, bh_, bl_)                                                                          \
+  {                                                                                                        \
+    h16x8 eh__ = EFX_RD(st_, 0, 0, 0), el__ = EFX_RD(st_, 0, 0, 1), oh__ = EFX_RD(st_, 0, 1, 0), ol__ = EFX_RD(st_, 0, 1, 1); \
+    _Pragma("unroll") for (int u = 0; u < 8; ++u) {                                                        \
+      EFX_USE(eh__, el__, oh__, ol__);                                                                     \
+      __builtin_amdgcn_sched_barrier(0);                                                                   \
+      h16x8 neh__ = eh__, nel__ = el__, noh__ = oh__, nol__ = ol__;                                        \
+      if (u + 1 < 8) {                                                                                     \
+        neh__ = EFX_RD(st_, u + 1, 0, 0); nel__ = EFX_RD(st_, u + 1, 0, 1);                                \
+        noh__ = EFX_RD(st_, u + 1, 1, 0); nol__ = EFX_RD(st_, u + 1, 1, 1);                                \
+      }                                                                                                    \
+      __builtin_amdgcn_sched_barrier(0);                                                                   \
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(eh__, bl_[2 * u], acc0, 0, 0, 0);                      \
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(el__, bh_[2 * u], acc1, 0, 0, 0);                      \
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(eh__, bh_[2 * u], acc0, 0, 0, 0);                      \
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(oh__, bl_[2 * u + 1], acc1, 0, 0, 0);                  \
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ol__, bh_[2 * u + 1], acc0, 0, 0, 0);                  \
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(oh__, bh_[2 * u + 1], acc1, 0, 0, 0);                  \
+      __builtin_amdgcn_sched_barrier(0);                                                                   \
+      eh__ = neh__; el__ = nel__; oh__ = noh__; ol__ = nol__;                                              \
+    }                                                                                                      \
+  }
+  // K panel: out_[jp] += W[32 jp .. + 31][32 k] . the two k-step fragments fh / fl; unit u = (output panels 2 j2, 2 j2 + 1,
+  // k-step s): six MFMAs alternating between the two accumulators
+#define EFX_KPANEL(st_, fh_, fl_, out_)                                                                    \
+  {                                                                                                        \
+    h16x8 ah__ = EFX_RD(st_, 0, 0, 0), al__ = EFX_RD(st_, 0, 0, 1), bh__ = EFX_RD(st_, 1, 0, 0), bl__ = EFX_RD(st_, 1, 0, 1); \
+    _Pragma("unroll") for (int u = 0; u < 8; ++u) {                                                        \
+      const int j2 = u >> 1, s = u & 1;                                                                    \
+      EFX_USE(ah__, al__, bh__, bl__);                                                                     \
+      __builtin_amdgcn_sched_barrier(0);                                                                   \
+      h16x8 nah__ = ah__, nal__ = al__, nbh__ = bh__, nbl__ = bl__;                                        \
+      if (u + 1 < 8) {                                                                                     \
+        const int nj = (u + 1) >> 1, ns = (u + 1) & 1;                                                     \
+        nah__ = EFX_RD(st_, 2 * nj, ns, 0); nal__ = EFX_RD(st_, 2 * nj, ns, 1);                            \
+        nbh__ = EFX_RD(st_, 2 * nj + 1, ns, 0); nbl__ = EFX_RD(st_, 2 * nj + 1, ns, 1);                    \
+      }                                                                                                    \
+      __builtin_amdgcn_sched_barrier(0);                                                                   \
+      out_[2 * j2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah__, fl_[s], out_[2 * j2], 0, 0, 0);          \
+      out_[2 * j2 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh__, fl_[s], out_[2 * j2 + 1], 0, 0, 0);  \
+      out_[2 * j2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al__, fh_[s], out_[2 * j2], 0, 0, 0);          \
+      out_[2 * j2 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl__, fh_[s], out_[2 * j2 + 1], 0, 0, 0);  \
+      out_[2 * j2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah__, fh_[s], out_[2 * j2], 0, 0, 0);          \
+      out_[2 * j2 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh__, fh_[s], out_[2 * j2 + 1], 0, 0, 0);  \
+      __builtin_amdgcn_sched_barrier(0);                                                                   \
+      ah__ = nah__; al__ = nal__; bh__ = nbh__; bl__ = nbl__;                                              \
+    }                                                                                                      \
+  }
+
+  LOFTR_WAITCNT_VM(0);                                  // x fragments, tables: complete before the first DMA
+  __syncthreads();
+  EFX_ISSUE(0);
+  EFX_ISSUE(1);
+
+  const int fq = 4 * g;                                 // first feature of register quad 0 inside a panel (quad q: + 8 q)
+  f32x16 acc0, acc1;
+  f32x16 big[8];                                        // message accumulators (pass 1), then output accumulators (pass 2)
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) big[j][r] = 0.f;
+
+  // ================= pass 1: per head h,  Q'_h = f(Wq_h x)  ->  message += P[:, h] Q'_h ==========================
+#pragma unroll 1
+  for (int h = 0; h < 8; ++h) {
+    const int p = 2 * h;
+    EFX_BEGIN(p);
+    h16x8 qh[2], ql[2];
+    if (live) {
+      const char* st = lds + (p % NST) * STAGE;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+      EFX_RPANEL(st, xh, xl);
+      // elu + 1, mask, attention normaliser z = S / (Q . Ksum + eps): the wave's 32 features ARE head h       linear_attention.py:31-36,44-45
+      float v[16];
+      float den = 0.f;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 ws = *reinterpret_cast<const f32x4*>(tab + T_WQS + 32 * h + fq + 8 * q);
+        const f32x4 ks4 = *reinterpret_cast<const f32x4*>(tab + T_KSUM + 32 * h + fq + 8 * q);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float x = (acc0[4 * q + e] + acc1[4 * q + e]) * ws[e];
+          x = x > 0.f ? x + 1.f : __expf(x);
+          x *= mk;
+          v[4 * q + e] = x;
+          den = fmaf(x, ks4[e], den);
+        }
+      }
+      den += swap32(den);
+      const float z = a.v_length * __builtin_amdgcn_rcpf(den + a.attn_eps);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) v[r] *= z;
+      pack_panel(v, qh, ql);
+    }
+    EFX_BEGIN(p + 1);
+    if (live) {
+      const char* st = lds + ((p + 1) % NST) * STAGE;
+      EFX_KPANEL(st, qh, ql, big);
+    }
+  }
+  // ---- message = LayerNorm1(p_out_scale * acc) -> B fragments (features 256 .. 511 of the mlp.0 input)     transformer.py:51-52
+  h16x8 mh[16], ml[16];
+  if (live) {
+    // the accumulators are only READ here (they stay where the MFMAs left them); p_out_scale is folded into the statistics
+    const float ps = a.p_out_scale;
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s += big[j][r];
+    s += swap32(s);
+    const float mean_a = s * (1.f / 256.f);             // mean of the unscaled accumulators
+    float m2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { const float d = big[j][r] - mean_a; m2 = fmaf(d, d, m2); }
+    m2 += swap32(m2);
+    const float rstd = ps * rsqrtf(ps * ps * m2 * (1.f / 256.f) + a.ln_eps);   // (ps v - ps mean) * rsqrt(var(ps v) + eps)
+    const float mean = mean_a;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float y[16];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 ga = *reinterpret_cast<const f32x4*>(tab + T_G1 + 32 * j + fq + 8 * q);
+        const f32x4 be = *reinterpret_cast<const f32x4*>(tab + T_B1 + 32 * j + fq + 8 * q);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) y[4 * q + e] = (big[j][4 * q + e] - mean) * rstd * ga[e] + be[e];
+      }
+      h16x8 fh[2], fl[2];
+      pack_panel(y, fh, fl);
+      mh[2 * j] = fh[0]; mh[2 * j + 1] = fh[1]; ml[2 * j] = fl[0]; ml[2 * j + 1] = fl[1];
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) big[j][r] = 0.f;
+
+  // ================= pass 2: per 32 hidden features,  hid = relu(W0[hp] [x, message])  ->  out += W2[:, hp] hid =====
+#define EFX_PASS2_HEAD(hp_)                                                                                \
+    const int p = 16 + 3 * (hp_);                       /* stages (p % 3) = 1, 2, 0: static */             \
+    h16x8 hh[2], hl[2];                                                                                    \
+    EFX_BEGIN(p);                                                                                          \
+    if (live) {                                                                                            \
+      _Pragma("unroll") for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }                     \
+      EFX_RPANEL(lds + 1 * STAGE, xh, xl);                                                                 \
+    }                                                                                                      \
+    EFX_BEGIN(p + 1);                                                                                      \
+    if (live) {                                                                                            \
+      EFX_RPANEL(lds + 2 * STAGE, mh, ml);                                                                 \
+      float v[16];                                                                                         \
+      _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                      \
+        const f32x4 ws = *reinterpret_cast<const f32x4*>(tab + T_W0S + 32 * (hp_) + fq + 8 * q);           \
+        _Pragma("unroll") for (int e = 0; e < 4; ++e)                                                      \
+          v[4 * q + e] = fmaxf((acc0[4 * q + e] + acc1[4 * q + e]) * ws[e], 0.f);   /* transformer.py:55 (ReLU) */ \
+      }                                                                                                    \
+      pack_panel(v, hh, hl);                                                                               \
+    }                                                                                                      \
+    EFX_BEGIN(p + 2);
+#pragma unroll 1
+  for (int hp = 0; hp < 16; ++hp) {
+    EFX_PASS2_HEAD(hp)
+    if (live) EFX_KPANEL(lds + 0 * STAGE, hh, hl, big);
+  }
+#undef EFX_PASS2_HEAD
+#undef EFX_ISSUE
+#undef EFX_BEGIN
+#undef EFX_RPANEL
+#undef EFX_KPANEL
+#undef EFX_RD
+#undef EFX_USE
+
+  // ================= out = x + LayerNorm2(mlp.2 output), fp32 and SP                                          transformer.py:55-58
+  if (!live) return;
+  {
+    // o = acc * w2 row scale, evaluated on the fly in each of the three passes (the accumulators are only read)
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 ws = *reinterpret_cast<const f32x4*>(tab + T_W2S + 32 * j + fq + 8 * q);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s = fmaf(big[j][4 * q + e], ws[e], s);
+      }
+    s += swap32(s);
+    const float mean = s * (1.f / 256.f);
+    float m2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 ws = *reinterpret_cast<const f32x4*>(tab + T_W2S + 32 * j + fq + 8 * q);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float d = big[j][4 * q + e] * ws[e] - mean; m2 = fmaf(d, d, m2); }
+      }
+    m2 += swap32(m2);
+    const float rstd = rsqrtf(m2 * (1.f / 256.f) + a.ln_eps);
+    // (both lanes of a token -- lane, lane ^ 32 -- take the same branch, so the exchanges inside stay paired)
+    if (tok < T) {
+      const float* xr = a.x_f32 + row * 256;
+      float* of = a.out_f32 + row * 256;
+      sp_t* os = a.out_sp + row * 256;
+      f32x4 xn[4];                                      // residual rows one panel ahead of their use (their loads are older than
+#pragma unroll                                          // the previous panel's stores: the wait for them is a counted vmcnt)
+      for (int q = 0; q < 4; ++q) xn[q] = *reinterpret_cast<const f32x4*>(xr + fq + 8 * q);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        f32x4 xc[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) xc[q] = xn[q];
+        if (j + 1 < 8) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) xn[q] = *reinterpret_cast<const f32x4*>(xr + 32 * (j + 1) + fq + 8 * q);
+        }
+        float y[16];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int f = 32 * j + fq + 8 * q;
+          const f32x4 ga = *reinterpret_cast<const f32x4*>(tab + T_G2 + f);
+          const f32x4 be = *reinterpret_cast<const f32x4*>(tab + T_B2 + f);
+          const f32x4 ws = *reinterpret_cast<const f32x4*>(tab + T_W2S + f);
+          f32x4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            o[e] = xc[q][e] + ((big[j][4 * q + e] * ws[e] - mean) * rstd * ga[e] + be[e]);
+            y[4 * q + e] = o[e];
+          }
+          *reinterpret_cast<f32x4*>(of + f) = o;
+        }
+        if (!a.out_sp) continue;                          // (loftr_encoder_layer_fwd: fp32 result only)
+        h16x8 fh[2], fl[2];
+        pack_panel(y, fh, fl);
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          *reinterpret_cast<u32x4*>(os + j * 32 + (2 * s2 + g) * 4) = __builtin_bit_cast(u32x4, fh[s2]);
+          *reinterpret_cast<u32x4*>(os + j * 32 + 16 + (2 * s2 + g) * 4) = __builtin_bit_cast(u32x4, fl[s2]);
+        }
+      }
+    }
+  }
+}
+}  // namespace efx
+}  // namespace
+
+// LOFTR_FUSED_ENCODER=0 keeps the four-kernel form (A/B)
+static bool fused_enabled() {
+  static const bool on = []() { const char* e = getenv("LOFTR_FUSED_ENCODER"); return !(e && atoi(e) == 0); }();
+  return on;
+}
+
+int launch_encoder_x(const EncoderXArgs& p, hipStream_t st) {
+  if (!fused_enabled() || p.C != 256 || p.nseq <= 0 || p.T <= 0 || !p.wq_s || !p.w0_s || !p.w2_s || !p.kv) return LOFTR_ERR_UNSUPPORTED;
+  efx::Args a{};
+  a.x_sp = p.x_sp; a.x_f32 = p.x_f32; a.out_f32 = p.out_f32; a.out_sp = p.out_sp;
+  a.wq = p.wq; a.pm = p.pm; a.pm_seq_stride = p.pm_seq_stride; a.w0 = p.w0; a.w2 = p.w2;
+  a.wq_s = p.wq_s; a.w0_s = p.w0_s; a.w2_s = p.w2_s; a.kv = p.kv; a.mask = p.mask;
+  a.g1 = p.g1; a.b1 = p.b1; a.g2 = p.g2; a.b2 = p.b2;
+  a.v_length = p.v_length; a.attn_eps = p.attn_eps; a.p_out_scale = p.p_out_scale; a.ln_eps = p.ln_eps;
+  a.nseq = p.nseq; a.T = p.T; a.groups = ceil_div(ceil_div(p.T, efx::PT), efx::W);
+  const int grid = NUM_XCD * ceil_div(p.nseq, NUM_XCD) * a.groups;
+  TimedLaunch tl(LOFTR_T_ENCODER_X, st);
+  hipLaunchKernelGGL(efx::encoder_x_kernel, dim3(grid), dim3(efx::W * 64), 0, st, a);
+  LOFTR_CHECK_LAUNCH();
+  return LOFTR_OK;
+}

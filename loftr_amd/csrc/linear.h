@@ -82,3 +82,18 @@ int launch_linear_ln(const LinearLNArgs& p, hipStream_t st);
 // LOFTR_ERR_UNSUPPORTED for any other shape / option; the caller then uses launch_proj / launch_linear_ln.
 int launch_rowsweep_q(const ProjArgs& p, hipStream_t st);
 int launch_rowsweep_ln(const LinearLNArgs& p, hipStream_t st);
+
+// The whole x side of a coarse encoder layer (q projection + feature map + normaliser, merge with the per-sequence P +
+// norm1, mlp.0 + ReLU, mlp.2 + norm2 + residual) in one launch with the tokens stationary in registers (encoder_fused.hip).
+// C = 256 only; LOFTR_ERR_UNSUPPORTED otherwise (the caller then runs the four separate kernels).
+struct EncoderXArgs {
+  const sp_t* x_sp; const float* x_f32; float* out_f32; sp_t* out_sp;   // [nseq * T, C]; out may alias x
+  int nseq, T, C;
+  const sp_t* wq; const sp_t* pm; long pm_seq_stride; const sp_t* w0; const sp_t* w2;
+  const float *wq_s, *w0_s, *w2_s;                    // inverse row scales of wq / w0 / w2
+  const float* kv;                                    // [nseq, 8, 33, 32]
+  const uint8_t* mask;                                // [nseq * T] or null
+  const float *g1, *b1, *g2, *b2;
+  float v_length, attn_eps, p_out_scale, ln_eps;
+};
+int launch_encoder_x(const EncoderXArgs& p, hipStream_t st);

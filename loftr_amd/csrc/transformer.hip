@@ -114,6 +114,12 @@ int encoder_layer(const float* x_f32, const sp_t* x_sp, const sp_t* src_sp, bool
     const float* kv = nullptr; const sp_t* pm = nullptr;
     if ((rc = launch_attention_finalize(w.merge_f32, nb, S, C, H, e.attn, e.attn_bytes, &kv, &pm, st))) return rc;
     (void)Ms;
+    // round 3: everything on the x side of the layer in ONE launch, tokens stationary in registers (encoder_fused.hip)
+    {
+      EncoderXArgs fx{x_sp, x_f32, out_f32, out_sp, nb, L, C, w.q, pm, (long)C * C, w.mlp0, w.mlp2, w.q_s, w.mlp0_s, w.mlp2_s,
+                      kv, x_mask, w.n1w, w.n1b, w.n2w, w.n2b, (float)S, attn_eps, 1.f / ATTN_P_SCALE, 1e-5f};
+      if ((rc = launch_encoder_x(fx, st)) != LOFTR_ERR_UNSUPPORTED) return rc;
+    }
     // q projection with the normaliser applied in its epilogue (per pair: grid.z = nb)
     ProjArgs pq{x_sp, L, C, nb, 1, {w.q, nullptr, nullptr}, {e.q, nullptr, nullptr}, {0, 0, 0}, x_mask, inv_s,
                 kv, (float)S, attn_eps, {w.q_s, nullptr, nullptr}};

@@ -41,9 +41,14 @@ def test_algorithmic_work_matches_design_table(bench):
     # k/v projection with the fused KV reduction, 8 layer passes over both images
     assert w["proj_kv_kernel"][0] == 8 * (2 * rows * C * 2 * C + 2 * rows * C * 32)
     # encoder per layer pass and pair (6.45 GFLOP per call incl. attention): projections + merge + MLP
-    w0 = bench.algorithmic_work(B, L, L, 0)                                # no matches: the coarse level alone
-    per_call = (w0["proj_kernel"][0] + w0["proj_kv_kernel"][0] + w0["linear_kernel"][0] + w0["linear_ln_kernel"][0]) / 8 / (2 * B)
-    assert abs(per_call / 1e9 - 6.45) < 0.2                                # 6.45 GFLOP per encoder call
+    for fused in (False, True):                                            # four kernels per layer call, or encoder_x_kernel (round 3)
+        w0 = bench.algorithmic_work(B, L, L, 0, fused=fused)               # no matches: the coarse level alone
+        per_call = sum(w0[k][0] for k in ("proj_kernel", "proj_kv_kernel", "linear_kernel", "linear_ln_kernel", "encoder_x_kernel")
+                       if k in w0) / 8 / (2 * B)
+        assert abs(per_call / 1e9 - 6.45) < 0.2                            # 6.45 GFLOP per encoder call
+    # fused x side: x (SP + fp32) in, out (fp32 + SP) in place -- 4 tensor streams per call
+    wf = bench.algorithmic_work(B, L, L, 0, fused=True)
+    assert wf["encoder_x_kernel"][1] == 8 * 4 * (4 * rows * C + 8 * C * C) and wf["proj_kernel"][0] == 0
     assert w["linear_kernel"][0] > w0["linear_kernel"][0]                  # the fine level rides on the same kernels
     # the three conv entries partition the 21 convolutions of 2B images
     convs = bench.backbone_convs(480, 640)
