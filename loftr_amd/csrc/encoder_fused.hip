@@ -12,8 +12,8 @@
 //
 // Design.  A workgroup is four waves, one per SIMD (up to 512 registers each); a wave owns 32 tokens for the whole layer:
 //   * its tokens' activations are the MFMA's B operand (lane = token, 8 consecutive features per lane and k-step, hi and lo
-//     halves), the weights are the A operand and stream through a three-stage LDS ring that the four waves share: panels
-//     of 32 KB = 8 blocks of (32 rows x 128 B), filled by global_load_lds two panels ahead, ONE barrier per panel
+//     halves), the weights are the A operand and stream through a four-stage LDS ring that the four waves share: panels
+//     of 32 KB = 8 blocks of (32 rows x 128 B), filled by global_load_lds NST - 1 panels ahead, ONE barrier per panel
 //     (48 MFMAs per wave);
 //   * with D[feature][token] the lane that owns a token RECEIVES that token's outputs (16 features per 32-feature panel,
 //     the other 16 in lane ^ 32): an output panel becomes the next GEMM's B fragments by a (hi, lo) split and eight
@@ -30,7 +30,20 @@
 
 namespace {
 namespace efx {
-constexpr int W = 4, PT = 32, STAGE = 32 * 1024, NST = 3, BLK = 4096;
+#ifndef EFX_NST
+#define EFX_NST 4
+#endif
+// timing probes (wrong results): 0 = no weight DMA after the prologue / no per-panel barrier / no epilogue arithmetic
+#ifndef EFX_PROBE_DMA
+#define EFX_PROBE_DMA 1
+#endif
+#ifndef EFX_PROBE_BARRIER
+#define EFX_PROBE_BARRIER 1
+#endif
+#ifndef EFX_PROBE_EPI
+#define EFX_PROBE_EPI 1
+#endif
+constexpr int W = 4, PT = 32, STAGE = 32 * 1024, NST = EFX_NST, BLK = 4096;     // ring stages: panels are fetched NST - 1 ahead
 constexpr int NPANEL = 16 + 48;                         // 8 x (Wq_h, P_h) + 16 x (W0a, W0b, W2_k)
 constexpr int DMA_PER_WAVE = 8;                         // global_load_lds per wave and panel: 2 blocks x 4 row octets
 // per-feature tables (floats) behind the ring
@@ -69,6 +82,11 @@ __device__ __forceinline__ void sp_pack4(float x0, float x1, float x2, float x3,
 // token) -> the lane's B-operand fragments of the panel's two k-steps (k-step s, element e = feature 16 s + 8 g + e).
 // g = 0 keeps its quads 0 / 2 and receives the partner's (features +4), g = 1 keeps 1 / 3 and receives the partner's.
 __device__ __forceinline__ void pack_panel(const float (&v)[16], h16x8 (&fh)[2], h16x8 (&fl)[2]) {
+  if (!EFX_PROBE_EPI) {                                 // probe: the accumulator bits as they are
+    fh[0] = __builtin_bit_cast(h16x8, f32x4{v[0], v[1], v[2], v[3]}); fl[0] = __builtin_bit_cast(h16x8, f32x4{v[4], v[5], v[6], v[7]});
+    fh[1] = __builtin_bit_cast(h16x8, f32x4{v[8], v[9], v[10], v[11]}); fl[1] = __builtin_bit_cast(h16x8, f32x4{v[12], v[13], v[14], v[15]});
+    return;
+  }
   uint2 H[4], L[4];
 #pragma unroll
   for (int q = 0; q < 4; ++q) sp_pack4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3], H[q], L[q]);
@@ -149,13 +167,16 @@ __global__ __launch_bounds__(W * 64, 1) void encoder_x_kernel(Args a) {
                                          (lds_ptr_t)(st__ + b__ * BLK + oct__ * 1024), 16, 0, 0);          \
     }                                                                                                      \
   }
-  // panel p has landed once at most the DMAs of panel p + 1 are outstanding (VMEM operations retire in order); the barrier
-  // makes every wave's share visible and proves every wave is past panel p - 1, whose stage panel p + 2 then overwrites
+  // panel p has landed once at most the DMAs of the NST - 2 newer panels are outstanding (VMEM operations retire in order); the
+  // barrier makes every wave's share visible and proves every wave is past panel p - 1, whose stage panel p + NST - 1 then overwrites
 #define EFX_BEGIN(p_)                                                                                      \
   {                                                                                                        \
-    if ((p_) + 1 < NPANEL) LOFTR_WAITCNT_VM(DMA_PER_WAVE); else LOFTR_WAITCNT_VM(0);                       \
-    __builtin_amdgcn_s_barrier();                                                                          \
-    if ((p_) + 2 < NPANEL) EFX_ISSUE((p_) + 2);                                                            \
+    if (!EFX_PROBE_DMA) LOFTR_WAITCNT_VM(0);                                                               \
+    else if (NST >= 4 && (p_) + 2 < NPANEL) LOFTR_WAITCNT_VM(2 * DMA_PER_WAVE);                            \
+    else if ((p_) + 1 < NPANEL) LOFTR_WAITCNT_VM(DMA_PER_WAVE);                                            \
+    else LOFTR_WAITCNT_VM(0);                                                                              \
+    if (EFX_PROBE_BARRIER) __builtin_amdgcn_s_barrier();                                                   \
+    if (EFX_PROBE_DMA && (p_) + NST - 1 < NPANEL) EFX_ISSUE((p_) + NST - 1);                               \
   }
   const int a_off = lds_chunk_off(li, g);               // hi chunk of the even k-step; odd k-step: ^ 32, lo: ^ 64
   // LDS fragment reads run one UNIT (four 16-B fragments, six MFMAs = 192 matrix-pipe cycles) ahead of the MFMAs that
@@ -218,6 +239,7 @@ __global__ __launch_bounds__(W * 64, 1) void encoder_x_kernel(Args a) {
   __syncthreads();
   EFX_ISSUE(0);
   EFX_ISSUE(1);
+  if (NST >= 4) EFX_ISSUE(2);
 
   const int fq = 4 * g;                                 // first feature of register quad 0 inside a panel (quad q: + 8 q)
   f32x16 acc0, acc1;
@@ -248,7 +270,7 @@ __global__ __launch_bounds__(W * 64, 1) void encoder_x_kernel(Args a) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           float x = (acc0[4 * q + e] + acc1[4 * q + e]) * ws[e];
-          x = x > 0.f ? x + 1.f : __expf(x);
+          if (EFX_PROBE_EPI) x = x > 0.f ? x + 1.f : __expf(x);
           x *= mk;
           v[4 * q + e] = x;
           den = fmaf(x, ks4[e], den);
@@ -308,16 +330,16 @@ __global__ __launch_bounds__(W * 64, 1) void encoder_x_kernel(Args a) {
 
   // ================= pass 2: per 32 hidden features,  hid = relu(W0[hp] [x, message])  ->  out += W2[:, hp] hid =====
 #define EFX_PASS2_HEAD(hp_)                                                                                \
-    const int p = 16 + 3 * (hp_);                       /* stages (p % 3) = 1, 2, 0: static */             \
+    const int p = 16 + 3 * (hp_);                                                                          \
     h16x8 hh[2], hl[2];                                                                                    \
     EFX_BEGIN(p);                                                                                          \
     if (live) {                                                                                            \
       _Pragma("unroll") for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }                     \
-      EFX_RPANEL(lds + 1 * STAGE, xh, xl);                                                                 \
+      EFX_RPANEL(lds + (p % NST) * STAGE, xh, xl);                                                                 \
     }                                                                                                      \
     EFX_BEGIN(p + 1);                                                                                      \
     if (live) {                                                                                            \
-      EFX_RPANEL(lds + 2 * STAGE, mh, ml);                                                                 \
+      EFX_RPANEL(lds + ((p + 1) % NST) * STAGE, mh, ml);                                                                 \
       float v[16];                                                                                         \
       _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                      \
         const f32x4 ws = *reinterpret_cast<const f32x4*>(tab + T_W0S + 32 * (hp_) + fq + 8 * q);           \
@@ -330,7 +352,7 @@ __global__ __launch_bounds__(W * 64, 1) void encoder_x_kernel(Args a) {
 #pragma unroll 1
   for (int hp = 0; hp < 16; ++hp) {
     EFX_PASS2_HEAD(hp)
-    if (live) EFX_KPANEL(lds + 0 * STAGE, hh, hl, big);
+    if (live) EFX_KPANEL(lds + ((p + 2) % NST) * STAGE, hh, hl, big);
   }
 #undef EFX_PASS2_HEAD
 #undef EFX_ISSUE

@@ -43,7 +43,10 @@ class RcclCounts:
         if self.rank == 0:
             _lib.check(self.lib.loftr_rccl_unique_id(buf, nbytes), "loftr_rccl_unique_id")
         box = [bytes(buf.raw) if self.rank == 0 else None]
-        dist.broadcast_object_list(box, src=0, group=group)
+        # `src` of a broadcast is a GLOBAL rank: the id comes from the process that is rank 0 OF THIS GROUP (a sub-group need not
+        # contain global rank 0)
+        src = dist.get_global_rank(group, 0) if group is not None else 0
+        dist.broadcast_object_list(box, src=src, group=group)
         handle = C.c_void_p()
         with torch.cuda.device(self.device):                    # the communicator binds to the current device
             _lib.check(self.lib.loftr_rccl_comm_create(box[0], nbytes, self.rank, self.world, C.byref(handle)),

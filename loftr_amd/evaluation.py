@@ -108,19 +108,43 @@ def estimate_pose_native(kpts0, kpts1, K0, K1, thresh, conf=0.99999, seed=0):
     return R.astype(np.float64), t.astype(np.float64), inl.astype(bool)
 
 
-def compute_pose_errors(data, config=None, estimator=None, on_missing="raise"):
-    """metrics.py:103-140.  Update: data['R_errs'], ['t_errs'] (lists of float), ['inliers'] (list of bool arrays).
+_WARNED_NATIVE = []
 
-    estimator(kpts0, kpts1, K0, K1, pixel_thr, conf=) -> (R, t, inlier_mask) | None; default: OpenCV as in the
-    reference when importable, else estimate_pose_native.  (on_missing is kept for callers of the round-1 signature.)"""
+
+def compute_pose_errors(data, config=None, estimator=None, on_missing="raise"):
+    """metrics.py:103-140.  Update: data['R_errs'], ['t_errs'] (lists of float), ['inliers'] (list of bool arrays) and
+    data['pose_estimator'] (which estimator produced them: the AUCs depend on it).
+
+    estimator(kpts0, kpts1, K0, K1, pixel_thr, conf=) -> (R, t, inlier_mask) | None.  Default: OpenCV, as the reference
+    uses.  When OpenCV is not importable, `on_missing` decides -- never silently:
+      'raise'  (default) ImportError, like the reference's `import cv2`;
+      'inf'    record R_err = t_err = inf for every pair (the reference's value for a failed estimate);
+      'native' the library's five-point RANSAC (csrc/pose.hip).  PARITY UNPINNED against cv2.findEssentialMat /
+               recoverPose (own sampling sequence): a one-time warning says so; passing estimator=estimate_pose_native is
+               the explicit form of the same opt-in."""
     pixel_thr = _cfg_get(config, ("TRAINER", "RANSAC_PIXEL_THR"), 0.5)
     conf = _cfg_get(config, ("TRAINER", "RANSAC_CONF"), 0.99999)
+    if on_missing not in ("raise", "inf", "native"):
+        raise ValueError(f"on_missing={on_missing!r}: expected 'raise', 'inf' or 'native'")
+    name = getattr(estimator, "__name__", "custom") if estimator is not None else None
     if estimator is None:
         try:
             import cv2  # noqa: F401
-            estimator = estimate_pose_cv2
+            estimator, name = estimate_pose_cv2, "cv2"
         except ImportError:
-            estimator = estimate_pose_native       # OpenCV absent: the library's five-point RANSAC (parity unpinned)
+            if on_missing == "raise":
+                raise ImportError("compute_pose_errors needs OpenCV (cv2.findEssentialMat / recoverPose, metrics.py:72-98); pass "
+                                  "on_missing='native' (library five-point RANSAC, parity unpinned) or 'inf', or an estimator")
+            if on_missing == "native":
+                estimator, name = estimate_pose_native, "estimate_pose_native"
+                if not _WARNED_NATIVE:
+                    _WARNED_NATIVE.append(True)
+                    import warnings
+                    warnings.warn("OpenCV is not importable: pose errors / AUC come from loftr_amd's five-point RANSAC, whose "
+                                  "parity with cv2.findEssentialMat(RANSAC) + recoverPose is unpinned", stacklevel=2)
+            else:
+                name = "none (inf)"
+    data["pose_estimator"] = name
     data.update({"R_errs": [], "t_errs": [], "inliers": []})
     m_bids = data["m_bids"].cpu().numpy()
     pts0, pts1 = data["mkpts0_f"].cpu().numpy(), data["mkpts1_f"].cpu().numpy()

@@ -130,18 +130,30 @@ class LocalFeatureTransformer(nn.Module):
         mats = [getattr(getattr(layer, n) if "." not in n else layer.mlp[int(n.split(".")[1])], "weight")
                 for layer in self.layers for n in ("q_proj", "k_proj", "v_proj", "merge", "mlp.0", "mlp.2")]
         key = tuple((t.data_ptr(), t._version) for t in mats) + (str(device),)
-        cached = getattr(self, "_loftr_prepared", None)
+        cached = ops._PREPARED.get(self)                 # module-keyed weak registry (not an attribute: modules stay picklable)
         if cached is None or cached[0] != key or not all(r() is t for r, t in zip(cached[2], mats)):
             cached = (key, ops.transformer_prepare(structs, self.d_model, device), [weakref.ref(t) for t in mats])
-            self._loftr_prepared = cached
+            ops._PREPARED[self] = cached
         return cached[1]
 
 
+def _valid_cells(mask):
+    """Cells of the top-left anchored valid rectangle of every sample of a padding mask [N, h, w] (what
+    pad_bottom_right produces): tallest column x widest row."""
+    return mask.sum(dim=1).amax(dim=-1) * mask.sum(dim=2).amax(dim=-1)
+
+
 def compute_max_candidates(p_m0, p_m1):
-    """coarse_matching.py:44-54: sum over the batch of min(valid area of image 0, of image 1) in coarse cells."""
-    h0s, w0s = p_m0.sum(1).max(-1)[0], p_m0.sum(-1).max(-1)[0]
-    h1s, w1s = p_m1.sum(1).max(-1)[0], p_m1.sum(-1).max(-1)[0]
-    return torch.sum(torch.min(torch.stack([h0s * w0s, h1s * w1s], -1), -1)[0])
+    """Upper bound on the number of coarse matches of a padded batch: per pair the smaller of the two valid areas, summed
+    (reference semantics: coarse_matching.py:44-54)."""
+    return torch.minimum(_valid_cells(p_m0), _valid_cells(p_m1)).sum()
+
+
+def _cell_points(ids, width, scale, image_scale, b_ids):
+    """Pixel coordinates (x, y) of coarse cell ids on a grid `width` cells wide: cell -> (id mod width, id div width),
+    times the coarse stride and, for resized images, the per-image (w, h) ratio of the owning pair."""
+    xy = torch.stack((ids.remainder(width), ids.div(width, rounding_mode="floor")), dim=1)
+    return xy * (scale if image_scale is None else scale * image_scale[b_ids])
 
 
 class CoarseMatching(nn.Module):
@@ -200,38 +212,32 @@ class CoarseMatching(nn.Module):
 
 
     def _train_sample(self, r, data, scale):
-        """coarse_matching.py:200-259 on the kernels' match list: sample / pad the fine-level training set with
-        ground-truth matches (mconf = 0 marks the padding), then the coordinate bookkeeping for the padded list.
-        Same torch.randint calls as the reference, in the same order."""
-        if data["conf_matrix"] is None:
+        """Training-mode match list (reference semantics: coarse_matching.py:200-259).  The fine level trains on a fixed
+        budget of windows: a share of the candidate cells, filled with the kernels' predictions (subsampled with
+        replacement when there are too many) and topped up -- by at least `train_pad_num_gt_min` -- with ground-truth
+        matches, which carry mconf = 0 and are dropped again from the coordinate / confidence lists (but NOT from the id
+        lists the fine stage gathers with).  The two torch.randint draws happen in the reference's order (predictions,
+        then padding) so that a seeded run reproduces its sample."""
+        conf = data["conf_matrix"]
+        if conf is None:
             raise ops._lib.LoftrHipError("CoarseMatching.train(): materialize_conf must stay True (the losses read conf_matrix)")
-        b_ids, i_ids, j_ids, mconf = r["b_ids"], r["i_ids"], r["j_ids"], r["mconf"]
-        dev = mconf.device
-        N, L, S = data["conf_matrix"].shape
-        if "mask0" not in data:
-            num_candidates_max = N * max(L, S)
-        else:
-            num_candidates_max = compute_max_candidates(data["mask0"], data["mask1"])
-        num_matches_train = int(num_candidates_max * self.train_coarse_percent)
-        num_matches_pred = len(b_ids)
-        assert self.train_pad_num_gt_min < num_matches_train, "min-num-gt-pad should be less than num-train-matches"
-        if num_matches_pred <= num_matches_train - self.train_pad_num_gt_min:
-            pred_indices = torch.arange(num_matches_pred, device=dev)
-        else:
-            pred_indices = torch.randint(num_matches_pred, (num_matches_train - self.train_pad_num_gt_min,), device=dev)
-        gt_pad_indices = torch.randint(len(data["spv_b_ids"]),
-                                       (max(num_matches_train - num_matches_pred, self.train_pad_num_gt_min),), device=dev)
-        mconf_gt = torch.zeros(len(data["spv_b_ids"]), device=dev)
-        b_ids, i_ids, j_ids, mconf = (torch.cat([x[pred_indices], y[gt_pad_indices]], dim=0) for x, y in
-                                      ((b_ids, data["spv_b_ids"]), (i_ids, data["spv_i_ids"]), (j_ids, data["spv_j_ids"]),
-                                       (mconf, mconf_gt)))
-        scale0 = scale * data["scale0"][b_ids] if "scale0" in data else scale
-        scale1 = scale * data["scale1"][b_ids] if "scale1" in data else scale
-        mkpts0_c = torch.stack([i_ids % data["hw0_c"][1], i_ids // data["hw0_c"][1]], dim=1) * scale0
-        mkpts1_c = torch.stack([j_ids % data["hw1_c"][1], j_ids // data["hw1_c"][1]], dim=1) * scale1
-        keep = mconf != 0
-        return {"b_ids": b_ids, "i_ids": i_ids, "j_ids": j_ids, "gt_mask": mconf == 0, "m_bids": b_ids[keep],
-                "mkpts0_c": mkpts0_c[keep], "mkpts1_c": mkpts1_c[keep], "mconf": mconf[keep]}
+        n_batch, n0, n1 = conf.shape
+        cells = compute_max_candidates(data["mask0"], data["mask1"]) if "mask0" in data else n_batch * max(n0, n1)
+        budget, pad_min = int(cells * self.train_coarse_percent), self.train_pad_num_gt_min
+        assert pad_min < budget, "min-num-gt-pad should be less than num-train-matches"
+        pred = (r["b_ids"], r["i_ids"], r["j_ids"])
+        truth = (data["spv_b_ids"], data["spv_i_ids"], data["spv_j_ids"])
+        n_pred, n_truth, dev = pred[0].numel(), truth[0].numel(), r["mconf"].device
+        room = budget - pad_min                              # slots the predictions may take
+        take = torch.arange(n_pred, device=dev) if n_pred <= room else torch.randint(n_pred, (room,), device=dev)
+        fill = torch.randint(n_truth, (max(budget - n_pred, pad_min),), device=dev)
+        b_ids, i_ids, j_ids = (torch.cat((p[take], t[fill])) for p, t in zip(pred, truth))
+        mconf = torch.cat((r["mconf"][take], r["mconf"].new_zeros(fill.numel())))
+        predicted = mconf != 0                               # ground-truth padding is recognised by its zero confidence
+        pts0 = _cell_points(i_ids, data["hw0_c"][1], scale, data.get("scale0"), b_ids)
+        pts1 = _cell_points(j_ids, data["hw1_c"][1], scale, data.get("scale1"), b_ids)
+        return {"b_ids": b_ids, "i_ids": i_ids, "j_ids": j_ids, "gt_mask": ~predicted, "m_bids": b_ids[predicted],
+                "mkpts0_c": pts0[predicted], "mkpts1_c": pts1[predicted], "mconf": mconf[predicted]}
 
 
 class FinePreprocess(nn.Module):

@@ -21,11 +21,19 @@ LAYER_FIELDS = (("q_proj", "q_proj.weight"), ("k_proj", "k_proj.weight"), ("v_pr
                 ("norm2_w", "norm2.weight"), ("norm2_b", "norm2.bias"))
 
 
+# Prepared (re-encoded) weights per module, keyed weakly by the module: kept OUT of the modules' __dict__ so that
+# pickle / torch.save(model) / spawn-based launchers keep working after a forward (weak references do not pickle).
+_PREPARED = weakref.WeakKeyDictionary()
+
+
 def _tensors_in(obj):
     if isinstance(obj, torch.Tensor):
         yield obj
     elif isinstance(obj, (list, tuple)):
         for o in obj:
+            yield from _tensors_in(o)
+    elif isinstance(obj, dict):                   # the batch dict of training.spvs_* / LoFTRLoss: its tensors decide the device
+        for o in obj.values():
             yield from _tensors_in(o)
     elif isinstance(obj, torch.nn.Module):
         for prm in obj.parameters():
@@ -348,7 +356,7 @@ def _prepared_conv(conv, bn):
     assert conv.bias is None and conv.dilation == (1, 1) and conv.groups == 1
     bnp = [] if bn is None else [bn.weight, bn.bias, bn.running_mean, bn.running_var]
     key = tuple((t.data_ptr(), t._version, tuple(t.stride())) for t in [w] + bnp) + (None if bn is None else float(bn.eps), str(w.device))
-    cached = getattr(conv, "_loftr_prepared", None)
+    cached = _PREPARED.get(conv)
     # ... or replaced by a NEW tensor object the allocator put at the same address (weak references to the originals)
     if cached is not None and cached[0] == key and all(r() is t for r, t in zip(cached[2], [w] + bnp)):
         return cached[1]
@@ -359,7 +367,7 @@ def _prepared_conv(conv, bn):
     ptrs = [_ptr(t) for t in bnp] if bnp else [None] * 4
     check(lib.loftr_conv_prepare(_ptr(w), wst, Cin, Cout, KH, KW, *ptrs, float(bn.eps) if bn is not None else 0.0, _ptr(buf),
                                  buf.numel(), _stream()), "loftr_conv_prepare")
-    conv._loftr_prepared = (key, buf, [weakref.ref(t) for t in [w] + bnp])
+    _PREPARED[conv] = (key, buf, [weakref.ref(t) for t in [w] + bnp])
     return buf
 
 

@@ -4,8 +4,14 @@ Host-side mirror of the reference's interface: ``compute_supervision_coarse(data
 ``compute_supervision_fine(data, config)`` (src/loftr/utils/supervision.py:110-151) and ``LoFTRLoss(config)(data)``
 (src/losses/loftr_loss.py:7-192) mutate the batch dict with the same keys.  The arithmetic runs in csrc/train.hip
 behind the C-ABI (loftr_spvs_coarse, loftr_spvs_fine, loftr_coarse_loss_sums, loftr_fine_loss_sums); there is no CPU
-fallback.  NOT provided: backward passes (the losses are plain tensors without a graph) and the RNG-dependent
-ground-truth padding of CoarseMatching's training branch (coarse_matching.py:200-236)."""
+fallback.  NOT provided: backward passes (the losses are plain tensors without a graph).  The RNG-dependent
+ground-truth padding of CoarseMatching's training branch (coarse_matching.py:200-236) lives in
+loftr_amd/loftr.py:CoarseMatching._train_sample.
+
+Signature deviation: ``LoFTRLoss.compute_coarse_loss(conf, data)`` takes the batch dict (ground-truth id lists,
+padding masks) where the reference takes ``(conf, conf_gt, weight=None)`` -- the dense conf_matrix_gt / weight volumes are
+never needed here.  Value deviation: with no ground truth AND padding masks the reference zeroes weight[0, 0, 0], which also
+removes that one cell from the NEGATIVE term; here it stays in (1 / (N L S) relative, below the test tolerance)."""
 import ctypes as C
 
 import torch

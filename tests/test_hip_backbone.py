@@ -90,14 +90,17 @@ def test_prepared_weights_follow_inplace_updates():
     with torch.no_grad():
         y0 = run()
         assert (y0 - ref()).abs().max().item() < 1e-4
-        first = conv._loftr_prepared[1]
-        assert run() is not None and conv._loftr_prepared[1] is first          # second call: cache hit
+        first = ops._PREPARED[conv][1]
+        assert run() is not None and ops._PREPARED[conv][1] is first          # second call: cache hit
         conv.weight.mul_(2.0)                                                    # in place -> _version bump
-        assert (run() - ref()).abs().max().item() < 1e-4 and conv._loftr_prepared[1] is not first
+        assert (run() - ref()).abs().max().item() < 1e-4 and ops._PREPARED[conv][1] is not first
         bn.running_var.add_(1.0)
         assert (run() - ref()).abs().max().item() < 1e-4
         conv.weight.data = torch.randn(64, 64, 3, 3, generator=g).cuda() * 0.05  # replaced storage
         assert (run() - ref()).abs().max().item() < 1e-4
+    # the cache lives in a module-keyed weak registry, not in the module: a used module still pickles
+    import pickle
+    assert "_loftr_prepared" not in conv.__dict__ and pickle.loads(pickle.dumps(conv)).weight.shape == conv.weight.shape
 
 
 def test_prepared_weights_follow_tensor_identity():

@@ -70,7 +70,7 @@ def test_test_step_loop_and_dump(tmp_path):
                  "T_0to1": torch.from_numpy(sc["T_0to1"]).to(DEV), "K0": torch.from_numpy(sc["K0"]).to(DEV),
                  "K1": torch.from_numpy(sc["K1"]).to(DEV),
                  "pair_names": [[f"s{step}/a{b}.jpg" for b in range(N)], [f"s{step}/b{b}.jpg" for b in range(N)]]}
-        out = evaluation.test_step(matcher, batch, dump=True)
+        out = evaluation.test_step(matcher, batch, dump=True, on_missing="native")
         outputs.append(out)
         M = batch["mkpts0_f"].shape[0]
         assert M > 0 and batch["epi_errs"].shape == (M,)
@@ -87,5 +87,5 @@ def test_test_step_loop_and_dump(tmp_path):
     assert set(res) == {"auc@5", "auc@10", "auc@20", "prec@5e-04"} and 0.0 <= res["auc@5"] <= res["auc@20"] <= 1.0
     dumped = np.load(os.path.join(str(tmp_path), "LoFTR_pred_eval.npy"), allow_pickle=True)
     assert len(dumped) == 4 and dumped[0]["identifier"] == "s0/a0.jpg#s0/b0.jpg"
-    evaluation.compute_pose_errors(batch)                                                          # no cv2: native estimator
+    evaluation.compute_pose_errors(batch, on_missing="native")                                     # no cv2: explicit opt-in to the native estimator
     assert len(batch["R_errs"]) == N and len(batch["inliers"]) == N

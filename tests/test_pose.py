@@ -111,6 +111,22 @@ def test_compute_pose_errors_uses_native_estimator_without_cv2(lib):
             "mkpts1_f": torch.from_numpy(np.concatenate([s[1] for s in scenes])),
             "K0": torch.from_numpy(np.stack([s[2] for s in scenes])), "K1": torch.from_numpy(np.stack([s[3] for s in scenes])),
             "T_0to1": torch.from_numpy(np.stack([s[4] for s in scenes]))}
-    EV.compute_pose_errors(data)
+    try:
+        import cv2  # noqa: F401
+        pytest.skip("OpenCV present: the reference's estimator is used")
+    except ImportError:
+        pass
+    with pytest.raises(ImportError):                      # the default keeps the reference's behaviour: no cv2, no pose
+        EV.compute_pose_errors(dict(data))
+    d_inf = dict(data)
+    EV.compute_pose_errors(d_inf, on_missing="inf")
+    assert d_inf["R_errs"] == [np.inf, np.inf] and d_inf["pose_estimator"] == "none (inf)"
+    with pytest.warns(UserWarning, match="parity"):        # explicit opt-in to the unpinned estimator, flagged once
+        EV._WARNED_NATIVE.clear()
+        EV.compute_pose_errors(data, on_missing="native")
+    assert data["pose_estimator"] == "estimate_pose_native"
     assert len(data["R_errs"]) == 2 and max(data["R_errs"]) < 1.0 and max(data["t_errs"]) < 5.0
     assert all(len(i) == len(s[0]) for i, s in zip(data["inliers"], scenes))
+    d2 = dict(data)
+    EV.compute_pose_errors(d2, estimator=EV.estimate_pose_native)          # the explicit form
+    assert d2["pose_estimator"] == "estimate_pose_native" and max(d2["R_errs"]) < 1.0
