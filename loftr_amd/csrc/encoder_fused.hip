@@ -185,7 +185,10 @@ __global__ __launch_bounds__(W * 64, 1) void encoder_x_kernel(Args a) {
   // unit's reads are issued, so it only ever waits for reads issued a whole unit earlier.
 #define EFX_RD(st_, blk_, odd_, lo_) (*reinterpret_cast<const h16x8*>((st_) + (blk_) * BLK + (a_off ^ (((odd_) ? 32 : 0) | ((lo_) ? 64 : 0)))))
 #define EFX_USE(a_, b_, c_, d_) asm volatile("" :: "v"(a_), "v"(b_), "v"(c_), "v"(d_))
-  // R panel: acc0 / acc1 (two chains) += W[32 rows][256 k] . B fragments bh / bl; unit u = k-group u = k-steps 2u, 2u + 1
+  // R panel: acc0 += W[32 rows][256 k] . B fragments bh / bl; unit u = k-group u = k-steps 2u, 2u + 1.  ONE accumulator chain:
+  // a dependent v_mfma_f32_32x32x16_f16 issues at the full rate (tools/micro/mfma_chain.hip: 32.7 cycles per MFMA with 1, 2, 3
+  // or 4 chains).  The next unit's four fragment reads are issued in pairs BEHIND the first two MFMAs of this unit -- each pair
+  // in the shadow of a 32-cycle MFMA instead of as a burst in front of the unit -- and still >= 4 MFMAs ahead of their wait.
 #define EFX_RPANEL(st_, bh_, bl_)                                                                          \
   {                                                                                                        \
     h16x8 eh__ = EFX_RD(st_, 0, 0, 0), el__ = EFX_RD(st_, 0, 0, 1), oh__ = EFX_RD(st_, 0, 1, 0), ol__ = EFX_RD(st_, 0, 1, 1); \
@@ -193,39 +196,41 @@ __global__ __launch_bounds__(W * 64, 1) void encoder_x_kernel(Args a) {
       EFX_USE(eh__, el__, oh__, ol__);                                                                     \
       __builtin_amdgcn_sched_barrier(0);                                                                   \
       h16x8 neh__ = eh__, nel__ = el__, noh__ = oh__, nol__ = ol__;                                        \
-      if (u + 1 < 8) {                                                                                     \
-        neh__ = EFX_RD(st_, u + 1, 0, 0); nel__ = EFX_RD(st_, u + 1, 0, 1);                                \
-        noh__ = EFX_RD(st_, u + 1, 1, 0); nol__ = EFX_RD(st_, u + 1, 1, 1);                                \
-      }                                                                                                    \
-      __builtin_amdgcn_sched_barrier(0);                                                                   \
       acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(eh__, bl_[2 * u], acc0, 0, 0, 0);                      \
-      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(el__, bh_[2 * u], acc1, 0, 0, 0);                      \
+      __builtin_amdgcn_sched_barrier(0);                                                                   \
+      if (u + 1 < 8) { neh__ = EFX_RD(st_, u + 1, 0, 0); nel__ = EFX_RD(st_, u + 1, 0, 1); }               \
+      __builtin_amdgcn_sched_barrier(0);                                                                   \
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(el__, bh_[2 * u], acc0, 0, 0, 0);                      \
+      __builtin_amdgcn_sched_barrier(0);                                                                   \
+      if (u + 1 < 8) { noh__ = EFX_RD(st_, u + 1, 1, 0); nol__ = EFX_RD(st_, u + 1, 1, 1); }               \
+      __builtin_amdgcn_sched_barrier(0);                                                                   \
       acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(eh__, bh_[2 * u], acc0, 0, 0, 0);                      \
-      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(oh__, bl_[2 * u + 1], acc1, 0, 0, 0);                  \
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(oh__, bl_[2 * u + 1], acc0, 0, 0, 0);                  \
       acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ol__, bh_[2 * u + 1], acc0, 0, 0, 0);                  \
-      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(oh__, bh_[2 * u + 1], acc1, 0, 0, 0);                  \
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(oh__, bh_[2 * u + 1], acc0, 0, 0, 0);                  \
       __builtin_amdgcn_sched_barrier(0);                                                                   \
       eh__ = neh__; el__ = nel__; oh__ = noh__; ol__ = nol__;                                              \
     }                                                                                                      \
   }
   // K panel: out_[jp] += W[32 jp .. + 31][32 k] . the two k-step fragments fh / fl; unit u = (output panels 2 j2, 2 j2 + 1,
-  // k-step s): six MFMAs alternating between the two accumulators
+  // k-step s): six MFMAs, the next unit's reads behind the first two
 #define EFX_KPANEL(st_, fh_, fl_, out_)                                                                    \
   {                                                                                                        \
     h16x8 ah__ = EFX_RD(st_, 0, 0, 0), al__ = EFX_RD(st_, 0, 0, 1), bh__ = EFX_RD(st_, 1, 0, 0), bl__ = EFX_RD(st_, 1, 0, 1); \
     _Pragma("unroll") for (int u = 0; u < 8; ++u) {                                                        \
       const int j2 = u >> 1, s = u & 1;                                                                    \
+      const int nj = (u + 1) >> 1, ns = (u + 1) & 1;                                                       \
       EFX_USE(ah__, al__, bh__, bl__);                                                                     \
       __builtin_amdgcn_sched_barrier(0);                                                                   \
       h16x8 nah__ = ah__, nal__ = al__, nbh__ = bh__, nbl__ = bl__;                                        \
-      if (u + 1 < 8) {                                                                                     \
-        const int nj = (u + 1) >> 1, ns = (u + 1) & 1;                                                     \
-        nah__ = EFX_RD(st_, 2 * nj, ns, 0); nal__ = EFX_RD(st_, 2 * nj, ns, 1);                            \
-        nbh__ = EFX_RD(st_, 2 * nj + 1, ns, 0); nbl__ = EFX_RD(st_, 2 * nj + 1, ns, 1);                    \
-      }                                                                                                    \
-      __builtin_amdgcn_sched_barrier(0);                                                                   \
       out_[2 * j2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah__, fl_[s], out_[2 * j2], 0, 0, 0);          \
+      __builtin_amdgcn_sched_barrier(0);                                                                   \
+      if (u + 1 < 8) { nah__ = EFX_RD(st_, 2 * nj, ns, 0); nal__ = EFX_RD(st_, 2 * nj, ns, 1); }           \
+      __builtin_amdgcn_sched_barrier(0);                                                                   \
       out_[2 * j2 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh__, fl_[s], out_[2 * j2 + 1], 0, 0, 0);  \
+      __builtin_amdgcn_sched_barrier(0);                                                                   \
+      if (u + 1 < 8) { nbh__ = EFX_RD(st_, 2 * nj + 1, ns, 0); nbl__ = EFX_RD(st_, 2 * nj + 1, ns, 1); }   \
+      __builtin_amdgcn_sched_barrier(0);                                                                   \
       out_[2 * j2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al__, fh_[s], out_[2 * j2], 0, 0, 0);          \
       out_[2 * j2 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl__, fh_[s], out_[2 * j2 + 1], 0, 0, 0);  \
       out_[2 * j2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah__, fh_[s], out_[2 * j2], 0, 0, 0);          \
@@ -242,7 +247,7 @@ __global__ __launch_bounds__(W * 64, 1) void encoder_x_kernel(Args a) {
   if (NST >= 4) EFX_ISSUE(2);
 
   const int fq = 4 * g;                                 // first feature of register quad 0 inside a panel (quad q: + 8 q)
-  f32x16 acc0, acc1;
+  f32x16 acc0;
   f32x16 big[8];                                        // message accumulators (pass 1), then output accumulators (pass 2)
 #pragma unroll
   for (int j = 0; j < 8; ++j)
@@ -258,7 +263,7 @@ __global__ __launch_bounds__(W * 64, 1) void encoder_x_kernel(Args a) {
     if (live) {
       const char* st = lds + (p % NST) * STAGE;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+      for (int r = 0; r < 16; ++r) acc0[r] = 0.f;
       EFX_RPANEL(st, xh, xl);
       // elu + 1, mask, attention normaliser z = S / (Q . Ksum + eps): the wave's 32 features ARE head h       linear_attention.py:31-36,44-45
       float v[16];
@@ -269,7 +274,7 @@ __global__ __launch_bounds__(W * 64, 1) void encoder_x_kernel(Args a) {
         const f32x4 ks4 = *reinterpret_cast<const f32x4*>(tab + T_KSUM + 32 * h + fq + 8 * q);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          float x = (acc0[4 * q + e] + acc1[4 * q + e]) * ws[e];
+          float x = acc0[4 * q + e] * ws[e];
           if (EFX_PROBE_EPI) x = x > 0.f ? x + 1.f : __expf(x);
           x *= mk;
           v[4 * q + e] = x;
@@ -334,7 +339,7 @@ __global__ __launch_bounds__(W * 64, 1) void encoder_x_kernel(Args a) {
     h16x8 hh[2], hl[2];                                                                                    \
     EFX_BEGIN(p);                                                                                          \
     if (live) {                                                                                            \
-      _Pragma("unroll") for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }                     \
+      _Pragma("unroll") for (int r = 0; r < 16; ++r) acc0[r] = 0.f;                     \
       EFX_RPANEL(lds + (p % NST) * STAGE, xh, xl);                                                                 \
     }                                                                                                      \
     EFX_BEGIN(p + 1);                                                                                      \
@@ -344,7 +349,7 @@ __global__ __launch_bounds__(W * 64, 1) void encoder_x_kernel(Args a) {
       _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                      \
         const f32x4 ws = *reinterpret_cast<const f32x4*>(tab + T_W0S + 32 * (hp_) + fq + 8 * q);           \
         _Pragma("unroll") for (int e = 0; e < 4; ++e)                                                      \
-          v[4 * q + e] = fmaxf((acc0[4 * q + e] + acc1[4 * q + e]) * ws[e], 0.f);   /* transformer.py:55 (ReLU) */ \
+          v[4 * q + e] = fmaxf(acc0[4 * q + e] * ws[e], 0.f);   /* transformer.py:55 (ReLU) */ \
       }                                                                                                    \
       pack_panel(v, hh, hl);                                                                               \
     }                                                                                                      \
@@ -378,7 +383,8 @@ __global__ __launch_bounds__(W * 64, 1) void encoder_x_kernel(Args a) {
     s += swap32(s);
     const float mean = s * (1.f / 256.f);
     float m2 = 0.f;
-#pragma unroll
+    asm volatile("" ::: "memory");                      // re-read the scale table per pass: kept in registers across the three passes it
+#pragma unroll                                          // (128 values) pushes the accumulators out to scratch
     for (int j = 0; j < 8; ++j)
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
@@ -388,6 +394,7 @@ __global__ __launch_bounds__(W * 64, 1) void encoder_x_kernel(Args a) {
       }
     m2 += swap32(m2);
     const float rstd = rsqrtf(m2 * (1.f / 256.f) + a.ln_eps);
+    asm volatile("" ::: "memory");
     // (both lanes of a token -- lane, lane ^ 32 -- take the same branch, so the exchanges inside stay paired)
     if (tok < T) {
       const float* xr = a.x_f32 + row * 256;
