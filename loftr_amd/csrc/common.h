@@ -33,7 +33,8 @@ enum LoftrTimedKernel {
   LOFTR_T_CONV3 = 11,        // conv.hip: conv3x3_kernel            (3x3 stride-1, input patch in LDS)
   LOFTR_T_CONV3W = 12,       // conv.hip: conv3x3_wide_kernel       (3x3 stride-1, 7 output column tiles: Cout 193..224)
   LOFTR_T_ENCODER_X = 13,   // encoder_fused.hip: encoder_x_kernel  (q proj -> merge + LN -> mlp.0 -> mlp.2 + LN + residual, one launch)
-  LOFTR_T_COUNT = 14
+  LOFTR_T_FINE_PAIR = 14,   // fine_fused.hip: fine_pair_kernel     (the whole fine-level transformer of a match, one launch)
+  LOFTR_T_COUNT = 15
 };
 extern unsigned g_loftr_timing_mask;
 void loftr_timing_mark(int id, hipStream_t st, bool end);

@@ -97,3 +97,14 @@ struct EncoderXArgs {
   float v_length, attn_eps, p_out_scale, ln_eps;
 };
 int launch_encoder_x(const EncoderXArgs& p, hipStream_t st);
+
+// The whole fine-level transformer (layers [self, cross]) on M window pairs of T <= 32 tokens, C = 128, in one launch
+// (fine_fused.hip).  [l] = layer 0 (self) / 1 (cross).  LOFTR_ERR_UNSUPPORTED for any other shape.
+struct FinePairArgs {
+  float* f0; float* f1; int M, T, C;                  // [M, T, C] fp32, updated in place
+  const sp_t *wq[2], *wk[2], *wv[2], *wm[2], *w0[2], *w2[2];
+  const float *sq[2], *sk[2], *sv[2], *sm[2], *s0[2], *s2[2];     // inverse row scales
+  const float *g1[2], *b1[2], *g2[2], *b2[2];
+  float attn_eps, ln_eps;
+};
+int launch_fine_pair(const FinePairArgs& p, hipStream_t st);

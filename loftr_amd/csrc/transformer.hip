@@ -261,9 +261,32 @@ extern "C" int loftr_transformer_fwd(float* feat0, float* feat1, const uint8_t* 
   if (!e.ok) return LOFTR_ERR_WORKSPACE;
   int rc;
   LayerSp lw[MAX_LAYERS];
+  // layer matrices -> SP, unless the caller hands in the block loftr_transformer_prepare built once for these weights
+  // (inference weights are constant)
+  bool weights_ready = false;
+  if (prepared) {
+    view_layers(layers, n_layers, C, reinterpret_cast<sp_t*>(const_cast<void*>(prepared)), lw);
+    weights_ready = true;
+  }
+  // Fine level (loftr.py:71-72): [self, cross] on window pairs of <= 32 tokens is local to a match -> ONE launch, the windows
+  // never leave the registers between the layers (fine_fused.hip); no SP mirror of the residual stream is needed.
+  if (C == 128 && n_layers == 2 && !layer_is_cross[0] && layer_is_cross[1] && L == S && L <= 32 && !mask0) {
+    if (!weights_ready) {
+      SpJobs wj;
+      if ((rc = convert_layers(layers, n_layers, C, w_sp, wj, lw, st))) return rc;
+      weights_ready = true;
+    }
+    FinePairArgs fp{};
+    fp.f0 = feat0; fp.f1 = feat1; fp.M = N; fp.T = L; fp.C = C; fp.attn_eps = 1e-6f; fp.ln_eps = 1e-5f;
+    for (int l = 0; l < 2; ++l) {
+      fp.wq[l] = lw[l].q; fp.wk[l] = lw[l].k; fp.wv[l] = lw[l].v; fp.wm[l] = lw[l].merge; fp.w0[l] = lw[l].mlp0; fp.w2[l] = lw[l].mlp2;
+      fp.sq[l] = lw[l].q_s; fp.sk[l] = lw[l].k_s; fp.sv[l] = lw[l].v_s; fp.sm[l] = lw[l].merge_s; fp.s0[l] = lw[l].mlp0_s; fp.s2[l] = lw[l].mlp2_s;
+      fp.g1[l] = lw[l].n1w; fp.b1[l] = lw[l].n1b; fp.g2[l] = lw[l].n2w; fp.b2[l] = lw[l].n2b;
+    }
+    if ((rc = launch_fine_pair(fp, st)) != LOFTR_ERR_UNSUPPORTED) return rc;
+  }
   {
-    // residual stream -> SP mirror; layer matrices -> SP (unless the caller hands in the block loftr_transformer_prepare
-    // built once for these weights: inference weights are constant)
+    // residual stream -> SP mirror (in the same launch as the layer matrices when those are still to be converted)
     SpJobs jobs;
     auto add = [&](const float* src, sp_t* dst, long rows) {
       const int i = jobs.n++;
@@ -271,8 +294,7 @@ extern "C" int loftr_transformer_fwd(float* feat0, float* feat1, const uint8_t* 
     };
     add(feat0, sp0, (long)N * L);
     add(feat1, sp1, (long)N * S);
-    if (prepared) {
-      view_layers(layers, n_layers, C, reinterpret_cast<sp_t*>(const_cast<void*>(prepared)), lw);
+    if (weights_ready) {
       if ((rc = launch_sp_convert(jobs, st))) return rc;
     } else if ((rc = convert_layers(layers, n_layers, C, w_sp, jobs, lw, st))) return rc;
   }
