@@ -58,7 +58,7 @@ MFMA_F16_PEAK_TF = 2500.0      # MI355X_MICROARCH.md: dense fp16/bf16 MFMA peak
 MFMA_F32_PEAK_TF = 157.3       # MI355X_MICROARCH.md: fp32-input MFMA = fp32 vector peak (for context only)
 SPLIT_FACTOR = 3               # every fp32 product = 3 fp16 MFMAs (hi*hi + hi*lo + lo*hi), csrc/gemm.h
 GEMM_KERNELS = ("proj_kernel", "proj_kv_kernel", "linear_kernel", "linear_ln_kernel", "score_stats_kernel", "score_conf_kernel",
-                "conv_kernel", "conv3x3_kernel", "conv3x3_wide_kernel", "encoder_x_kernel")
+                "conv_kernel", "conv3x3_kernel", "conv3x3_wide_kernel", "encoder_x_kernel", "fine_pair_kernel")
 
 K_IDS = {}
 
@@ -76,10 +76,11 @@ def read_timing(lib, kid, reset=True):
     return ms.value, n.value
 
 
-def algorithmic_work(B, L, S, M, C_=256, Cf=128, WW=25, fused=True):
+def algorithmic_work(B, L, S, M, C_=256, Cf=128, WW=25, fused=True, fused_fine=True):
     """Algorithmic (flops, bytes) per STEP of every instrumented kernel for a batch of B pairs with
     M matches in total.  fp32 everywhere: 4 bytes per element.  fused: the x side of a coarse
-    layer runs as encoder_x_kernel (csrc/encoder_fused.hip) instead of proj / linear_ln / linear / linear_ln."""
+    layer runs as encoder_x_kernel (csrc/encoder_fused.hip) instead of proj / linear_ln / linear / linear_ln; fused_fine: the whole
+    fine-level transformer runs as fine_pair_kernel (csrc/fine_fused.hip) instead of proj / attn_small / linear_ln / linear / linear_ln."""
     w = {}
     rows_c = 2 * B * L                      # both images, L == S
     n_self = n_cross = 4
@@ -101,6 +102,14 @@ def algorithmic_work(B, L, S, M, C_=256, Cf=128, WW=25, fused=True):
         # q + merge (2 C^2), mlp.0 (4 C^2), mlp.2 (2 C^2) per token; x (SP + fp32) in, out (fp32 + SP) in place, 2 MB of weights per call
         w["encoder_x_kernel"] = (nlc * 2 * rows_c * 8 * C_ * C_, nlc * 4 * (4 * rows_c * C_ + 8 * C_ * C_))
         coarse = {k: (0, 0) for k in coarse}
+    w["attn_small_kernel"] = (2 * 2 * (2 * 2 * M * WW * Cf * 16), 2 * 4 * 4 * 2 * M * WW * Cf)
+    if fused_fine:
+        # 4 encoder calls per match (2 layers x 2 windows): q, k, v, merge (4 Cf^2), mlp.0 (4 Cf^2), mlp.2 (2 Cf^2) per token + the
+        # attention itself; both windows in and out as fp32, once
+        fl = sum(v[0] for v in fine.values()) + w["attn_small_kernel"][0]
+        w["fine_pair_kernel"] = (fl, 4 * (2 * 2 * M * WW * Cf) + 2 * 4 * 10 * Cf * Cf)
+        fine = {k: (0, 0) for k in fine}
+        w["attn_small_kernel"] = (0, 0)
     for k in coarse:
         w[k] = (coarse[k][0] + fine[k][0], coarse[k][1] + fine[k][1])
     # fine preprocess linears ride on linear_kernel: down_proj, ctx, window merge (x2 sides)
@@ -109,7 +118,6 @@ def algorithmic_work(B, L, S, M, C_=256, Cf=128, WW=25, fused=True):
     w["linear_kernel"] = (w["linear_kernel"][0] + fp_f, w["linear_kernel"][1] + fp_b)
     nl = n_self + n_cross
     w["proj_kv_kernel"] = (nl * (2 * rows_c * C_ * 2 * C_ + 2 * rows_c * C_ * 32), nl * 4 * (rows_c * C_ + 2 * C_ * C_))
-    w["attn_small_kernel"] = (2 * 2 * (2 * 2 * M * WW * Cf * 16), 2 * 4 * 4 * 2 * M * WW * Cf)
     w["score_stats_kernel"] = (2 * B * L * S * C_, 4 * B * (L + S) * C_)
     w["score_conf_kernel"] = (2 * B * L * S * C_, 4 * B * ((L + S) * C_ + L * S))
     w["gather_windows_kernel"] = (0, 2 * 4 * 2 * M * WW * Cf)
@@ -246,7 +254,17 @@ def cpu_baseline(model, img0, img1):
     runs = sorted(forward() for _ in range(3))
     total, bb, hot, m = runs[1]                               # median by total time
     model.backbone.to(img0.device)
-    return {"value": round(1.0 / total, 4), "unit": "image-pairs/s", "cores": threads, "kind": "port",
+    ref = {}
+    try:                                                     # the reference's OWN CPU forward on this very pair, timed where the golden was made
+        gz = np.load(os.path.join(ROOT, "tests", "golden", "e2e_synth.npz"))
+        rc = json.loads(str(gz["recipe"]))
+        ref = {"reference_forward_s": round(float(np.median(gz["ref_cpu_seconds"])), 3), "reference_forward_cores": rc.get("ref_cpu_count"),
+               "reference_forward_note": "zju3dv/LoFTR LoFTR.forward (its own ResNet-FPN included) on pair 0 of this batch, torch CPU fp32, median of 3, "
+                                         "measured in the authoring container when tests/golden/e2e_synth.npz was generated (the reference cannot travel "
+                                         "to the GPU box)"}
+    except Exception:                                        # noqa: BLE001
+        pass
+    return {**ref, "value": round(1.0 / total, 4), "unit": "image-pairs/s", "cores": threads, "kind": "port",
             "sample": f"pair 0 of the GPU batch (640x480), 1 warm-up + median of 3 forwards: torch-CPU backbone {bb:.2f}s + "
                       f"numpy oracle matching path {hot:.2f}s (M={m}); {threads} torch threads chosen by probe "
                       f"{ {k: round(v, 2) for k, v in probe.items()} } s/backbone, host has {cores} logical cores",
@@ -254,7 +272,7 @@ def cpu_baseline(model, img0, img1):
             "runs_s": [round(r[0], 3) for r in runs]}
 
 
-ENCODER_KERNELS = ("proj_kv_kernel", "proj_kernel", "linear_kernel", "linear_ln_kernel", "encoder_x_kernel")
+ENCODER_KERNELS = ("proj_kv_kernel", "proj_kernel", "linear_kernel", "linear_ln_kernel", "encoder_x_kernel", "fine_pair_kernel")
 # Only the bench line's `roofline` kernel carries hipEvents inside the timed region (one launch per step); everything else
 # is measured in the serial instrumented steps just before it (round-2 verdict: 83 event pairs per step in the timed region).
 NORTH_STAR_TIMED = ("score_conf_kernel",)
@@ -303,6 +321,81 @@ def group_roofline(names, timing, work, steps):
     return e
 
 
+def other_configs(lib, ids, dev, sd, backbone, steps=5, warmup=2):
+    """BASELINE configs[3] (MegaDepth outdoor_ds: 840 x 840 pairs zero-padded from 840 x 560, coarse padding masks, scale0 / scale1,
+    L = S = 11 025, /root/reference configs/loftr/outdoor/loftr_ds.py:1-5) and configs[4] (indoor_ot: Sinkhorn matching,
+    configs/loftr/indoor/loftr_ot.py:1-3) through the SAME library, after the headline's timed region and outside it:
+    a few full forwards each (same seeded weights, thr 0.0), plus two instrumented ones for the score-volume kernels."""
+    out = {}
+
+    def run(tag, cfg, batch_fn, n_pairs, L, extra):
+        model = LoFTR(cfg).eval()
+        model.load_state_dict(sd, strict=False)
+        model = model.to(dev)
+        model.backbone_impl = backbone
+        for _ in range(warmup):
+            d = batch_fn(); model(d)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(steps):
+            d = batch_fn(); model(d)
+        e1.record(); torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / steps
+        M = int(d["mconf"].shape[0])
+        names = [n for n in ("score_conf_kernel", "score_stats_kernel", "score_store_kernel", "encoder_x_kernel", "fine_pair_kernel") if n in ids]
+        mask = 0
+        for n in names:
+            mask |= 1 << ids[n]; read_timing(lib, ids[n])
+        lib.loftr_hip_timing_enable(mask)
+        for _ in range(2):
+            d = batch_fn(); model(d)
+        torch.cuda.synchronize()
+        lib.loftr_hip_timing_enable(0)
+        ent = {"pairs_per_s": round(n_pairs / ms * 1e3, 2), "ms_per_step": round(ms, 3), "pairs_per_step": n_pairs, "matches_per_pair": round(M / n_pairs, 1),
+               "L": L, "steps": steps}
+        ent.update(extra)
+        kt = {}
+        for n in names:
+            t, c = read_timing(lib, ids[n])
+            if c:
+                kt[n] = round(t / c * 1e3, 1)
+        ent["kernel_avg_us"] = kt
+        if "score_conf_kernel" in kt:                       # dual-softmax pass B against the HBM roof at THIS L (DESIGN.md §4)
+            by = 4 * n_pairs * (2 * L * 256 + L * L)
+            gbs = by / (kt["score_conf_kernel"] * 1e-6) / 1e9
+            ent["score_conf_roofline"] = {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                          "frac": round(gbs / HBM_PEAK_GBS, 4), "algorithmic_bytes": by}
+        out[tag] = ent
+        del model
+        torch.cuda.empty_cache()
+
+    # ---- configs[3]: outdoor
+    N = 2
+    cfg = get_cfg(thr=0.0, border_rm=2)
+    cfg["coarse"]["temp_bug_fix"] = False                    # configs/loftr/outdoor/buggy_pos_enc/loftr_ds.py:3-4 (outdoor_ds.ckpt)
+    g = torch.Generator().manual_seed(1234)
+    i0 = torch.rand(N, 1, 840, 840, generator=g)
+    i1 = (i0.roll((8, 16), (2, 3)) + 0.02 * torch.rand(N, 1, 840, 840, generator=g)).clamp(0, 1)
+    i0[:, :, 560:] = 0; i1[:, :, 560:] = 0
+    mask = torch.zeros(N, 105, 105, dtype=torch.bool); mask[:, :70] = True
+    fixed = {"image0": i0.to(dev), "image1": i1.to(dev), "mask0": mask.to(dev), "mask1": mask.to(dev),
+             "scale0": torch.full((N, 2), 1.9).to(dev), "scale1": torch.full((N, 2), 1.9).to(dev)}
+    run("outdoor_840_masked", cfg, lambda: dict(fixed), N, 105 * 105,
+        {"workload": "BASELINE configs[3]: 2 pairs 840x840 (valid 840x560, zero-padded), mask0/1 [2,105,105], scale 1.9, dual-softmax, thr 0.0"})
+    del fixed
+    # ---- configs[4]: indoor_ot
+    B = 8
+    cfg = get_cfg(thr=0.0)
+    cfg["coarse"]["temp_bug_fix"] = True
+    cfg["match_coarse"].update(match_type="sinkhorn", skh_prefilter=False, sparse_spvs=True)
+    a0, a1 = make_images(1234, B, H_IMG, W_IMG)
+    a0, a1 = torch.from_numpy(a0).to(dev), torch.from_numpy(a1).to(dev)
+    run("indoor_ot", cfg, lambda: {"image0": a0, "image1": a1}, B, (H_IMG // 8) * (W_IMG // 8),
+        {"workload": "BASELINE configs[4]: 8 pairs 640x480, match_type sinkhorn (3 iterations, conf_matrix_with_bin), thr 0.0"})
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -315,6 +408,7 @@ def main():
     ap.add_argument("--thr", type=float, default=0.0)
     ap.add_argument("--no-conf", action="store_true", help="elide data['conf_matrix'] (not the headline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the untimed outdoor / Sinkhorn forwards reported as other_configs")
     ap.add_argument("--no-overlap", action="store_true", help="run the FPN fine branch on the main stream (no second HIP stream)")
     ap.add_argument("--match-type", default="dual_softmax", choices=["dual_softmax", "sinkhorn"],
                     help="sinkhorn = BASELINE configs[4] (indoor_ot); not the headline")
@@ -459,7 +553,8 @@ def main():
     M = int(data["mconf"].shape[0])
     L = (H_IMG // 8) * (W_IMG // 8)
     raw = {name: read_timing(lib, kid) for name, kid in ids.items()}
-    work = algorithmic_work(B, L, L, M, fused=raw.get("encoder_x_kernel", (0, 0))[1] > 0)
+    work = algorithmic_work(B, L, L, M, fused=raw.get("encoder_x_kernel", (0, 0))[1] > 0,
+                            fused_fine=raw.get("fine_pair_kernel", (0, 0))[1] > 0)
     kernels = []
     for name, (ms, n) in raw.items():
         if name in work and n:
@@ -550,6 +645,11 @@ def main():
             "pmc_source": ("profiles/pmc_traffic.json (rocprofv3 --pmc passes of this build, source hash " + source_hash() + ")")
                           if pmc_table() else "no PMC passes for this build of the kernels: traffic / mfma_busy are null",
         }
+        if world == 1 and not args.no_other_configs and args.match_type == "dual_softmax":
+            try:
+                out["other_configs"] = other_configs(lib, ids, dev, sd, args.backbone)
+            except Exception as e:                          # noqa: BLE001  (the headline line must not depend on the extras)
+                out["other_configs"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(model, img0, img1)
         sys.stdout.flush()

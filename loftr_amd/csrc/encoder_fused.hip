@@ -74,9 +74,8 @@ __device__ __forceinline__ void swap_halves(uint32_t& a, uint32_t& b) {
   a = r[0]; b = r[1];
 }
 __device__ __forceinline__ void sp_pack4(float x0, float x1, float x2, float x3, uint2& hi, uint2& lo) {
-  const uint32_t a = sp_pack(x0), b = sp_pack(x1), c = sp_pack(x2), d = sp_pack(x3);
-  hi = make_uint2((a & 0xffffu) | (b << 16), (c & 0xffffu) | (d << 16));
-  lo = make_uint2((a >> 16) | (b & 0xffff0000u), (c >> 16) | (d & 0xffff0000u));
+  sp_pack2(x0, x1, hi.x, lo.x);
+  sp_pack2(x2, x3, hi.y, lo.y);
 }
 // 16 outputs of one 32-feature panel (register r of a lane in half-wave g = feature 8 (r >> 2) + 4 g + (r & 3) of the lane's
 // token) -> the lane's B-operand fragments of the panel's two k-steps (k-step s, element e = feature 16 s + 8 g + e).

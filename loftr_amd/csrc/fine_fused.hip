@@ -8,8 +8,8 @@
 // as fp32 and read back, attn_small_kernel, merge + LN, mlp.0, mlp.2 + LN, three times) moving ~6 GB per step through HBM.
 // Here (same scheme as encoder_fused.hip): a workgroup is four waves, one per SIMD; a wave owns one match, holds both
 // windows as MFMA fragments in registers (lane = token, 32 slots for the 25 tokens) and runs the four encoder calls back to
-// back; the four waves share ONE stream of weight panels (16 KB = 4 blocks of 32 rows x 128 B) through an eight-stage LDS
-// ring filled by global_load_lds seven panels ahead, one barrier per panel (24 MFMAs per wave).  Per call and match:
+// back; the four waves share ONE stream of weight panels (16 KB = 4 blocks of 32 rows x 128 B) through a six-stage LDS
+// ring filled by global_load_lds five panels ahead, one barrier per panel (24 MFMAs per wave).  Per call and match:
 //   * K = elu(src Wk^T) + 1 and V = src Wv^T / S are computed in the TRANSPOSED orientation (activation as the MFMA's A operand:
 //     lane = feature, registers = tokens), 32 features = two heads at a time; tokens beyond WW are zeroed; K and V tiles are split
 //     into (hi, lo) halves IN their register order -- the contraction over tokens does not care about the order as long as both
@@ -24,12 +24,15 @@
 
 namespace {
 namespace ffx {
-constexpr int W = 4, PT = 32, STAGE = 16 * 1024, BLK = 4096, NST = 8, DMA_PER_WAVE = 4;
+constexpr int W = 4, STAGE = 16 * 1024, BLK = 4096, NST = 6, DMA_PER_WAVE = 4;
 constexpr int PPC = 8 + 8 + 24, NCALL = 4, NPANEL = PPC * NCALL;     // per call: 4 x (Wk, Wv), 4 x (Wq, Wm), 8 x (W0a, W0b, W2)
 // per-layer tables (floats)
 constexpr int T_QS = 0, T_KS = 128, T_VS = 256, T_MS = 384, T_W0S = 512, T_W2S = 768, T_G1 = 896, T_B1 = 1024, T_G2 = 1152,
               T_B2 = 1280, T_LAYER = 1408;
-constexpr int OFF_TAB = NST * STAGE, OFF_KSUM = OFF_TAB + 2 * T_LAYER * 4, LDS_BYTES = OFF_KSUM + W * 128 * 4;
+constexpr int OFF_TAB = NST * STAGE, OFF_KSUM = OFF_TAB + 2 * T_LAYER * 4;     // per wave: Ksum[128] floats
+constexpr int OFF_KV = OFF_KSUM + W * 512;                                     // per wave: 4 head pairs x (hi, lo) x 64 lanes x 16 B
+constexpr int OFF_DESC = OFF_KV + W * 8192;                                    // per panel: {source offset (bytes, from the base of its
+constexpr int LDS_BYTES = OFF_DESC + NPANEL * 16;                              //  matrix), row pitch (dwords), matrix id, K-type flag}
 static_assert(LDS_BYTES <= 160 * 1024, "one workgroup per CU");
 
 struct Args {
@@ -49,9 +52,8 @@ __device__ __forceinline__ void swap_halves(uint32_t& a, uint32_t& b) {     // s
   a = r[0]; b = r[1];
 }
 __device__ __forceinline__ void sp_pack4(float x0, float x1, float x2, float x3, uint2& hi, uint2& lo) {
-  const uint32_t a = sp_pack(x0), b = sp_pack(x1), c = sp_pack(x2), d = sp_pack(x3);
-  hi = make_uint2((a & 0xffffu) | (b << 16), (c & 0xffffu) | (d << 16));
-  lo = make_uint2((a >> 16) | (b & 0xffff0000u), (c >> 16) | (d & 0xffff0000u));
+  sp_pack2(x0, x1, hi.x, lo.x);
+  sp_pack2(x2, x3, hi.y, lo.y);
 }
 // D layout of a 32-row tile (register r of half-wave g = row 8 (r >> 2) + 4 g + (r & 3), lane = column) -> the lane's MFMA
 // fragments over the ROW index (k-step s, element e = row 16 s + 8 g + e), as in encoder_fused.hip
@@ -102,9 +104,65 @@ __device__ __forceinline__ float wave_absmax16(const float (&v)[16]) {
 }
 // eight values in REGISTER order -> one (hi, lo) fragment pair (element e = value e)
 __device__ __forceinline__ void pack8(const float (&v)[8], h16x8& fh, h16x8& fl) {
-  u32x4 hi, lo;
-  sp_pack8(v, hi, lo);
-  fh = __builtin_bit_cast(h16x8, hi); fl = __builtin_bit_cast(h16x8, lo);
+  uint32_t hi[4], lo[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) sp_pack2(v[2 * e], v[2 * e + 1], hi[e], lo[e]);
+  fh = __builtin_bit_cast(h16x8, u32x4{hi[0], hi[1], hi[2], hi[3]});
+  fl = __builtin_bit_cast(h16x8, u32x4{lo[0], lo[1], lo[2], lo[3]});
+}
+
+// One head-pair tile of the source side: K = elu(k) + 1 and V = v / S (tokens beyond the window zeroed) in the transposed layout
+// (lane = feature, register r of half-wave g = token 8 (r >> 2) + 4 g + (r & 3)) -> Ksum to the wave's LDS scratch, KV = K^T V on
+// the matrix cores, its block-diagonal fragments (one (hi, lo) pair per lane) to the wave's LDS scratch.  LDS stores are inline
+// asm: a compiler-visible LDS store makes hipcc drain the in-flight weight DMA first.  Returns what undoes the tile's scales.
+__device__ __forceinline__ float kv_tile(const f32x16& kacc, const f32x16& vacc, float ksc, float vsc, int T, int g, int li,
+                                         unsigned ksum_ad, unsigned kv_ad) {
+  float kk[16], vv[16], ksum = 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const bool ok = (r & 3) + 8 * (r >> 2) + 4 * g < T;             // tokens beyond the window contribute nothing
+    const float kx = kacc[r] * ksc;
+    kk[r] = ok ? (kx > 0.f ? kx + 1.f : __expf(kx)) : 0.f;          // elu + 1     linear_attention.py:31-33
+    vv[r] = ok ? vacc[r] * vsc : 0.f;                               // values / v_length   :41-42
+    ksum += kk[r];
+  }
+  ksum += swap32(ksum);
+  float v_inv;
+  const float v_sc = pow2_lift(wave_absmax16(vv), v_inv);           // one exponent per tile: factors out of K^T V
+#pragma unroll
+  for (int r = 0; r < 16; ++r) vv[r] *= v_sc;
+  if (g == 0) asm volatile("ds_write_b32 %0, %1" :: "v"(ksum_ad), "v"(ksum) : "memory");
+  // K^T V over the tokens: both tiles split in REGISTER order (k-step s = registers 8 s .. 8 s + 7)
+  h16x8 kfh[2], kfl[2], vfh[2], vfl[2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const float k8[8] = {kk[8 * s], kk[8 * s + 1], kk[8 * s + 2], kk[8 * s + 3], kk[8 * s + 4], kk[8 * s + 5], kk[8 * s + 6], kk[8 * s + 7]};
+    const float v8[8] = {vv[8 * s], vv[8 * s + 1], vv[8 * s + 2], vv[8 * s + 3], vv[8 * s + 4], vv[8 * s + 5], vv[8 * s + 6], vv[8 * s + 7]};
+    pack8(k8, kfh[s], kfl[s]);
+    pack8(v8, vfh[s], vfl[s]);
+  }
+  f32x16 kv;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) kv[r] = 0.f;
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {                                      // kv[d][v]: lane = v, register = d
+    kv = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfh[s], vfl[s], kv, 0, 0, 0);
+    kv = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfl[s], vfh[s], kv, 0, 0, 0);
+    kv = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfh[s], vfh[s], kv, 0, 0, 0);
+  }
+  float kvv[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) kvv[r] = kv[r];
+  float kv_inv;
+  const float kv_sc = pow2_lift(wave_absmax16(kvv), kv_inv);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) kvv[r] *= kv_sc;
+  h16x8 fh[2], fl[2];
+  pack_panel(kvv, fh, fl);                                           // A fragments of KV^T: lane = v, k = d = 16 s + 8 g + e
+  // head 2 t = rows / columns 0 .. 15 of the tile, head 2 t + 1 = 16 .. 31: a lane keeps the k-step of ITS head only
+  const u32x4 mh = __builtin_bit_cast(u32x4, li < 16 ? fh[0] : fh[1]), ml = __builtin_bit_cast(u32x4, li < 16 ? fl[0] : fl[1]);
+  asm volatile("ds_write_b128 %0, %1\n\tds_write_b128 %0, %2 offset:1024" :: "v"(kv_ad), "v"(mh), "v"(ml) : "memory");
+  return v_inv * kv_inv;
 }
 
 __global__ __launch_bounds__(W * 64, 1) void fine_pair_kernel(Args a) {
@@ -117,6 +175,8 @@ __global__ __launch_bounds__(W * 64, 1) void fine_pair_kernel(Args a) {
   float* tab = reinterpret_cast<float*>(lds + OFF_TAB);
   const unsigned ksum_addr = (unsigned)(size_t)(lds_ptr_t)(lds + OFF_KSUM + wave * 512);
   const float* ksum_tab = reinterpret_cast<const float*>(lds + OFF_KSUM + wave * 512);
+  const unsigned kv_addr = (unsigned)(size_t)(lds_ptr_t)(lds + OFF_KV + wave * 8192);
+  const char* kv_tab = lds + OFF_KV + wave * 8192 + lane * 16;
 
   // ---- tables of both layers -> LDS (before any DMA)
   for (int f = threadIdx.x; f < 256; f += W * 64) {
@@ -170,25 +230,28 @@ __global__ __launch_bounds__(W * 64, 1) void fine_pair_kernel(Args a) {
     dro[oct] = oct * 8 + (lane >> 3);
     dch[oct] = ((lane & 7) ^ ((oct * 4 + (lane >> 4)) & 7)) << 2;
   }
+  // where panel p comes from: decoded once per workgroup into an LDS table (the divisions by 40 and 3 per panel and wave were a
+  // few hundred scalar instructions per barrier interval): {address of its first row / k-group (lo, hi), row pitch, K-type}
+  for (int p = threadIdx.x; p < NPANEL; p += W * 64) {
+    const int c = p / PPC, q = p - c * PPC, l = c >> 1;
+    int off, pitch = 128, mat, kt = 0;
+    if (q < 8) { mat = (q & 1) ? 2 : 1; off = (q >> 1) * 32 * 128; }                                  // Wk / Wv rows 32 t ..
+    else if (q < 16) { const int t = (q - 8) >> 1; if (q & 1) { mat = 3; off = t * 32; kt = 1; } else { mat = 0; off = t * 32 * 128; } }
+    else { const int hp = (q - 16) / 3, i = (q - 16) - 3 * hp; pitch = 256;
+           if (i == 2) { mat = 5; off = hp * 32; kt = 1; } else { mat = 4; off = hp * 32 * 256 + i * 128; } }
+    const sp_t* mp = mat == 0 ? a.wq[l] : mat == 1 ? a.wk[l] : mat == 2 ? a.wv[l] : mat == 3 ? a.wm[l] : mat == 4 ? a.w0[l] : a.w2[l];
+    const unsigned long long ad = (unsigned long long)(size_t)(mp + off);
+    reinterpret_cast<int4*>(lds + OFF_DESC)[p] = make_int4((int)(unsigned)ad, (int)(unsigned)(ad >> 32), pitch, kt);
+  }
 #define FFX_ISSUE(p_)                                                                                      \
   {                                                                                                        \
     const int p__ = (p_);                                                                                  \
-    const int c__ = p__ / PPC, q__ = p__ - c__ * PPC, l__ = c__ >> 1;                                      \
-    const sp_t* base__; int pitch__; bool kt__ = false;                                                    \
-    if (q__ < 8) {                                                                                         \
-      const int t__ = q__ >> 1;                                                                            \
-      base__ = ((q__ & 1) ? a.wv[l__] : a.wk[l__]) + t__ * 32 * 128; pitch__ = 128;                        \
-    } else if (q__ < 16) {                                                                                 \
-      const int t__ = (q__ - 8) >> 1;                                                                      \
-      if (q__ & 1) { base__ = a.wm[l__] + t__ * 32; kt__ = true; } else base__ = a.wq[l__] + t__ * 32 * 128; \
-      pitch__ = 128;                                                                                       \
-    } else {                                                                                               \
-      const int hp__ = (q__ - 16) / 3, i__ = (q__ - 16) - 3 * hp__;                                        \
-      if (i__ == 2) { base__ = a.w2[l__] + hp__ * 32; kt__ = true; } else base__ = a.w0[l__] + hp__ * 32 * 256 + i__ * 128; \
-      pitch__ = 256;                                                                                       \
-    }                                                                                                      \
+    const int4 d__ = reinterpret_cast<const int4*>(lds + OFF_DESC)[p__];                                   \
+    const unsigned lo__ = (unsigned)__builtin_amdgcn_readfirstlane(d__.x), hi__ = (unsigned)__builtin_amdgcn_readfirstlane(d__.y); \
+    const int pitch__ = __builtin_amdgcn_readfirstlane(d__.z), kt__ = __builtin_amdgcn_readfirstlane(d__.w);        \
+    const sp_t* base__ = reinterpret_cast<const sp_t*>((size_t)(((unsigned long long)hi__ << 32) | lo__)); \
     char* st__ = lds + (p__ % NST) * STAGE + wave * BLK;                                                   \
-    const sp_t* bb__ = kt__ ? base__ + (long)wave * 32 * pitch__ : base__ + wave * 32;                     \
+    const sp_t* bb__ = base__ + (kt__ ? (long)wave * 32 * pitch__ : (long)wave * 32);              \
     _Pragma("unroll") for (int oct__ = 0; oct__ < 4; ++oct__)                                              \
       __builtin_amdgcn_global_load_lds((gbl_ptr_t)(bb__ + dro[oct__] * pitch__ + dch[oct__]),              \
                                        (lds_ptr_t)(st__ + oct__ * 1024), 16, 0, 0);                        \
@@ -198,9 +261,7 @@ __global__ __launch_bounds__(W * 64, 1) void fine_pair_kernel(Args a) {
 #define FFX_BEGIN(p_)                                                                                      \
   {                                                                                                        \
     const int rem__ = NPANEL - 1 - (p_);                                                                   \
-    if (rem__ >= 6) LOFTR_WAITCNT_VM(6 * DMA_PER_WAVE);                                                    \
-    else if (rem__ == 5) LOFTR_WAITCNT_VM(5 * DMA_PER_WAVE);                                               \
-    else if (rem__ == 4) LOFTR_WAITCNT_VM(4 * DMA_PER_WAVE);                                               \
+    if (rem__ >= 4) LOFTR_WAITCNT_VM(4 * DMA_PER_WAVE);                                                    \
     else if (rem__ == 3) LOFTR_WAITCNT_VM(3 * DMA_PER_WAVE);                                               \
     else if (rem__ == 2) LOFTR_WAITCNT_VM(2 * DMA_PER_WAVE);                                               \
     else if (rem__ == 1) LOFTR_WAITCNT_VM(1 * DMA_PER_WAVE);                                               \
@@ -277,78 +338,30 @@ __global__ __launch_bounds__(W * 64, 1) void fine_pair_kernel(Args a) {
     const float* tl = tab + (c >> 1) * T_LAYER;
     const bool self = c < 2;
     // ============ source side: KV_h = K_h^T V_h, Ksum_h for the four head pairs ================================
-    h16x8 sh[8], sl[8];                                   // the source window: this window (self layer) or the other one
-#pragma unroll
-    for (int ks = 0; ks < 8; ++ks) { sh[ks] = self ? wah[ks] : wbh[ks]; sl[ks] = self ? wal[ks] : wbl[ks]; }
+    // (the source is this window in the self layer, the other one in the cross layer: the panel loop is instantiated for both
+    //  register sets -- a per-call copy of the source cost 64 registers and the moves)
     const float src_sc = self ? wa_sc : wb_sc, src_inv = self ? wa_inv : wb_inv;
-    h16x8 kvh[4] = {zero8, zero8, zero8, zero8}, kvl[4] = {zero8, zero8, zero8, zero8};   // block-diagonal KV^T fragments: one (hi, lo) pair per head pair and lane
-    float kvi[4] = {1.f, 1.f, 1.f, 1.f};                  // ... and what undoes the tile's two power-of-two scales (V, then KV)
-#pragma unroll 1
-    for (int t = 0; t < 4; ++t) {
-      const int p = p0 + 2 * t;
-      FFX_BEGIN(p);
-      if (live) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        FFX_TPANEL(lds + (p % NST) * STAGE, sh, sl, acc);             // K tile: lane = feature 32 t + li, register = token
-      }
-      FFX_BEGIN(p + 1);
-      if (live) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc2[r] = 0.f;
-        FFX_TPANEL(lds + ((p + 1) % NST) * STAGE, sh, sl, acc2);      // V tile
-        const float ksc = tl[T_KS + 32 * t + li] * src_inv, vsc = tl[T_VS + 32 * t + li] * inv_s * src_inv;
-        float kk[16], vv[16], ksum = 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const bool ok = (r & 3) + 8 * (r >> 2) + 4 * g < T;         // tokens beyond the window contribute nothing
-          const float kx = acc[r] * ksc;
-          kk[r] = ok ? (kx > 0.f ? kx + 1.f : __expf(kx)) : 0.f;      // elu + 1     linear_attention.py:31-33
-          vv[r] = ok ? acc2[r] * vsc : 0.f;                           // values / v_length   :41-42
-          ksum += kk[r];
-        }
-        ksum += swap32(ksum);
-        float v_inv;
-        const float v_sc = pow2_lift(wave_absmax16(vv), v_inv);       // one exponent per tile: factors out of K^T V
-#pragma unroll
-        for (int r = 0; r < 16; ++r) vv[r] *= v_sc;
-        if (g == 0) {                                                 // Ksum of feature 32 t + li -> this wave's scratch (asm: a
-          const unsigned ad = ksum_addr + (unsigned)((32 * t + li) * 4);   // compiler-visible LDS store would drain the DMA ring)
-          asm volatile("ds_write_b32 %0, %1" :: "v"(ad), "v"(ksum) : "memory");
-        }
-        // K^T V over the tokens: both tiles split in REGISTER order (k-step s = registers 8 s .. 8 s + 7)
-        h16x8 kfh[2], kfl[2], vfh[2], vfl[2];
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-          const float k8[8] = {kk[8 * s], kk[8 * s + 1], kk[8 * s + 2], kk[8 * s + 3], kk[8 * s + 4], kk[8 * s + 5], kk[8 * s + 6], kk[8 * s + 7]};
-          const float v8[8] = {vv[8 * s], vv[8 * s + 1], vv[8 * s + 2], vv[8 * s + 3], vv[8 * s + 4], vv[8 * s + 5], vv[8 * s + 6], vv[8 * s + 7]};
-          pack8(k8, kfh[s], kfl[s]);
-          pack8(v8, vfh[s], vfl[s]);
-        }
-        f32x16 kv;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) kv[r] = 0.f;
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {                                  // kv[d][v]: lane = v (32 t + li), register = d
-          FFX_MF(kfh[s], vfl[s], kv); FFX_MF(kfl[s], vfh[s], kv); FFX_MF(kfh[s], vfh[s], kv);
-        }
-        float kvv[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) kvv[r] = kv[r];
-        float kv_inv;
-        const float kv_sc = pow2_lift(wave_absmax16(kvv), kv_inv);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) kvv[r] *= kv_sc;
-        h16x8 fh[2], fl[2];
-        pack_panel(kvv, fh, fl);                                       // A fragments of KV^T: lane = v, k = d = 16 s + 8 g + e
-        // head 2 t = rows / columns 0 .. 15 of the tile, head 2 t + 1 = 16 .. 31: a lane keeps the k-step of ITS head only
-        const h16x8 mine_h = li < 16 ? fh[0] : fh[1], mine_l = li < 16 ? fl[0] : fl[1];
-        kvh[0] = kvh[1]; kvh[1] = kvh[2]; kvh[2] = kvh[3]; kvh[3] = mine_h;      // (rolled loop: the tile enters at the end of a
-        kvl[0] = kvl[1]; kvl[1] = kvl[2]; kvl[2] = kvl[3]; kvl[3] = mine_l;      //  rotating register window: after 4 turns [t] = tile t)
-        kvi[0] = kvi[1]; kvi[1] = kvi[2]; kvi[2] = kvi[3]; kvi[3] = v_inv * kv_inv;
-      }
+    float kvi[4] = {1.f, 1.f, 1.f, 1.f};                  // what undoes a tile's two power-of-two scales (V, then KV)
+#define FFX_KV_LOOP(SH_, SL_)                                                                              \
+    _Pragma("unroll 1") for (int t = 0; t < 4; ++t) {                                                      \
+      const int p = p0 + 2 * t;                                                                            \
+      FFX_BEGIN(p);                                                                                        \
+      if (live) {                                                                                          \
+        _Pragma("unroll") for (int r = 0; r < 16; ++r) acc[r] = 0.f;                                       \
+        FFX_TPANEL(lds + (p % NST) * STAGE, SH_, SL_, acc);       /* K tile: lane = feature 32 t + li, register = token */ \
+      }                                                                                                    \
+      FFX_BEGIN(p + 1);                                                                                    \
+      if (live) {                                                                                          \
+        _Pragma("unroll") for (int r = 0; r < 16; ++r) acc2[r] = 0.f;                                      \
+        FFX_TPANEL(lds + ((p + 1) % NST) * STAGE, SH_, SL_, acc2);                       /* V tile */      \
+        const float inv__ = kv_tile(acc, acc2, tl[T_KS + 32 * t + li] * src_inv, tl[T_VS + 32 * t + li] * inv_s * src_inv, T, g, li, \
+                                    ksum_addr + (unsigned)((32 * t + li) * 4), kv_addr + (unsigned)(t * 2048 + lane * 16));  \
+        kvi[0] = kvi[1]; kvi[1] = kvi[2]; kvi[2] = kvi[3]; kvi[3] = inv__;                                 \
+      }                                                                                                    \
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                 // the Ksum stores (asm) have left this wave
+    if (self) { FFX_KV_LOOP(wah, wal) } else { FFX_KV_LOOP(wbh, wbl) }
+#undef FFX_KV_LOOP
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                 // the Ksum / KV stores (asm) have left this wave
     // ============ x side: Q_t -> attention of head pair t -> merge, accumulated over t ============================
 #pragma unroll
     for (int j = 0; j < 4; ++j)
@@ -390,14 +403,14 @@ __global__ __launch_bounds__(W * 64, 1) void fine_pair_kernel(Args a) {
         h16x8 qh[2], ql[2];
         pack_panel(v, qh, ql);                                         // k-step 0 = head 2 t (d 0 .. 15), k-step 1 = head 2 t + 1
         // message[v][token] = sum_d KV_h[d][v] Q_h[token][d]: block-diagonal A operand (a lane's fragment belongs to one k-step)
-        const h16x8 a0h = li < 16 ? kvh[0] : zero8, a0l = li < 16 ? kvl[0] : zero8;
-        const h16x8 a1h = li < 16 ? zero8 : kvh[0], a1l = li < 16 ? zero8 : kvl[0];
+        const h16x8 kvh0 = *reinterpret_cast<const h16x8*>(kv_tab + t * 2048), kvl0 = *reinterpret_cast<const h16x8*>(kv_tab + t * 2048 + 1024);
+        const h16x8 a0h = li < 16 ? kvh0 : zero8, a0l = li < 16 ? kvl0 : zero8;
+        const h16x8 a1h = li < 16 ? zero8 : kvh0, a1l = li < 16 ? zero8 : kvl0;
         f32x16 at;
 #pragma unroll
         for (int r = 0; r < 16; ++r) at[r] = 0.f;
         FFX_MF(a0h, ql[0], at); FFX_MF(a0l, qh[0], at); FFX_MF(a0h, qh[0], at);
         FFX_MF(a1h, ql[1], at); FFX_MF(a1l, qh[1], at); FFX_MF(a1h, qh[1], at);
-        kvh[0] = kvh[1]; kvh[1] = kvh[2]; kvh[2] = kvh[3]; kvl[0] = kvl[1]; kvl[1] = kvl[2]; kvl[2] = kvl[3];
         kvi[0] = kvi[1]; kvi[1] = kvi[2]; kvi[2] = kvi[3];
         float av[16];
 #pragma unroll

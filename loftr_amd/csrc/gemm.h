@@ -134,6 +134,19 @@ __device__ __forceinline__ uint32_t sp_pack(float v) {
   const _Float16 l = (_Float16)(v - (float)h);
   return (uint32_t)__builtin_bit_cast(uint16_t, h) | ((uint32_t)__builtin_bit_cast(uint16_t, l) << 16);
 }
+// Two consecutive values -> the hi dword (hi_a | hi_b << 16) and the lo dword of their SP pair.  Written on 2-vectors so that hipcc
+// selects gfx950's packed conversions: v_cvt_pk_f16_f32 (round to nearest even, both values), two v_cvt_f32_f16, one v_pk_add_f32,
+// v_cvt_pk_f16_f32 -- 5 instructions per PAIR and the results are already packed (the scalar form costs ~6 per VALUE with the
+// and / or / shift packing).  Same values as sp_pack() bit for bit.
+typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void sp_pack2(float a, float b, uint32_t& hi, uint32_t& lo) {
+  const f32x2 v = {a, b};
+  const h16x2 h = __builtin_convertvector(v, h16x2);
+  const f32x2 r = v - __builtin_convertvector(h, f32x2);
+  const h16x2 l = __builtin_convertvector(r, h16x2);
+  hi = __builtin_bit_cast(uint32_t, h);
+  lo = __builtin_bit_cast(uint32_t, l);
+}
 // The dword a lane must store so that a pair of lanes (even, odd) owning two consecutive columns
 // (c, c+1) of one SP row emits: even lane -> hi dword (hi_c | hi_c+1 << 16) at group*32 + c/2,
 // odd lane -> lo dword (lo_c | lo_c+1 << 16) at group*32 + 16 + c/2.  32 lanes = one 128-B group.

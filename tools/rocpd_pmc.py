@@ -45,7 +45,7 @@ def bench_name(full):
         return "proj_kernel"                # coarse q projection (timed under LOFTR_T_PROJ)
     if "rowsweep_kernel<1" in full:
         return "linear_ln_kernel"           # coarse merge + LayerNorm (LOFTR_T_LINEAR_LN)
-    return short(full)
+    return short(full).split("::")[-1]    # efx::encoder_x_kernel, ffx::fine_pair_kernel -> the timing table's names
 
 
 def main():
