@@ -32,12 +32,13 @@ typedef enum {
   LOFTR_ERR_WORKSPACE = -3,     /* workspace smaller than *_workspace_bytes()                  */
   LOFTR_ERR_LAUNCH = -4,        /* HIP reported a launch error                                 */
   LOFTR_ERR_NO_DEVICE = -5,     /* no gfx950 device visible                                    */
-  LOFTR_ERR_COMM = -6           /* RCCL unavailable or a collective / communicator call failed */
+  LOFTR_ERR_COMM = -6,          /* RCCL unavailable or a collective / communicator call failed */
+  LOFTR_ERR_RANGE = -7          /* range guard (loftr_hip_range_check_enable): |activation| >= 65504 or not finite */
 } loftr_status;
 
 /* 13: prepared transformer weights, RCCL entry points, scaled activations, pose estimation;
  * 14: training-side consumers (loftr_spvs_coarse / _fine, loftr_coarse_loss_sums, loftr_fine_loss_sums) */
-#define LOFTR_HIP_ABI_VERSION 14
+#define LOFTR_HIP_ABI_VERSION 15
 
 int loftr_hip_abi_version(void);
 const char* loftr_hip_status_string(int status);
@@ -340,6 +341,15 @@ int loftr_hip_timing_enable(unsigned mask);
 int loftr_hip_timing_kernel_count(void);
 const char* loftr_hip_timing_kernel_name(int id);
 int loftr_hip_timing_read(int id, double* total_ms, long long* launches, int reset);
+
+/* ---- fp16-range guard (debug aid, process-global like the timing switch) -----------------------
+ * The GEMM chain holds every operand as two fp16 numbers (csrc/gemm.h).  Weights, convolution filters and tensors entering through
+ * loftr_linear_fwd / loftr_sp_from_f32_scaled are pre-scaled by powers of two and cannot overflow; the fine-level transformer
+ * rescales its windows at run time (csrc/fine_fused.hip).  Activations that enter the chain UNSCALED -- the coarse feature maps after
+ * the positional encoding, the coarse descriptors at the matcher, the fine preprocess inputs -- must stay below the fp16 maximum
+ * 65504: beyond it the affected products are inf / NaN where the fp32 reference (src/loftr/loftr.py:56-75) is still finite.  With the
+ * guard on, every such conversion is followed by a (synchronous) scan and the entry point returns LOFTR_ERR_RANGE instead. */
+int loftr_hip_range_check_enable(int on);
 
 /* ---- building block exposed for tests / profiling ------------------------------------------
  * out[M,N] = A[M,K] @ Wt[N,K]^T  (the fp32-accurate split-fp16 MFMA GEMM every linear layer above

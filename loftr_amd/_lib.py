@@ -88,6 +88,7 @@ SIGNATURES = {
     "loftr_rccl_comm_destroy": (_i, [_p]),
     "loftr_rccl_allgather_counts": (_i, [_p, _p, _p, _i, _p]),
     "loftr_hip_timing_enable": (_i, [C.c_uint]),
+    "loftr_hip_range_check_enable": (_i, [_i]),
     "loftr_hip_timing_kernel_count": (_i, []),
     "loftr_hip_timing_kernel_name": (C.c_char_p, [_i]),
     "loftr_hip_timing_read": (_i, [_i, C.POINTER(C.c_double), C.POINTER(C.c_longlong), _i]),
@@ -95,7 +96,7 @@ SIGNATURES = {
     "loftr_linear_fwd": (_i, [_p, _p, _p, _i, _i, _i, _p, _sz, _p]),
 }
 
-ABI_VERSION = 14
+ABI_VERSION = 15
 _lib = None
 
 

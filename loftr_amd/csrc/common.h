@@ -37,6 +37,7 @@ enum LoftrTimedKernel {
   LOFTR_T_COUNT = 15
 };
 extern unsigned g_loftr_timing_mask;
+extern int g_loftr_range_check;      // loftr_hip_range_check_enable: fp16-range guard on unscaled operands (sp_convert.hip)
 void loftr_timing_mark(int id, hipStream_t st, bool end);
 struct TimedLaunch {          // RAII: records an event pair around the launches in its scope
   int id; hipStream_t st; bool on;

@@ -54,6 +54,8 @@ extern "C" int loftr_pos_encode_flatten(const loftr_fmap* feat, const float* pe,
 
 // ---- per-kernel timing ---------------------------------------------------------------------
 unsigned g_loftr_timing_mask = 0;
+int g_loftr_range_check = 0;
+extern "C" int loftr_hip_range_check_enable(int on) { g_loftr_range_check = on ? 1 : 0; return LOFTR_OK; }
 namespace {
 constexpr int T_POOL = 4096;                 // event pairs per kernel id; recording stops when full
 struct TimingSlot {
@@ -126,6 +128,7 @@ extern "C" const char* loftr_hip_status_string(int status) {
     case LOFTR_ERR_LAUNCH: return "HIP kernel launch failed";
     case LOFTR_ERR_NO_DEVICE: return "no gfx950 (MI355X) device";
     case LOFTR_ERR_COMM: return "RCCL unavailable or a communicator / collective call failed";
+    case LOFTR_ERR_RANGE: return "an activation entering the split-fp16 GEMM chain is not below the fp16 maximum 65504 (or not finite)";
     default: return "unknown status";
   }
 }

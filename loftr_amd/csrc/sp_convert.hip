@@ -34,6 +34,22 @@ __global__ void tensor_scale_finish_kernel(float* __restrict__ slot) {
   *slot = inv;
 }
 
+// Range guard (debug aid, loftr_hip_range_check_enable): flags a value stored UNSCALED whose magnitude is not below the fp16
+// maximum (or is not finite) -- its hi half would be inf and every product it enters NaN, where the fp32 reference is fine.
+__global__ __launch_bounds__(256) void sp_range_kernel(SpJobs jobs, int* __restrict__ flag) {
+  const int job = blockIdx.y;
+  if (jobs.inv_scale[job] || jobs.tensor_inv[job]) return;          // scaled operands cannot overflow
+  const float* src = jobs.src[job];
+  const int K = jobs.K[job], ld = jobs.ld[job];
+  const long n = (long)jobs.rows[job] * K;
+  bool bad = false;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const long row = i / K;
+    bad |= !(fabsf(src[row * ld + (i - row * K)]) < 65504.f);
+  }
+  if (bad) atomicOr(flag, 1);
+}
+
 // One thread per (row, channel octet): two 16-B loads of fp32, one 16-B store each of the hi and the lo chunk.
 // Sources whose row pitch is not a multiple of 4 floats (or K not a multiple of 8) take the scalar tail path.
 __global__ __launch_bounds__(256) void sp_convert_kernel(SpJobs jobs) {
@@ -99,6 +115,15 @@ int launch_sp_convert(const SpJobs& jobs, hipStream_t st) {
   }
   hipLaunchKernelGGL(sp_convert_kernel, dim3((unsigned)bx, jobs.n), dim3(256), 0, st, jobs);
   LOFTR_CHECK_LAUNCH();
+  if (g_loftr_range_check) {                 // debug: synchronous (one host-mapped flag word, allocated on first use)
+    static int* flag = nullptr;
+    if (!flag && hipHostMalloc(reinterpret_cast<void**>(&flag), sizeof(int), hipHostMallocMapped) != hipSuccess) return LOFTR_ERR_LAUNCH;
+    *flag = 0;
+    long cx = bx > 1024 ? 1024 : bx;
+    hipLaunchKernelGGL(sp_range_kernel, dim3((unsigned)cx, jobs.n), dim3(256), 0, st, jobs, flag);
+    if (hipStreamSynchronize(st) != hipSuccess) return LOFTR_ERR_LAUNCH;
+    if (*flag) return LOFTR_ERR_RANGE;
+  }
   return LOFTR_OK;
 }
 

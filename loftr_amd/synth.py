@@ -51,11 +51,13 @@ def make_weights(seed=0, cfg=None, with_bin_score=False):
     return w
 
 
-def make_features(seed, n, hw0_c, hw1_c, dc=256, df=128, fine_ratio=4, corr=0.0):
+def make_features(seed, n, hw0_c, hw1_c, dc=256, df=128, fine_ratio=4, corr=0.0, scale_c=1.0):
     """Backbone-like outputs: feat_c0/1 [n,dc,h,w], feat_f0/1 [n,df,4h,4w] float32.
 
     ``corr`` in [0,1] mixes image-0 content into image-1 (shifted by one coarse cell), so that
-    some pairs produce confident mutual matches.
+    some pairs produce confident mutual matches.  ``scale_c`` multiplies the coarse maps: with a random-weight transformer the
+    residual stream then dominates its (LayerNorm-bounded) updates and corresponding cells keep near-identical descriptors --
+    the peaked score statistics of a TRAINED network (conf close to 1, |sim / temperature| in the hundreds).
     """
     rng = np.random.default_rng(seed)
     h0, w0 = hw0_c
@@ -69,6 +71,8 @@ def make_features(seed, n, hw0_c, hw1_c, dc=256, df=128, fine_ratio=4, corr=0.0)
         b = np.float32(np.sqrt(1 - corr ** 2))
         c1 = a * np.roll(c0, (1, 1), (2, 3)) + b * c1
         f1 = a * np.roll(f0, (fine_ratio, fine_ratio), (2, 3)) + b * f1
+    if scale_c != 1.0:
+        c0, c1 = (np.float32(scale_c) * c0).astype(np.float32), (np.float32(scale_c) * c1).astype(np.float32)
     return c0, c1, f0, f1
 
 

@@ -19,9 +19,11 @@ make_golden = importlib.util.module_from_spec(_spec)
 _spec.loader.exec_module(make_golden)
 
 SMALL_CASES = ["small_ds", "small_ds_corr", "small_mask", "small_ot", "small_ot_prefilter",
-               "small_ot_mask", "small_empty"]
+               "small_ot_mask", "small_empty",
+               # round 3: peaked ("trained-like") statistics; Sinkhorn prefilter with surviving matches
+               "peaked_small_ds", "peaked_ot_prefilter", "peaked_ot_mask_prefilter"]
 MID_CASES = ["mid_ds"]
-FULL_CASES = ["full_ds_thr0", "full_ds_thr02", "full_ot", "outdoor_mask"]
+FULL_CASES = ["full_ds_thr0", "full_ds_thr02", "full_ot", "outdoor_mask", "peaked_ds"]
 
 
 def load_case(name, check=True):

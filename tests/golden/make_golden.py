@@ -79,6 +79,24 @@ CASES = {
                          mc=dict(thr=0.2, border_rm=2), temp_bug_fix=False, full=False,
                          valid0=[(70, 105)], valid1=[(70, 105)],
                          scale0=[[1.9, 1.9]], scale1=[[1.9, 1.9]]),
+    # ---- round 3: "trained-like" statistics.  Random weights give flat score distributions (conf.max ~ 0.2); scale_c makes the
+    # residual stream dominate, so that corresponding cells keep near-identical descriptors: conf close to 1, |sim / temperature|
+    # in the hundreds, hundreds of matches at the STOCK threshold 0.2 -- the regime a checkpoint would put the kernels in
+    # (pass B of the dual-softmax carries its largest rounding at conf ~ 1: csrc/score_sweep.h)
+    "peaked_ds": dict(n=1, hw0_c=(60, 80), hw1_c=(60, 80), wseed=0, fseed=21, corr=0.9, scale_c=3.0,
+                      mc=dict(thr=0.2, border_rm=2), temp_bug_fix=True, full=False, ref64=True),
+    "peaked_small_ds": dict(n=2, hw0_c=(12, 16), hw1_c=(12, 16), wseed=1, fseed=22, corr=0.9, scale_c=3.0,
+                            mc=dict(thr=0.2, border_rm=2), temp_bug_fix=True, full=True),
+    # Sinkhorn with skh_prefilter=True (eval: coarse_matching.py:136-140) where matches SURVIVE the dustbin test
+    # (small_ot_prefilter has M = 0: with flat scores every row's arg-max is the dustbin)
+    "peaked_ot_prefilter": dict(n=2, hw0_c=(12, 16), hw1_c=(12, 16), wseed=3, fseed=23, corr=0.9, scale_c=3.0,
+                                mc=dict(thr=0.2, border_rm=2, match_type="sinkhorn", skh_prefilter=True,
+                                        sparse_spvs=True), temp_bug_fix=True, full=True),
+    "peaked_ot_mask_prefilter": dict(n=2, hw0_c=(12, 12), hw1_c=(12, 12), wseed=5, fseed=24, corr=0.9, scale_c=3.0,
+                                     mc=dict(thr=0.2, border_rm=1, match_type="sinkhorn", skh_prefilter=True,
+                                             sparse_spvs=False), temp_bug_fix=False, full=True,
+                                     valid0=[(9, 12), (12, 10)], valid1=[(12, 8), (10, 12)],
+                                     scale0=[[1.9, 1.9], [1.25, 1.5]], scale1=[[1.0, 2.0], [1.6, 1.6]]),
 }
 
 
@@ -89,7 +107,7 @@ def build_case_inputs(rc):
     cfg["coarse"]["temp_bug_fix"] = rc["temp_bug_fix"]
     w = make_weights(rc["wseed"], cfg)
     c0, c1, f0, f1 = make_features(rc["fseed"], rc["n"], tuple(rc["hw0_c"]), tuple(rc["hw1_c"]),
-                                   corr=rc["corr"])
+                                   corr=rc["corr"], scale_c=rc.get("scale_c", 1.0))
     inp = dict(cfg=cfg, w=w, feat_c0=c0, feat_c1=c1, feat_f0=f0, feat_f1=f1,
                hw0_i=(rc["hw0_c"][0] * 8, rc["hw0_c"][1] * 8),
                hw1_i=(rc["hw1_c"][0] * 8, rc["hw1_c"][1] * 8),
@@ -115,14 +133,15 @@ def input_checksums(inp):
 class _BackboneStub(torch.nn.Module):
     """Stands in for ResNetFPN: returns the synthetic (feat_c, feat_f) (loftr.py:45-49)."""
 
-    def __init__(self, inp):
+    def __init__(self, inp, dtype=torch.float32):
         super().__init__()
         self.inp = inp
         self.calls = 0
+        self.dtype = dtype
 
     def forward(self, x):
         i = self.inp
-        t = torch.from_numpy
+        t = lambda a: torch.from_numpy(a).to(self.dtype)
         if x.shape[0] == 2 * i["feat_c0"].shape[0] and i["hw0_i"] == i["hw1_i"]:
             return [torch.cat([t(i["feat_c0"]), t(i["feat_c1"])], 0),
                     torch.cat([t(i["feat_f0"]), t(i["feat_f1"])], 0)]
@@ -132,8 +151,9 @@ class _BackboneStub(torch.nn.Module):
         return [t(i["feat_c1"]), t(i["feat_f1"])]
 
 
-def run_reference(inp):
-    """The reference's own LoFTR.forward on the synthetic backbone outputs.  Returns the dict."""
+def run_reference(inp, dtype=torch.float32):
+    """The reference's own LoFTR.forward on the synthetic backbone outputs.  Returns the dict.  dtype=torch.float64 runs the SAME
+    module in double precision: its distance from the float32 run is the reference's own rounding noise on that input."""
     RefLoFTR, _ = import_reference()
     cfg = copy.deepcopy(inp["cfg"])
     model = RefLoFTR(cfg).eval()
@@ -142,12 +162,13 @@ def run_reference(inp):
         assert k in sd and tuple(sd[k].shape) == tuple(np.shape(v)), k
         sd[k] = torch.from_numpy(np.asarray(v))
     model.load_state_dict(sd, strict=True)
-    model.backbone = _BackboneStub(inp)
+    model = model.to(dtype)
+    model.backbone = _BackboneStub(inp, dtype)
     n = inp["feat_c0"].shape[0]
-    data = {"image0": torch.zeros(n, 1, *inp["hw0_i"]), "image1": torch.zeros(n, 1, *inp["hw1_i"])}
+    data = {"image0": torch.zeros(n, 1, *inp["hw0_i"], dtype=dtype), "image1": torch.zeros(n, 1, *inp["hw1_i"], dtype=dtype)}
     if inp["mask0"] is not None:
         data.update(mask0=torch.from_numpy(inp["mask0"]), mask1=torch.from_numpy(inp["mask1"]),
-                    scale0=torch.from_numpy(inp["scale0"]), scale1=torch.from_numpy(inp["scale1"]))
+                    scale0=torch.from_numpy(inp["scale0"]).to(dtype), scale1=torch.from_numpy(inp["scale1"]).to(dtype))
     # also capture the coarse / fine transformer outputs (stage boundaries of SURVEY §8a)
     grabbed = {}
     model.loftr_coarse.register_forward_hook(
@@ -202,6 +223,15 @@ def make(name):
         for k in KEEP_FULL_HEAD:
             if k in out:
                 store[k] = np.asarray(out[k])[:HEAD]
+    if rc.get("ref64"):                                  # the reference's own fp32 rounding noise: the same module in float64
+        o64 = run_reference(inp, torch.float64)
+        for k in ("b_ids", "i_ids", "j_ids", "mconf", "mkpts1_f"):
+            store["ref64/" + k] = np.asarray(o64[k])
+        k32 = {k: n for n, k in enumerate(zip(store["b_ids"].tolist(), store["i_ids"].tolist(), store["j_ids"].tolist()))}
+        com = [(k32[k], n) for n, k in enumerate(zip(o64["b_ids"].tolist(), o64["i_ids"].tolist(), o64["j_ids"].tolist())) if k in k32]
+        ia, ib = [c[0] for c in com], [c[1] for c in com]
+        print(f"{name} ref fp32 vs ref fp64: common {len(com)}/{len(k32)}/{len(o64['mconf'])} "
+              f"d_mconf={np.abs(store['mconf'][ia] - o64['mconf'][ib]).max():.2e} d_mkpts1_f={np.abs(store['mkpts1_f'][ia] - o64['mkpts1_f'][ib]).max():.2e}px")
     store["recipe"] = np.array(json.dumps(rc))
     store["checksums"] = np.array(json.dumps(input_checksums(inp)))
     store["hw"] = np.array([out["hw0_c"], out["hw1_c"], out["hw0_f"], out["hw1_f"]], np.int64)

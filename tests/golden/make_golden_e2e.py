@@ -77,14 +77,19 @@ CASES = {"e2e_scannet": dict(images="scannet", bn_strength=0.3),
          # Sinkhorn matching from images (conf_matrix_with_bin is produced as well: sparse_spvs)
          "e2e_ot": dict(images="synth", bn_strength=0.3, crop0=(384, 512), crop1=(384, 512), match_type="sinkhorn"),
          "e2e_r16_4": dict(images="synth", bn_strength=0.3, crop0=(384, 512), crop1=(384, 512), resolution=(16, 4),
-                           block_dims=(128, 128, 196, 256))}
+                           block_dims=(128, 128, 196, 256)),
+         # round 3, "trained-like" statistics from IMAGES: the coarse head of the backbone (layer3_outconv) is scaled so that the
+         # residual stream of the random-weight transformer dominates its updates; image1 is image0 shifted by whole coarse cells, so
+         # corresponding cells keep near-identical descriptors: conf close to 1 and hundreds of matches at the STOCK threshold 0.2
+         "e2e_peaked": dict(images="synth", bn_strength=0.3, crop0=(384, 512), crop1=(384, 512), coarse_gain=6.0)}
 
 
-def e2e_state_dict(module_with_backbone, cfg, bn_strength):
-    """Seeded full state_dict (torch tensors): matcher weights + backbone weights / BN statistics."""
+def e2e_state_dict(module_with_backbone, cfg, bn_strength, coarse_gain=1.0):
+    """Seeded full state_dict (torch tensors): matcher weights + backbone weights / BN statistics.  coarse_gain multiplies the
+    1x1 convolution that produces the coarse map (layer3_outconv, resnet_fpn.py:64), i.e. feat_c itself."""
     sd = {k: torch.from_numpy(np.ascontiguousarray(np.asarray(v))) for k, v in make_weights(MATCHER_SEED, cfg).items()}
     for k, v in make_backbone_weights(BACKBONE_SEED, module_with_backbone.backbone, bn_strength).items():
-        sd["backbone." + k] = v
+        sd["backbone." + k] = v * coarse_gain if (coarse_gain != 1.0 and k == "layer3_outconv.weight") else v
     return sd
 
 
@@ -141,7 +146,7 @@ def run_reference(img0, img1, thr, bn_strength, timing=False, dtype=torch.float3
     RefLoFTR, _ = import_reference()
     cfg = e2e_cfg(thr, rc)
     model = RefLoFTR(copy.deepcopy(cfg)).eval()
-    model.load_state_dict(e2e_state_dict(model, cfg, bn_strength), strict=True)
+    model.load_state_dict(e2e_state_dict(model, cfg, bn_strength, (rc or {}).get("coarse_gain", 1.0)), strict=True)
     model = model.to(dtype)
     grabbed = {}
     model.backbone.register_forward_hook(lambda m, a, out: grabbed.update(feat_c=out[0].numpy().copy(), feat_f=out[1].numpy().copy()))

@@ -36,12 +36,14 @@ def make_inputs(seed=5):
     return f0, f1
 
 
-def run_reference(f0, f1, thr=0.0, border_rm=1):
+def run_reference(f0, f1, thr=0.0, border_rm=1, match_type="dual_softmax"):
     from oracle.ref_shim import import_reference
     import_reference()
     from src.loftr.utils.coarse_matching import CoarseMatching
-    cm = CoarseMatching(dict(thr=thr, border_rm=border_rm, train_coarse_percent=0.4, train_pad_num_gt_min=200,
-                             match_type="dual_softmax", dsmax_temperature=0.1)).eval()
+    cfg = dict(thr=thr, border_rm=border_rm, train_coarse_percent=0.4, train_pad_num_gt_min=200, match_type=match_type, dsmax_temperature=0.1)
+    if match_type == "sinkhorn":                         # coarse_matching.py:121-143 (round 3: the tie golden for the OT branch)
+        cfg.update(skh_init_bin_score=1.0, skh_iters=3, skh_prefilter=False, sparse_spvs=False)
+    cm = CoarseMatching(cfg).eval()
     data = {"hw0_i": (H0 * 8, W0 * 8), "hw1_i": (H1 * 8, W1 * 8), "hw0_c": (H0, W0), "hw1_c": (H1, W1)}
     with torch.no_grad():
         cm(torch.from_numpy(f0), torch.from_numpy(f1), data)
@@ -61,3 +63,15 @@ if __name__ == "__main__":
     np.savez_compressed(os.path.join(HERE, "ties_ds.npz"), feat_c0=f0, feat_c1=f1, thr=0.0, border_rm=1,
                         **{k: v for k, v in out.items() if k != "conf_matrix"}, conf_row_max=conf.max(2), conf_col_max=conf.max(1))
     print("->", os.path.join(HERE, "ties_ds.npz"), os.path.getsize(os.path.join(HERE, "ties_ds.npz")) // 1000, "kB")
+    # ---- the same descriptors through the Sinkhorn branch: duplicated descriptors give bitwise equal columns of the assignment too
+    out = run_reference(f0, f1, match_type="sinkhorn")
+    conf = out["conf_matrix"]
+    for dst, src in DUPS:
+        assert np.array_equal(conf[:, :, dst], conf[:, :, src]), "sinkhorn: conf columns of duplicated descriptors are not bitwise equal"
+    later = sum(1 for b, i, j in zip(out["b_ids"], out["i_ids"], out["j_ids"])
+                if any(j == src and conf[b, i, dst] == conf[b, i, j] and dst < src for dst, src in DUPS))
+    assert later >= 2, later
+    print(f"sinkhorn: M={len(out['mconf'])}, matches that are a LATER tied column: {later}")
+    np.savez_compressed(os.path.join(HERE, "ties_ot.npz"), feat_c0=f0, feat_c1=f1, thr=0.0, border_rm=1,
+                        **{k: v for k, v in out.items() if k != "conf_matrix"}, conf_row_max=conf.max(2), conf_col_max=conf.max(1))
+    print("->", os.path.join(HERE, "ties_ot.npz"), os.path.getsize(os.path.join(HERE, "ties_ot.npz")) // 1000, "kB")

@@ -38,7 +38,7 @@ def test_header_symbols_exported(lib):
 def test_abi_version_and_status_strings(lib):
     assert lib.loftr_hip_abi_version() == _lib.ABI_VERSION
     assert lib.loftr_hip_status_string(0) == b"ok"
-    for code in (-1, -2, -3, -4, -5, -6):
+    for code in (-1, -2, -3, -4, -5, -6, -7):
         assert lib.loftr_hip_status_string(code) not in (b"ok", b"unknown status")
     assert lib.loftr_hip_status_string(-99) == b"unknown status"
 

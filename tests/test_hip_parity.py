@@ -15,8 +15,22 @@ from _cases import (SMALL_CASES, MID_CASES, FULL_CASES, TOL_CONF, load_case, com
 pytestmark = pytest.mark.gpu
 
 
+def _ref_noise_px(g):
+    """|mkpts1_f| distance between the reference's float32 run (the golden) and the SAME reference module run in float64, stored by
+    make_golden.py for the cases that ask for it ('ref64': the "trained-like" peaked cases): the reference's own rounding noise."""
+    if "ref64/mkpts1_f" not in g:
+        return 0.0
+    k64 = {k: n for n, k in enumerate(zip(g["ref64/b_ids"].tolist(), g["ref64/i_ids"].tolist(), g["ref64/j_ids"].tolist()))}
+    com = [(n, k64[k]) for n, k in enumerate(zip(g["b_ids"].tolist(), g["i_ids"].tolist(), g["j_ids"].tolist())) if k in k64]
+    ia, ib = [c[0] for c in com], [c[1] for c in com]
+    return float(np.abs(g["mkpts1_f"][ia].astype(np.float64) - g["ref64/mkpts1_f"][ib]).max())
+
+
 def _check_against_golden(name, out, inp, g, max_flips=0):
-    rep = compare_to_golden(out, g, inp["cfg"]["match_coarse"]["thr"], max_flips=max_flips)
+    # two independent fp32 roundings of the same exact result cannot be asked to sit closer than ~1.5x the reference's own distance
+    # from exact arithmetic (peaked_ds: the reference's fp32 forward is 9.2e-4 px from its fp64 forward; same rule as tests/test_e2e_golden.py)
+    tol_px = max(1e-3, 1.5 * _ref_noise_px(g))
+    rep = compare_to_golden(out, g, inp["cfg"]["match_coarse"]["thr"], tol_px=tol_px, max_flips=max_flips)
     check_conf_digest(out["conf_matrix"], g)
     if "conf_matrix" in g:
         assert np.abs(out["conf_matrix"] - g["conf_matrix"]).max() <= TOL_CONF

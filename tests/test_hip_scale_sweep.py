@@ -91,3 +91,33 @@ def test_transformer_layer_with_small_weights_and_gammas():
     upd = np.abs(ref - x).max()                      # size of the layer's update (the residual x itself is exact)
     err = np.abs(out - ref).max()
     assert err <= 2e-5 * max(upd, 1e-3) + 1e-7, (float(err), float(upd))
+
+
+@pytest.mark.gpu
+def test_fp16_range_guard_on_unscaled_activations():
+    """Activations enter the coarse GEMM chain unscaled (include/loftr_hip.h, range guard): a value at or beyond the fp16 maximum
+    65504 is not represented faithfully (observed on MI355X: fp16 overflow clamps, the (hi, lo) pair saturates at +-131 008 -- finite
+    but wrong beyond that); with loftr_hip_range_check_enable(1) the entry point reports LOFTR_ERR_RANGE instead.  (The fine-level transformer rescales its windows at run time: tests/test_hip_fine_fused.py.)"""
+    import numpy as np
+    import torch
+    from loftr_amd import LoFTR, get_cfg, _lib
+    from loftr_amd.synth import make_weights
+    cfg = get_cfg(thr=0.0)
+    model = LoFTR(cfg).eval()
+    model.load_state_dict({k: torch.from_numpy(np.ascontiguousarray(np.asarray(v))) for k, v in make_weights(0, cfg).items()}, strict=False)
+    tf = model.cuda().loftr_coarse
+    g = torch.Generator(device="cpu").manual_seed(0)
+    f0, f1 = torch.randn(1, 96, 256, generator=g).cuda(), torch.randn(1, 96, 256, generator=g).cuda()
+    lib = _lib.load()
+    try:
+        lib.loftr_hip_range_check_enable(1)
+        with torch.no_grad():
+            o0, _ = tf(f0, f1)                            # in range: the guard is silent
+            assert torch.isfinite(o0).all()
+            big = f0.clone(); big[0, 5, 7] = 7.0e4
+            with pytest.raises(_lib.LoftrHipError, match="65504"):
+                tf(big, f1)
+            big[0, 5, 7] = 6.0e4                          # representable: fine
+            assert torch.isfinite(tf(big, f1)[0]).all()
+    finally:
+        lib.loftr_hip_range_check_enable(0)

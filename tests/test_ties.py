@@ -12,34 +12,39 @@ from _cases import GOLDEN_DIR, TOL_CONF
 H, W = 8, 10
 
 
-def _golden():
-    return dict(np.load(os.path.join(GOLDEN_DIR, "ties_ds.npz")))
+def _golden(match_type="dual_softmax"):
+    return dict(np.load(os.path.join(GOLDEN_DIR, "ties_ds.npz" if match_type == "dual_softmax" else "ties_ot.npz")))
 
 
 def _ids(d):
     return list(zip(np.asarray(d["b_ids"]).tolist(), np.asarray(d["i_ids"]).tolist(), np.asarray(d["j_ids"]).tolist()))
 
 
-def test_oracle_takes_first_surviving_tied_column():
+@pytest.mark.parametrize("match_type", ["dual_softmax", "sinkhorn"])
+def test_oracle_takes_first_surviving_tied_column(match_type):
     from oracle import loftr_oracle as O
-    g = _golden()
-    conf = O.dual_softmax_conf(g["feat_c0"], g["feat_c1"], 0.1)
+    g = _golden(match_type)
+    if match_type == "dual_softmax":
+        conf = O.dual_softmax_conf(g["feat_c0"], g["feat_c1"], 0.1)
+    else:                                                 # coarse_matching.py:121-143, bin_score 1.0, 3 iterations, no prefilter
+        conf = O.sinkhorn_conf(g["feat_c0"], g["feat_c1"], np.float32(1.0), iters=3)
+        conf = conf[0] if isinstance(conf, tuple) else conf
     sel = O.coarse_match_select(conf, float(g["thr"]), int(g["border_rm"]), (H, W), (H, W), (H * 8, W * 8))
     assert _ids(sel) == _ids(g)
     assert np.abs(sel["mconf"] - g["mconf"]).max() <= TOL_CONF
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("match_type", ["dual_softmax"])
+@pytest.mark.parametrize("match_type", ["dual_softmax", "sinkhorn"])
 def test_hip_takes_first_surviving_tied_column(match_type):
     import torch
     from loftr_amd import ops
     from oracle import loftr_oracle as O
-    g = _golden()
+    g = _golden(match_type)
     dev = "cuda:0"
     f0, f1 = torch.from_numpy(g["feat_c0"]).to(dev), torch.from_numpy(g["feat_c1"]).to(dev)
     r = ops.coarse_match(f0, f1, (H, W), (H, W), thr=float(g["thr"]), border_rm=int(g["border_rm"]), scale=8.0,
-                         match_type=match_type, temperature=0.1)
+                         match_type=match_type, **(dict(temperature=0.1) if match_type == "dual_softmax" else dict(bin_score=1.0, skh_iters=3)))
     torch.cuda.synchronize()
     out = {k: v.cpu().numpy() for k, v in r.items() if torch.is_tensor(v)}
     # 1. identical to the reference, later tied columns included
