@@ -13,6 +13,7 @@ index arithmetic on the kernels' outputs); no sub-module builds an autograd grap
 passes are not provided (forward only).
 """
 import math
+import os
 import weakref
 
 import torch
@@ -345,7 +346,7 @@ class LoFTR(nn.Module):
                 feats_c, fine_fn = run(x, defer_fine=True)
                 main = torch.cuda.current_stream(x.device)
                 if self._side_stream is None:
-                    self._side_stream = torch.cuda.Stream(device=x.device)
+                    self._side_stream = torch.cuda.Stream(device=x.device)    # (ROCm's priority range is (0, -1): no LOW priority to give it)
                 side = self._side_stream
                 side.wait_stream(main)                       # the fine branch reads what the trunk produced
                 for t in fine_fn.reads:                      # ... and the caching allocator must not recycle those
@@ -375,6 +376,13 @@ class LoFTR(nn.Module):
         if "mask0" in data:
             mask_c0, mask_c1 = data["mask0"].flatten(-2), data["mask1"].flatten(-2)
         feat_c0, feat_c1 = self.loftr_coarse(feat_c0, feat_c1, mask_c0, mask_c1, inplace=True)   # fresh pos-encoded copies
+        # Join the side stream (FPN fine branch) HERE, not after coarse matching (LOFTR_FINE_JOIN=late restores that): the encoder
+        # launches leave partly filled rounds that the convolution workgroups use, the score-volume kernels do not -- sharing the
+        # GPU only doubled their duration (660 vs 340 us for pass B, profiles/r03_overlap_ab.txt) without shortening the step.
+        late = os.environ.get("LOFTR_FINE_JOIN") == "late"
+        if not late and getattr(self, "_fine_join", None) is not None:
+            torch.cuda.current_stream(feat_f0.device).wait_stream(self._fine_join)
+            self._fine_join = None
         self.coarse_matching(feat_c0, feat_c1, data, mask_c0=mask_c0, mask_c1=mask_c1)
         if getattr(self, "_fine_join", None) is not None:    # fine maps come from the side stream
             torch.cuda.current_stream(feat_f0.device).wait_stream(self._fine_join)
