@@ -43,6 +43,9 @@ namespace efx {
 #ifndef EFX_PROBE_EPI
 #define EFX_PROBE_EPI 1
 #endif
+#ifndef EFX_PIPE
+#define EFX_PIPE 0                // 1, 2: inline-asm fragment reads with counted lgkmcnt waits, that many units ahead (measured: 2.88 / 2.97 / 3.27 ms per transformer call for 0 / 1 / 2 -- the third buffer spills inside the loops)
+#endif
 constexpr int W = 4, PT = 32, STAGE = 32 * 1024, NST = EFX_NST, BLK = 4096;     // ring stages: panels are fetched NST - 1 ahead
 constexpr int NPANEL = 16 + 48;                         // 8 x (Wq_h, P_h) + 16 x (W0a, W0b, W2_k)
 constexpr int DMA_PER_WAVE = 8;                         // global_load_lds per wave and panel: 2 blocks x 4 row octets
@@ -184,6 +187,75 @@ __global__ __launch_bounds__(W * 64, 1) void encoder_x_kernel(Args a) {
   // unit's reads are issued, so it only ever waits for reads issued a whole unit earlier.
 #define EFX_RD(st_, blk_, odd_, lo_) (*reinterpret_cast<const h16x8*>((st_) + (blk_) * BLK + (a_off ^ (((odd_) ? 32 : 0) | ((lo_) ? 64 : 0)))))
 #define EFX_USE(a_, b_, c_, d_) asm volatile("" :: "v"(a_), "v"(b_), "v"(c_), "v"(d_))
+#if EFX_PIPE
+  // ---- fragment reads as inline asm with COUNTED lgkmcnt waits, EFX_PIPE units ahead (the idiom of score_sweep.h, SWEEP_PIPE).
+  // With compiler-visible reads every wait is lgkmcnt(0) (previous note), i.e. a unit can only be ONE unit ahead, and a read
+  // issued behind the first MFMAs of unit u has ~5 MFMAs (160 cycles) to land: the measured LDS latency under four waves' fragment
+  // traffic plus the DMA fills is longer, and with one wave per SIMD every late fragment is a matrix-pipe bubble (bare loop: 42
+  // cycles per MFMA against the 32.7 of tools/micro/mfma_chain.hip).  LDS reads return in order: "unit u has landed" is
+  // lgkmcnt(4 x younger units in flight); the wait statement names the fragments it releases ("+v"), which keeps their MFMAs below it.
+  h16x8 fr[EFX_PIPE + 1][4];
+  const unsigned lds_base = (unsigned)(size_t)(lds_ptr_t)lds;
+#define EFX_LOADU(buf_, A0_, A1_, A2_, A3_, O01_, O23_)                                                    \
+    asm volatile("ds_read_b128 %0, %4 offset:%8\n\tds_read_b128 %1, %5 offset:%8\n\t"                      \
+                 "ds_read_b128 %2, %6 offset:%9\n\tds_read_b128 %3, %7 offset:%9"                           \
+                 : "=&v"(fr[buf_][0]), "=&v"(fr[buf_][1]), "=&v"(fr[buf_][2]), "=&v"(fr[buf_][3])          \
+                 : "v"(A0_), "v"(A1_), "v"(A2_), "v"(A3_), "i"(O01_), "i"(O23_));
+#define EFX_WAITU(buf_, n_)                                                                                \
+    asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(fr[buf_][0]), "+v"(fr[buf_][1]), "+v"(fr[buf_][2]), "+v"(fr[buf_][3]) : "i"(n_));
+#define EFX_YOUNGER(u_) (4 * ((u_) + EFX_PIPE < 8 ? EFX_PIPE : 7 - (u_)))
+  // R panel (32 rows x 256 k): unit u = k-group u (block u): even k-step hi / lo, odd k-step hi / lo
+#define EFX_RLOAD(u_) EFX_LOADU((u_) % (EFX_PIPE + 1), ad0__, ad1__, ad2__, ad3__, (u_) * BLK, (u_) * BLK)
+#define EFX_RUNIT(u_, bh_, bl_)                                                                            \
+    if ((u_) + EFX_PIPE < 8) EFX_RLOAD((u_) + EFX_PIPE)                                                    \
+    EFX_WAITU((u_) % (EFX_PIPE + 1), EFX_YOUNGER(u_))                                                      \
+    {                                                                                                      \
+      const h16x8 eh__ = fr[(u_) % (EFX_PIPE + 1)][0], el__ = fr[(u_) % (EFX_PIPE + 1)][1];                \
+      const h16x8 oh__ = fr[(u_) % (EFX_PIPE + 1)][2], ol__ = fr[(u_) % (EFX_PIPE + 1)][3];                \
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(eh__, bl_[2 * (u_)], acc0, 0, 0, 0);                   \
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(el__, bh_[2 * (u_)], acc0, 0, 0, 0);                   \
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(eh__, bh_[2 * (u_)], acc0, 0, 0, 0);                   \
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(oh__, bl_[2 * (u_) + 1], acc0, 0, 0, 0);               \
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ol__, bh_[2 * (u_) + 1], acc0, 0, 0, 0);               \
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(oh__, bh_[2 * (u_) + 1], acc0, 0, 0, 0);               \
+    }                                                                                                      \
+    __builtin_amdgcn_sched_barrier(0);
+#define EFX_RPANEL(st_, bh_, bl_)                                                                          \
+  {                                                                                                        \
+    const unsigned stb__ = (unsigned)(size_t)(lds_ptr_t)(st_);                                             \
+    const unsigned ad0__ = stb__ + a_off, ad1__ = stb__ + (a_off ^ 64), ad2__ = stb__ + (a_off ^ 32), ad3__ = stb__ + (a_off ^ 96); \
+    EFX_RLOAD(0) if (EFX_PIPE > 1) EFX_RLOAD(1)                                                            \
+    EFX_RUNIT(0, bh_, bl_) EFX_RUNIT(1, bh_, bl_) EFX_RUNIT(2, bh_, bl_) EFX_RUNIT(3, bh_, bl_)            \
+    EFX_RUNIT(4, bh_, bl_) EFX_RUNIT(5, bh_, bl_) EFX_RUNIT(6, bh_, bl_) EFX_RUNIT(7, bh_, bl_)            \
+  }
+  // K panel (256 rows x 32 k): unit u = (output panels 2 (u >> 1), 2 (u >> 1) + 1; k-step u & 1): blocks 2 (u >> 1) and + 1
+#define EFX_KLOAD(u_)                                                                                      \
+    if ((u_) & 1) EFX_LOADU((u_) % (EFX_PIPE + 1), ad2__, ad3__, ad2__, ad3__, 2 * ((u_) >> 1) * BLK, (2 * ((u_) >> 1) + 1) * BLK) \
+    else EFX_LOADU((u_) % (EFX_PIPE + 1), ad0__, ad1__, ad0__, ad1__, 2 * ((u_) >> 1) * BLK, (2 * ((u_) >> 1) + 1) * BLK)
+#define EFX_KUNIT(u_, fh_, fl_, out_)                                                                      \
+    if ((u_) + EFX_PIPE < 8) { EFX_KLOAD((u_) + EFX_PIPE) }                                                \
+    EFX_WAITU((u_) % (EFX_PIPE + 1), EFX_YOUNGER(u_))                                                      \
+    {                                                                                                      \
+      const h16x8 ah__ = fr[(u_) % (EFX_PIPE + 1)][0], al__ = fr[(u_) % (EFX_PIPE + 1)][1];                \
+      const h16x8 bh__ = fr[(u_) % (EFX_PIPE + 1)][2], bl__ = fr[(u_) % (EFX_PIPE + 1)][3];                \
+      constexpr int ja__ = 2 * ((u_) >> 1), jb__ = 2 * ((u_) >> 1) + 1, s__ = (u_) & 1;                    \
+      out_[ja__] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah__, fl_[s__], out_[ja__], 0, 0, 0);            \
+      out_[jb__] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh__, fl_[s__], out_[jb__], 0, 0, 0);            \
+      out_[ja__] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al__, fh_[s__], out_[ja__], 0, 0, 0);            \
+      out_[jb__] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl__, fh_[s__], out_[jb__], 0, 0, 0);            \
+      out_[ja__] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah__, fh_[s__], out_[ja__], 0, 0, 0);            \
+      out_[jb__] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh__, fh_[s__], out_[jb__], 0, 0, 0);            \
+    }                                                                                                      \
+    __builtin_amdgcn_sched_barrier(0);
+#define EFX_KPANEL(st_, fh_, fl_, out_)                                                                    \
+  {                                                                                                        \
+    const unsigned stb__ = (unsigned)(size_t)(lds_ptr_t)(st_);                                             \
+    const unsigned ad0__ = stb__ + a_off, ad1__ = stb__ + (a_off ^ 64), ad2__ = stb__ + (a_off ^ 32), ad3__ = stb__ + (a_off ^ 96); \
+    { EFX_KLOAD(0) } if (EFX_PIPE > 1) { EFX_KLOAD(1) }                                                    \
+    EFX_KUNIT(0, fh_, fl_, out_) EFX_KUNIT(1, fh_, fl_, out_) EFX_KUNIT(2, fh_, fl_, out_) EFX_KUNIT(3, fh_, fl_, out_) \
+    EFX_KUNIT(4, fh_, fl_, out_) EFX_KUNIT(5, fh_, fl_, out_) EFX_KUNIT(6, fh_, fl_, out_) EFX_KUNIT(7, fh_, fl_, out_) \
+  }
+#else
   // R panel: acc0 += W[32 rows][256 k] . B fragments bh / bl; unit u = k-group u = k-steps 2u, 2u + 1.  ONE accumulator chain:
   // a dependent v_mfma_f32_32x32x16_f16 issues at the full rate (tools/micro/mfma_chain.hip: 32.7 cycles per MFMA with 1, 2, 3
   // or 4 chains).  The next unit's four fragment reads are issued in pairs BEHIND the first two MFMAs of this unit -- each pair
@@ -239,6 +311,7 @@ __global__ __launch_bounds__(W * 64, 1) void encoder_x_kernel(Args a) {
     }                                                                                                      \
   }
 
+#endif
   LOFTR_WAITCNT_VM(0);                                  // x fragments, tables: complete before the first DMA
   __syncthreads();
   EFX_ISSUE(0);
@@ -365,6 +438,15 @@ __global__ __launch_bounds__(W * 64, 1) void encoder_x_kernel(Args a) {
 #undef EFX_KPANEL
 #undef EFX_RD
 #undef EFX_USE
+#if EFX_PIPE
+#undef EFX_LOADU
+#undef EFX_WAITU
+#undef EFX_YOUNGER
+#undef EFX_RLOAD
+#undef EFX_RUNIT
+#undef EFX_KLOAD
+#undef EFX_KUNIT
+#endif
 
   // ================= out = x + LayerNorm2(mlp.2 output), fp32 and SP                                          transformer.py:55-58
   if (!live) return;
