@@ -432,8 +432,6 @@ __global__ __launch_bounds__(W * 64, 1) void encoder_x_kernel(Args a) {
     if (live) EFX_KPANEL(lds + ((p + 2) % NST) * STAGE, hh, hl, big);
   }
 #undef EFX_PASS2_HEAD
-#undef EFX_ISSUE
-#undef EFX_BEGIN
 #undef EFX_RPANEL
 #undef EFX_KPANEL
 #undef EFX_RD
@@ -520,6 +518,291 @@ __global__ __launch_bounds__(W * 64, 1) void encoder_x_kernel(Args a) {
     }
   }
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// The TAIL of a launch.  encoder_x_kernel's unit of work is one wave x 32 tokens for the whole layer (~110 us): a call with
+// 1200 blocks on the 1024 SIMDs costs two rounds although it holds 1.17 rounds of work.  The blocks beyond the last full
+// round of workgroups go through this kernel instead: ONE 32-token block per workgroup, its four waves sharing every panel:
+//   * an R panel (32 output features x 256 k) is split along K -- wave w owns k-steps 4 w .. 4 w + 3, i.e. features 64 w .. + 63 of
+//     the input, and holds only that slice of x and of the message (32 registers each); the four partial 32 x 32 tiles are
+//     all-reduced through a 16 KB LDS buffer (fixed order: every wave gets bitwise the same sum) and every wave runs the
+//     (cheap) epilogue redundantly, so all of them hold the resulting Q' / hidden fragments;
+//   * a K panel (256 output features x 32 k) is split along N -- wave w owns output panels 2 w, 2 w + 1: no exchange, and what it
+//     accumulates (features 64 w .. + 63 of the message, then of the output) is exactly the K slice it needs next: the N split
+//     of one stage IS the K split of the following one.  LayerNorm combines four per-wave (mean, M2) pairs (exact parallel form).
+// Per block: 864 MFMAs per wave instead of 3072, 24 exchanges; the weights are streamed per 32 tokens here (4x the main kernel's
+// L2 traffic per token), which is why this is the tail path and not the kernel.
+constexpr int OFF_XB = OFF_TAB + T_N * 4, OFF_ST = OFF_XB + 4 * 4096, LDS_BYTES_C = OFF_ST + 4 * 32 * 8;
+static_assert(LDS_BYTES_C <= 160 * 1024, "one workgroup per CU");
+
+__global__ __launch_bounds__(W * 64, 1) void encoder_xc_kernel(Args a, int id0) {
+  __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES_C];
+  const int id = id0 + (int)(blockIdx.x >> 2), xcd = id % NUM_XCD, slot = id / NUM_XCD;
+  const int seq = (slot / a.groups) * NUM_XCD + xcd, grp = slot % a.groups;
+  const int blk = grp * W + (int)(blockIdx.x & 3);
+  const int T = a.T;
+  if (seq >= a.nseq || blk * PT >= T) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 5, li = lane & 31;
+  const int tok = blk * PT + li;
+  const long row = (long)seq * T + min(tok, T - 1);
+  float* tab = reinterpret_cast<float*>(lds + OFF_TAB);
+  for (int f = threadIdx.x; f < 256; f += W * 64) {
+    tab[T_WQS + f] = a.wq_s[f];
+    tab[T_KSUM + f] = a.kv[((long)seq * 8 + (f >> 5)) * (33 * 32) + 32 * 32 + (f & 31)];
+    tab[T_G1 + f] = a.g1[f]; tab[T_B1 + f] = a.b1[f];
+    tab[T_W0S + f] = a.w0_s[f]; tab[T_W0S + 256 + f] = a.w0_s[256 + f];
+    tab[T_W2S + f] = a.w2_s[f];
+    tab[T_G2 + f] = a.g2[f]; tab[T_B2 + f] = a.b2[f];
+  }
+  const float mk = (a.mask && !a.mask[row]) ? 0.f : 1.f;
+  // this wave's K slice of x: k-steps 4 wave + i (features 64 wave + 16 i + 8 g + e)
+  h16x8 xh[4], xl[4];
+  {
+    const u32x4* src = reinterpret_cast<const u32x4*>(a.x_sp + row * 256);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int ks = 4 * wave + i, c = (ks >> 1) * 8 + 2 * (ks & 1) + g;
+      xh[i] = __builtin_bit_cast(h16x8, src[c]);
+      xl[i] = __builtin_bit_cast(h16x8, src[c + 4]);
+    }
+  }
+  const sp_t* pm = a.pm + (long)seq * a.pm_seq_stride;
+  int dro[4], dch[4];
+#pragma unroll
+  for (int oct = 0; oct < 4; ++oct) {
+    dro[oct] = oct * 8 + (lane >> 3);
+    dch[oct] = ((lane & 7) ^ ((oct * 4 + (lane >> 4)) & 7)) << 2;
+  }
+  const int a_off = lds_chunk_off(li, g);
+  const bool live = true; (void)live;
+  // exchange buffer: partial tile of wave w, register quad q, lane l at ((w * 4 + q) * 64 + l) * 16
+  const unsigned xb_w = (unsigned)(size_t)(lds_ptr_t)(lds + OFF_XB) + (unsigned)((wave * 4 * 64 + lane) * 16);
+  const char* xb_r = lds + OFF_XB + lane * 16;
+  const unsigned st_w = (unsigned)(size_t)(lds_ptr_t)(lds + OFF_ST) + (unsigned)((wave * 32 + li) * 8);
+  const float2* st_r = reinterpret_cast<const float2*>(lds + OFF_ST) + li;
+#define EFX_CRD(st_, blk_, odd_, lo_) (*reinterpret_cast<const h16x8*>((st_) + (blk_) * BLK + (a_off ^ (((odd_) ? 32 : 0) | ((lo_) ? 64 : 0)))))
+  // this wave's share of an R panel: k-groups 2 wave, 2 wave + 1 against its K slice bh / bl (four k-steps)
+#define EFX_CR(st_, bh_, bl_, acc_)                                                                        \
+  {                                                                                                        \
+    const char* s0__ = (st_) + (2 * wave) * BLK;                                                           \
+    const h16x8 e0h = EFX_CRD(s0__, 0, 0, 0), e0l = EFX_CRD(s0__, 0, 0, 1), o0h = EFX_CRD(s0__, 0, 1, 0), o0l = EFX_CRD(s0__, 0, 1, 1); \
+    const h16x8 e1h = EFX_CRD(s0__, 1, 0, 0), e1l = EFX_CRD(s0__, 1, 0, 1), o1h = EFX_CRD(s0__, 1, 1, 0), o1l = EFX_CRD(s0__, 1, 1, 1); \
+    acc_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(e0h, bl_[0], acc_, 0, 0, 0);                             \
+    acc_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(e0l, bh_[0], acc_, 0, 0, 0);                             \
+    acc_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(e0h, bh_[0], acc_, 0, 0, 0);                             \
+    acc_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(o0h, bl_[1], acc_, 0, 0, 0);                             \
+    acc_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(o0l, bh_[1], acc_, 0, 0, 0);                             \
+    acc_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(o0h, bh_[1], acc_, 0, 0, 0);                             \
+    acc_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(e1h, bl_[2], acc_, 0, 0, 0);                             \
+    acc_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(e1l, bh_[2], acc_, 0, 0, 0);                             \
+    acc_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(e1h, bh_[2], acc_, 0, 0, 0);                             \
+    acc_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(o1h, bl_[3], acc_, 0, 0, 0);                             \
+    acc_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(o1l, bh_[3], acc_, 0, 0, 0);                             \
+    acc_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(o1h, bh_[3], acc_, 0, 0, 0);                             \
+  }
+  // this wave's share of a K panel: output panels 2 wave, 2 wave + 1 against the two k-step fragments fh / fl
+#define EFX_CK(st_, fh_, fl_, o0_, o1_)                                                                    \
+  {                                                                                                        \
+    const char* s0__ = (st_) + (2 * wave) * BLK;                                                           \
+    const h16x8 a0h = EFX_CRD(s0__, 0, 0, 0), a0l = EFX_CRD(s0__, 0, 0, 1), a1h = EFX_CRD(s0__, 0, 1, 0), a1l = EFX_CRD(s0__, 0, 1, 1); \
+    const h16x8 b0h = EFX_CRD(s0__, 1, 0, 0), b0l = EFX_CRD(s0__, 1, 0, 1), b1h = EFX_CRD(s0__, 1, 1, 0), b1l = EFX_CRD(s0__, 1, 1, 1); \
+    o0_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h, fl_[0], o0_, 0, 0, 0);                               \
+    o1_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(b0h, fl_[0], o1_, 0, 0, 0);                               \
+    o0_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0l, fh_[0], o0_, 0, 0, 0);                               \
+    o1_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(b0l, fh_[0], o1_, 0, 0, 0);                               \
+    o0_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h, fh_[0], o0_, 0, 0, 0);                               \
+    o1_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(b0h, fh_[0], o1_, 0, 0, 0);                               \
+    o0_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, fl_[1], o0_, 0, 0, 0);                               \
+    o1_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(b1h, fl_[1], o1_, 0, 0, 0);                               \
+    o0_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1l, fh_[1], o0_, 0, 0, 0);                               \
+    o1_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(b1l, fh_[1], o1_, 0, 0, 0);                               \
+    o0_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, fh_[1], o0_, 0, 0, 0);                               \
+    o1_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(b1h, fh_[1], o1_, 0, 0, 0);                               \
+  }
+  // all-reduce of the four waves' partial tiles (asm LDS stores: a compiler-visible one would drain the weight DMA); the
+  // buffer is reused by the next exchange only after at least one panel barrier, which every wave reaches after its reads
+#define EFX_XCHG(acc_, full_)                                                                              \
+  {                                                                                                        \
+    _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                        \
+      const f32x4 v4__ = {acc_[4 * q], acc_[4 * q + 1], acc_[4 * q + 2], acc_[4 * q + 3]};                 \
+      asm volatile("ds_write_b128 %0, %1 offset:%2" :: "v"(xb_w), "v"(v4__), "i"(q * 1024) : "memory");    \
+    }                                                                                                      \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                     \
+    __builtin_amdgcn_s_barrier();                                                                          \
+    _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                        \
+      f32x4 s4__ = *reinterpret_cast<const f32x4*>(xb_r + (0 * 4 + q) * 1024);                             \
+      s4__ += *reinterpret_cast<const f32x4*>(xb_r + (1 * 4 + q) * 1024);                                  \
+      s4__ += *reinterpret_cast<const f32x4*>(xb_r + (2 * 4 + q) * 1024);                                  \
+      s4__ += *reinterpret_cast<const f32x4*>(xb_r + (3 * 4 + q) * 1024);                                  \
+      full_[4 * q] = s4__[0]; full_[4 * q + 1] = s4__[1]; full_[4 * q + 2] = s4__[2]; full_[4 * q + 3] = s4__[3]; \
+    }                                                                                                      \
+  }
+  // LayerNorm statistics over the 256 features of a token: this wave holds 64 of them (v_[2][16] + the partner lane's)
+#define EFX_CSTATS(v_, mean_, rstd_, eps_)                                                                 \
+  {                                                                                                        \
+    float s__ = 0.f;                                                                                       \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j) _Pragma("unroll") for (int r = 0; r < 16; ++r) s__ += v_[j][r]; \
+    s__ += swap32(s__);                                                                                    \
+    const float mw__ = s__ * (1.f / 64.f);                                                                 \
+    float m2__ = 0.f;                                                                                      \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j) _Pragma("unroll") for (int r = 0; r < 16; ++r) { const float d = v_[j][r] - mw__; m2__ = fmaf(d, d, m2__); } \
+    m2__ += swap32(m2__);                                                                                  \
+    if (g == 0) { const f32x2 pr__ = {mw__, m2__}; asm volatile("ds_write_b64 %0, %1" :: "v"(st_w), "v"(pr__) : "memory"); } \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                     \
+    __builtin_amdgcn_s_barrier();                                                                          \
+    const float2 e0 = st_r[0], e1 = st_r[32], e2 = st_r[64], e3 = st_r[96];                                \
+    mean_ = (e0.x + e1.x + e2.x + e3.x) * 0.25f;                                                           \
+    const float d0 = e0.x - mean_, d1 = e1.x - mean_, d2 = e2.x - mean_, d3 = e3.x - mean_;                \
+    const float M2__ = (e0.y + e1.y + e2.y + e3.y) + 64.f * (d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3);       \
+    rstd_ = rsqrtf(M2__ * (1.f / 256.f) + (eps_));                                                         \
+  }
+
+  LOFTR_WAITCNT_VM(0);
+  __syncthreads();
+  EFX_ISSUE(0);
+  EFX_ISSUE(1);
+  if (NST >= 4) EFX_ISSUE(2);
+  const int fq = 4 * g;
+  f32x16 acc, big0, big1;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { big0[r] = 0.f; big1[r] = 0.f; }
+  // ================= pass 1
+#pragma unroll 1
+  for (int h = 0; h < 8; ++h) {
+    const int p = 2 * h;
+    EFX_BEGIN(p);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    EFX_CR(lds + (p % NST) * STAGE, xh, xl, acc);
+    float full[16];
+    EFX_XCHG(acc, full);
+    float v[16], den = 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 ws = *reinterpret_cast<const f32x4*>(tab + T_WQS + 32 * h + fq + 8 * q);
+      const f32x4 ks4 = *reinterpret_cast<const f32x4*>(tab + T_KSUM + 32 * h + fq + 8 * q);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float x = full[4 * q + e] * ws[e];
+        x = x > 0.f ? x + 1.f : __expf(x);
+        x *= mk;
+        v[4 * q + e] = x;
+        den = fmaf(x, ks4[e], den);
+      }
+    }
+    den += swap32(den);
+    const float z = a.v_length * __builtin_amdgcn_rcpf(den + a.attn_eps);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r] *= z;
+    h16x8 qh[2], ql[2];
+    pack_panel(v, qh, ql);
+    EFX_BEGIN(p + 1);
+    EFX_CK(lds + ((p + 1) % NST) * STAGE, qh, ql, big0, big1);
+  }
+  // ---- message slice = LayerNorm1 over all 256 features, this wave's 64 -> its K slice of the mlp.0 input
+  h16x8 mh[4], ml[4];
+  {
+    float vv[2][16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { vv[0][r] = big0[r] * a.p_out_scale; vv[1][r] = big1[r] * a.p_out_scale; }
+    float mean, rstd;
+    EFX_CSTATS(vv, mean, rstd, a.ln_eps);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      float y[16];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int f = 32 * (2 * wave + j) + fq + 8 * q;
+        const f32x4 ga = *reinterpret_cast<const f32x4*>(tab + T_G1 + f);
+        const f32x4 be = *reinterpret_cast<const f32x4*>(tab + T_B1 + f);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) y[4 * q + e] = (vv[j][4 * q + e] - mean) * rstd * ga[e] + be[e];
+      }
+      h16x8 fh[2], fl[2];
+      pack_panel(y, fh, fl);
+      mh[2 * j] = fh[0]; mh[2 * j + 1] = fh[1]; ml[2 * j] = fl[0]; ml[2 * j + 1] = fl[1];
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { big0[r] = 0.f; big1[r] = 0.f; }
+  // ================= pass 2
+#pragma unroll 1
+  for (int hp = 0; hp < 16; ++hp) {
+    const int p = 16 + 3 * hp;
+    EFX_BEGIN(p);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    EFX_CR(lds + (p % NST) * STAGE, xh, xl, acc);
+    EFX_BEGIN(p + 1);
+    EFX_CR(lds + ((p + 1) % NST) * STAGE, mh, ml, acc);
+    float full[16];
+    EFX_XCHG(acc, full);
+    float v[16];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 ws = *reinterpret_cast<const f32x4*>(tab + T_W0S + 32 * hp + fq + 8 * q);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[4 * q + e] = fmaxf(full[4 * q + e] * ws[e], 0.f);
+    }
+    h16x8 hh[2], hl[2];
+    pack_panel(v, hh, hl);
+    EFX_BEGIN(p + 2);
+    EFX_CK(lds + ((p + 2) % NST) * STAGE, hh, hl, big0, big1);
+  }
+  // ================= out slice = x + LayerNorm2(mlp.2 output), features 64 wave .. + 63
+  {
+    float vv[2][16];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 ws = *reinterpret_cast<const f32x4*>(tab + T_W2S + 32 * (2 * wave + j) + fq + 8 * q);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) vv[j][4 * q + e] = (j ? big1[4 * q + e] : big0[4 * q + e]) * ws[e];
+      }
+    float mean, rstd;
+    EFX_CSTATS(vv, mean, rstd, a.ln_eps);
+    if (tok < T) {
+      const float* xr = a.x_f32 + row * 256;
+      float* of = a.out_f32 + row * 256;
+      sp_t* os = a.out_sp + row * 256;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int jp = 2 * wave + j;
+        float y[16];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int f = 32 * jp + fq + 8 * q;
+          const f32x4 ga = *reinterpret_cast<const f32x4*>(tab + T_G2 + f);
+          const f32x4 be = *reinterpret_cast<const f32x4*>(tab + T_B2 + f);
+          const f32x4 xr4 = *reinterpret_cast<const f32x4*>(xr + f);
+          f32x4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            o[e] = xr4[e] + ((vv[j][4 * q + e] - mean) * rstd * ga[e] + be[e]);
+            y[4 * q + e] = o[e];
+          }
+          *reinterpret_cast<f32x4*>(of + f) = o;
+        }
+        if (!a.out_sp) continue;
+        h16x8 fh[2], fl[2];
+        pack_panel(y, fh, fl);
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          *reinterpret_cast<u32x4*>(os + jp * 32 + (2 * s2 + g) * 4) = __builtin_bit_cast(u32x4, fh[s2]);
+          *reinterpret_cast<u32x4*>(os + jp * 32 + 16 + (2 * s2 + g) * 4) = __builtin_bit_cast(u32x4, fl[s2]);
+        }
+      }
+    }
+  }
+#undef EFX_CRD
+#undef EFX_CR
+#undef EFX_CK
+#undef EFX_XCHG
+#undef EFX_CSTATS
+}
+#undef EFX_ISSUE
+#undef EFX_BEGIN
 }  // namespace efx
 }  // namespace
 
@@ -539,8 +822,27 @@ int launch_encoder_x(const EncoderXArgs& p, hipStream_t st) {
   a.v_length = p.v_length; a.attn_eps = p.attn_eps; a.p_out_scale = p.p_out_scale; a.ln_eps = p.ln_eps;
   a.nseq = p.nseq; a.T = p.T; a.groups = ceil_div(ceil_div(p.T, efx::PT), efx::W);
   const int grid = NUM_XCD * ceil_div(p.nseq, NUM_XCD) * a.groups;
+  // Split the launch: the largest whole number of 256-workgroup rounds goes to the main kernel (a wave x 32 tokens for the whole
+  // layer), the remainder to the cooperative tail kernel (a workgroup x 32 tokens) when that is the cheaper way to finish:
+  // OFF by default (LOFTR_ENCODER_TAIL=1 enables it).  Measured at the bench size (tools/gpu/r3_tail.sh): a cooperative round costs
+  // 65 us, not a third of the main kernel's 110 -- 64 barriers, 24 exchanges and a 2 MB weight stream per 32 tokens -- so only a
+  // single tail round pays (cross calls: 221 -> 175 us; 2.91 -> 2.79 ms per transformer call, -4 %), while a pair's result would
+  // then depend, in the last bits, on the batch it was part of (test_batch_consistency_full_size) and the two-stream bench fills
+  // the idle SIMDs of a partial round with convolution workgroups anyway.
+  static const bool tail_on = []() { const char* e = getenv("LOFTR_ENCODER_TAIL"); return e && atoi(e) == 1; }();
+  auto live = [&](int id) { const int xcd = id % NUM_XCD, slot = id / NUM_XCD; return (slot / a.groups) * NUM_XCD + xcd < a.nseq; };
+  int total = 0;
+  for (int id = 0; id < grid; ++id) total += live(id);
+  const int full = total / 256 * 256;
+  int g_main = 0;
+  for (int cnt = 0; g_main < grid && cnt < full; ++g_main) cnt += live(g_main);
+  int tail = 0;
+  for (int id = g_main; id < grid; ++id) tail += live(id);
+  const bool use_tail = tail_on && tail > 0 && ceil_div(tail * efx::W, 256) <= 1;
+  if (!use_tail) g_main = grid;
   TimedLaunch tl(LOFTR_T_ENCODER_X, st);
-  hipLaunchKernelGGL(efx::encoder_x_kernel, dim3(grid), dim3(efx::W * 64), 0, st, a);
+  if (g_main > 0) hipLaunchKernelGGL(efx::encoder_x_kernel, dim3(g_main), dim3(efx::W * 64), 0, st, a);
+  if (g_main < grid) hipLaunchKernelGGL(efx::encoder_xc_kernel, dim3((grid - g_main) * efx::W), dim3(efx::W * 64), 0, st, a, g_main);
   LOFTR_CHECK_LAUNCH();
   return LOFTR_OK;
 }
