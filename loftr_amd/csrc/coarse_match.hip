@@ -397,6 +397,16 @@ __device__ __forceinline__ bool candidate_ok(const SelectParams& sp, const float
   return bv == colmax[(long)n * g.S + j];
 }
 
+// the part of the border / padding test that depends on the ROW alone
+__device__ __forceinline__ bool row_ok(const SelectParams& sp, int n, int i) {
+  const Geometry& g = sp.g;
+  if (sp.border <= 0) return true;
+  const int y0 = i / g.w0c, x0 = i % g.w0c;
+  int l_h0 = g.h0c - sp.border, l_w0 = g.w0c - sp.border;
+  if (sp.valid) { l_h0 = upper_limit(sp.valid[n * 4], sp.border, g.h0c); l_w0 = upper_limit(sp.valid[n * 4 + 1], sp.border, g.w0c); }
+  return y0 >= sp.border && x0 >= sp.border && y0 < l_h0 && x0 < l_w0;
+}
+
 // one thread per row of the flattened [N*L] rows; 256 rows per block
 //
 // Exact ties.  The reference ANDs threshold, border and mutual-maximum masks over the whole row and takes the FIRST
@@ -413,7 +423,7 @@ __global__ __launch_bounds__(256) void select_kernel(SelectParams sp, const floa
   const Geometry& g = sp.g;
   const long row = (long)blockIdx.x * 256 + threadIdx.x;
   const long rows = (long)g.N * g.L;
-  bool flag = false;
+  bool flag = false, walk = false;
   int bj = 0; float bv = 0.f; int n = 0;
   if (row < rows) {
     n = (int)(row / g.L);
@@ -444,10 +454,32 @@ __global__ __launch_bounds__(256) void select_kernel(SelectParams sp, const floa
       bj = first >= 0 ? first : c0;
     }
     flag = candidate_ok(sp, colmax, n, i, bj, bv);
-    if (!flag && tie && conf && bv > sp.thr) {          // rare: exact tie at the row maximum and the first one failed
-      const float* cr = conf + ((long)n * g.L + i) * g.S;
-      for (int j = bj + 1; j < g.S; ++j)
-        if (cr[j] == bv && candidate_ok(sp, colmax, n, i, j, bv)) { bj = j; flag = true; break; }
+    // rare: exact tie at the row maximum and the first one failed.  Not for a row that fails the border / padding test on its
+    // OWN coordinates: no column can pass for it (every padded row of a MegaDepth-style batch is such a row, and its uniform
+    // confidences tie everywhere: walking them was 3.3 ms of the 840 x 840 configuration, profiles/r03_kernel_stats_outdoor.txt)
+    walk = !flag && tie && conf && bv > sp.thr && row_ok(sp, n, i);
+  }
+  // The walk itself is done by the whole wave for one row at a time (64 columns per step, coalesced) instead of by the row's
+  // thread alone (one dependent load per column: 0.5 ms for a single 4800-column row).
+  {
+    unsigned long long todo = __ballot(walk);
+    while (todo) {                                     // wave-uniform
+      const int src = __ffsll((long long)todo) - 1;
+      todo &= todo - 1;
+      const long r_s = __shfl((int)(row >> 31), src) * (1L << 31) + (long)(__shfl((int)(row & 0x7fffffff), src));
+      const int n_s = __shfl(n, src), bj_s = __shfl(bj, src);
+      const float bv_s = __shfl(bv, src);
+      const int i_s = (int)(r_s - (long)n_s * g.L);
+      const float* cr = conf + r_s * g.S;
+      const int lane_ = threadIdx.x & 63;
+      int found = -1;
+      for (int base = bj_s + 1; base < g.S && found < 0; base += 64) {
+        const int j = base + lane_;
+        const bool hit = j < g.S && cr[j] == bv_s && candidate_ok(sp, colmax, n_s, i_s, j, bv_s);
+        const unsigned long long hb = __ballot(hit);
+        if (hb) found = base + (__ffsll((long long)hb) - 1);
+      }
+      if (lane_ == src && found >= 0) { bj = found; flag = true; }
     }
   }
   // block-local exclusive scan of the flags (ballot per wave + wave offsets through LDS)
