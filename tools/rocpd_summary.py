@@ -35,6 +35,31 @@ def main(path, skip_until=None):
     print(f"{'calls':>7} {'total_us':>12} {'avg_us':>10} {'min_us':>10} {'max_us':>10} {'pct':>6}  kernel")
     for n, c, t, a, mn, mx in rows:
         print(f"{c:7d} {t / 1e3:12.1f} {a / 1e3:10.2f} {mn / 1e3:10.2f} {mx / 1e3:10.2f} {100 * t / total:6.2f}  {short(n)}")
+    coverage(db, where)
+
+
+def coverage(db, where):
+    """GPU coverage over the LAST 40 % of the trace (the timed steps; warm-up and instrumented steps come first): union of the kernel
+    intervals / wall span, and the idle gaps by size -- the launch-gap evidence DESIGN.md §6b quotes."""
+    iv = sorted(db.execute(f"select start, end from kernels {where}").fetchall())
+    if len(iv) < 10:
+        return
+    t_lo = iv[0][0] + 0.6 * (iv[-1][1] - iv[0][0])
+    iv = [(a, b) for a, b in iv if a >= t_lo]
+    busy, gaps, cur_a, cur_b = 0, [], iv[0][0], iv[0][1]
+    for a, b in iv[1:]:
+        if a > cur_b:
+            busy += cur_b - cur_a
+            gaps.append(a - cur_b)
+            cur_a, cur_b = a, b
+        else:
+            cur_b = max(cur_b, b)
+    busy += cur_b - cur_a
+    span = iv[-1][1] - iv[0][0]
+    big = sorted(gaps, reverse=True)[:8]
+    print(f"# coverage over the last 40 % of the trace ({span / 1e6:.1f} ms, {len(iv)} dispatches): kernels cover {100 * busy / span:.2f} % of the wall time; "
+          f"{len(gaps)} gaps, total {sum(gaps) / 1e6:.3f} ms, > 20 us: {sum(1 for g in gaps if g > 20000)} (sum {sum(g for g in gaps if g > 20000) / 1e6:.3f} ms); "
+          f"largest [us]: {[round(g / 1e3, 1) for g in big]}")
 
 
 if __name__ == "__main__":
