@@ -27,9 +27,9 @@ def _ref_noise_px(g):
 
 
 def _check_against_golden(name, out, inp, g, max_flips=0):
-    # two independent fp32 roundings of the same exact result cannot be asked to sit closer than ~1.5x the reference's own distance
-    # from exact arithmetic (peaked_ds: the reference's fp32 forward is 9.2e-4 px from its fp64 forward; same rule as tests/test_e2e_golden.py)
-    tol_px = max(1e-3, 1.5 * _ref_noise_px(g))
+    # two independent fp32 roundings of the same exact result, each within n of it, are within 2n of each other: the bar cannot be below
+    # twice the reference's own distance from exact arithmetic (peaked_ds: the reference's fp32 forward is 9.2e-4 px from its fp64 forward; same rule as tests/test_e2e_golden.py)
+    tol_px = max(1e-3, 2.0 * _ref_noise_px(g))
     rep = compare_to_golden(out, g, inp["cfg"]["match_coarse"]["thr"], tol_px=tol_px, max_flips=max_flips)
     check_conf_digest(out["conf_matrix"], g)
     if "conf_matrix" in g:
