@@ -37,8 +37,9 @@ typedef enum {
 } loftr_status;
 
 /* 13: prepared transformer weights, RCCL entry points, scaled activations, pose estimation;
- * 14: training-side consumers (loftr_spvs_coarse / _fine, loftr_coarse_loss_sums, loftr_fine_loss_sums) */
-#define LOFTR_HIP_ABI_VERSION 15
+ * 14: training-side consumers (loftr_spvs_coarse / _fine, loftr_coarse_loss_sums, loftr_fine_loss_sums);
+ * 16: backward of the matching heads and their losses (loftr_*_grad, loftr_dual_softmax_bwd, loftr_fine_match_bwd) */
+#define LOFTR_HIP_ABI_VERSION 16
 
 int loftr_hip_abi_version(void);
 const char* loftr_hip_status_string(int status);
@@ -265,7 +266,7 @@ int loftr_epipolar_errors(const float* mkpts0_f, const float* mkpts1_f, const lo
  *   multiplied by scale1[b] when given (the reference applies it iff 'scale0' is in the batch).
  * loftr_coarse_loss_sums / loftr_fine_loss_sums produce the reduction sums of LoFTRLoss (src/losses/loftr_loss.py:22-157)
  *   in fp64, one pass each (see csrc/train.hip for the layout of `sums`); the means, weights and corner cases are
- *   finished by the caller (loftr_amd/training.py).  Backward passes are not provided. */
+ *   finished by the caller (loftr_amd/training.py).  Their gradients: loftr_coarse_loss_grad / loftr_fine_loss_grad below. */
 typedef struct {
   int N, H0, W0, H1, W1, scale;
   int dh0, dw0, dh1, dw1;
@@ -286,6 +287,35 @@ int loftr_coarse_loss_sums(const float* conf, int N, int L, int S, int kind, con
                            double* sums, void* ws, size_t ws_bytes, void* stream);
 int loftr_fine_loss_sums(const float* expec_f, int ld, const float* expec_f_gt, long M, int with_std, float correct_thr,
                          double* sums, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- backward of the matching heads and of the losses that read them -----------------------------------------------
+ * What torch.autograd derives for the reference between `loss` (src/lightning/lightning_loftr.py:112-133,
+ * src/losses/loftr_loss.py:165-192) and the INPUTS OF THE TWO HEADS: feat_c0 / feat_c1 entering CoarseMatching
+ * (src/loftr/utils/coarse_matching.py:105-119, dual-softmax) and feat_f0 / feat_f1 entering FineMatching
+ * (src/loftr/utils/fine_matching.py:43-57).  One kernel per node; each recomputes the forward quantities it needs from the
+ * node's inputs.  The chain stops there: the transformers, FinePreprocess, the backbone and the Sinkhorn head have no backward.
+ *
+ * loftr_coarse_loss_grad: grad_conf [N,L,S] = d(pos_scale * sum_pos + neg_scale * sum_neg) / d conf for the sums of
+ *   loftr_coarse_loss_sums with the same kind (0, 2, 3; kind 1 -> LOFTR_ERR_UNSUPPORTED), ids and masks; the gradient of
+ *   torch.clamp(conf, 1e-6, 1 - 1e-6) (:45,:54) is included.  The caller folds means, loss weights, corner cases (:31-42) and
+ *   the upstream gradient into pos_scale = up * c_pos_w / M and neg_scale = up * c_neg_w / (N L S - M).
+ * loftr_fine_loss_grad: grad_expec [M,ld] = upstream * d loss_f / d expec_f (:108-157); `sums` is the DEVICE array the forward
+ *   (loftr_fine_loss_sums) filled; the std column gets 0 (weight.detach(), :131); training = the module's .training (:113-117).
+ * loftr_dual_softmax_bwd: dsim [N,L,S] = dL/d sim_matrix from grad_conf = dL/d conf_matrix (:110-119; 0 on the mask-filled
+ *   entries).  sim = <feat_c0, feat_c1> / (C * temperature), so dL/dfeat_c0 = dsim . feat_c1 / (C T) and dL/dfeat_c1 =
+ *   dsim^T . feat_c0 / (C T): two plain batched GEMMs left to the caller (rocBLAS via torch.bmm in loftr_amd/autograd.py).
+ *   Workspace: loftr_coarse_match_workspace_bytes(N, L, S, C).
+ * loftr_fine_match_bwd: grad_f0 / grad_f1 [M,WW,C] from grad_expec [M,3] = dL/d expec_f (x, y, std) (:43-57; grad_f0 is
+ *   non-zero at the centre row only, :43). */
+int loftr_coarse_loss_grad(const float* conf, int N, int L, int S, int kind, const int64_t* gt_b, const int64_t* gt_i,
+                           const int64_t* gt_j, long M, const uint8_t* mask0, const uint8_t* mask1, float alpha, float gamma,
+                           double pos_scale, double neg_scale, float* grad_conf, void* stream);
+int loftr_fine_loss_grad(const float* expec_f, int ld, const float* expec_f_gt, long M, int with_std, float correct_thr,
+                         int training, const double* sums, float upstream, float* grad_expec, void* stream);
+int loftr_dual_softmax_bwd(const float* feat_c0, const float* feat_c1, const loftr_coarse_params* p, float temperature,
+                           const float* grad_conf, float* dsim, void* ws, size_t ws_bytes, void* stream);
+int loftr_fine_match_bwd(const float* feat_f0, const float* feat_f1, int M, int WW, int C, const float* grad_expec,
+                         float* grad_f0, float* grad_f1, void* stream);
 
 /* Replaces estimate_pose (src/utils/metrics.py:72-98: cv2.findEssentialMat(RANSAC) + cv2.recoverPose on intrinsics-
  * normalised key points), the pose step of compute_pose_errors (:101-136).  HOST function (cv2 is a CPU library too):

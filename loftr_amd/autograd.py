@@ -1,0 +1,75 @@
+"""torch.autograd nodes for the two matching heads: forward AND backward are the HIP kernels behind the C-ABI.
+
+What the reference gets from autograd between ``batch['loss']`` (src/lightning/lightning_loftr.py:112-133) and the heads'
+inputs, for the dual-softmax configuration:
+
+    feat_c0, feat_c1 --CoarseMatching (coarse_matching.py:105-119)--> conf_matrix --LoFTRLoss (loftr_loss.py:22-99)---> loss_c
+    feat_f0, feat_f1 --FineMatching   (fine_matching.py:43-57)-----> expec_f     --LoFTRLoss (loftr_loss.py:108-157)-> loss_f
+
+The loss nodes are loftr_amd.training.LoFTRLoss (same mechanism).  Nothing upstream of the heads has a backward: the
+gradients stop at the transformer outputs (LoFTR.head_grads hands those out as leaves).  The Sinkhorn head has no backward
+either; with match_type = 'sinkhorn' conf_matrix stays graph-less.
+
+No CPU fallback: the nodes call loftr_amd.ops, which raises on non-GPU tensors.
+"""
+import torch
+
+from . import ops
+
+
+class _DualSoftmaxMatch(torch.autograd.Function):
+    """conf_matrix = softmax(sim, 1) * softmax(sim, 2) with the match selection riding along (non-differentiable, like the
+    reference's @torch.no_grad() get_coarse_match): `holder` receives ops.coarse_match's result dict."""
+
+    @staticmethod
+    def forward(ctx, feat_c0, feat_c1, hw0_c, hw1_c, kw, holder):
+        r = ops.coarse_match(feat_c0.detach(), feat_c1.detach(), hw0_c, hw1_c, **kw)
+        holder.update(r)
+        ctx.save_for_backward(feat_c0, feat_c1)
+        ctx.meta = (hw0_c, hw1_c, kw["temperature"], kw.get("mask0"), kw.get("mask1"))
+        return r["conf_matrix"]
+
+    @staticmethod
+    def backward(ctx, grad_conf):
+        feat_c0, feat_c1 = ctx.saved_tensors
+        hw0_c, hw1_c, temperature, mask0, mask1 = ctx.meta
+        f0, f1 = feat_c0.detach().contiguous(), feat_c1.detach().contiguous()
+        dsim = ops.dual_softmax_bwd(f0, f1, grad_conf.contiguous(), hw0_c, hw1_c, temperature, mask0, mask1)
+        k = 1.0 / (f0.shape[-1] * temperature)           # sim = <feat_c0, feat_c1> / (C T): two plain library GEMMs remain
+        g0 = torch.bmm(dsim, f1).mul_(k) if ctx.needs_input_grad[0] else None
+        g1 = torch.bmm(dsim.transpose(1, 2), f0).mul_(k) if ctx.needs_input_grad[1] else None
+        return g0, g1, None, None, None, None
+
+
+def dual_softmax_match(feat_c0, feat_c1, hw0_c, hw1_c, **kw):
+    """ops.coarse_match(match_type='dual_softmax') whose 'conf_matrix' carries the graph back to feat_c0 / feat_c1."""
+    assert kw.get("match_type", "dual_softmax") == "dual_softmax" and kw.get("want_conf", True)
+    holder = {}
+    conf = _DualSoftmaxMatch.apply(feat_c0, feat_c1, tuple(hw0_c), tuple(hw1_c), kw, holder)
+    holder["conf_matrix"] = conf
+    return holder
+
+
+class _FineMatch(torch.autograd.Function):
+    """expec_f [M,3] (differentiable) and the refined key points' offsets (not: get_fine_match is @torch.no_grad())."""
+
+    @staticmethod
+    def forward(ctx, feat_f0, feat_f1, mkpts1_c, b_ids, scale, scale1):
+        expec, mk1f = ops.fine_match(feat_f0.detach(), feat_f1.detach(), mkpts1_c, b_ids, scale, scale1)
+        ctx.save_for_backward(feat_f0, feat_f1)
+        ctx.mark_non_differentiable(mk1f)
+        return expec, mk1f
+
+    @staticmethod
+    def backward(ctx, grad_expec, _):
+        feat_f0, feat_f1 = ctx.saved_tensors
+        g0, g1 = ops.fine_match_bwd(feat_f0.detach().contiguous(), feat_f1.detach().contiguous(), grad_expec.contiguous())
+        return (g0 if ctx.needs_input_grad[0] else None), (g1 if ctx.needs_input_grad[1] else None), None, None, None, None
+
+
+def fine_match(feat_f0, feat_f1, mkpts1_c, b_ids, scale, scale1=None):
+    return _FineMatch.apply(feat_f0, feat_f1, mkpts1_c, b_ids, scale, scale1)
+
+
+def wants_grad(*tensors):
+    return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)

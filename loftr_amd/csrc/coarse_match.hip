@@ -573,6 +573,7 @@ __global__ __launch_bounds__(256) void scatter_kernel(ScatterParams sp, const in
 }
 
 #include "sinkhorn.h"         // Sinkhorn: iteration / finalize kernels (row-streaming and round-1 forms), prefilter, dustbins
+#include "dual_softmax_bwd.h" // dual-softmax backward: the streaming passes after the recomputed statistics / scores
 
 // ------------------------------------------------------------------------------------------
 // upper bound of the number of sweep work units (pair x column chunk x 256-row block)
@@ -829,7 +830,7 @@ extern "C" int loftr_coarse_match_sinkhorn(const float* feat_c0, const float* fe
   for (int it = 0; it < iters; ++it) {
     if (rowstream) {
       hipLaunchKernelGGL((otp::ot_pass_kernel<5, 2, false>), dim3(wgs, g.N), dim3(256), 0, st, conf_out, g, bin_score, norm, w.ot_v, w.ot_u,
-                         w.ot_part, rpws, nullptr, nullptr, nullptr, nullptr, nullptr);
+                         w.ot_part, rpws, nullptr, nullptr, nullptr, nullptr);
       hipLaunchKernelGGL(ot_col_merge2_kernel, dim3(ceil_div((int)cols, 256)), dim3(256), 0, st, w.ot_part, g, bin_score, norm, wgs, w.ot_u, w.ot_v);
       continue;
     }
@@ -849,17 +850,78 @@ extern "C" int loftr_coarse_match_sinkhorn(const float* feat_c0, const float* fe
     hipLaunchKernelGGL(ot_colkill_kernel, dim3(ceil_div(g.S, 256), g.N), dim3(256), 0, st, conf_out, g, bin_score, w.ot_u, w.ot_v, w.colkill);
     rk = w.rowkill; ck = w.colkill;
   }
-  if (assign_out)
-    hipLaunchKernelGGL(ot_assign_bins_kernel, dim3(ceil_div((g.L > g.S ? g.L : g.S) + 1, 256), g.N), dim3(256), 0, st, g, bin_score, norm, w.ot_u, w.ot_v, assign_out);
+  auto fill_assign = [&] {                                 // conf_matrix_with_bin from the finished conf (+ dustbins)
+    if (!assign_out) return;
+    const long quads = ((long)g.N * (g.L + 1) * (g.S + 1) + 3) / 4;
+    hipLaunchKernelGGL(ot_assign_fill_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, st, g, bin_score, norm, w.ot_u, w.ot_v,
+                       conf_out, assign_out);
+  };
   if (rowstream) {
     hipLaunchKernelGGL((otp::ot_pass_kernel<5, 2, true>), dim3(wgs, g.N), dim3(256), 0, st, conf_out, g, bin_score, norm, w.ot_v, w.ot_u,
-                       nullptr, rpws, rk, ck, assign_out, w.rowmax_part, w.colmax_part);
+                       nullptr, rpws, rk, ck, w.rowmax_part, w.colmax_part);
+    fill_assign();
     LOFTR_CHECK_LAUNCH();
     Geometry gs = g;
     gs.PJ = 1; gs.PI = wgs;                                // one row partial per row, one column-maximum partial per workgroup
     return select_and_compact(gs, *p, *out, w, conf_out, st);
   }
-  hipLaunchKernelGGL(ot_finalize_kernel, grid, block, 0, st, conf_out, g, norm, w.ot_u, w.ot_v, rk, ck, assign_out, w.rowmax_part, w.colmax_part);
+  hipLaunchKernelGGL(ot_finalize_kernel, grid, block, 0, st, conf_out, g, norm, w.ot_u, w.ot_v, rk, ck, w.rowmax_part, w.colmax_part);
+  fill_assign();
   LOFTR_CHECK_LAUNCH();
   return select_and_compact(g, *p, *out, w, conf_out, st);
+}
+
+// ---- backward of the dual-softmax confidence ---------------------------------------------------------------------------
+// dsim [N, L, S] <- dL/d sim_matrix given grad_conf = dL/d conf_matrix (dual_softmax_bwd.h).  The caller finishes with
+// the two plain GEMMs  dL/dfeat_c0 = dsim feat_c1 / (C T),  dL/dfeat_c1 = dsim^T feat_c0 / (C T)  (library GEMMs).
+// Workspace: loftr_coarse_match_workspace_bytes (the forward's).
+extern "C" int loftr_dual_softmax_bwd(const float* feat_c0, const float* feat_c1, const loftr_coarse_params* p, float temperature,
+                                      const float* grad_conf, float* dsim, void* ws, size_t ws_bytes, void* stream) {
+  LOFTR_CHECK_ARG(feat_c0 && feat_c1 && p && grad_conf && dsim && temperature > 0.f);
+  LOFTR_CHECK_ARG(p->N >= 0 && p->h0c > 0 && p->w0c > 0 && p->h1c > 0 && p->w1c > 0 && (p->mask0 == nullptr) == (p->mask1 == nullptr));
+  if (p->C % 32 != 0) return LOFTR_ERR_UNSUPPORTED;
+  if (p->N == 0) return LOFTR_OK;
+  LOFTR_CHECK_ARG(ws != nullptr);
+  hipStream_t st = (hipStream_t)stream;
+  const Geometry g = make_geometry(*p);
+  MatchWs w = carve(ws, ws_bytes, g);
+  if (!w.ok) return LOFTR_ERR_WORKSPACE;
+  { int rc = stage_descriptors(feat_c0, feat_c1, g, w, st); if (rc) return rc; }
+  const float scale = 1.f / ((float)g.C * temperature);
+  const long NL = (long)g.N * g.L, NS = (long)g.N * g.S;
+  if (g.C == 256) {                                        // the forward's sweeps: statistics, then the store-only pass
+    sweep::Args a{};
+    sweep_plan(g, a);
+    a.f0 = w.f0sp; a.f1 = w.f1sp; a.scale = scale; a.mask0 = p->mask0; a.mask1 = p->mask1;
+    a.rowpart = w.rowpart; a.colpart = w.colpart; a.rowstat = w.rowstat; a.colstat = w.colstat;
+    a.conf = dsim; a.exact_flags = nullptr;
+    const dim3 grid(NUM_XCD * ceil_div(g.N * a.NCH, NUM_XCD) * a.RB), block(512);
+    if (p->mask0) hipLaunchKernelGGL((sweep::score_sweep_kernel<0, true, false>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((sweep::score_sweep_kernel<0, false, false>), grid, block, 0, st, a);
+    hipLaunchKernelGGL(merge_stats_kernel, dim3(ceil_div((int)NL, 256)), dim3(256), 0, st, w.rowpart, w.rowstat, NL, a.NCH, g.L);
+    hipLaunchKernelGGL(merge_stats_kernel, dim3(ceil_div((int)NS, 256)), dim3(256), 0, st, w.colpart, w.colstat, NS, a.RB * sweep::W, g.S);
+    if (p->mask0) hipLaunchKernelGGL((sweep::score_sweep_kernel<2, true>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((sweep::score_sweep_kernel<2, false>), grid, block, 0, st, a);
+  } else {
+    const dim3 sgrid(score_grid(g)), block(Cfg::THREADS);
+    if (p->mask0)
+      hipLaunchKernelGGL((score_stats_kernel<true>), sgrid, block, 0, st, w.f0sp, w.f1sp, g, scale, p->mask0, p->mask1, w.rowpart, w.colpart);
+    else
+      hipLaunchKernelGGL((score_stats_kernel<false>), sgrid, block, 0, st, w.f0sp, w.f1sp, g, scale, p->mask0, p->mask1, w.rowpart, w.colpart);
+    hipLaunchKernelGGL(merge_stats_kernel, dim3(ceil_div((int)NL, 256)), dim3(256), 0, st, w.rowpart, w.rowstat, NL, g.PJ, g.L);
+    hipLaunchKernelGGL(merge_stats_kernel, dim3(ceil_div((int)NS, 256)), dim3(256), 0, st, w.colpart, w.colstat, NS, g.PI, g.S);
+    hipLaunchKernelGGL(score_store_kernel, sgrid, block, 0, st, w.f0sp, w.f1sp, g, scale, p->mask0, p->mask1, dsim);
+  }
+  float* r = w.ot_u;                                       // Sinkhorn's buffers are idle on this path: [N (L+1)], [N (S+1)],
+  float* c = w.ot_v;                                       //   [N (S+1) OT_RCH] float2 >= [N RCH S] floats
+  float* part = reinterpret_cast<float*>(w.ot_part);
+  static_assert(dsb::RCH <= 2 * OT_RCH, "column partials must fit Sinkhorn's partial buffer");
+  hipLaunchKernelGGL(dsb::row_dot_kernel, dim3((unsigned)((NL + 3) / 4)), dim3(256), 0, st, dsim, grad_conf, g, w.rowstat, w.colstat, r);
+  hipLaunchKernelGGL(dsb::col_dot_part_kernel, dim3(ceil_div(g.S, 256), dsb::RCH, g.N), dim3(256), 0, st, dsim, grad_conf, g, w.rowstat,
+                     w.colstat, part);
+  hipLaunchKernelGGL(dsb::col_dot_merge_kernel, dim3(ceil_div((int)NS, 256)), dim3(256), 0, st, part, g, c);
+  hipLaunchKernelGGL(dsb::dsim_kernel, dim3((unsigned)((NL + 3) / 4)), dim3(256), 0, st, dsim, grad_conf, g, w.rowstat, w.colstat, r, c,
+                     p->mask0, p->mask1);
+  LOFTR_CHECK_LAUNCH();
+  return LOFTR_OK;
 }

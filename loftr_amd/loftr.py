@@ -7,11 +7,14 @@ exceptions.  Every sub-module after the backbone holds parameters only; its arit
 call into ``libloftr_hip.so`` (``loftr_amd/ops.py``).  There is no PyTorch fallback: on a box
 without the built extension or without a GPU the forward raises.
 
-Scope: forward values.  In ``.train()`` mode CoarseMatching also performs the reference's random
-sampling / ground-truth padding of the coarse matches (``coarse_matching.py:200-236``, host-side
-index arithmetic on the kernels' outputs); no sub-module builds an autograd graph -- backward
-passes are not provided (forward only).
+Scope: forward values, plus the backward of the two matching heads.  In ``.train()`` mode CoarseMatching
+also performs the reference's random sampling / ground-truth padding of the coarse matches
+(``coarse_matching.py:200-236``, host-side index arithmetic on the kernels' outputs).  The dual-softmax
+CoarseMatching and FineMatching are autograd nodes whose backward is HIP too (``loftr_amd/autograd.py``);
+with ``LoFTR.head_grads = True`` a training step ends with d loss / d (transformer outputs).  The
+transformers, FinePreprocess, the backbone and the Sinkhorn head have no backward.
 """
+import contextlib
 import math
 import os
 import weakref
@@ -19,7 +22,7 @@ import weakref
 import torch
 import torch.nn as nn
 
-from . import ops
+from . import autograd, ops
 from .backbone import build_backbone
 
 
@@ -191,7 +194,11 @@ class CoarseMatching(nn.Module):
             kw.update(bin_score=float(self.bin_score.detach()), skh_iters=self.skh_iters,
                       skh_prefilter=self.skh_prefilter and not self.training,      # "if not self.training and ..." (:136)
                       want_assign=bool(sparse))
-        r = ops.coarse_match(feat_c0, feat_c1, tuple(data["hw0_c"]), tuple(data["hw1_c"]), **kw)
+        if self.match_type == "dual_softmax" and autograd.wants_grad(feat_c0, feat_c1):
+            # conf_matrix with its graph: forward and backward are the HIP kernels (loftr_amd/autograd.py)
+            r = autograd.dual_softmax_match(feat_c0, feat_c1, tuple(data["hw0_c"]), tuple(data["hw1_c"]), **dict(kw, want_conf=True))
+        else:
+            r = ops.coarse_match(feat_c0, feat_c1, tuple(data["hw0_c"]), tuple(data["hw1_c"]), **kw)
         if "conf_matrix_with_bin" in r:
             data.update({"conf_matrix_with_bin": r["conf_matrix_with_bin"]})
         data.update({"conf_matrix": r["conf_matrix"]})
@@ -289,15 +296,16 @@ class FineMatching(nn.Module):
         # reference quirk kept: scale1 is applied iff 'scale0' is in the batch (fine_matching.py:68)
         scale1 = data["scale1"] if "scale0" in data else None
         n = len(data["mconf"])
+        fine_match = autograd.fine_match if autograd.wants_grad(feat_f0, feat_f1) else ops.fine_match
         if data["mkpts1_c"].shape[0] == M:
-            expec, mk1f = ops.fine_match(feat_f0, feat_f1, data["mkpts1_c"], data["b_ids"], scale, scale1)
+            expec, mk1f = fine_match(feat_f0, feat_f1, data["mkpts1_c"], data["b_ids"], scale, scale1)
             mk1f = mk1f[:n]
         else:
             # thr < 0 or .train(): CoarseMatching dropped the `mconf == 0` rows from mkpts*_c (coarse_matching.py:254-258)
             # but not from b_ids, so there are M windows and n < M coarse points.  The reference then adds the
             # refinement of the FIRST n windows to the n kept points (fine_matching.py:69, `[:len(mconf)]`): the
             # kernel computes all M offsets from a zero base (one base point per window, never out of bounds).
-            expec, off = ops.fine_match(feat_f0, feat_f1, torch.zeros(M, 2, device=feat_f0.device), data["b_ids"], scale, scale1)
+            expec, off = fine_match(feat_f0, feat_f1, torch.zeros(M, 2, device=feat_f0.device), data["b_ids"], scale, scale1)
             mk1f = data["mkpts1_c"] + off[:n]
         data.update({"expec_f": expec, "mkpts0_f": data["mkpts0_c"], "mkpts1_f": mk1f})
 
@@ -318,6 +326,10 @@ class LoFTR(nn.Module):
         # coarse transformer + coarse matching it does not feed; joined before FinePreprocess.
         self.overlap_fine_branch = True
         self._side_stream = None
+        # .train() only: hand the two matching heads their inputs as autograd LEAVES (data['_head_inputs']) and run the heads
+        # with a graph, so that LoFTRLoss(...)(data); data['loss'].backward() leaves d loss / d (transformer outputs) in
+        # their .grad -- the part of the reference's backward pass this library provides (loftr_amd/autograd.py).
+        self.head_grads = False
         self.pos_encoding = PositionEncodingSine(config["coarse"]["d_model"],
                                                  temp_bug_fix=config["coarse"]["temp_bug_fix"])
         self.loftr_coarse = LocalFeatureTransformer(config["coarse"])
@@ -383,14 +395,23 @@ class LoFTR(nn.Module):
         if not late and getattr(self, "_fine_join", None) is not None:
             torch.cuda.current_stream(feat_f0.device).wait_stream(self._fine_join)
             self._fine_join = None
-        self.coarse_matching(feat_c0, feat_c1, data, mask_c0=mask_c0, mask_c1=mask_c1)
+        grads = self.training and self.head_grads
+        if grads:
+            feat_c0, feat_c1 = feat_c0.detach().requires_grad_(True), feat_c1.detach().requires_grad_(True)
+            data["_head_inputs"] = {"feat_c0": feat_c0, "feat_c1": feat_c1}
+        with torch.enable_grad() if grads else contextlib.nullcontext():
+            self.coarse_matching(feat_c0, feat_c1, data, mask_c0=mask_c0, mask_c1=mask_c1)
         if getattr(self, "_fine_join", None) is not None:    # fine maps come from the side stream
             torch.cuda.current_stream(feat_f0.device).wait_stream(self._fine_join)
             self._fine_join = None
         feat_f0_unfold, feat_f1_unfold = self.fine_preprocess(feat_f0, feat_f1, feat_c0, feat_c1, data)
         if feat_f0_unfold.size(0) != 0:
             feat_f0_unfold, feat_f1_unfold = self.loftr_fine(feat_f0_unfold, feat_f1_unfold, inplace=True)
-        self.fine_matching(feat_f0_unfold, feat_f1_unfold, data)
+        if grads:
+            feat_f0_unfold, feat_f1_unfold = feat_f0_unfold.detach().requires_grad_(True), feat_f1_unfold.detach().requires_grad_(True)
+            data["_head_inputs"].update({"feat_f0_unfold": feat_f0_unfold, "feat_f1_unfold": feat_f1_unfold})
+        with torch.enable_grad() if grads else contextlib.nullcontext():
+            self.fine_matching(feat_f0_unfold, feat_f1_unfold, data)
 
     @torch.no_grad()
     def forward(self, data):

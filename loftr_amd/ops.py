@@ -312,6 +312,39 @@ def fine_match(feat_f0, feat_f1, mkpts1_c, b_ids, scale, scale1=None):
 
 
 # ---------------------------------------------------------------------------------------------
+# Backward of the two matching heads (include/loftr_hip.h: "backward of the matching heads"); the autograd.Function
+# wrappers that call these live in loftr_amd/autograd.py.
+@_on_device
+def dual_softmax_bwd(feat_c0, feat_c1, grad_conf, hw0_c, hw1_c, temperature, mask0=None, mask1=None):
+    """dL/d sim_matrix [N,L,S] from dL/d conf_matrix (coarse_matching.py:110-119)."""
+    _need(feat_c0, "feat_c0"); _need(feat_c1, "feat_c1"); _need(grad_conf, "grad_conf")
+    N, L, Cc = feat_c0.shape
+    S = feat_c1.shape[1]
+    assert tuple(grad_conf.shape) == (N, L, S) and L == hw0_c[0] * hw0_c[1] and S == hw1_c[0] * hw1_c[1]
+    m0, m1 = _mask_u8(mask0, "mask0"), _mask_u8(mask1, "mask1")
+    p = CoarseParams(N, hw0_c[0], hw0_c[1], hw1_c[0], hw1_c[1], Cc, 0.0, 0, 1.0,
+                     m0.data_ptr() if m0 is not None else None, m1.data_ptr() if m1 is not None else None, None, None)
+    dsim = torch.empty(N, L, S, device=feat_c0.device, dtype=torch.float32)
+    lib = _lib.load()
+    ws = workspace(lib.loftr_coarse_match_workspace_bytes(N, L, S, Cc), feat_c0.device)
+    check(lib.loftr_dual_softmax_bwd(_ptr(feat_c0), _ptr(feat_c1), C.byref(p), float(temperature), _ptr(grad_conf), _ptr(dsim),
+                                     _ptr(ws), ws.numel(), _stream()), "loftr_dual_softmax_bwd")
+    return dsim
+
+
+@_on_device
+def fine_match_bwd(feat_f0, feat_f1, grad_expec):
+    """(dL/d feat_f0, dL/d feat_f1) [M,WW,C] from dL/d expec_f [M,3] (fine_matching.py:43-57)."""
+    _need(feat_f0, "feat_f0"); _need(feat_f1, "feat_f1"); _need(grad_expec, "grad_expec")
+    M, WW, Cf = feat_f0.shape
+    assert tuple(grad_expec.shape) == (M, 3)
+    g0, g1 = torch.empty_like(feat_f0), torch.empty_like(feat_f1)
+    check(_lib.load().loftr_fine_match_bwd(_ptr(feat_f0), _ptr(feat_f1), M, WW, Cf, _ptr(grad_expec), _ptr(g0), _ptr(g1), _stream()),
+          "loftr_fine_match_bwd")
+    return g0, g1
+
+
+# ---------------------------------------------------------------------------------------------
 # ResNet-FPN building blocks.  An SP activation is carried as (tensor int32 [B,H,W,Cp], C).
 def ceil32(c):
     return (c + 31) // 32 * 32

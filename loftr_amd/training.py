@@ -1,10 +1,13 @@
-"""Training-side consumers of the matching path's outputs, FORWARD VALUES ONLY.
+"""Training-side consumers of the matching path's outputs: forward values, and the gradients of
+the two losses with respect to the heads' outputs.
 
 Host-side mirror of the reference's interface: ``compute_supervision_coarse(data, config)`` /
 ``compute_supervision_fine(data, config)`` (src/loftr/utils/supervision.py:110-151) and ``LoFTRLoss(config)(data)``
 (src/losses/loftr_loss.py:7-192) mutate the batch dict with the same keys.  The arithmetic runs in csrc/train.hip
 behind the C-ABI (loftr_spvs_coarse, loftr_spvs_fine, loftr_coarse_loss_sums, loftr_fine_loss_sums); there is no CPU
-fallback.  NOT provided: backward passes (the losses are plain tensors without a graph).  The RNG-dependent
+fallback.  Backward: when conf_matrix / expec_f carry an autograd graph (loftr_amd/autograd.py: the dual-softmax and
+FineMatching heads), LoFTRLoss is differentiable through loftr_coarse_loss_grad / loftr_fine_loss_grad; the chain ends at the
+heads' inputs (no backward for the transformers, FinePreprocess, the backbone, or the Sinkhorn head).  The RNG-dependent
 ground-truth padding of CoarseMatching's training branch (coarse_matching.py:200-236) lives in
 loftr_amd/loftr.py:CoarseMatching._train_sample.
 
@@ -97,7 +100,7 @@ def compute_supervision_fine(data, config):
 
 
 class LoFTRLoss(torch.nn.Module):
-    """loftr_loss.py:7-192 (values only: the returned tensors carry no autograd graph)."""
+    """loftr_loss.py:7-192.  Differentiable with respect to conf_matrix / expec_f when those carry a graph."""
 
     def __init__(self, config):
         super().__init__()
@@ -110,9 +113,9 @@ class LoFTRLoss(torch.nn.Module):
         self.c_neg_w = self.loss_config["neg_weight"]
         self.fine_type = self.loss_config["fine_type"]
 
-    @_on_device
-    def compute_coarse_loss(self, conf, data):
-        """:22-99 from the ground-truth id lists (data['spv_*_ids']) instead of the dense conf_matrix_gt."""
+    def _coarse_terms(self, conf, data):
+        """Everything of compute_coarse_loss that does not depend on conf's VALUES: kind, ids, masks, the loss weights
+        after the corner cases (:31-42)."""
         ctype = self.loss_config["coarse_type"]
         if ctype == "cross_entropy":
             assert not self.sparse_spvs, "Sparse Supervision for cross-entropy not implemented!"
@@ -121,44 +124,55 @@ class LoFTRLoss(torch.nn.Module):
             kind = (1 if self.match_type == "sinkhorn" else 0) if self.sparse_spvs else 2
         else:
             raise ValueError("Unknown coarse loss: {type}".format(type=ctype))
-        dev = conf.device
         bins = kind == 1
         N, L, S = conf.shape[0], conf.shape[1] - bins, conf.shape[2] - bins
         M = int(data.get("_spv_count", data["spv_b_ids"].shape[0]))
         if "_spv_count" not in data and M == 1 and int(data["spv_i_ids"][0]) == 0:
             M = 0                     # the reference's placeholder (0, 0, 0) of a pair without ground truth (cell 0 is never supervised)
-        c_pos_w, c_neg_w = self.c_pos_w, self.c_neg_w
         b, i, j = (_need(data[k].contiguous(), k, torch.int64) for k in ("spv_b_ids", "spv_i_ids", "spv_j_ids"))
         m0 = _mask_u8(data["mask0"].flatten(-2), "mask0") if "mask0" in data else None
         m1 = _mask_u8(data["mask1"].flatten(-2), "mask1") if "mask0" in data else None
-        sums = torch.zeros(4, dtype=torch.float64, device=dev)
-        lib = _lib.load()
-        ws = workspace(lib.loftr_loss_workspace_bytes(N, L, S), dev)
-        _lib.check(lib.loftr_coarse_loss_sums(_ptr(_need(conf.contiguous(), "conf")), N, L, S, kind, _ptr(b), _ptr(i), _ptr(j), M,
-                                              _ptr(m0), _ptr(m1), float(self.loss_config.get("focal_alpha", 0.25)),
-                                              float(self.loss_config.get("focal_gamma", 2.0)), _ptr(sums), _ptr(ws), ws.numel(),
-                                              _stream()), "loftr_coarse_loss_sums")
-        s = sums.cpu()
+        c_pos_w, c_neg_w = self.c_pos_w, self.c_neg_w
         if M == 0:                    # :32-36: a wrong gt at (0,0,0) with weight 0 and c_pos_w = 0: the positive mean is 0 * x
             c_pos_w = 0.0
-        pos_mean = s[0] / max(M, 1)
-        if kind == 0:
-            loss = c_pos_w * pos_mean
-        elif kind == 1:
-            loss = c_pos_w * pos_mean + c_neg_w * (s[2] / s[3])
+        n_neg = N * L * S - M
+        if kind >= 2 and n_neg == 0:
+            c_neg_w, n_neg = 0.0, 1
+        return dict(kind=kind, N=N, L=L, S=S, M=M, ids=(b, i, j), masks=(m0, m1), c_pos_w=c_pos_w, c_neg_w=c_neg_w, n_neg=n_neg,
+                    alpha=float(self.loss_config.get("focal_alpha", 0.25)), gamma=float(self.loss_config.get("focal_gamma", 2.0)))
+
+    def _coarse_value(self, conf, t):
+        dev = conf.device
+        b, i, j = t["ids"]
+        m0, m1 = t["masks"]
+        sums = torch.zeros(4, dtype=torch.float64, device=dev)
+        lib = _lib.load()
+        ws = workspace(lib.loftr_loss_workspace_bytes(t["N"], t["L"], t["S"]), dev)
+        _lib.check(lib.loftr_coarse_loss_sums(_ptr(_need(conf.contiguous(), "conf")), t["N"], t["L"], t["S"], t["kind"], _ptr(b), _ptr(i),
+                                              _ptr(j), t["M"], _ptr(m0), _ptr(m1), t["alpha"], t["gamma"], _ptr(sums), _ptr(ws), ws.numel(),
+                                              _stream()), "loftr_coarse_loss_sums")
+        s = sums.cpu()
+        pos_mean = s[0] / max(t["M"], 1)
+        if t["kind"] == 0:
+            loss = t["c_pos_w"] * pos_mean
+        elif t["kind"] == 1:
+            loss = t["c_pos_w"] * pos_mean + t["c_neg_w"] * (s[2] / s[3])
         else:
-            n_neg = N * L * S - M
-            if n_neg == 0:
-                c_neg_w, n_neg = 0.0, 1
-            loss = c_pos_w * pos_mean + c_neg_w * ((s[2] - s[3]) / n_neg)
+            loss = t["c_pos_w"] * pos_mean + t["c_neg_w"] * ((s[2] - s[3]) / t["n_neg"])
         return loss.to(torch.float32).to(dev)
 
     @_on_device
-    def compute_fine_loss(self, expec_f, expec_f_gt):
-        """:101-157.  None where the reference returns None (eval mode without a correct coarse match)."""
-        if self.fine_type not in ("l2_with_std", "l2"):
-            raise NotImplementedError()
-        with_std = self.fine_type == "l2_with_std"
+    def compute_coarse_loss(self, conf, data):
+        """:22-99 from the ground-truth id lists (data['spv_*_ids']) instead of the dense conf_matrix_gt.  When `conf` carries an
+        autograd graph (loftr_amd.autograd) the result does too: d loss_c / d conf is loftr_coarse_loss_grad."""
+        t = self._coarse_terms(conf, data)
+        if torch.is_grad_enabled() and conf.requires_grad:
+            if t["kind"] == 1:
+                raise _lib.LoftrHipError("compute_coarse_loss: no backward for the sparse Sinkhorn loss (conf_matrix_with_bin)")
+            return _CoarseLossFn.apply(conf, self, t)
+        return self._coarse_value(conf, t)
+
+    def _fine_value(self, expec_f, expec_f_gt, with_std):
         dev = expec_f.device
         M = expec_f.shape[0]
         sums = torch.zeros(3, dtype=torch.float64, device=dev)
@@ -170,12 +184,26 @@ class LoFTRLoss(torch.nn.Module):
         s = sums.cpu()
         if s[1] == 0:                 # no correct coarse match
             if not self.training:
-                return None
+                return None, sums
             if with_std:                              # training: correct_mask[0] = True with weight[0] = 0 (:138-143)
-                return torch.zeros((), device=dev)
-            return ((expec_f_gt[0] - expec_f[0, :2]) ** 2).sum()      # plain l2: the false supervision of entry 0 (:113-117)
+                return torch.zeros((), device=dev), sums
+            return ((expec_f_gt[0] - expec_f[0, :2]) ** 2).sum().detach(), sums      # plain l2: the false supervision of entry 0 (:113-117)
         norm = (M / s[2]) if with_std else 1.0        # weight = inverse_std / mean(inverse_std)
-        return (s[0] * norm / s[1]).to(torch.float32).to(dev)
+        return (s[0] * norm / s[1]).to(torch.float32).to(dev), sums
+
+    @_on_device
+    def compute_fine_loss(self, expec_f, expec_f_gt):
+        """:101-157.  None where the reference returns None (eval mode without a correct coarse match).  With a graph on
+        `expec_f` (loftr_amd.autograd.fine_match) the result is differentiable: loftr_fine_loss_grad."""
+        if self.fine_type not in ("l2_with_std", "l2"):
+            raise NotImplementedError()
+        with_std = self.fine_type == "l2_with_std"
+        if torch.is_grad_enabled() and expec_f.requires_grad:
+            value, sums = self._fine_value(expec_f.detach(), expec_f_gt, with_std)
+            if value is None:
+                return None
+            return _FineLossFn.apply(expec_f, expec_f_gt, self, with_std, value, sums)
+        return self._fine_value(expec_f, expec_f_gt, with_std)[0]
 
     def forward(self, data):
         """:165-192.  Update: data['loss'], data['loss_scalars']."""
@@ -193,3 +221,49 @@ class LoFTRLoss(torch.nn.Module):
             loss_scalars.update({"loss_f": torch.tensor(1.)})
         loss_scalars.update({"loss": loss.clone().detach().cpu()})
         data.update({"loss": loss, "loss_scalars": loss_scalars})
+
+
+class _CoarseLossFn(torch.autograd.Function):
+    """loss_c with d loss_c / d conf from loftr_coarse_loss_grad (csrc/train_bwd.hip)."""
+
+    @staticmethod
+    def forward(ctx, conf, module, t):
+        ctx.save_for_backward(conf)
+        ctx.t = t
+        return module._coarse_value(conf.detach(), t)
+
+    @staticmethod
+    def backward(ctx, up):
+        (conf,), t = ctx.saved_tensors, ctx.t
+        c = _need(conf.detach().contiguous(), "conf")
+        g = torch.empty_like(c)
+        b, i, j = t["ids"]
+        m0, m1 = t["masks"]
+        u = float(up)
+        with torch.cuda.device(c.device):
+            _lib.check(_lib.load().loftr_coarse_loss_grad(_ptr(c), t["N"], t["L"], t["S"], t["kind"], _ptr(b), _ptr(i), _ptr(j), t["M"],
+                                                          _ptr(m0), _ptr(m1), t["alpha"], t["gamma"], u * t["c_pos_w"] / max(t["M"], 1),
+                                                          u * t["c_neg_w"] / t["n_neg"], _ptr(g), _stream()), "loftr_coarse_loss_grad")
+        return g, None, None
+
+
+class _FineLossFn(torch.autograd.Function):
+    """loss_f with d loss_f / d expec_f from loftr_fine_loss_grad (csrc/train_bwd.hip)."""
+
+    @staticmethod
+    def forward(ctx, expec_f, expec_f_gt, module, with_std, value, sums):
+        ctx.save_for_backward(expec_f, expec_f_gt, sums)
+        ctx.args = (with_std, float(module.correct_thr), bool(module.training))
+        return value.clone()
+
+    @staticmethod
+    def backward(ctx, up):
+        expec_f, gt, sums = ctx.saved_tensors
+        with_std, thr, training = ctx.args
+        e = _need(expec_f.detach().contiguous(), "expec_f")
+        g = torch.empty_like(e)
+        with torch.cuda.device(e.device):
+            _lib.check(_lib.load().loftr_fine_loss_grad(_ptr(e), e.shape[1], _ptr(_need(gt.contiguous(), "expec_f_gt")), e.shape[0],
+                                                        int(with_std), thr, int(training), _ptr(sums), float(up), _ptr(g), _stream()),
+                       "loftr_fine_loss_grad")
+        return g, None, None, None, None, None

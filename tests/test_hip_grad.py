@@ -1,0 +1,141 @@
+"""Backward of the two matching heads and their losses (HIP: csrc/train_bwd.hip, dual_softmax_bwd.h; host: loftr_amd/autograd.py,
+training.py) against torch.autograd of the reference's own modules (tests/golden/grad_*.npz) and against the float64 oracle."""
+import importlib.util
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+_spec = importlib.util.spec_from_file_location("make_golden_grad", os.path.join(HERE, "golden", "make_golden_grad.py"))
+MG = importlib.util.module_from_spec(_spec)
+_spec.loader.exec_module(MG)
+
+# gradients are compared relative to the largest entry of the reference gradient: the reference itself is a float32 autograd
+# chain (its own rounding is ~1e-6 relative per node); 1e-3 leaves room for the different summation orders and __expf
+REL = 1e-3
+
+
+def rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
+
+
+def run_heads(rc, inp, dev):
+    from loftr_amd.loftr import CoarseMatching, FineMatching
+    from loftr_amd.training import LoFTRLoss
+    h, w = rc["hc"]
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    leaf = {k: t(inp[k]).requires_grad_(True) for k in ("feat_c0", "feat_c1", "feat_f0", "feat_f1")}
+    data = {"hw0_c": (h, w), "hw1_c": (h, w), "hw0_i": (8 * h, 8 * w), "hw1_i": (8 * h, 8 * w), "hw0_f": (4 * h, 4 * w), "hw1_f": (4 * h, 4 * w)}
+    m0 = m1 = None
+    if rc["masks"]:
+        data.update(mask0=t(inp["mask0"]), mask1=t(inp["mask1"]))
+        m0, m1 = data["mask0"].flatten(-2), data["mask1"].flatten(-2)
+    cm = CoarseMatching(MG.matcher_cfg(rc)).eval()
+    cm(leaf["feat_c0"], leaf["feat_c1"], data, mask_c0=m0, mask_c1=m1)
+    conf = data["conf_matrix"]
+    assert conf.requires_grad and conf.grad_fn is not None
+    conf.retain_grad()
+    M = rc["M"]
+    data.update(mkpts0_c=torch.zeros(M, 2, device=dev), mkpts1_c=torch.zeros(M, 2, device=dev), mconf=torch.zeros(M, device=dev),
+                b_ids=torch.zeros(M, dtype=torch.long, device=dev))
+    FineMatching().train()(leaf["feat_f0"], leaf["feat_f1"], data)
+    expec = data["expec_f"]
+    assert expec.requires_grad
+    expec.retain_grad()
+    b, i, j = np.nonzero(inp["conf_gt"])
+    if len(b) == 0:                                  # supervision.py:94-99: the placeholder (0, 0, 0)
+        b = i = j = np.zeros(1, np.int64)
+        data["_spv_count"] = 0
+    data.update(spv_b_ids=t(b.astype(np.int64)), spv_i_ids=t(i.astype(np.int64)), spv_j_ids=t(j.astype(np.int64)), expec_f_gt=t(inp["expec_f_gt"]))
+    loss = LoFTRLoss(MG.loss_cfg(rc)).train()
+    loss(data)
+    return leaf, data, conf, expec
+
+
+@pytest.mark.parametrize("name", list(MG.CASES))
+def test_head_gradients_against_reference_autograd(name):
+    from oracle import grad_oracle as GO
+    dev = torch.device("cuda", 0)
+    g = dict(np.load(os.path.join(HERE, "golden", f"{name}.npz")))
+    rc = json.loads(str(g["recipe"]))
+    inp = MG.build_inputs(rc)
+    leaf, data, conf, expec = run_heads(rc, inp, dev)
+    want = {k: float(v) for k, v in data["loss_scalars"].items()}
+    assert abs(want["loss_c"] - float(g["loss_c"])) <= 2e-4 * max(1.0, abs(float(g["loss_c"])))
+    assert abs(want["loss_f"] - float(g["loss_f"])) <= 2e-4 * max(1.0, abs(float(g["loss_f"])))
+    data["loss"].backward()
+    torch.cuda.synchronize()
+    got = {"grad_conf": conf.grad, "grad_expec": expec.grad, **{f"grad_{k}": v.grad for k, v in leaf.items()}}
+    for k, v in got.items():
+        ref = g[k]
+        if np.abs(ref).max() == 0:
+            assert v is None or float(v.abs().max()) == 0, k
+            continue
+        assert v is not None, k
+        assert rel(v.cpu().numpy(), ref) <= REL, (k, rel(v.cpu().numpy(), ref))
+    # and against the float64 oracle on the same inputs (tighter: no float32 autograd noise on the reference side)
+    m0 = m1 = None
+    if rc["masks"]:
+        m0, m1 = inp["mask0"].reshape(rc["N"], -1), inp["mask1"].reshape(rc["N"], -1)
+    if np.abs(g["grad_conf"]).max() > 0:
+        o0, o1 = GO.dual_softmax_conf_grad(inp["feat_c0"], inp["feat_c1"], conf.grad.cpu().numpy(), MG.TEMPERATURE, m0, m1)
+        assert rel(leaf["feat_c0"].grad.cpu().numpy(), o0) <= 2e-4 and rel(leaf["feat_c1"].grad.cpu().numpy(), o1) <= 2e-4
+    if np.abs(g["grad_expec"]).max() > 0:
+        o0, o1 = GO.fine_matching_grad(inp["feat_f0"], inp["feat_f1"], expec.grad.cpu().numpy())
+        assert rel(leaf["feat_f0"].grad.cpu().numpy(), o0) <= 2e-4 and rel(leaf["feat_f1"].grad.cpu().numpy(), o1) <= 2e-4
+
+
+def test_fine_match_backward_std_column_against_oracle():
+    """d expec_f[:, 2] (the std): the losses detach it, so no golden exercises that branch of the kernel."""
+    from loftr_amd import autograd
+    from oracle import grad_oracle as GO
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(3)
+    f0, f1 = rng.standard_normal((37, 25, 128)).astype(np.float32), rng.standard_normal((37, 25, 128)).astype(np.float32)
+    f1[5] = 0                                                              # uniform heat map
+    f1[6, 12] = 40 * f0[6, 12]                                             # one-hot heat map: variance clamped, no gradient through std
+    ge = rng.standard_normal((37, 3)).astype(np.float32)
+    a, b = (torch.from_numpy(x).to(dev).requires_grad_(True) for x in (f0, f1))
+    expec, _ = autograd.fine_match(a, b, torch.zeros(37, 2, device=dev), torch.zeros(37, dtype=torch.long, device=dev), 2.0)
+    expec.backward(torch.from_numpy(ge).to(dev))
+    o0, o1 = GO.fine_matching_grad(f0, f1, ge)
+    assert rel(a.grad.cpu().numpy(), o0) <= 2e-4 and rel(b.grad.cpu().numpy(), o1) <= 2e-4
+
+
+@pytest.mark.parametrize("shape", [(1, (60, 80), False), (2, (13, 17), True)])
+def test_dual_softmax_backward_dense_gradient_full_size(shape):
+    """A dense upstream gradient at the bench's grid (L = S = 4800: the 256-wide sweep kernels) and at a ragged masked grid
+    (L = S = 221), against float64 autograd of the same formula in PyTorch on the GPU."""
+    from loftr_amd import autograd
+    N, (h, w), masked = shape
+    dev = torch.device("cuda", 0)
+    gen = torch.Generator(device="cpu").manual_seed(7)
+    L = h * w
+    f0 = (1.2 * torch.randn(N, L, 256, generator=gen)).to(dev)
+    f1 = (0.25 * f0.cpu()[:, torch.randperm(L, generator=gen)] + 1.2 * torch.randn(N, L, 256, generator=gen)).to(dev)
+    G = torch.randn(N, L, L, generator=gen).to(dev)
+    kw = dict(thr=0.2, border_rm=2, scale=8.0, match_type="dual_softmax", temperature=0.1, want_conf=True)
+    m0 = m1 = None
+    if masked:
+        m0, m1 = torch.ones(N, h, w, dtype=torch.bool, device=dev), torch.ones(N, h, w, dtype=torch.bool, device=dev)
+        m0[0, h - 3:], m1[0, :, w - 4:], m0[1, :, w - 2:], m1[1, h - 5:] = False, False, False, False
+        kw.update(mask0=m0.flatten(-2), mask1=m1.flatten(-2))
+    a, b = f0.clone().requires_grad_(True), f1.clone().requires_grad_(True)
+    r = autograd.dual_softmax_match(a, b, (h, w), (h, w), **kw)
+    r["conf_matrix"].backward(G)
+    a64, b64 = f0.double().requires_grad_(True), f1.double().requires_grad_(True)
+    sim = torch.einsum("nlc,nsc->nls", a64 / 16, b64 / 16) / 0.1
+    if masked:
+        sim = sim.masked_fill(~(m0.flatten(-2)[..., None] & m1.flatten(-2)[:, None]), -1e9)
+    conf = torch.softmax(sim, 1) * torch.softmax(sim, 2)
+    assert (r["conf_matrix"].detach() - conf.detach()).abs().max().item() <= 1e-4
+    conf.backward(G.double())
+    for got, ref in ((a.grad, a64.grad), (b.grad, b64.grad)):
+        err = (got.double() - ref).abs().max().item() / ref.abs().max().item()
+        assert err <= 2e-4, err
