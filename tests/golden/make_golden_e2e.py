@@ -84,12 +84,14 @@ CASES = {"e2e_scannet": dict(images="scannet", bn_strength=0.3),
          "e2e_peaked": dict(images="synth", bn_strength=0.3, crop0=(384, 512), crop1=(384, 512), coarse_gain=6.0)}
 
 
-def e2e_state_dict(module_with_backbone, cfg, bn_strength, coarse_gain=1.0):
+def e2e_state_dict(module_with_backbone, cfg, bn_strength, coarse_gain=1.0, fine_gain=1.0):
     """Seeded full state_dict (torch tensors): matcher weights + backbone weights / BN statistics.  coarse_gain multiplies the
-    1x1 convolution that produces the coarse map (layer3_outconv, resnet_fpn.py:64), i.e. feat_c itself."""
+    1x1 convolution that produces the coarse map (layer3_outconv, resnet_fpn.py:64), i.e. feat_c itself; fine_gain the last
+    convolution of the fine branch (layer1_outconv2[3], resnet_fpn.py:84), i.e. feat_f."""
     sd = {k: torch.from_numpy(np.ascontiguousarray(np.asarray(v))) for k, v in make_weights(MATCHER_SEED, cfg).items()}
+    gains = {"layer3_outconv.weight": coarse_gain, "layer1_outconv2.3.weight": fine_gain}
     for k, v in make_backbone_weights(BACKBONE_SEED, module_with_backbone.backbone, bn_strength).items():
-        sd["backbone." + k] = v * coarse_gain if (coarse_gain != 1.0 and k == "layer3_outconv.weight") else v
+        sd["backbone." + k] = v * gains[k] if gains.get(k, 1.0) != 1.0 else v
     return sd
 
 

@@ -264,6 +264,87 @@ def make_step(name):
           {k: float(v) for k, v in data["loss_scalars"].items()})
 
 
+# ---- the same step WITH autograd: d loss / d (inputs of the two matching heads) ---------------------------------------------
+# lightning_loftr.py:112-133 back-propagates batch['loss'] through the whole network; this library provides the backward of
+# the heads only, so the golden keeps the gradients AT the heads' inputs: d loss / d feat_f*_unfold (reached through loss_f
+# alone) and, for the coarse features, the part that flows through conf_matrix (their other part -- through FinePreprocess
+# and the fine transformer -- has no counterpart here).
+GRAD_STEP_CASES = {"tgrad_ds": dict(step="tstep_ds", coarse_gain=0.25, fine_gain=0.25)}     # gain: conf at the ground truth inside the clamp (1e-6, 1 - 1e-6)
+GRAD_F1_FULL = 32                 # the LAST windows (the ground-truth padding: the ones with a fine loss) keep d loss / d feat_f1_unfold
+                                  # in full; all windows: its per-window norm
+
+
+def make_step_grads(name):
+    import copy
+    from oracle.ref_shim import import_reference
+    from tests.golden.make_golden_e2e import e2e_state_dict
+    RefLoFTR, _ = import_reference()
+    sup, LoFTRLoss = __import__("oracle.ref_shim", fromlist=["x"]).import_reference_training()
+    gc = GRAD_STEP_CASES[name]
+    rc = STEP_CASES[gc["step"]]
+    batch, geo = step_batch(rc)
+    cfg = step_matcher_cfg(rc)
+    model = RefLoFTR(copy.deepcopy(cfg))
+    model.load_state_dict(e2e_state_dict(model, cfg, 0.3, gc["coarse_gain"], gc["fine_gain"]), strict=True)
+    model.train()
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+    data = {"dataset_name": ["scannet"] * geo["N"], "pair_names": [["a"] * geo["N"], ["b"] * geo["N"]], **{k: t(v) for k, v in batch.items()}}
+    seen = {}
+
+    def tap(module, key):
+        inner = module.forward
+
+        def forward(a, b, *args, **kw):
+            a.retain_grad(); b.retain_grad()
+            seen[key] = (a, b)
+            return inner(a, b, *args, **kw)
+        module.forward = forward
+    tap(model.coarse_matching, "coarse")
+    tap(model.fine_matching, "fine")
+    real = torch.randint
+    torch.randint = det_randint
+    try:
+        C = {"LOFTR": {"RESOLUTION": (8, 2), "FINE_WINDOW_SIZE": 5}}
+        with torch.no_grad():
+            sup.spvs_coarse(data, C)
+        model(data)
+        with torch.no_grad():
+            sup.spvs_fine(data, C)
+        data["conf_matrix"].retain_grad(); data["expec_f"].retain_grad()
+        LoFTRLoss(step_loss_cfg(rc)).train()(data)
+    finally:
+        torch.randint = real
+    data["loss"].backward()
+    # d loss / d conf_matrix and d loss / d expec_f are now known.  The heads' OWN backward, cut from the rest of the graph
+    # (the final feat_*1 of a transformer is computed from the final feat_*0, so feat_*0.grad of the full graph also contains
+    # the transformer's share): re-run each head on detached copies of its inputs and back-propagate the node gradient.
+    fc0, fc1 = (x.detach().requires_grad_(True) for x in seen["coarse"])
+    ff0, ff1 = (x.detach().requires_grad_(True) for x in seen["fine"])
+    scratch = {k: data[k] for k in ("hw0_c", "hw1_c", "hw0_i", "hw1_i") }
+    model.coarse_matching.eval()                                       # same conf_matrix (:105-119), no sampling
+    model.coarse_matching(fc0, fc1, scratch)
+    assert torch.equal(scratch["conf_matrix"].detach(), data["conf_matrix"].detach())
+    scratch["conf_matrix"].backward(data["conf_matrix"].grad)
+    g_c0, g_c1 = fc0.grad, fc1.grad
+    scratch = {k: data[k] for k in ("hw0_i", "hw0_f", "mkpts0_c", "mkpts1_c", "mconf", "b_ids")}
+    model.fine_matching(ff0, ff1, scratch)
+    assert torch.equal(scratch["expec_f"].detach(), data["expec_f"].detach())
+    scratch["expec_f"].backward(data["expec_f"].grad)
+    WW = ff0.shape[1]
+    off_centre = ff0.grad.clone(); off_centre[:, WW // 2] = 0
+    assert float(off_centre.abs().max()) == 0                     # feat_f0 is read at the centre only (fine_matching.py:43)
+    gb, gi, gj = (data[k].numpy() for k in ("spv_b_ids", "spv_i_ids", "spv_j_ids"))
+    print("conf at the ground truth:", np.sort(data["conf_matrix"].detach().numpy()[gb, gi, gj])[[0, len(gb) // 2, -1]])
+    store = dict(recipe=np.array(json.dumps(dict(rc, **gc))), b_ids=data["b_ids"].numpy(), i_ids=data["i_ids"].numpy(), j_ids=data["j_ids"].numpy(),
+                 expec_f=data["expec_f"].detach().numpy(), expec_f_gt=data["expec_f_gt"].numpy(), grad_expec=data["expec_f"].grad.numpy(), grad_feat_c0=g_c0.numpy(), grad_feat_c1=g_c1.numpy(),
+                 grad_feat_f0_centre=ff0.grad[:, WW // 2].numpy(), grad_feat_f1_tail=ff1.grad[-GRAD_F1_FULL:].numpy(),
+                 grad_feat_f1_norm=ff1.grad.flatten(1).norm(dim=1).numpy(),
+                 losses=np.array(json.dumps({k: float(v) for k, v in data["loss_scalars"].items()})))
+    np.savez_compressed(os.path.join(HERE, f"{name}.npz"), **store)
+    print(name, "windows", len(data["b_ids"]), {k: float(np.abs(v).max()) for k, v in store.items() if k.startswith("grad_")},
+          json.loads(str(store["losses"])))
+
+
 if __name__ == "__main__":
-    for nm in sys.argv[1:] or list(CASES) + list(COARSE_TRAIN) + list(STEP_CASES):
-        (make if nm in CASES else make_coarse_train if nm in COARSE_TRAIN else make_step)(nm)
+    for nm in sys.argv[1:] or list(CASES) + list(COARSE_TRAIN) + list(STEP_CASES) + list(GRAD_STEP_CASES):
+        (make if nm in CASES else make_coarse_train if nm in COARSE_TRAIN else make_step if nm in STEP_CASES else make_step_grads)(nm)

@@ -221,3 +221,65 @@ def test_train_mode_forward_from_images_runs(monkeypatch):
     assert data["mkpts0_f"].shape == data["mkpts1_f"].shape == (n, 2) == tuple(data["mkpts1_c"].shape)
     assert torch.isfinite(data["expec_f"]).all() and torch.isfinite(data["mkpts1_f"]).all()
     assert model.backbone.bn1.num_batches_tracked.item() == 1          # BatchNorm really ran in training mode
+
+
+def test_training_step_head_gradients_against_reference(monkeypatch):
+    """The training step of test_training_step_chain_against_reference WITH the heads' backward (LoFTR.head_grads): after
+    data['loss'].backward() the leaves data['_head_inputs'] hold d loss / d (inputs of CoarseMatching / FineMatching), compared
+    with torch.autograd of the reference's heads inside the reference's own training step (tests/golden/tgrad_ds.npz)."""
+    import copy
+    import importlib.util
+    import os
+    from _cases import GOLDEN_DIR
+    from loftr_amd import LoFTR
+    from loftr_amd.training import LoFTRLoss, compute_supervision_coarse, compute_supervision_fine
+    spec = importlib.util.spec_from_file_location("make_golden_e2e", os.path.join(GOLDEN_DIR, "make_golden_e2e.py"))
+    E2E = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(E2E)
+    dev = torch.device("cuda", 0)
+    g = dict(np.load(os.path.join(GOLDEN_DIR, "tgrad_ds.npz")))
+    rc = json.loads(str(g["recipe"]))
+    batch, geo = MG.step_batch(rc)
+    N = geo["N"]
+    cfg = MG.step_matcher_cfg(rc)
+    cpu = LoFTR(copy.deepcopy(cfg))
+    sd = E2E.e2e_state_dict(cpu, cfg, 0.3, rc["coarse_gain"], rc["fine_gain"])
+    cpu.load_state_dict(sd, strict=True)
+    cpu.train()
+    with torch.no_grad():
+        fc, ff = cpu.backbone(torch.from_numpy(np.concatenate([batch["image0"], batch["image1"]], 0)))
+    model = LoFTR(copy.deepcopy(cfg))
+    model.load_state_dict(sd, strict=True)
+    model = model.to(dev).train()
+    model.head_grads = True
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    data = {"dataset_name": ["scannet"] * N, **{k: t(v) for k, v in batch.items()}}
+    monkeypatch.setattr(torch, "randint", MG.det_randint)
+    compute_supervision_coarse(data, CFG)
+    data.update({"bs": N, "hw0_i": data["image0"].shape[2:], "hw1_i": data["image1"].shape[2:]})
+    with torch.no_grad():                                  # like LoFTR.forward: the heads re-enable grad themselves
+        model.match_from_features(fc[:N].to(dev), fc[N:].to(dev), ff[:N].to(dev), ff[N:].to(dev), data)
+    compute_supervision_fine(data, CFG)
+    LoFTRLoss(MG.step_loss_cfg(rc)).train()(data)
+    for k in ("b_ids", "i_ids", "j_ids"):
+        assert np.array_equal(data[k].cpu().numpy(), g[k]), k
+    assert np.abs(data["expec_f"].detach().cpu().numpy() - g["expec_f"]).max() <= 3e-4
+    want = json.loads(str(g["losses"]))
+    for k in ("loss_c", "loss_f", "loss"):
+        assert abs(float(data["loss_scalars"][k]) - want[k]) <= 2e-4 * max(1.0, abs(want[k])), (k, data["loss_scalars"], want)
+    assert data["loss"].requires_grad
+    data["loss"].backward()
+    torch.cuda.synchronize()
+    leaves = data["_head_inputs"]
+    rel = lambda a, b: np.abs(a.astype(np.float64) - b).max() / np.abs(b).max()
+    # the head inputs come from the HIP transformers (~1e-5 from the reference's): the gradients inherit that, on top of float32 autograd
+    WW = leaves["feat_f0_unfold"].shape[1]
+    f0g, f1g = leaves["feat_f0_unfold"].grad.cpu().numpy(), leaves["feat_f1_unfold"].grad.cpu().numpy()
+    assert rel(leaves["feat_c0"].grad.cpu().numpy(), g["grad_feat_c0"]) <= 2e-3
+    assert rel(leaves["feat_c1"].grad.cpu().numpy(), g["grad_feat_c1"]) <= 2e-3
+    off = f0g.copy(); off[:, WW // 2] = 0
+    assert np.abs(off).max() == 0
+    assert rel(f0g[:, WW // 2], g["grad_feat_f0_centre"]) <= 2e-3
+    n_tail = g["grad_feat_f1_tail"].shape[0]
+    assert rel(f1g[-n_tail:], g["grad_feat_f1_tail"]) <= 2e-3
+    assert rel(np.sqrt((f1g.reshape(f1g.shape[0], -1).astype(np.float64) ** 2).sum(1)), g["grad_feat_f1_norm"]) <= 2e-3
