@@ -830,7 +830,7 @@ extern "C" int loftr_coarse_match_sinkhorn(const float* feat_c0, const float* fe
   for (int it = 0; it < iters; ++it) {
     if (rowstream) {
       hipLaunchKernelGGL((otp::ot_pass_kernel<5, 2, false>), dim3(wgs, g.N), dim3(256), 0, st, conf_out, g, bin_score, norm, w.ot_v, w.ot_u,
-                         w.ot_part, rpws, nullptr, nullptr, nullptr, nullptr);
+                         w.ot_part, rpws, nullptr, nullptr, nullptr, nullptr, nullptr);
       hipLaunchKernelGGL(ot_col_merge2_kernel, dim3(ceil_div((int)cols, 256)), dim3(256), 0, st, w.ot_part, g, bin_score, norm, wgs, w.ot_u, w.ot_v);
       continue;
     }
@@ -850,23 +850,17 @@ extern "C" int loftr_coarse_match_sinkhorn(const float* feat_c0, const float* fe
     hipLaunchKernelGGL(ot_colkill_kernel, dim3(ceil_div(g.S, 256), g.N), dim3(256), 0, st, conf_out, g, bin_score, w.ot_u, w.ot_v, w.colkill);
     rk = w.rowkill; ck = w.colkill;
   }
-  auto fill_assign = [&] {                                 // conf_matrix_with_bin from the finished conf (+ dustbins)
-    if (!assign_out) return;
-    const long quads = ((long)g.N * (g.L + 1) * (g.S + 1) + 3) / 4;
-    hipLaunchKernelGGL(ot_assign_fill_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, st, g, bin_score, norm, w.ot_u, w.ot_v,
-                       conf_out, assign_out);
-  };
+  if (assign_out)
+    hipLaunchKernelGGL(ot_assign_bins_kernel, dim3(ceil_div((g.L > g.S ? g.L : g.S) + 1, 256), g.N), dim3(256), 0, st, g, bin_score, norm, w.ot_u, w.ot_v, assign_out);
   if (rowstream) {
     hipLaunchKernelGGL((otp::ot_pass_kernel<5, 2, true>), dim3(wgs, g.N), dim3(256), 0, st, conf_out, g, bin_score, norm, w.ot_v, w.ot_u,
-                       nullptr, rpws, rk, ck, w.rowmax_part, w.colmax_part);
-    fill_assign();
+                       nullptr, rpws, rk, ck, assign_out, w.rowmax_part, w.colmax_part);
     LOFTR_CHECK_LAUNCH();
     Geometry gs = g;
     gs.PJ = 1; gs.PI = wgs;                                // one row partial per row, one column-maximum partial per workgroup
     return select_and_compact(gs, *p, *out, w, conf_out, st);
   }
-  hipLaunchKernelGGL(ot_finalize_kernel, grid, block, 0, st, conf_out, g, norm, w.ot_u, w.ot_v, rk, ck, w.rowmax_part, w.colmax_part);
-  fill_assign();
+  hipLaunchKernelGGL(ot_finalize_kernel, grid, block, 0, st, conf_out, g, norm, w.ot_u, w.ot_v, rk, ck, assign_out, w.rowmax_part, w.colmax_part);
   LOFTR_CHECK_LAUNCH();
   return select_and_compact(g, *p, *out, w, conf_out, st);
 }

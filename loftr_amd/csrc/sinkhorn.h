@@ -267,13 +267,14 @@ __global__ __launch_bounds__(256) void ot_colkill_kernel(const float* __restrict
   colkill[(long)n * g.S + j] = (alpha + un[g.L]) > m;
 }
 
-// conf = exp(z + u + v - norm) in place (+ prefilter; the assignment matrix is ot_assign_fill_kernel's) and the row/col
+// conf = exp(z + u + v - norm) in place (+ full assignment matrix, + prefilter) and the row/col
 // max partials of conf.  Tile = 128 x 128 like the GEMM kernels so that conf_partials applies.
 __global__ __launch_bounds__(Cfg::THREADS, 2) void ot_finalize_kernel(float* __restrict__ z, Geometry g, float norm,
                                                                    const float* __restrict__ u,
                                                                    const float* __restrict__ v,
                                                                    const uint8_t* __restrict__ rowkill,
                                                                    const uint8_t* __restrict__ colkill,
+                                                                   float* __restrict__ assign,
                                                                    float2* __restrict__ rowmax_part,
                                                                    float* __restrict__ colmax_part) {
   const int n = blockIdx.z, m0 = blockIdx.y * Cfg::BM, n0 = blockIdx.x * Cfg::BN;
@@ -293,6 +294,9 @@ __global__ __launch_bounds__(Cfg::THREADS, 2) void ot_finalize_kernel(float* __r
           const long o = ((long)n * g.L + row) * g.S + col;
           c = expf(z[o] + un[row] + vn[col] - norm);
           if (rowkill && (rowkill[(long)n * g.L + row] || colkill[(long)n * g.S + col])) c = 0.f;
+          // conf_matrix is a VIEW of assign_matrix in the reference (:133), so the prefilter
+          // zeroing (:139-140) is visible in conf_matrix_with_bin (:143) as well
+          if (assign) assign[((long)n * (g.L + 1) + row) * (g.S + 1) + col] = c;
           z[o] = c;
         }
         acc[i][j][r] = c;
@@ -312,7 +316,7 @@ __global__ __launch_bounds__(Cfg::THREADS, 2) void ot_finalize_kernel(float* __r
 //     per column and round (R + 1 exponentials per R elements instead of 2 R); every thread derives u_i itself from the
 //     block sums (no broadcast round trip) and the reduction buffers alternate by round parity: two barriers per round;
 //   * FINAL = true is the last pass (ot_finalize_kernel's job) on the same skeleton: conf = exp(Z + u + v - norm) written
-//     over Z, per-row (max, FIRST arg-max, attained-twice flag) by a block reduction -- one
+//     over Z (and into assign_matrix), per-row (max, FIRST arg-max, attained-twice flag) by a block reduction -- one
 //     partial per row, PJ = 1 -- and per-workgroup column maxima (P = workgroups per pair partial rows).
 //   grid (WGP, N), 256 threads.
 namespace otp {
@@ -342,7 +346,7 @@ __global__ __launch_bounds__(256, OTP_PREFETCH ? 2 : 3) void ot_pass_kernel(floa
                                                       const float* __restrict__ v, float* __restrict__ u,
                                                       float2* __restrict__ part, int rows_per_wg,
                                                       const uint8_t* __restrict__ rowkill, const uint8_t* __restrict__ colkill,
-                                                      float2* __restrict__ rowmax_part,
+                                                      float* __restrict__ assign, float2* __restrict__ rowmax_part,
                                                       float* __restrict__ colmax_part) {
   __shared__ float red_a[2][R][4], red_b[2][R][4];
   __shared__ int red_w[2][R][4];
@@ -448,6 +452,7 @@ __global__ __launch_bounds__(256, OTP_PREFETCH ? 2 : 3) void ot_pass_kernel(floa
         const float ub = u[(long)n * (L + 1) + ic];
         const bool rk = rowkill && rowkill[(long)n * L + ic];
         float* zr = z + ((long)n * L + ic) * S;
+        float* ar = assign ? assign + ((long)n * (L + 1) + ic) * (S + 1) : nullptr;
         float best = -1.f; int bw = 0;
 #pragma unroll
         for (int k = 0; k < G4; ++k) {
@@ -459,7 +464,13 @@ __global__ __launch_bounds__(256, OTP_PREFETCH ? 2 : 3) void ot_pass_kernel(floa
             if (rk || ((kill >> (4 * k + e)) & 1u)) x = 0.f;       // skh_prefilter: coarse_matching.py:136-140
             c[e] = (q < S4 && valid) ? x : -1.f;
           }
-          if (q < S4 && valid) *reinterpret_cast<f32x4*>(zr + 4 * q) = c;
+          if (q < S4 && valid) {
+            *reinterpret_cast<f32x4*>(zr + 4 * q) = c;
+            // conf_matrix is a VIEW of assign_matrix in the reference (:133): the prefilter zeroing is visible there too
+            // (row pitch S + 1: only 4-byte aligned.  Scalar stores: +147 us for the 737 MB at N = 8, i.e. 5 TB/s -- already the HBM
+            //  write rate; one unaligned dwordx4 per group measured 40 % slower, a separate aligned fill kernel re-reading conf 120 us slower)
+            if (ar) { ar[4 * q] = c[0]; ar[4 * q + 1] = c[1]; ar[4 * q + 2] = c[2]; ar[4 * q + 3] = c[3]; }
+          }
 #pragma unroll
           for (int e = 0; e < 4; ++e) {                  // this thread's columns ascend with (k, e): > keeps the first
             if (c[e] > best) { best = c[e]; bw = 4 * q + e; }
@@ -532,35 +543,15 @@ __global__ __launch_bounds__(256, OTP_PREFETCH ? 2 : 3) void ot_pass_kernel(floa
 }
 }  // namespace otp
 
-// conf_matrix_with_bin [N, L + 1, S + 1] (coarse_matching.py:130-143): the interior is conf -- conf_matrix is a VIEW of assign_matrix
-// in the reference (:133), so the prefilter zeroing (:139-140) shows there too -- plus the dustbin column / row / corner.
-// The row pitch S + 1 is odd: rows are only 4-byte aligned, and writing them from the finalize pass cost 240 of its 514 us
-// in scalar stores (one unaligned dwordx4 per group measured 40 % slower still).  The tensor is contiguous, so this kernel
-// walks it FLAT in aligned groups of four: one 16-byte store per thread, fed by four 4-byte loads of conf (hot in L2 / MALL,
-// just written) that a wave coalesces into the same lines.
-__global__ __launch_bounds__(256) void ot_assign_fill_kernel(Geometry g, float alpha, float norm, const float* __restrict__ u,
-                                                             const float* __restrict__ v, const float* __restrict__ conf,
-                                                             float* __restrict__ assign) {
-  const long total = (long)g.N * (g.L + 1) * (g.S + 1);
-  const long f0 = 4 * ((long)blockIdx.x * 256 + threadIdx.x);
-  if (f0 >= total) return;
-  const long row0 = f0 / (g.S + 1);                     // over N (L + 1) rows
-  int j = (int)(f0 - row0 * (g.S + 1));
-  int n = (int)(row0 / (g.L + 1));
-  int i = (int)(row0 - (long)n * (g.L + 1));
-  f32x4 c;
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    float x = 0.f;
-    if (f0 + e < total) {
-      if (i < g.L && j < g.S) x = conf[((long)n * g.L + i) * g.S + j];
-      else x = expf(alpha + u[(long)n * (g.L + 1) + i] + v[(long)n * (g.S + 1) + j] - norm);
-    }
-    c[e] = x;
-    if (++j > g.S) { j = 0; if (++i > g.L) { i = 0; ++n; } }
-  }
-  if (f0 + 3 < total && (reinterpret_cast<uintptr_t>(assign) & 15) == 0) *reinterpret_cast<f32x4*>(assign + f0) = c;
-  else
-    for (int e = 0; e < 4 && f0 + e < total; ++e) assign[f0 + e] = c[e];
+// dustbin column / row / corner of the assignment matrix
+__global__ void ot_assign_bins_kernel(Geometry g, float alpha, float norm, const float* __restrict__ u,
+                                      const float* __restrict__ v, float* __restrict__ assign) {
+  const int n = blockIdx.y;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const float* un = u + (long)n * (g.L + 1);
+  const float* vn = v + (long)n * (g.S + 1);
+  float* an = assign + (long)n * (g.L + 1) * (g.S + 1);
+  if (t < g.L) an[(long)t * (g.S + 1) + g.S] = expf(alpha + un[t] + vn[g.S] - norm);
+  if (t <= g.S) an[(long)g.L * (g.S + 1) + t] = expf(alpha + un[g.L] + vn[t] - norm);
 }
 
