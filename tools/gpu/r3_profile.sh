@@ -6,11 +6,19 @@ T=${1:-r03}
 O=$R/gpurun_out
 mkdir -p $O; export TMPDIR=/tmp; cd /tmp
 B="python $R/bench.py --no-cpu-baseline --no-other-configs --warmup 2"
-timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof_$T -o p -- $B --steps 5 > $O/${T}_prof_bench.json 2> $O/${T}_prof.err
-timeout 600 rocprofv3 --kernel-trace --stats -d $O/profs_$T -o p -- $B --steps 5 --no-overlap > $O/${T}_prof_bench_serial.json 2> $O/${T}_profs.err
-timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/pmc_fetch_$T -o p -- $B --steps 2 > /dev/null 2> $O/${T}_pmc_fetch.err
-timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/pmc_write_$T -o p -- $B --steps 2 > /dev/null 2> $O/${T}_pmc_write.err
-timeout 600 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -d $O/pmc_sq_$T -o p -- $B --steps 2 > /dev/null 2> $O/${T}_pmc_sq.err
+python -c 'import torch' 2> /dev/null     # page the image in before the first timed-out-able run
+# (an aborted process under rocprofv3 does not exit by itself: short timeouts, and stop at the first failure)
+fail() { echo "FAILED: $1"; grep -v "^W2026\|^E2026\|^I2026" $2 | tail -6 | cut -c1-300; exit 1; }
+timeout -k 5 180 rocprofv3 --kernel-trace --stats -d $O/prof_$T -o p -- $B --steps 5 > $O/${T}_prof_bench.json 2> $O/${T}_prof.err
+[ $? -eq 0 ] || fail "$O/prof_$T" $O/${T}_prof.err
+timeout -k 5 180 rocprofv3 --kernel-trace --stats -d $O/profs_$T -o p -- $B --steps 5 --no-overlap > $O/${T}_prof_bench_serial.json 2> $O/${T}_profs.err
+[ $? -eq 0 ] || fail "$O/profs_$T" $O/${T}_profs.err
+timeout -k 5 180 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/pmc_fetch_$T -o p -- $B --steps 2 > /dev/null 2> $O/${T}_pmc_fetch.err
+[ $? -eq 0 ] || fail "$O/pmc_fetch_$T" $O/${T}_pmc_fetch.err
+timeout -k 5 180 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/pmc_write_$T -o p -- $B --steps 2 > /dev/null 2> $O/${T}_pmc_write.err
+[ $? -eq 0 ] || fail "$O/pmc_write_$T" $O/${T}_pmc_write.err
+timeout -k 5 180 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -d $O/pmc_sq_$T -o p -- $B --steps 2 > /dev/null 2> $O/${T}_pmc_sq.err
+[ $? -eq 0 ] || fail "$O/pmc_sq_$T" $O/${T}_pmc_sq.err
 cd $R
 db() { find $1 -name '*.db' | head -1; }
 python tools/rocpd_summary.py $(db $O/prof_$T) > $O/${T}_kernel_stats.txt 2>&1
