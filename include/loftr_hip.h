@@ -293,12 +293,13 @@ int loftr_fine_loss_sums(const float* expec_f, int ld, const float* expec_f_gt, 
  * src/losses/loftr_loss.py:165-192) and the INPUTS OF THE TWO HEADS: feat_c0 / feat_c1 entering CoarseMatching
  * (src/loftr/utils/coarse_matching.py:105-119, dual-softmax) and feat_f0 / feat_f1 entering FineMatching
  * (src/loftr/utils/fine_matching.py:43-57).  One kernel per node; each recomputes the forward quantities it needs from the
- * node's inputs.  The chain stops there: the transformers, FinePreprocess, the backbone and the Sinkhorn head have no backward.
+ * node's inputs.  The chain stops there: the transformers, FinePreprocess and the backbone have no backward.
  *
- * loftr_coarse_loss_grad: grad_conf [N,L,S] = d(pos_scale * sum_pos + neg_scale * sum_neg) / d conf for the sums of
- *   loftr_coarse_loss_sums with the same kind (0, 2, 3; kind 1 -> LOFTR_ERR_UNSUPPORTED), ids and masks; the gradient of
- *   torch.clamp(conf, 1e-6, 1 - 1e-6) (:45,:54) is included.  The caller folds means, loss weights, corner cases (:31-42) and
- *   the upstream gradient into pos_scale = up * c_pos_w / M and neg_scale = up * c_neg_w / (N L S - M).
+ * loftr_coarse_loss_grad: grad_conf = d(pos_scale * sum_pos + neg_scale * sum_neg) / d conf for the sums of
+ *   loftr_coarse_loss_sums with the same kind, ids and masks ([N,L,S]; kind 1: [N,L+1,S+1] = conf_matrix_with_bin, workspace
+ *   loftr_loss_workspace_bytes); the gradient of torch.clamp(conf, 1e-6, 1 - 1e-6) (:45,:54) is included.  The caller folds
+ *   means, loss weights, corner cases (:31-42) and the upstream gradient into pos_scale = up * c_pos_w / M and neg_scale =
+ *   up * c_neg_w / (N L S - M) (kind 1: / sums[3], the number of supervised dustbin entries).
  * loftr_fine_loss_grad: grad_expec [M,ld] = upstream * d loss_f / d expec_f (:108-157); `sums` is the DEVICE array the forward
  *   (loftr_fine_loss_sums) filled; the std column gets 0 (weight.detach(), :131); training = the module's .training (:113-117).
  * loftr_dual_softmax_bwd: dsim [N,L,S] = dL/d sim_matrix from grad_conf = dL/d conf_matrix (:110-119; 0 on the mask-filled
@@ -306,16 +307,23 @@ int loftr_fine_loss_sums(const float* expec_f, int ld, const float* expec_f_gt, 
  *   dsim^T . feat_c0 / (C T): two plain batched GEMMs left to the caller (rocBLAS via torch.bmm in loftr_amd/autograd.py).
  *   Workspace: loftr_coarse_match_workspace_bytes(N, L, S, C).
  * loftr_fine_match_bwd: grad_f0 / grad_f1 [M,WW,C] from grad_expec [M,3] = dL/d expec_f (x, y, std) (:43-57; grad_f0 is
- *   non-zero at the centre row only, :43). */
+ *   non-zero at the centre row only, :43).
+ * loftr_sinkhorn_bwd: the Sinkhorn head (coarse_matching.py:121-143 + SuperGlue log_optimal_transport) in reverse mode through
+ *   the `iters` unrolled iterations: dZ [N,L+1,S+1] = dL/d couplings (scores padded with bin_score) from grad_assign =
+ *   dL/d conf_matrix_with_bin, *dbin = dL/d bin_score (device float); z_scratch [N,L,S] receives the re-created scores.
+ *   sim = <feat_c0, feat_c1> / C: the caller slices dZ[:, :L, :S] (zero on mask-filled entries) and finishes with two GEMMs. */
 int loftr_coarse_loss_grad(const float* conf, int N, int L, int S, int kind, const int64_t* gt_b, const int64_t* gt_i,
                            const int64_t* gt_j, long M, const uint8_t* mask0, const uint8_t* mask1, float alpha, float gamma,
-                           double pos_scale, double neg_scale, float* grad_conf, void* stream);
+                           double pos_scale, double neg_scale, float* grad_conf, void* ws, size_t ws_bytes, void* stream);
 int loftr_fine_loss_grad(const float* expec_f, int ld, const float* expec_f_gt, long M, int with_std, float correct_thr,
                          int training, const double* sums, float upstream, float* grad_expec, void* stream);
 int loftr_dual_softmax_bwd(const float* feat_c0, const float* feat_c1, const loftr_coarse_params* p, float temperature,
                            const float* grad_conf, float* dsim, void* ws, size_t ws_bytes, void* stream);
 int loftr_fine_match_bwd(const float* feat_f0, const float* feat_f1, int M, int WW, int C, const float* grad_expec,
                          float* grad_f0, float* grad_f1, void* stream);
+size_t loftr_sinkhorn_bwd_workspace_bytes(int N, int L, int S, int C, int iters);
+int loftr_sinkhorn_bwd(const float* feat_c0, const float* feat_c1, const loftr_coarse_params* p, float bin_score, int iters,
+                       const float* grad_assign, float* z_scratch, float* dZ, float* dbin, void* ws, size_t ws_bytes, void* stream);
 
 /* Replaces estimate_pose (src/utils/metrics.py:72-98: cv2.findEssentialMat(RANSAC) + cv2.recoverPose on intrinsics-
  * normalised key points), the pose step of compute_pose_errors (:101-136).  HOST function (cv2 is a CPU library too):

@@ -74,7 +74,9 @@ SIGNATURES = {
     "loftr_loss_workspace_bytes": (_sz, [_i, _i, _i]),
     "loftr_coarse_loss_sums": (_i, [_p, _i, _i, _i, _i, _p, _p, _p, _l, _p, _p, _f, _f, _p, _p, _sz, _p]),
     "loftr_fine_loss_sums": (_i, [_p, _i, _p, _l, _i, _f, _p, _p, _sz, _p]),
-    "loftr_coarse_loss_grad": (_i, [_p, _i, _i, _i, _i, _p, _p, _p, _l, _p, _p, _f, _f, C.c_double, C.c_double, _p, _p]),
+    "loftr_coarse_loss_grad": (_i, [_p, _i, _i, _i, _i, _p, _p, _p, _l, _p, _p, _f, _f, C.c_double, C.c_double, _p, _p, _sz, _p]),
+    "loftr_sinkhorn_bwd_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
+    "loftr_sinkhorn_bwd": (_i, [_p, _p, C.POINTER(CoarseParams), _f, _i, _p, _p, _p, _p, _p, _sz, _p]),
     "loftr_fine_loss_grad": (_i, [_p, _i, _p, _l, _i, _f, _i, _p, _f, _p, _p]),
     "loftr_dual_softmax_bwd": (_i, [_p, _p, C.POINTER(CoarseParams), _f, _p, _p, _p, _sz, _p]),
     "loftr_fine_match_bwd": (_i, [_p, _p, _i, _i, _i, _p, _p, _p, _p]),

@@ -1,14 +1,14 @@
 """torch.autograd nodes for the two matching heads: forward AND backward are the HIP kernels behind the C-ABI.
 
 What the reference gets from autograd between ``batch['loss']`` (src/lightning/lightning_loftr.py:112-133) and the heads'
-inputs, for the dual-softmax configuration:
+inputs, for the dual-softmax configuration (the Sinkhorn one swaps the first node):
 
     feat_c0, feat_c1 --CoarseMatching (coarse_matching.py:105-119)--> conf_matrix --LoFTRLoss (loftr_loss.py:22-99)---> loss_c
     feat_f0, feat_f1 --FineMatching   (fine_matching.py:43-57)-----> expec_f     --LoFTRLoss (loftr_loss.py:108-157)-> loss_f
 
 The loss nodes are loftr_amd.training.LoFTRLoss (same mechanism).  Nothing upstream of the heads has a backward: the
-gradients stop at the transformer outputs (LoFTR.head_grads hands those out as leaves).  The Sinkhorn head has no backward
-either; with match_type = 'sinkhorn' conf_matrix stays graph-less.
+gradients stop at the transformer outputs (LoFTR.head_grads hands those out as leaves).  The Sinkhorn head
+(coarse_matching.py:121-143, conf_matrix_with_bin, the bin_score parameter) has its backward too: _SinkhornMatch.
 
 No CPU fallback: the nodes call loftr_amd.ops, which raises on non-GPU tensors.
 """
@@ -47,6 +47,46 @@ def dual_softmax_match(feat_c0, feat_c1, hw0_c, hw1_c, **kw):
     holder = {}
     conf = _DualSoftmaxMatch.apply(feat_c0, feat_c1, tuple(hw0_c), tuple(hw1_c), kw, holder)
     holder["conf_matrix"] = conf
+    return holder
+
+
+class _SinkhornMatch(torch.autograd.Function):
+    """conf_matrix_with_bin = exp(log_optimal_transport(sim, bin_score, iters)) (coarse_matching.py:121-143), differentiable with
+    respect to feat_c0, feat_c1 and the bin_score parameter; the match selection rides along in `holder`."""
+
+    @staticmethod
+    def forward(ctx, feat_c0, feat_c1, bin_score, hw0_c, hw1_c, kw, holder):
+        r = ops.coarse_match(feat_c0.detach(), feat_c1.detach(), hw0_c, hw1_c, **dict(kw, bin_score=float(bin_score.detach()), want_assign=True))
+        holder.update(r)
+        ctx.save_for_backward(feat_c0, feat_c1, bin_score)
+        ctx.meta = (hw0_c, hw1_c, kw["skh_iters"], kw.get("mask0"), kw.get("mask1"))
+        return r["conf_matrix_with_bin"]
+
+    @staticmethod
+    def backward(ctx, grad_assign):
+        feat_c0, feat_c1, bin_score = ctx.saved_tensors
+        hw0_c, hw1_c, iters, mask0, mask1 = ctx.meta
+        f0, f1 = feat_c0.detach().contiguous(), feat_c1.detach().contiguous()
+        dz, dbin = ops.sinkhorn_bwd(f0, f1, grad_assign.contiguous(), hw0_c, hw1_c, float(bin_score.detach()), iters, mask0, mask1)
+        L, S = f0.shape[1], f1.shape[1]
+        dsim = dz[:, :L, :S]
+        if mask0 is not None:                          # masked_fill_ cuts the graph at the padding (:124-127)
+            dsim = dsim.masked_fill(~(mask0.bool()[..., None] & mask1.bool()[:, None]), 0.0)
+        k = 1.0 / f0.shape[-1]                         # sim = <feat_c0, feat_c1> / C (no temperature, :123)
+        g0 = torch.bmm(dsim, f1).mul_(k) if ctx.needs_input_grad[0] else None
+        g1 = torch.bmm(dsim.transpose(1, 2), f0).mul_(k) if ctx.needs_input_grad[1] else None
+        gb = dbin.reshape(bin_score.shape).to(bin_score.dtype) if ctx.needs_input_grad[2] else None
+        return g0, g1, gb, None, None, None, None
+
+
+def sinkhorn_match(feat_c0, feat_c1, bin_score, hw0_c, hw1_c, **kw):
+    """ops.coarse_match(match_type='sinkhorn') whose 'conf_matrix_with_bin' (and 'conf_matrix', its interior view, :133) carry the
+    graph back to feat_c0 / feat_c1 / bin_score.  Training only: skh_prefilter never applies there (:136)."""
+    assert kw.get("match_type") == "sinkhorn" and not kw.get("skh_prefilter")
+    holder = {}
+    assign = _SinkhornMatch.apply(feat_c0, feat_c1, bin_score, tuple(hw0_c), tuple(hw1_c), kw, holder)
+    holder["conf_matrix_with_bin"] = assign
+    holder["conf_matrix"] = assign[:, :-1, :-1]
     return holder
 
 

@@ -574,6 +574,7 @@ __global__ __launch_bounds__(256) void scatter_kernel(ScatterParams sp, const in
 
 #include "sinkhorn.h"         // Sinkhorn: iteration / finalize kernels (row-streaming and round-1 forms), prefilter, dustbins
 #include "dual_softmax_bwd.h" // dual-softmax backward: the streaming passes after the recomputed statistics / scores
+#include "sinkhorn_bwd.h"     // Sinkhorn backward: reverse mode through the unrolled iterations
 
 // ------------------------------------------------------------------------------------------
 // upper bound of the number of sweep work units (pair x column chunk x 256-row block)
@@ -773,6 +774,64 @@ extern "C" int loftr_coarse_match_dual_softmax(const float* feat_c0, const float
   return select_and_compact(g, *p, *out, w, conf_out, st);
 }
 
+
+namespace {
+// Work decomposition of the Sinkhorn iteration passes (a function of the geometry only) and the iteration loop itself, shared
+// by the forward and by the backward's re-creation of (u_t, v_t).
+struct OtPlan { bool rowstream, fused; int wgs, rpws, wgp, rpw, cpt; };
+OtPlan ot_plan(const Geometry& g) {
+  OtPlan p{};
+  // row-streaming passes (otp::ot_pass_kernel): aligned rows and at most 5 x 1024 columns incl. the dustbin (indoor)
+  p.rowstream = (g.S & 3) == 0 && g.S + 1 <= 4 * 256 * 5;
+  if (p.rowstream) {
+    constexpr int R = 2;
+    const int capP = [&] { const int a = ceil_div(g.L, 256) * 8; const int c = a > g.PI ? a : g.PI; return c < OT_RCH ? c : OT_RCH; }();
+    int wgs = 768 / g.N;                                   // ~3 workgroups (of 4 waves) per CU over the batch
+    wgs = wgs < 1 ? 1 : (wgs > capP ? capP : wgs);
+    if (wgs > ceil_div(g.L, R)) wgs = ceil_div(g.L, R);
+    p.rpws = ceil_div(ceil_div(g.L, wgs), R) * R;
+    p.wgs = ceil_div(g.L, p.rpws);
+  }
+  // fused iteration (one pass over Z): up to 19 x 256 (indoor) / 44 x 256 (outdoor 840 x 840) columns incl. the dustbin
+  p.cpt = ceil_div(g.S + 1, 256);
+  p.fused = p.cpt <= 44;
+  int wgp = 512 / (g.N > 0 ? g.N : 1);                     // ~2 workgroups per CU over the batch
+  wgp = wgp < 1 ? 1 : (wgp > OT_RCH ? OT_RCH : wgp);       // the partial buffer holds OT_RCH rows per column
+  if (wgp > ceil_div(g.L, 4)) wgp = ceil_div(g.L, 4);
+  int rpw = ceil_div(g.L, wgp);
+  p.rpw = ceil_div(rpw, 4) * 4;
+  p.wgp = ceil_div(g.L, p.rpw);
+  return p;
+}
+// u = v = 0, then `iters` iterations on z (the scaled, mask-filled scores) in w.ot_u / w.ot_v.  save_u [iters][N (L+1)] /
+// save_v [iters + 1][N (S+1)] (or null): the potentials after every iteration (save_v[0] = 0), for the backward.
+void ot_iterate(const Geometry& g, const OtPlan& pl, float* z, const MatchWs& w, float bin_score, float norm, int iters, hipStream_t st,
+                float* save_u, float* save_v) {
+  const size_t ub = sizeof(float) * g.N * (g.L + 1), vb = sizeof(float) * g.N * (g.S + 1);
+  (void)hipMemsetAsync(w.ot_u, 0, ub, st);
+  (void)hipMemsetAsync(w.ot_v, 0, vb, st);
+  if (save_v) (void)hipMemsetAsync(save_v, 0, vb, st);
+  const long cols = (long)g.N * (g.S + 1);
+  for (int it = 0; it < iters; ++it) {
+    if (pl.rowstream) {
+      hipLaunchKernelGGL((otp::ot_pass_kernel<5, 2, false>), dim3(pl.wgs, g.N), dim3(256), 0, st, z, g, bin_score, norm, w.ot_v, w.ot_u,
+                         w.ot_part, pl.rpws, nullptr, nullptr, nullptr, nullptr, nullptr);
+      hipLaunchKernelGGL(ot_col_merge2_kernel, dim3(ceil_div((int)cols, 256)), dim3(256), 0, st, w.ot_part, g, bin_score, norm, pl.wgs, w.ot_u, w.ot_v);
+    } else if (pl.fused) {
+      if (pl.cpt <= 19) hipLaunchKernelGGL((ot_iter_kernel<19, 4>), dim3(pl.wgp, g.N), dim3(256), 0, st, z, g, bin_score, norm, w.ot_v, w.ot_u, w.ot_part, pl.rpw);
+      else hipLaunchKernelGGL((ot_iter_kernel<44, 2>), dim3(pl.wgp, g.N), dim3(256), 0, st, z, g, bin_score, norm, w.ot_v, w.ot_u, w.ot_part, pl.rpw);
+      hipLaunchKernelGGL(ot_col_merge2_kernel, dim3(ceil_div((int)cols, 256)), dim3(256), 0, st, w.ot_part, g, bin_score, norm, pl.wgp, w.ot_u, w.ot_v);
+    } else {
+      hipLaunchKernelGGL(ot_row_lse_kernel, dim3(ceil_div(g.L + 1, 4), g.N), dim3(256), 0, st, z, g, bin_score, norm, w.ot_v, w.ot_u);
+      hipLaunchKernelGGL(ot_col_part_kernel, dim3(ceil_div(g.S + 1, 64), OT_RCH, g.N), dim3(256), 0, st, z, g, bin_score, w.ot_u, w.ot_part);
+      hipLaunchKernelGGL(ot_col_merge_kernel, dim3(ceil_div((int)cols, 256)), dim3(256), 0, st, w.ot_part, g, norm, w.ot_v);
+    }
+    if (save_u) (void)hipMemcpyAsync(save_u + (size_t)it * g.N * (g.L + 1), w.ot_u, ub, hipMemcpyDeviceToDevice, st);
+    if (save_v) (void)hipMemcpyAsync(save_v + (size_t)(it + 1) * g.N * (g.S + 1), w.ot_v, vb, hipMemcpyDeviceToDevice, st);
+  }
+}
+}  // namespace
+
 extern "C" int loftr_coarse_match_sinkhorn(const float* feat_c0, const float* feat_c1,
                                            const loftr_coarse_params* p, float bin_score, int iters,
                                            int prefilter, float* conf_out, float* assign_out,
@@ -802,48 +861,10 @@ extern "C" int loftr_coarse_match_sinkhorn(const float* feat_c0, const float* fe
       hipLaunchKernelGGL(score_store_kernel, sgrid, block, 0, st, w.f0sp, w.f1sp, g, scale, p->mask0, p->mask1, conf_out);
     }
   }
-  (void)hipMemsetAsync(w.ot_u, 0, sizeof(float) * g.N * (g.L + 1), st);
-  (void)hipMemsetAsync(w.ot_v, 0, sizeof(float) * g.N * (g.S + 1), st);
-  const long cols = (long)g.N * (g.S + 1);
-  // row-streaming passes (otp::ot_pass_kernel): aligned rows and at most 5 x 1024 columns incl. the dustbin (indoor)
-  const bool rowstream = (g.S & 3) == 0 && g.S + 1 <= 4 * 256 * 5;
-  int wgs = 0;                                             // workgroups per pair of the row-streaming passes
-  int rpws = 0;
-  if (rowstream) {
-    constexpr int R = 2;
-    const int capP = [&] { const int a = ceil_div(g.L, 256) * 8; const int c = a > g.PI ? a : g.PI; return c < OT_RCH ? c : OT_RCH; }();
-    wgs = 768 / g.N;                                       // ~3 workgroups (of 4 waves) per CU over the batch
-    wgs = wgs < 1 ? 1 : (wgs > capP ? capP : wgs);
-    if (wgs > ceil_div(g.L, R)) wgs = ceil_div(g.L, R);
-    rpws = ceil_div(ceil_div(g.L, wgs), R) * R;
-    wgs = ceil_div(g.L, rpws);
-  }
-  // fused iteration (one pass over Z): up to 19 x 256 (indoor) / 44 x 256 (outdoor 840 x 840) columns incl. the dustbin
-  const int cpt = ceil_div(g.S + 1, 256);
-  const bool fused = cpt <= 44;
-  int wgp = 512 / (g.N > 0 ? g.N : 1);                     // ~2 workgroups per CU over the batch
-  wgp = wgp < 1 ? 1 : (wgp > OT_RCH ? OT_RCH : wgp);       // the partial buffer holds OT_RCH rows per column
-  if (wgp > ceil_div(g.L, 4)) wgp = ceil_div(g.L, 4);
-  int rpw = ceil_div(g.L, wgp);
-  rpw = ceil_div(rpw, 4) * 4;
-  wgp = ceil_div(g.L, rpw);
-  for (int it = 0; it < iters; ++it) {
-    if (rowstream) {
-      hipLaunchKernelGGL((otp::ot_pass_kernel<5, 2, false>), dim3(wgs, g.N), dim3(256), 0, st, conf_out, g, bin_score, norm, w.ot_v, w.ot_u,
-                         w.ot_part, rpws, nullptr, nullptr, nullptr, nullptr, nullptr);
-      hipLaunchKernelGGL(ot_col_merge2_kernel, dim3(ceil_div((int)cols, 256)), dim3(256), 0, st, w.ot_part, g, bin_score, norm, wgs, w.ot_u, w.ot_v);
-      continue;
-    }
-    if (fused) {
-      if (cpt <= 19) hipLaunchKernelGGL((ot_iter_kernel<19, 4>), dim3(wgp, g.N), dim3(256), 0, st, conf_out, g, bin_score, norm, w.ot_v, w.ot_u, w.ot_part, rpw);
-      else hipLaunchKernelGGL((ot_iter_kernel<44, 2>), dim3(wgp, g.N), dim3(256), 0, st, conf_out, g, bin_score, norm, w.ot_v, w.ot_u, w.ot_part, rpw);
-      hipLaunchKernelGGL(ot_col_merge2_kernel, dim3(ceil_div((int)cols, 256)), dim3(256), 0, st, w.ot_part, g, bin_score, norm, wgp, w.ot_u, w.ot_v);
-      continue;
-    }
-    hipLaunchKernelGGL(ot_row_lse_kernel, dim3(ceil_div(g.L + 1, 4), g.N), dim3(256), 0, st, conf_out, g, bin_score, norm, w.ot_v, w.ot_u);
-    hipLaunchKernelGGL(ot_col_part_kernel, dim3(ceil_div(g.S + 1, 64), OT_RCH, g.N), dim3(256), 0, st, conf_out, g, bin_score, w.ot_u, w.ot_part);
-    hipLaunchKernelGGL(ot_col_merge_kernel, dim3(ceil_div((int)cols, 256)), dim3(256), 0, st, w.ot_part, g, norm, w.ot_v);
-  }
+  const OtPlan plan = ot_plan(g);
+  ot_iterate(g, plan, conf_out, w, bin_score, norm, iters, st, nullptr, nullptr);
+  const bool rowstream = plan.rowstream;
+  const int wgs = plan.wgs, rpws = plan.rpws;
   const uint8_t *rk = nullptr, *ck = nullptr;
   if (prefilter) {
     hipLaunchKernelGGL(ot_rowkill_kernel, dim3(ceil_div(g.L, 4), g.N), dim3(256), 0, st, conf_out, g, bin_score, w.ot_u, w.ot_v, w.rowkill);
@@ -916,6 +937,71 @@ extern "C" int loftr_dual_softmax_bwd(const float* feat_c0, const float* feat_c1
   hipLaunchKernelGGL(dsb::col_dot_merge_kernel, dim3(ceil_div((int)NS, 256)), dim3(256), 0, st, part, g, c);
   hipLaunchKernelGGL(dsb::dsim_kernel, dim3((unsigned)((NL + 3) / 4)), dim3(256), 0, st, dsim, grad_conf, g, w.rowstat, w.colstat, r, c,
                      p->mask0, p->mask1);
+  LOFTR_CHECK_LAUNCH();
+  return LOFTR_OK;
+}
+
+// ---- backward of the Sinkhorn head (sinkhorn_bwd.h) ---------------------------------------------------------------------------
+// dZ [N, L+1, S+1] <- dL/d couplings (the padded score matrix) given grad_assign = dL/d conf_matrix_with_bin; *dbin <- dL/d bin_score.
+// z_scratch [N, L, S]: the re-created scores.  The caller slices dZ[:, :L, :S] (zeroing mask-filled entries) and finishes with
+// dL/dfeat_c0 = dsim feat_c1 / C, dL/dfeat_c1 = dsim^T feat_c0 / C.   Workspace: loftr_sinkhorn_bwd_workspace_bytes.
+extern "C" size_t loftr_sinkhorn_bwd_workspace_bytes(int N, int L, int S, int C, int iters) {
+  if (N <= 0 || L <= 0 || S <= 0 || C <= 0 || iters < 0) return 0;
+  const size_t un = (size_t)N * (L + 1), vn = (size_t)N * (S + 1);
+  return match_ws_bytes(N, L, S, C) + align_up(un * 4 * (iters > 0 ? iters : 1), 256) + align_up(vn * 4 * (iters + 1), 256) +
+         align_up(un * 4, 256) + align_up(vn * 4, 256) + align_up(vn * 4 * otb::RCH, 256) + 4096;
+}
+
+extern "C" int loftr_sinkhorn_bwd(const float* feat_c0, const float* feat_c1, const loftr_coarse_params* p, float bin_score, int iters,
+                                  const float* grad_assign, float* z_scratch, float* dZ, float* dbin, void* ws, size_t ws_bytes,
+                                  void* stream) {
+  LOFTR_CHECK_ARG(feat_c0 && feat_c1 && p && grad_assign && z_scratch && dZ && dbin && iters >= 0);
+  LOFTR_CHECK_ARG(p->N >= 0 && p->h0c > 0 && p->w0c > 0 && p->h1c > 0 && p->w1c > 0 && (p->mask0 == nullptr) == (p->mask1 == nullptr));
+  if (p->C % 32 != 0) return LOFTR_ERR_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  if (p->N == 0) { (void)hipMemsetAsync(dbin, 0, sizeof(float), st); return LOFTR_OK; }
+  LOFTR_CHECK_ARG(ws != nullptr);
+  const Geometry g = make_geometry(*p);
+  const size_t base = match_ws_bytes(g.N, g.L, g.S, g.C);
+  if (ws_bytes < base) return LOFTR_ERR_WORKSPACE;
+  MatchWs w = carve(ws, base, g);
+  if (!w.ok) return LOFTR_ERR_WORKSPACE;
+  WsAlloc wa(static_cast<char*>(ws) + base, ws_bytes - base);
+  const size_t un = (size_t)g.N * (g.L + 1), vn = (size_t)g.N * (g.S + 1);
+  float* save_u = wa.take<float>(un * (iters > 0 ? iters : 1));
+  float* save_v = wa.take<float>(vn * (iters + 1));
+  float* du = wa.take<float>(un);
+  float* dv = wa.take<float>(vn);
+  float* part = wa.take<float>(vn * otb::RCH);
+  if (!wa.ok()) return LOFTR_ERR_WORKSPACE;
+  { int rc = stage_descriptors(feat_c0, feat_c1, g, w, st); if (rc) return rc; }
+  const float scale = 1.f / (float)g.C, norm = -logf((float)(g.L + g.S));
+  if (g.C == 256) {
+    sweep::Args a{};
+    sweep_plan(g, a);
+    a.f0 = w.f0sp; a.f1 = w.f1sp; a.scale = scale; a.mask0 = p->mask0; a.mask1 = p->mask1; a.conf = z_scratch;
+    const dim3 swgrid(NUM_XCD * ceil_div(g.N * a.NCH, NUM_XCD) * a.RB);
+    if (p->mask0) hipLaunchKernelGGL((sweep::score_sweep_kernel<2, true>), swgrid, dim3(512), 0, st, a);
+    else hipLaunchKernelGGL((sweep::score_sweep_kernel<2, false>), swgrid, dim3(512), 0, st, a);
+  } else {
+    hipLaunchKernelGGL(score_store_kernel, dim3(score_grid(g)), dim3(Cfg::THREADS), 0, st, w.f0sp, w.f1sp, g, scale, p->mask0, p->mask1, z_scratch);
+  }
+  if (iters == 0) (void)hipMemsetAsync(save_u, 0, un * sizeof(float), st);
+  ot_iterate(g, ot_plan(g), z_scratch, w, bin_score, norm, iters, st, save_u, save_v);
+  const otb::Pad pad{z_scratch, bin_score, norm, logf((float)g.S) + norm, logf((float)g.L) + norm, g.N, g.L, g.S};
+  const dim3 rgrid((unsigned)((un + 3) / 4)), cgrid(ceil_div(g.S + 1, 256), otb::RCH, g.N), mgrid(ceil_div((int)vn, 256));
+  const float* uT = save_u + (iters > 0 ? (size_t)(iters - 1) * un : 0);
+  const float* vT = save_v + (size_t)iters * vn;
+  hipLaunchKernelGGL((otb::row_step_kernel<0>), rgrid, dim3(256), 0, st, pad, grad_assign, dZ, uT, vT, nullptr, du, 0);
+  hipLaunchKernelGGL((otb::col_step_kernel<0>), cgrid, dim3(256), 0, st, pad, dZ, nullptr, nullptr, nullptr, part);
+  hipLaunchKernelGGL(otb::col_merge_kernel, mgrid, dim3(256), 0, st, part, g.N, g.S + 1, dv);
+  for (int t = iters; t >= 1; --t) {
+    const float* ut = save_u + (size_t)(t - 1) * un;
+    hipLaunchKernelGGL((otb::row_step_kernel<1>), rgrid, dim3(256), 0, st, pad, nullptr, dZ, ut, save_v + (size_t)t * vn, dv, du, t == iters ? 1 : 0);
+    hipLaunchKernelGGL((otb::col_step_kernel<1>), cgrid, dim3(256), 0, st, pad, dZ, ut, save_v + (size_t)(t - 1) * vn, du, part);
+    hipLaunchKernelGGL(otb::col_merge_kernel, mgrid, dim3(256), 0, st, part, g.N, g.S + 1, dv);
+  }
+  hipLaunchKernelGGL(otb::dbin_kernel, dim3(1), dim3(1024), 0, st, dZ, g.N, g.L, g.S, dbin);
   LOFTR_CHECK_LAUNCH();
   return LOFTR_OK;
 }

@@ -1,4 +1,4 @@
-// Training-side consumers of the matching path, forward values only:
+// Training-side consumers of the matching path, forward values (their gradients: train_bwd.hip):
 //   * coarse supervision      spvs_coarse, src/loftr/utils/supervision.py:22-109 (+ warp_kpts, src/loftr/utils/geometry.py:5-54)
 //   * fine supervision        spvs_fine,   src/loftr/utils/supervision.py:124-142
 //   * loss values             LoFTRLoss,   src/losses/loftr_loss.py:22-192 (focal / cross-entropy, sparse / dense; l2 / l2_with_std)
@@ -6,7 +6,7 @@
 // another 92 MB per pair).  Here the supervision is two small kernels over the N (L + S) grid cells (the ground-truth
 // matrix is only materialised on request) and every loss is ONE pass: the sparse losses gather the supervised entries,
 // the dense ones stream conf_matrix once and correct for the positives (sum over negatives = sum over all - sum over
-// positives), with fp64 block partials reduced in a fixed order (deterministic).  Backward passes are not built.
+// positives), with fp64 block partials reduced in a fixed order (deterministic).
 #include "common.h"
 
 namespace {

@@ -1,9 +1,9 @@
 // Backward passes of the matching heads and of the losses that read them (second half):
-//   * d loss_c / d conf_matrix      LoFTRLoss.compute_coarse_loss,  src/losses/loftr_loss.py:22-99   (kinds 0, 2, 3 of train.hip)
+//   * d loss_c / d conf_matrix      LoFTRLoss.compute_coarse_loss,  src/losses/loftr_loss.py:22-99   (all four kinds of train.hip)
 //   * d loss_f / d expec_f          LoFTRLoss._compute_fine_loss_*, src/losses/loftr_loss.py:108-157
 //   * d expec_f / d feat_f0, feat_f1   FineMatching.forward,        src/loftr/utils/fine_matching.py:43-57
-// (d conf_matrix / d sim_matrix of the dual-softmax is loftr_dual_softmax_bwd in coarse_match.hip: it shares the forward's
-// descriptor staging and score sweep.)  What torch.autograd does for the reference as a chain of a dozen ATen backward nodes
+// (d conf_matrix / d sim_matrix of the dual-softmax and the Sinkhorn backward are loftr_dual_softmax_bwd / loftr_sinkhorn_bwd in
+// coarse_match.hip: they share the forward's descriptor staging, score sweeps and iteration kernels.)  What torch.autograd does for the reference as a chain of a dozen ATen backward nodes
 // is ONE kernel per head here: each recomputes the forward quantities it needs from the head's inputs (nothing but the
 // inputs is kept alive between forward and backward) and writes the gradient in a single pass.
 // The chain stops at the heads' inputs -- the transformer outputs: the transformers, FinePreprocess and the backbone
@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256) void loss_grad_dense_kernel(const float* __res
 
 // ... then the supervised entries are OVERWRITTEN with the positive term's gradient (ids are unique: they come from a
 // boolean mask, loftr_loss.py:29).  Sparse kind 0: the volume was zero-filled before.
-__global__ __launch_bounds__(256) void loss_grad_gather_kernel(const float* __restrict__ conf, const int64_t* __restrict__ b,
+__global__ __launch_bounds__(256) void loss_grad_gather_kernel(const float* __restrict__ conf, long ldL, long ldS, const int64_t* __restrict__ b,
                                                                const int64_t* __restrict__ i, const int64_t* __restrict__ j, long M, int L,
                                                                int S, const uint8_t* __restrict__ mask0, const uint8_t* __restrict__ mask1,
                                                                int mode, double alpha, double gamma, double scale,
@@ -58,9 +58,50 @@ __global__ __launch_bounds__(256) void loss_grad_gather_kernel(const float* __re
   if (m >= M) return;
   const long bb = b[m], ii = i[m], jj = j[m];
   const bool w = !mask0 || (mask0[bb * L + ii] != 0 && mask1[bb * S + jj] != 0);
-  const long o = (bb * L + ii) * S + jj;
+  const long o = (bb * ldL + ii) * ldS + jj;
   const float c = conf[o];
   grad[o] = (w && clamp_open(c)) ? (float)(scale * loss_term_grad(clampd(c), mode, alpha, gamma)) : 0.f;
+}
+
+// sparse Sinkhorn 'negatives' (loftr_loss.py:63-79, train.hip:loss_bins_kernel): the dustbin entry of every row / column without a
+// ground-truth match, kept iff the row / column carries some loss weight; same focal form as the positives (mode 0).
+__global__ void mark_gt_bwd_kernel(const int64_t* __restrict__ b, const int64_t* __restrict__ i, const int64_t* __restrict__ j, long M, int L,
+                                   int S, uint8_t* __restrict__ has0, uint8_t* __restrict__ has1) {
+  const long m = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= M) return;
+  has0[b[m] * L + i[m]] = 1;
+  has1[b[m] * S + j[m]] = 1;
+}
+__global__ void any_mask_bwd_kernel(const uint8_t* __restrict__ mask0, const uint8_t* __restrict__ mask1, int L, int S,
+                                    uint8_t* __restrict__ any0, uint8_t* __restrict__ any1) {
+  const int n = blockIdx.x;
+  __shared__ int a0, a1;
+  if (threadIdx.x == 0) { a0 = 0; a1 = 0; }
+  __syncthreads();
+  for (int k = threadIdx.x; k < L; k += blockDim.x) if (mask0[(long)n * L + k]) a0 = 1;
+  for (int k = threadIdx.x; k < S; k += blockDim.x) if (mask1[(long)n * S + k]) a1 = 1;
+  __syncthreads();
+  if (threadIdx.x == 0) { any0[n] = (uint8_t)a0; any1[n] = (uint8_t)a1; }
+}
+__global__ __launch_bounds__(256) void loss_grad_bins_kernel(const float* __restrict__ conf_bin, int N, int L, int S,
+                                                             const uint8_t* __restrict__ has0, const uint8_t* __restrict__ has1,
+                                                             const uint8_t* __restrict__ mask0, const uint8_t* __restrict__ mask1,
+                                                             const uint8_t* __restrict__ any0, const uint8_t* __restrict__ any1,
+                                                             double alpha, double gamma, double scale, float* __restrict__ grad) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long)N * (L + S)) return;
+  const int n = (int)(idx / (L + S)), r = (int)(idx - (long)n * (L + S));
+  long o;
+  if (r < L) {
+    if (has0[(long)n * L + r] || (mask0 && !(mask0[(long)n * L + r] && any1[n]))) return;
+    o = ((long)n * (L + 1) + r) * (S + 1) + S;
+  } else {
+    const int jj = r - L;
+    if (has1[(long)n * S + jj] || (mask1 && !(mask1[(long)n * S + jj] && any0[n]))) return;
+    o = ((long)n * (L + 1) + L) * (S + 1) + jj;
+  }
+  const float c = conf_bin[o];
+  if (clamp_open(c)) grad[o] = (float)(scale * loss_term_grad(clampd(c), 0, alpha, gamma));
 }
 
 // d loss_f / d expec_f.  sums = loftr_fine_loss_sums' output of the forward (device): [1] = number of correct entries,
@@ -147,24 +188,43 @@ __global__ __launch_bounds__(256) void fine_match_bwd_kernel(const float* __rest
 
 }  // namespace
 
-// grad_conf [N, L, S] = d (pos_scale * sum_pos + neg_scale * sum_neg) / d conf, the sums being loftr_coarse_loss_sums' (same
-// kind, ids and masks).  The caller folds the means, loss weights, corner cases and the upstream gradient into the scales:
-//   pos_scale = upstream c_pos_w / M (0 without ground truth), neg_scale = upstream c_neg_w / (N L S - M) (dense kinds).
-// kind 1 (sparse Sinkhorn, conf_matrix_with_bin) is not provided: the Sinkhorn head has no backward to hand it to.
+// grad_conf = d (pos_scale * sum_pos + neg_scale * sum_neg) / d conf, the sums being loftr_coarse_loss_sums' (same kind, ids and
+// masks): [N, L, S] for kinds 0, 2, 3; [N, L+1, S+1] (conf_matrix_with_bin) for kind 1.  The caller folds the means, loss weights,
+// corner cases and the upstream gradient into the scales: pos_scale = upstream c_pos_w / M (0 without ground truth), neg_scale =
+// upstream c_neg_w / (N L S - M) (dense kinds) or / sums[3] (kind 1: the number of supervised dustbin entries).
+// Workspace: loftr_loss_workspace_bytes(N, L, S) (kind 1 only; may be null otherwise).
 extern "C" int loftr_coarse_loss_grad(const float* conf, int N, int L, int S, int kind, const int64_t* gt_b, const int64_t* gt_i,
                                       const int64_t* gt_j, long M, const uint8_t* mask0, const uint8_t* mask1, float alpha,
-                                      float gamma, double pos_scale, double neg_scale, float* grad_conf, void* stream) {
+                                      float gamma, double pos_scale, double neg_scale, float* grad_conf, void* ws, size_t ws_bytes,
+                                      void* stream) {
   LOFTR_CHECK_ARG(conf && grad_conf && N > 0 && L > 0 && S > 0 && M >= 0 && kind >= 0 && kind <= 3 && (M == 0 || (gt_b && gt_i && gt_j)));
   LOFTR_CHECK_ARG((mask0 == nullptr) == (mask1 == nullptr));
-  if (kind == 1) return LOFTR_ERR_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
+  const bool bins = kind == 1;
+  const long ldL = bins ? L + 1 : L, ldS = bins ? S + 1 : S;
   const int pos_mode = kind == 3 ? 2 : 0, neg_mode = kind == 3 ? 3 : 1;
-  if (kind == 0) (void)hipMemsetAsync(grad_conf, 0, sizeof(float) * (size_t)N * L * S, st);
+  if (kind <= 1) (void)hipMemsetAsync(grad_conf, 0, sizeof(float) * (size_t)N * ldL * ldS, st);
   else hipLaunchKernelGGL(loss_grad_dense_kernel, dim3(1024), dim3(256), 0, st, conf, N, L, S, mask0, mask1, neg_mode, (double)alpha,
                           (double)gamma, neg_scale, grad_conf);
   if (M > 0)
-    hipLaunchKernelGGL(loss_grad_gather_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, st, conf, gt_b, gt_i, gt_j, M, L, S, mask0,
-                       mask1, pos_mode, (double)alpha, (double)gamma, pos_scale, grad_conf);
+    hipLaunchKernelGGL(loss_grad_gather_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, st, conf, ldL, ldS, gt_b, gt_i, gt_j, M, L, S,
+                       mask0, mask1, pos_mode, (double)alpha, (double)gamma, pos_scale, grad_conf);
+  if (bins) {
+    LOFTR_CHECK_ARG(ws != nullptr);
+    WsAlloc wa(ws, ws_bytes);
+    uint8_t* has0 = wa.take<uint8_t>((size_t)N * L);
+    uint8_t* has1 = wa.take<uint8_t>((size_t)N * S);
+    uint8_t* any0 = wa.take<uint8_t>(N);
+    uint8_t* any1 = wa.take<uint8_t>(N);
+    if (!wa.ok()) return LOFTR_ERR_WORKSPACE;
+    (void)hipMemsetAsync(has0, 0, (size_t)N * L, st);
+    (void)hipMemsetAsync(has1, 0, (size_t)N * S, st);
+    if (M > 0) hipLaunchKernelGGL(mark_gt_bwd_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, st, gt_b, gt_i, gt_j, M, L, S, has0, has1);
+    if (mask0) hipLaunchKernelGGL(any_mask_bwd_kernel, dim3(N), dim3(256), 0, st, mask0, mask1, L, S, any0, any1);
+    const long tot = (long)N * (L + S);
+    hipLaunchKernelGGL(loss_grad_bins_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, conf, N, L, S, has0, has1, mask0, mask1,
+                       any0, any1, (double)alpha, (double)gamma, neg_scale, grad_conf);
+  }
   LOFTR_CHECK_LAUNCH();
   return LOFTR_OK;
 }

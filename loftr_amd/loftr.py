@@ -194,11 +194,16 @@ class CoarseMatching(nn.Module):
             kw.update(bin_score=float(self.bin_score.detach()), skh_iters=self.skh_iters,
                       skh_prefilter=self.skh_prefilter and not self.training,      # "if not self.training and ..." (:136)
                       want_assign=bool(sparse))
+        hw = (tuple(data["hw0_c"]), tuple(data["hw1_c"]))
         if self.match_type == "dual_softmax" and autograd.wants_grad(feat_c0, feat_c1):
             # conf_matrix with its graph: forward and backward are the HIP kernels (loftr_amd/autograd.py)
-            r = autograd.dual_softmax_match(feat_c0, feat_c1, tuple(data["hw0_c"]), tuple(data["hw1_c"]), **dict(kw, want_conf=True))
+            r = autograd.dual_softmax_match(feat_c0, feat_c1, *hw, **dict(kw, want_conf=True))
+        elif self.match_type == "sinkhorn" and autograd.wants_grad(feat_c0, feat_c1, self.bin_score) and not kw["skh_prefilter"]:
+            r = autograd.sinkhorn_match(feat_c0, feat_c1, self.bin_score, *hw, **{k: v for k, v in kw.items() if k != "bin_score"})
+            if not kw["want_assign"]:
+                r.pop("conf_matrix_with_bin")
         else:
-            r = ops.coarse_match(feat_c0, feat_c1, tuple(data["hw0_c"]), tuple(data["hw1_c"]), **kw)
+            r = ops.coarse_match(feat_c0, feat_c1, *hw, **kw)
         if "conf_matrix_with_bin" in r:
             data.update({"conf_matrix_with_bin": r["conf_matrix_with_bin"]})
         data.update({"conf_matrix": r["conf_matrix"]})

@@ -333,6 +333,27 @@ def dual_softmax_bwd(feat_c0, feat_c1, grad_conf, hw0_c, hw1_c, temperature, mas
 
 
 @_on_device
+def sinkhorn_bwd(feat_c0, feat_c1, grad_assign, hw0_c, hw1_c, bin_score, iters, mask0=None, mask1=None):
+    """(dL/d couplings [N,L+1,S+1], dL/d bin_score [1]) from dL/d conf_matrix_with_bin (coarse_matching.py:121-143)."""
+    _need(feat_c0, "feat_c0"); _need(feat_c1, "feat_c1"); _need(grad_assign, "grad_assign")
+    N, L, Cc = feat_c0.shape
+    S = feat_c1.shape[1]
+    assert tuple(grad_assign.shape) == (N, L + 1, S + 1) and L == hw0_c[0] * hw0_c[1] and S == hw1_c[0] * hw1_c[1]
+    m0, m1 = _mask_u8(mask0, "mask0"), _mask_u8(mask1, "mask1")
+    p = CoarseParams(N, hw0_c[0], hw0_c[1], hw1_c[0], hw1_c[1], Cc, 0.0, 0, 1.0,
+                     m0.data_ptr() if m0 is not None else None, m1.data_ptr() if m1 is not None else None, None, None)
+    dev = feat_c0.device
+    dz = torch.empty(N, L + 1, S + 1, device=dev, dtype=torch.float32)
+    z = torch.empty(N, L, S, device=dev, dtype=torch.float32)
+    dbin = torch.zeros(1, device=dev, dtype=torch.float32)
+    lib = _lib.load()
+    ws = workspace(lib.loftr_sinkhorn_bwd_workspace_bytes(N, L, S, Cc, int(iters)), dev)
+    check(lib.loftr_sinkhorn_bwd(_ptr(feat_c0), _ptr(feat_c1), C.byref(p), float(bin_score), int(iters), _ptr(grad_assign), _ptr(z), _ptr(dz),
+                                 _ptr(dbin), _ptr(ws), ws.numel(), _stream()), "loftr_sinkhorn_bwd")
+    return dz, dbin
+
+
+@_on_device
 def fine_match_bwd(feat_f0, feat_f1, grad_expec):
     """(dL/d feat_f0, dL/d feat_f1) [M,WW,C] from dL/d expec_f [M,3] (fine_matching.py:43-57)."""
     _need(feat_f0, "feat_f0"); _need(feat_f1, "feat_f1"); _need(grad_expec, "grad_expec")

@@ -7,7 +7,7 @@ Host-side mirror of the reference's interface: ``compute_supervision_coarse(data
 behind the C-ABI (loftr_spvs_coarse, loftr_spvs_fine, loftr_coarse_loss_sums, loftr_fine_loss_sums); there is no CPU
 fallback.  Backward: when conf_matrix / expec_f carry an autograd graph (loftr_amd/autograd.py: the dual-softmax and
 FineMatching heads), LoFTRLoss is differentiable through loftr_coarse_loss_grad / loftr_fine_loss_grad; the chain ends at the
-heads' inputs (no backward for the transformers, FinePreprocess, the backbone, or the Sinkhorn head).  The RNG-dependent
+heads' inputs (no backward for the transformers, FinePreprocess or the backbone).  The RNG-dependent
 ground-truth padding of CoarseMatching's training branch (coarse_matching.py:200-236) lives in
 loftr_amd/loftr.py:CoarseMatching._train_sample.
 
@@ -152,6 +152,7 @@ class LoFTRLoss(torch.nn.Module):
                                               _ptr(j), t["M"], _ptr(m0), _ptr(m1), t["alpha"], t["gamma"], _ptr(sums), _ptr(ws), ws.numel(),
                                               _stream()), "loftr_coarse_loss_sums")
         s = sums.cpu()
+        t["bin_count"] = float(s[3])                  # kind 1: number of supervised dustbin entries (the backward's normaliser)
         pos_mean = s[0] / max(t["M"], 1)
         if t["kind"] == 0:
             loss = t["c_pos_w"] * pos_mean
@@ -167,8 +168,6 @@ class LoFTRLoss(torch.nn.Module):
         autograd graph (loftr_amd.autograd) the result does too: d loss_c / d conf is loftr_coarse_loss_grad."""
         t = self._coarse_terms(conf, data)
         if torch.is_grad_enabled() and conf.requires_grad:
-            if t["kind"] == 1:
-                raise _lib.LoftrHipError("compute_coarse_loss: no backward for the sparse Sinkhorn loss (conf_matrix_with_bin)")
             return _CoarseLossFn.apply(conf, self, t)
         return self._coarse_value(conf, t)
 
@@ -240,10 +239,14 @@ class _CoarseLossFn(torch.autograd.Function):
         b, i, j = t["ids"]
         m0, m1 = t["masks"]
         u = float(up)
+        n_neg = t["bin_count"] if t["kind"] == 1 else t["n_neg"]
         with torch.cuda.device(c.device):
-            _lib.check(_lib.load().loftr_coarse_loss_grad(_ptr(c), t["N"], t["L"], t["S"], t["kind"], _ptr(b), _ptr(i), _ptr(j), t["M"],
-                                                          _ptr(m0), _ptr(m1), t["alpha"], t["gamma"], u * t["c_pos_w"] / max(t["M"], 1),
-                                                          u * t["c_neg_w"] / t["n_neg"], _ptr(g), _stream()), "loftr_coarse_loss_grad")
+            lib = _lib.load()
+            ws = workspace(lib.loftr_loss_workspace_bytes(t["N"], t["L"], t["S"]), c.device)
+            _lib.check(lib.loftr_coarse_loss_grad(_ptr(c), t["N"], t["L"], t["S"], t["kind"], _ptr(b), _ptr(i), _ptr(j), t["M"],
+                                                  _ptr(m0), _ptr(m1), t["alpha"], t["gamma"], u * t["c_pos_w"] / max(t["M"], 1),
+                                                  u * t["c_neg_w"] / n_neg if n_neg else 0.0, _ptr(g), _ptr(ws), ws.numel(), _stream()),
+                       "loftr_coarse_loss_grad")
         return g, None, None
 
 

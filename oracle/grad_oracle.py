@@ -119,3 +119,79 @@ def fine_matching_grad(feat_f0, feat_f1, grad_expec):
     d0 = np.zeros_like(f0)
     d0[:, WW // 2, :] = np.einsum("mr,mrc->mc", dsim, f1)
     return d0, d1
+
+
+# ---- Sinkhorn head (coarse_matching.py:121-143 + SuperGlue log_optimal_transport) -------------------------------------------
+def sparse_sinkhorn_loss_grad(assign, conf_gt, weight=None, alpha=0.25, gamma=2.0, pos_w=1.0, neg_w=1.0):
+    """d compute_coarse_loss / d conf_matrix_with_bin [N, L+1, S+1] for sparse_spvs + match_type 'sinkhorn' (loftr_loss.py:56-81):
+    focal positives at the ground-truth cells of the interior, focal 'negatives' at the dustbin entries of the rows / columns
+    without a ground-truth match (kept iff the row / column has some loss weight)."""
+    pos = conf_gt == 1
+    weight = None if weight is None else weight.astype(np.float64).copy()
+    if not pos.any():
+        pos = pos.copy(); pos[0, 0, 0] = True
+        if weight is not None:
+            weight[0, 0, 0] = 0.
+        pos_w = 0.
+    thru = _open(assign, 1e-6, 1 - 1e-6)
+    p = np.clip(assign.astype(F), F(1e-6), F(1 - 1e-6)).astype(np.float64)
+    dfocal = alpha * (gamma * np.power(1 - p, gamma - 1) * np.log(p) - np.power(1 - p, gamma) / p)
+    g = np.zeros_like(p)
+    w = np.ones(conf_gt.shape) if weight is None else weight
+    gi = g[:, :-1, :-1]
+    gi[pos] = pos_w * (dfocal[:, :-1, :-1] * w)[pos] / pos.sum()
+    neg0, neg1 = conf_gt.sum(-1) == 0, conf_gt.sum(1) == 0          # [N, L], [N, S]
+    if weight is not None:
+        neg0 = neg0 & (weight.sum(-1) != 0)
+        neg1 = neg1 & (weight.sum(1) != 0)
+    n_neg = neg0.sum() + neg1.sum()
+    g[:, :-1, -1][neg0] = neg_w * dfocal[:, :-1, -1][neg0] / n_neg
+    g[:, -1, :-1][neg1] = neg_w * dfocal[:, -1, :-1][neg1] / n_neg
+    return g * thru
+
+
+def _lse(x, axis):
+    m = x.max(axis=axis, keepdims=True)
+    return (m + np.log(np.exp(x - m).sum(axis=axis, keepdims=True))).squeeze(axis)
+
+
+def sinkhorn_conf_grad(feat_c0, feat_c1, bin_score, grad_assign, iters=3, mask_c0=None, mask_c1=None):
+    """(d L / d feat_c0, d L / d feat_c1, d L / d bin_score) for assign = exp(log_optimal_transport(sim, bin_score, iters)),
+    sim = <feat_c0, feat_c1> / C with -1e9 on padding (coarse_matching.py:121-132).  Reverse mode through the unrolled
+    iterations u_t = log_mu - LSE_j(Z + v_{t-1}), v_t = log_nu - LSE_i(Z + u_t), written out by hand."""
+    N, L, C = feat_c0.shape
+    S = feat_c1.shape[1]
+    f0, f1 = feat_c0.astype(np.float64), feat_c1.astype(np.float64)
+    sim = np.einsum("nlc,nsc->nls", f0, f1) / C
+    keep = None
+    if mask_c0 is not None:
+        keep = mask_c0[:, :, None].astype(bool) & mask_c1[:, None, :].astype(bool)
+        sim = np.where(keep, sim, -1e9)
+    Z = np.full((N, L + 1, S + 1), float(bin_score))
+    Z[:, :L, :S] = sim
+    norm = -np.log(L + S)
+    log_mu = np.concatenate([np.full(L, norm), [np.log(S) + norm]])[None].repeat(N, 0)
+    log_nu = np.concatenate([np.full(S, norm), [np.log(L) + norm]])[None].repeat(N, 0)
+    us, vs = [], [np.zeros((N, S + 1))]
+    for _ in range(iters):
+        us.append(log_mu - _lse(Z + vs[-1][:, None, :], 2))
+        vs.append(log_nu - _lse(Z + us[-1][:, :, None], 1))
+    if iters == 0:
+        us.append(np.zeros((N, L + 1)))
+    out = Z + us[-1][:, :, None] + vs[-1][:, None, :] - norm
+    D = grad_assign.astype(np.float64) * np.exp(out)                 # d L / d out
+    dZ = D.copy()
+    du, dv = D.sum(2), D.sum(1)
+    for t in range(iters, 0, -1):
+        Pc = np.exp(Z + us[t - 1][:, :, None] + vs[t][:, None, :] - log_nu[:, None, :])         # softmax over i of Z + u_t
+        dZ -= dv[:, None, :] * Pc
+        du = du - (dv[:, None, :] * Pc).sum(2)
+        Pr = np.exp(Z + vs[t - 1][:, None, :] + us[t - 1][:, :, None] - log_mu[:, :, None])     # softmax over j of Z + v_{t-1}
+        dZ -= du[:, :, None] * Pr
+        dv = -(du[:, :, None] * Pr).sum(1)
+        du = np.zeros_like(du)
+    dbin = dZ[:, L, :].sum() + dZ[:, :L, S].sum()
+    dsim = dZ[:, :L, :S]
+    if keep is not None:
+        dsim = np.where(keep, dsim, 0.0)
+    return np.einsum("nls,nsc->nlc", dsim, f1) / C, np.einsum("nls,nlc->nsc", dsim, f0) / C, dbin

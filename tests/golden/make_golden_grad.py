@@ -30,7 +30,15 @@ CASES = {
     # no ground truth and no correct fine match (.train(): loftr_loss.py:31-36, :113-117, :138-143)
     "grad_nogt": dict(seed=15, N=1, hc=(6, 8), masks=False, coarse_type="focal", sparse=False, fine_type="l2", M=12, n_gt=0),
     "grad_nogt_std": dict(seed=16, N=1, hc=(6, 8), masks=False, coarse_type="focal", sparse=True, fine_type="l2_with_std", M=12, n_gt=0),
+    # Sinkhorn head (configs/loftr/*/loftr_ot*.py): sparse focal on conf_matrix_with_bin incl. the dustbin negatives; bin_score is a parameter
+    "grad_ot": dict(seed=17, N=2, hc=(6, 8), masks=False, coarse_type="focal", sparse=True, fine_type="l2_with_std", M=12, n_gt=22,
+                    match_type="sinkhorn"),
+    "grad_ot_mask": dict(seed=18, N=2, hc=(6, 8), masks=True, coarse_type="focal", sparse=True, fine_type="l2_with_std", M=12, n_gt=18,
+                         match_type="sinkhorn"),
+    "grad_ot_nogt": dict(seed=19, N=1, hc=(6, 8), masks=False, coarse_type="focal", sparse=True, fine_type="l2_with_std", M=12, n_gt=0,
+                         match_type="sinkhorn"),
 }
+BIN_SCORE, SKH_ITERS = 1.0, 3
 TEMPERATURE, C_COARSE, C_FINE, WW = 0.1, 256, 128, 25
 
 
@@ -39,11 +47,13 @@ def build_inputs(rc):
     rng = np.random.default_rng(rc["seed"])
     N, (h, w) = rc["N"], rc["hc"]
     L = S = h * w
-    f0 = (1.5 * rng.standard_normal((N, L, C_COARSE))).astype(np.float32)
+    ot = rc.get("match_type") == "sinkhorn"                                 # no temperature there: sim = <f0, f1> / C
+    a, c = (4.0, 0.45) if ot else (1.5, 0.2)
+    f0 = (a * rng.standard_normal((N, L, C_COARSE))).astype(np.float32)
     perm = np.stack([rng.permutation(L) for _ in range(N)])
     f1 = np.empty_like(f0)
     for n in range(N):
-        f1[n, perm[n]] = 0.2 * f0[n] + (1.5 * rng.standard_normal((L, C_COARSE))).astype(np.float32)
+        f1[n, perm[n]] = c * f0[n] + (a * rng.standard_normal((L, C_COARSE))).astype(np.float32)
     mask0 = mask1 = None
     if rc["masks"]:
         mask0, mask1 = np.ones((N, h, w), bool), np.ones((N, h, w), bool)
@@ -72,12 +82,12 @@ def build_inputs(rc):
 def loss_cfg(rc):
     return {"loftr": {"loss": dict(coarse_type=rc["coarse_type"], coarse_weight=1.0, focal_alpha=0.25, focal_gamma=2.0, pos_weight=1.0,
                                    neg_weight=1.0, fine_type=rc["fine_type"], fine_weight=1.0, fine_correct_thr=1.0),
-                      "match_coarse": dict(match_type="dual_softmax", sparse_spvs=rc["sparse"])}}
+                      "match_coarse": dict(match_type=rc.get("match_type", "dual_softmax"), sparse_spvs=rc["sparse"])}}
 
 
 def matcher_cfg(rc):
-    return dict(thr=0.2, border_rm=2, match_type="dual_softmax", dsmax_temperature=TEMPERATURE, train_coarse_percent=0.4,
-                train_pad_num_gt_min=200, sparse_spvs=rc["sparse"])
+    return dict(thr=0.2, border_rm=2, match_type=rc.get("match_type", "dual_softmax"), dsmax_temperature=TEMPERATURE, train_coarse_percent=0.4,
+                train_pad_num_gt_min=200, sparse_spvs=rc["sparse"], skh_init_bin_score=BIN_SCORE, skh_iters=SKH_ITERS, skh_prefilter=False)
 
 
 def make(name):
@@ -100,7 +110,14 @@ def make(name):
         m0, m1 = data["mask0"].flatten(-2), data["mask1"].flatten(-2)
     cm = RefCoarse(matcher_cfg(rc)).eval()                  # eval: no sampling; conf_matrix is built the same way (:105-119)
     cm(leaf["feat_c0"], leaf["feat_c1"], data, mask_c0=m0, mask_c1=m1)
-    conf = data["conf_matrix"]
+    ot = rc.get("match_type") == "sinkhorn"
+    conf = data["conf_matrix_with_bin"] if ot else data["conf_matrix"]          # the tensor the loss reads (loftr_loss.py:174-177)
+    if ot:                                                  # .clone() of assign_matrix (:143): re-derive it WITH the graph
+        log_assign = cm.log_optimal_transport(torch.einsum("nlc,nsc->nls", leaf["feat_c0"] / 16, leaf["feat_c1"] / 16) if m0 is None else
+                                              torch.einsum("nlc,nsc->nls", leaf["feat_c0"] / 16, leaf["feat_c1"] / 16).masked_fill(
+                                                  ~(m0[..., None] * m1[:, None]).bool(), -1e9), cm.bin_score, cm.skh_iters)
+        assert torch.equal(log_assign.exp().detach(), conf.detach())
+        conf = log_assign.exp()
     conf.retain_grad()
     M = rc["M"]
     data.update(mkpts0_c=torch.zeros(M, 2), mkpts1_c=torch.zeros(M, 2), mconf=torch.zeros(M), b_ids=torch.zeros(M, dtype=torch.long))
@@ -115,7 +132,8 @@ def make(name):
     (loss_c + loss_f).backward()
     z = lambda v, like: (v.grad if v.grad is not None else torch.zeros_like(like)).numpy()
     b, i, j = np.nonzero(inp["conf_gt"])
-    store = dict(recipe=np.array(json.dumps(rc)), loss_c=float(loss_c.detach()), loss_f=float(loss_f.detach()),
+    extra = {"grad_bin_score": np.float64(cm.bin_score.grad)} if ot else {}
+    store = dict(recipe=np.array(json.dumps(rc)), loss_c=float(loss_c.detach()), loss_f=float(loss_f.detach()), **extra,
                  conf_at_gt=conf.detach().numpy()[b, i, j], expec_f=expec.detach().numpy(),
                  grad_conf=z(conf, conf), grad_expec=z(expec, expec),
                  **{f"grad_{k}": z(v, v) for k, v in leaf.items()})

@@ -36,10 +36,13 @@ def run_heads(rc, inp, dev):
     if rc["masks"]:
         data.update(mask0=t(inp["mask0"]), mask1=t(inp["mask1"]))
         m0, m1 = data["mask0"].flatten(-2), data["mask1"].flatten(-2)
-    cm = CoarseMatching(MG.matcher_cfg(rc)).eval()
+    cm = CoarseMatching(MG.matcher_cfg(rc)).eval().to(dev)
     cm(leaf["feat_c0"], leaf["feat_c1"], data, mask_c0=m0, mask_c1=m1)
-    conf = data["conf_matrix"]
-    assert conf.requires_grad and conf.grad_fn is not None
+    ot = rc.get("match_type") == "sinkhorn"
+    conf = data["conf_matrix_with_bin"] if ot else data["conf_matrix"]          # the tensor the loss reads (loftr_loss.py:174-177)
+    assert conf.requires_grad and conf.grad_fn is not None and data["conf_matrix"].requires_grad
+    if ot:
+        leaf["bin_score"] = cm.bin_score
     conf.retain_grad()
     M = rc["M"]
     data.update(mkpts0_c=torch.zeros(M, 2, device=dev), mkpts1_c=torch.zeros(M, 2, device=dev), mconf=torch.zeros(M, device=dev),
@@ -72,8 +75,10 @@ def test_head_gradients_against_reference_autograd(name):
     data["loss"].backward()
     torch.cuda.synchronize()
     got = {"grad_conf": conf.grad, "grad_expec": expec.grad, **{f"grad_{k}": v.grad for k, v in leaf.items()}}
+    if "bin_score" in leaf:
+        got["grad_bin_score"] = got["grad_bin_score"].reshape(1)
     for k, v in got.items():
-        ref = g[k]
+        ref = np.atleast_1d(g[k])
         if np.abs(ref).max() == 0:
             assert v is None or float(v.abs().max()) == 0, k
             continue
@@ -83,7 +88,11 @@ def test_head_gradients_against_reference_autograd(name):
     m0 = m1 = None
     if rc["masks"]:
         m0, m1 = inp["mask0"].reshape(rc["N"], -1), inp["mask1"].reshape(rc["N"], -1)
-    if np.abs(g["grad_conf"]).max() > 0:
+    if rc.get("match_type") == "sinkhorn":
+        o0, o1, ob = GO.sinkhorn_conf_grad(inp["feat_c0"], inp["feat_c1"], MG.BIN_SCORE, conf.grad.cpu().numpy(), MG.SKH_ITERS, m0, m1)
+        assert rel(leaf["feat_c0"].grad.cpu().numpy(), o0) <= 2e-4 and rel(leaf["feat_c1"].grad.cpu().numpy(), o1) <= 2e-4
+        assert abs(float(leaf["bin_score"].grad) - ob) <= 2e-4 * abs(ob)
+    elif np.abs(g["grad_conf"]).max() > 0:
         o0, o1 = GO.dual_softmax_conf_grad(inp["feat_c0"], inp["feat_c1"], conf.grad.cpu().numpy(), MG.TEMPERATURE, m0, m1)
         assert rel(leaf["feat_c0"].grad.cpu().numpy(), o0) <= 2e-4 and rel(leaf["feat_c1"].grad.cpu().numpy(), o1) <= 2e-4
     if np.abs(g["grad_expec"]).max() > 0:
@@ -139,3 +148,38 @@ def test_dual_softmax_backward_dense_gradient_full_size(shape):
     for got, ref in ((a.grad, a64.grad), (b.grad, b64.grad)):
         err = (got.double() - ref).abs().max().item() / ref.abs().max().item()
         assert err <= 2e-4, err
+
+
+def test_sinkhorn_backward_full_size():
+    """The Sinkhorn backward at the bench's grid (L = S = 4800: the row-streaming iteration kernels re-create u_t, v_t) with a dense
+    upstream gradient, against float64 autograd of log_optimal_transport restated in PyTorch on the GPU."""
+    from loftr_amd import autograd
+    dev = torch.device("cuda", 0)
+    gen = torch.Generator(device="cpu").manual_seed(11)
+    h, w = 60, 80
+    L = h * w
+    f0 = (3.0 * torch.randn(1, L, 256, generator=gen)).to(dev)
+    f1 = (0.4 * f0.cpu()[:, torch.randperm(L, generator=gen)] + 3.0 * torch.randn(1, L, 256, generator=gen)).to(dev)
+    G = torch.randn(1, L + 1, L + 1, generator=gen).to(dev)
+    a, b = f0.clone().requires_grad_(True), f1.clone().requires_grad_(True)
+    bin_score = torch.tensor(1.0, device=dev, requires_grad=True)
+    kw = dict(thr=0.2, border_rm=2, scale=8.0, match_type="sinkhorn", skh_iters=3, skh_prefilter=False, want_assign=True)
+    r = autograd.sinkhorn_match(a, b, bin_score, (h, w), (h, w), **kw)
+    r["conf_matrix_with_bin"].backward(G)
+
+    a64, b64, s64 = f0.double().requires_grad_(True), f1.double().requires_grad_(True), torch.tensor(1.0, device=dev, dtype=torch.float64, requires_grad=True)
+    sim = torch.einsum("nlc,nsc->nls", a64 / 16, b64 / 16)
+    Z = torch.cat([torch.cat([sim, s64.expand(1, L, 1)], -1), s64.expand(1, 1, L + 1)], 1)
+    norm = -torch.log(torch.tensor(2.0 * L, device=dev, dtype=torch.float64))
+    log_mu = torch.cat([norm.expand(L), (torch.log(torch.tensor(float(L), device=dev, dtype=torch.float64)) + norm)[None]])[None]
+    u, v = torch.zeros_like(log_mu), torch.zeros_like(log_mu)
+    for _ in range(3):
+        u = log_mu - torch.logsumexp(Z + v.unsqueeze(1), dim=2)
+        v = log_mu - torch.logsumexp(Z + u.unsqueeze(2), dim=1)
+    assign = (Z + u.unsqueeze(2) + v.unsqueeze(1) - norm).exp()
+    # (the dustbin corner holds most of the unmatched mass: assign[L, S] ~ 1e3, hence the relative form)
+    assert ((r["conf_matrix_with_bin"].detach() - assign.detach()).abs() / assign.detach().clamp(min=1.0)).max().item() <= 1e-4
+    assign.backward(G.double())
+    for got, ref in ((a.grad, a64.grad), (b.grad, b64.grad), (bin_score.grad, s64.grad)):
+        err = (got.double() - ref).abs().max().item() / ref.abs().max().item()
+        assert err <= 5e-4, err
