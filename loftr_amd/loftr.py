@@ -198,7 +198,8 @@ class CoarseMatching(nn.Module):
         if self.match_type == "dual_softmax" and autograd.wants_grad(feat_c0, feat_c1):
             # conf_matrix with its graph: forward and backward are the HIP kernels (loftr_amd/autograd.py)
             r = autograd.dual_softmax_match(feat_c0, feat_c1, *hw, **dict(kw, want_conf=True))
-        elif self.match_type == "sinkhorn" and autograd.wants_grad(feat_c0, feat_c1, self.bin_score) and not kw["skh_prefilter"]:
+        elif (self.match_type == "sinkhorn" and not kw["skh_prefilter"] and
+              (autograd.wants_grad(feat_c0, feat_c1) or (self.training and autograd.wants_grad(self.bin_score)))):
             r = autograd.sinkhorn_match(feat_c0, feat_c1, self.bin_score, *hw, **{k: v for k, v in kw.items() if k != "bin_score"})
             if not kw["want_assign"]:
                 r.pop("conf_matrix_with_bin")
