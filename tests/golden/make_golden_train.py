@@ -269,7 +269,8 @@ def make_step(name):
 # the heads only, so the golden keeps the gradients AT the heads' inputs: d loss / d feat_f*_unfold (reached through loss_f
 # alone) and, for the coarse features, the part that flows through conf_matrix (their other part -- through FinePreprocess
 # and the fine transformer -- has no counterpart here).
-GRAD_STEP_CASES = {"tgrad_ds": dict(step="tstep_ds", coarse_gain=0.25, fine_gain=0.25)}     # gain: conf at the ground truth inside the clamp (1e-6, 1 - 1e-6)
+GRAD_STEP_CASES = {"tgrad_ds": dict(step="tstep_ds", coarse_gain=0.25, fine_gain=0.25),
+                   "tgrad_ot": dict(step="tstep_ot", coarse_gain=1.0, fine_gain=0.25)}     # gain: conf at the ground truth inside the clamp (1e-6, 1 - 1e-6)
 GRAD_F1_FULL = 32                 # the LAST windows (the ground-truth padding: the ones with a fine loss) keep d loss / d feat_f1_unfold
                                   # in full; all windows: its per-window norm
 
@@ -310,7 +311,9 @@ def make_step_grads(name):
         model(data)
         with torch.no_grad():
             sup.spvs_fine(data, C)
-        data["conf_matrix"].retain_grad(); data["expec_f"].retain_grad()
+        ot = rc["match_type"] == "sinkhorn"
+        ckey = "conf_matrix_with_bin" if ot else "conf_matrix"          # the tensor the coarse loss reads (loftr_loss.py:174-177)
+        data[ckey].retain_grad(); data["expec_f"].retain_grad()
         LoFTRLoss(step_loss_cfg(rc)).train()(data)
     finally:
         torch.randint = real
@@ -322,10 +325,15 @@ def make_step_grads(name):
     ff0, ff1 = (x.detach().requires_grad_(True) for x in seen["fine"])
     scratch = {k: data[k] for k in ("hw0_c", "hw1_c", "hw0_i", "hw1_i") }
     model.coarse_matching.eval()                                       # same conf_matrix (:105-119), no sampling
+    extra = {}
+    if ot:
+        model.coarse_matching.bin_score.grad = None
     model.coarse_matching(fc0, fc1, scratch)
-    assert torch.equal(scratch["conf_matrix"].detach(), data["conf_matrix"].detach())
-    scratch["conf_matrix"].backward(data["conf_matrix"].grad)
+    assert torch.equal(scratch[ckey].detach(), data[ckey].detach())
+    scratch[ckey].backward(data[ckey].grad)
     g_c0, g_c1 = fc0.grad, fc1.grad
+    if ot:
+        extra["grad_bin_score"] = np.float64(model.coarse_matching.bin_score.grad)
     scratch = {k: data[k] for k in ("hw0_i", "hw0_f", "mkpts0_c", "mkpts1_c", "mconf", "b_ids")}
     model.fine_matching(ff0, ff1, scratch)
     assert torch.equal(scratch["expec_f"].detach(), data["expec_f"].detach())
@@ -335,7 +343,7 @@ def make_step_grads(name):
     assert float(off_centre.abs().max()) == 0                     # feat_f0 is read at the centre only (fine_matching.py:43)
     gb, gi, gj = (data[k].numpy() for k in ("spv_b_ids", "spv_i_ids", "spv_j_ids"))
     print("conf at the ground truth:", np.sort(data["conf_matrix"].detach().numpy()[gb, gi, gj])[[0, len(gb) // 2, -1]])
-    store = dict(recipe=np.array(json.dumps(dict(rc, **gc))), b_ids=data["b_ids"].numpy(), i_ids=data["i_ids"].numpy(), j_ids=data["j_ids"].numpy(),
+    store = dict(recipe=np.array(json.dumps(dict(rc, **gc))), **extra, b_ids=data["b_ids"].numpy(), i_ids=data["i_ids"].numpy(), j_ids=data["j_ids"].numpy(),
                  expec_f=data["expec_f"].detach().numpy(), expec_f_gt=data["expec_f_gt"].numpy(), grad_expec=data["expec_f"].grad.numpy(), grad_feat_c0=g_c0.numpy(), grad_feat_c1=g_c1.numpy(),
                  grad_feat_f0_centre=ff0.grad[:, WW // 2].numpy(), grad_feat_f1_tail=ff1.grad[-GRAD_F1_FULL:].numpy(),
                  grad_feat_f1_norm=ff1.grad.flatten(1).norm(dim=1).numpy(),

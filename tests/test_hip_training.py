@@ -223,10 +223,11 @@ def test_train_mode_forward_from_images_runs(monkeypatch):
     assert model.backbone.bn1.num_batches_tracked.item() == 1          # BatchNorm really ran in training mode
 
 
-def test_training_step_head_gradients_against_reference(monkeypatch):
+@pytest.mark.parametrize("name", list(MG.GRAD_STEP_CASES))
+def test_training_step_head_gradients_against_reference(name, monkeypatch):
     """The training step of test_training_step_chain_against_reference WITH the heads' backward (LoFTR.head_grads): after
     data['loss'].backward() the leaves data['_head_inputs'] hold d loss / d (inputs of CoarseMatching / FineMatching), compared
-    with torch.autograd of the reference's heads inside the reference's own training step (tests/golden/tgrad_ds.npz)."""
+    with torch.autograd of the reference's heads inside the reference's own training step (tests/golden/tgrad_*.npz: dual-softmax and Sinkhorn)."""
     import copy
     import importlib.util
     import os
@@ -237,7 +238,7 @@ def test_training_step_head_gradients_against_reference(monkeypatch):
     E2E = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(E2E)
     dev = torch.device("cuda", 0)
-    g = dict(np.load(os.path.join(GOLDEN_DIR, "tgrad_ds.npz")))
+    g = dict(np.load(os.path.join(GOLDEN_DIR, f"{name}.npz")))
     rc = json.loads(str(g["recipe"]))
     batch, geo = MG.step_batch(rc)
     N = geo["N"]
@@ -283,3 +284,6 @@ def test_training_step_head_gradients_against_reference(monkeypatch):
     n_tail = g["grad_feat_f1_tail"].shape[0]
     assert rel(f1g[-n_tail:], g["grad_feat_f1_tail"]) <= 2e-3
     assert rel(np.sqrt((f1g.reshape(f1g.shape[0], -1).astype(np.float64) ** 2).sum(1)), g["grad_feat_f1_norm"]) <= 2e-3
+    if "grad_bin_score" in g:                              # the Sinkhorn head's parameter
+        got = float(model.coarse_matching.bin_score.grad)
+        assert abs(got - float(g["grad_bin_score"])) <= 2e-3 * abs(float(g["grad_bin_score"])), (got, g["grad_bin_score"])
