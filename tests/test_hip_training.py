@@ -287,3 +287,39 @@ def test_training_step_head_gradients_against_reference(name, monkeypatch):
     if "grad_bin_score" in g:                              # the Sinkhorn head's parameter
         got = float(model.coarse_matching.bin_score.grad)
         assert abs(got - float(g["grad_bin_score"])) <= 2e-3 * abs(float(g["grad_bin_score"])), (got, g["grad_bin_score"])
+
+
+@pytest.mark.parametrize("match_type", ["dual_softmax", "sinkhorn"])
+def test_train_mode_forward_from_images_with_head_grads(match_type, monkeypatch):
+    """LoFTR.forward(data) in .train() mode with head_grads straight from images, then LoFTRLoss and loss.backward(): the four
+    transformer outputs come back as leaves with finite, non-trivial gradients (the Sinkhorn head also fills bin_score.grad),
+    and nothing upstream of them is touched (no parameter of the transformers / backbone receives a gradient)."""
+    import copy
+    from loftr_amd import LoFTR
+    from loftr_amd.training import LoFTRLoss, compute_supervision_coarse, compute_supervision_fine
+    dev = torch.device("cuda", 0)
+    rc = dict(MG.STEP_CASES["tstep_ds"], match_type=match_type)
+    batch, geo = MG.step_batch(rc)
+    cfg = MG.step_matcher_cfg(rc)
+    torch.manual_seed(0)
+    model = LoFTR(copy.deepcopy(cfg)).to(dev).train()
+    model.head_grads = True
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    data = {"dataset_name": ["scannet"] * geo["N"], **{k: t(v) for k, v in batch.items()}}
+    monkeypatch.setattr(torch, "randint", MG.det_randint)
+    compute_supervision_coarse(data, CFG)
+    model(data)
+    compute_supervision_fine(data, CFG)
+    LoFTRLoss(MG.step_loss_cfg(rc)).train()(data)
+    assert data["loss"].requires_grad and torch.isfinite(data["loss"])
+    data["loss"].backward()
+    leaves = data["_head_inputs"]
+    assert set(leaves) == {"feat_c0", "feat_c1", "feat_f0_unfold", "feat_f1_unfold"}
+    for k, v in leaves.items():
+        assert v.grad is not None and v.grad.shape == v.shape and torch.isfinite(v.grad).all(), k
+    assert float(leaves["feat_c0"].grad.abs().max()) > 0 and float(leaves["feat_c1"].grad.abs().max()) > 0
+    for name, prm in model.named_parameters():
+        if name == "coarse_matching.bin_score":
+            assert prm.grad is not None and torch.isfinite(prm.grad)
+        else:
+            assert prm.grad is None, name
