@@ -70,3 +70,34 @@ def test_roofline_entry_classification(bench):
     e = bench.roofline_entry("linear_ln_kernel", total_ms=0.1, launches=1, flops=2e10, nbytes=3.2e8, steps=1)
     assert e["bound"] == "hbm" and e["hbm_frac"] > e["mfma_frac"]
     assert bench.roofline_entry("linear_kernel", 0.0, 0, 1, 1, 1) is None
+
+
+def test_single_gpu_launch_retries_once_after_a_signal(monkeypatch, capsys):
+    """bench.run_with_retry: a child killed by a signal is run once more in a fresh process; an ordinary failure is not."""
+    import subprocess
+    import bench
+
+    class P:
+        def __init__(self, rc, out):
+            self.returncode, self.stdout = rc, out
+
+    calls = []
+
+    def fake(seq):
+        it = iter(seq)
+
+        def run(cmd, env=None, stdout=None):
+            calls.append((cmd[-2:], env["LOFTR_BENCH_CHILD"], env["LOFTR_BENCH_ATTEMPT"]))
+            return next(it)
+        return run
+
+    monkeypatch.setattr(subprocess, "run", fake([P(-6, b""), P(0, b'{"value": 1}\\n')]))
+    assert bench.run_with_retry(["--steps", "2"]) == 0
+    assert capsys.readouterr().out == '{"value": 1}\\n'
+    assert [c[1:] for c in calls] == [("1", "1"), ("1", "2")] and calls[0][0] == ["--steps", "2"]
+    calls.clear()
+    monkeypatch.setattr(subprocess, "run", fake([P(1, b"")]))
+    assert bench.run_with_retry([]) == 1 and len(calls) == 1          # Python exception: deterministic, no retry
+    calls.clear()
+    monkeypatch.setattr(subprocess, "run", fake([P(-11, b""), P(-6, b"")]))
+    assert bench.run_with_retry([]) == 134 and len(calls) == 2         # out of attempts: 128 + signal

@@ -1,7 +1,7 @@
 #!/bin/bash
 # rocprofv3 kernel-trace summaries of BASELINE configs[3] (outdoor 840x840 masked, N = 4) and configs[4] (indoor_ot) -> gpurun_out/<tag>_*
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
-T=${1:-r03}; O=$R/gpurun_out; mkdir -p $O; export TMPDIR=/tmp; cd /tmp
+T=${1:-r03}; O=$R/gpurun_out; mkdir -p $O; export TMPDIR=/tmp LOFTR_BENCH_NO_RETRY=1; cd /tmp
 timeout -k 5 200 rocprofv3 --kernel-trace --stats -d $O/prof_out_$T -o p -- python $R/tools/micro/outdoor_bench.py 4 5 > $O/${T}_outdoor_n4.txt 2>&1
 timeout -k 5 200 rocprofv3 --kernel-trace --stats -d $O/prof_ot_$T -o p -- python $R/bench.py --match-type sinkhorn --no-cpu-baseline --no-other-configs --warmup 2 --steps 5 --no-overlap > $O/${T}_ot_bench.json 2> $O/${T}_ot.err
 cd $R

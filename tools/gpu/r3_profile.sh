@@ -4,7 +4,7 @@
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 T=${1:-r03}
 O=$R/gpurun_out
-mkdir -p $O; export TMPDIR=/tmp; cd /tmp
+mkdir -p $O; export TMPDIR=/tmp LOFTR_BENCH_NO_RETRY=1; cd /tmp
 B="python $R/bench.py --no-cpu-baseline --no-other-configs --warmup 2"
 python -c 'import torch' 2> /dev/null     # page the image in before the first timed-out-able run
 # (an aborted process under rocprofv3 does not exit by itself: short timeouts, and stop at the first failure)
