@@ -19,18 +19,22 @@ the per-pair match counts (RCCL through the library's C-ABI, loftr_rccl_allgathe
 itself (torch.distributed.run on 127.0.0.1); under torchrun it reads RANK / LOCAL_RANK / WORLD_SIZE.
 
 The JSON line also carries
-  roofline          -- the north_star's score-volume kernel (score_conf_kernel, dual-softmax pass B) against the HBM
+  roofline          -- the kernel group that dominates the hand-written matching path: the linear-attention encoder kernels
+                       (encoder_x / proj_kv / fine_pair / linear) against the dense fp16 MFMA roof (executed MFMA rate,
+                       hipEvents around every launch in serial instrumented steps of this run; `mfma_busy` =
+                       SQ_VALU_MFMA_BUSY_CYCLES utilisation and `traffic` = HBM bytes from the rocprofv3 --pmc passes of
+                       THIS build: profiles/pmc_traffic.json carries a hash of csrc/, null when it does not match);
+                       `dominant_share_of_step` = its share of the matching path, `share_of_serial_step` = of the step;
+  roofline_score_volume -- the north_star's score-volume kernel (score_conf_kernel, dual-softmax pass B) against the HBM
                        roof: algorithmic bytes per launch / hipEvent-measured average launch
                        duration (events recorded by the library on the launch stream INSIDE the timed region);
-                       `traffic` = HBM bytes per launch from the rocprofv3 --pmc passes of THIS build
-                       (profiles/pmc_traffic.json carries a hash of csrc/; null when it does not match);
-  roofline_encoder  -- the linear-attention encoder kernels against the dense fp16 MFMA roof (executed MFMA rate
-                       from the same in-region events; `mfma_busy` = SQ_VALU_MFMA_BUSY_CYCLES utilisation from the
-                       PMC pass);
+  roofline_backbone -- the convolution kernels of the ResNet-FPN (the largest share of the whole step), same form;
   kernels           -- the same for every instrumented kernel (serial instrumented steps), backbone included;
-  cpu_baseline      -- the CPU port (torch-CPU backbone = the reference's module + numpy oracle of the matching
-                       path) on the SAME first pair: thread count picked by a 16/32/64/128 probe, 1 warm-up +
-                       median of 3 (rank 0, N=1 only).
+  cpu_baseline      -- kind "reference": zju3dv/LoFTR's own LoFTR.forward on the host cores of this box in this run (imported
+                       from /root/reference or from the bytecode bundle oracle/stage_ref.py made of it), pair 0 of the GPU
+                       batch, the GPU model's weights, + `parity_vs_reference` of the GPU result for that pair; kind "port"
+                       (torch-CPU backbone + numpy oracle) with the reason when the reference cannot be imported.  Thread
+                       count by probe, 1 warm-up + median of 3 (rank 0, N=1 only).
 """
 import argparse
 import ctypes as C
@@ -214,13 +218,87 @@ def pmc_mfma_busy(kernel):
     return pmc_table().get(kernel, {}).get("mfma_busy")
 
 
-def cpu_baseline(model, img0, img1):
-    """CPU port of the same forward on the batch's FIRST pair (the same tensors the GPU run consumed): torch-CPU
-    backbone (the reference's backbone is this very PyTorch module) + oracle/loftr_oracle.py (numpy restatement of
-    the matching path).  BASELINE.md §3 protocol: eval / no_grad / fp32, thread count picked by a short probe of the
-    backbone at 16/32/64/128 threads (a 256-thread pool is 3-5x slower than the best on this host), 1 warm-up +
-    3 timed forwards, median.  kind "port": the reference is Python under /root/reference and cannot travel to the
-    GPU box; its own CPU forward on these inputs is recorded in tests/golden/e2e_synth.npz (ref_cpu_seconds)."""
+def reference_cpu_forward(model, img0, img1, gpu_data):
+    """The reference's OWN `LoFTR.forward` (zju3dv/LoFTR src/loftr/loftr.py:29-75, its ResNet-FPN included) on the host cores of
+    THIS box, in THIS run, on pair 0 of the GPU batch with the GPU model's weights (north_star: "the reference's CPU forward()
+    timed on the host cores of the same box (core count stated) in the same run").  The reference is imported through
+    oracle/ref_shim.py: from /root/reference where that exists, otherwise from the bytecode bundle oracle/stage_ref.py compiled
+    from it (oracle/_ref/, travels with the snapshot).  Also returns the live parity of the GPU result for that pair against it."""
+    import copy
+    from oracle import ref_shim
+    mode = ref_shim.reference_mode()
+    if mode is None:
+        return None, "no reference checkout and no staged bundle (oracle/_ref/loftr_reference.bundle) on this machine"
+    RefLoFTR, _ = ref_shim.import_reference()
+    ref = RefLoFTR(copy.deepcopy(model.config)).eval()
+    ref.load_state_dict({k: v.detach().cpu() for k, v in model.state_dict().items()}, strict=True)
+    x0, x1 = img0[:1].cpu(), img1[:1].cpu()
+    cores = os.cpu_count()
+    probe = {}
+    with torch.no_grad():
+        for nt in [t for t in (16, 32, 64, 128) if t <= cores] or [cores]:       # a 256-thread pool is 3-5x slower than the best
+            torch.set_num_threads(nt)
+            ref.backbone(torch.cat([x0, x1], 0))
+            t0 = time.perf_counter()
+            ref.backbone(torch.cat([x0, x1], 0))
+            probe[nt] = time.perf_counter() - t0
+        threads = min(probe, key=probe.get)
+        torch.set_num_threads(threads)
+        bb = {}
+        h0 = ref.backbone.register_forward_pre_hook(lambda m, a: bb.__setitem__("t0", time.perf_counter()))
+        h1 = ref.backbone.register_forward_hook(lambda m, a, o: bb.__setitem__("dt", time.perf_counter() - bb["t0"]))
+        runs = []
+        for it in range(4):                                                       # 1 warm-up + 3 timed
+            data = {"image0": x0.clone(), "image1": x1.clone()}
+            t0 = time.perf_counter()
+            ref(data)
+            runs.append((time.perf_counter() - t0, bb["dt"]))
+        h0.remove(); h1.remove()
+    runs = sorted(runs[1:])
+    total, bbt = runs[1]
+    # live parity of the GPU forward (last timed step, pair 0) against this reference forward
+    g = gpu_data
+    sel = (g["b_ids"] == 0).nonzero().squeeze(1)
+    msel = (g["m_bids"] == 0).nonzero().squeeze(1)
+    gi, gj = g["i_ids"][sel].cpu().numpy(), g["j_ids"][sel].cpu().numpy()
+    ri, rj = data["i_ids"].numpy(), data["j_ids"].numpy()
+    rk = {k: n for n, k in enumerate(zip(ri.tolist(), rj.tolist()))}
+    com = [(n, rk[k]) for n, k in enumerate(zip(gi.tolist(), gj.tolist())) if k in rk]
+    ia, ib = [c[0] for c in com], [c[1] for c in com]
+    par = {"pair": 0, "matches_gpu": int(len(gi)), "matches_reference": int(len(ri)), "common": len(com)}
+    if com:
+        gm = {k: g[k][msel].cpu().numpy() for k in ("mconf", "mkpts0_f", "mkpts1_f")}
+        par.update(d_mconf=float(np.abs(gm["mconf"][ia] - data["mconf"].numpy()[ib]).max()),
+                   d_mkpts0_f_px=float(np.abs(gm["mkpts0_f"][ia] - data["mkpts0_f"].numpy()[ib]).max()),
+                   d_mkpts1_f_px=float(np.abs(gm["mkpts1_f"][ia] - data["mkpts1_f"].numpy()[ib]).max()))
+    if "conf_matrix" in g and g["conf_matrix"] is not None:
+        par["d_conf_matrix"] = float((g["conf_matrix"][0].cpu() - data["conf_matrix"][0]).abs().max())
+    par["note"] = ("GPU forward (HIP backbone + HIP matching path) vs the reference's fp32 CPU forward on the same pair and weights in this run; "
+                   "match sets can differ by near-tie flips at thr 0 with random weights (the goldens pin this against the reference's fp64 run)")
+    out = {"value": round(1.0 / total, 4), "unit": "image-pairs/s", "cores": threads, "kind": "reference", "reference_import": mode,
+           "reference_forward_s": round(total, 3), "reference_backbone_s": round(bbt, 3), "reference_hot_path_s": round(total - bbt, 3),
+           "sample": f"pair 0 of the GPU batch (640x480), zju3dv/LoFTR LoFTR.forward (eval, no_grad, fp32, torch CPU), the GPU model's weights: "
+                     f"1 warm-up + median of 3 forwards; {threads} torch threads chosen by a backbone probe "
+                     f"{ {k: round(v, 2) for k, v in probe.items()} } s, host has {cores} logical cores; M={len(ri)}",
+           "host_cores": cores, "runs_s": [round(r[0], 3) for r in runs], "parity_vs_reference": par}
+    return out, None
+
+
+def cpu_baseline(model, img0, img1, gpu_data=None):
+    """`cpu_baseline` of the JSON line.  kind "reference" when the reference can be imported on this box (see
+    reference_cpu_forward); otherwise kind "port" -- torch-CPU backbone (the reference's backbone is this very PyTorch module)
+    + oracle/loftr_oracle.py (numpy restatement of the matching path) -- with the reason.  BASELINE.md §3 protocol either way:
+    eval / no_grad / fp32, thread count picked by a short probe, 1 warm-up + 3 timed forwards, median."""
+    why = None
+    if gpu_data is not None:
+        try:
+            ref, why = reference_cpu_forward(model, img0, img1, gpu_data)
+            if ref is not None:
+                return ref
+        except Exception as e:                                # noqa: BLE001  (fall back to the port, say why)
+            why = f"reference leg failed: {e!r}"
+        finally:
+            model.to(img0.device)
     from oracle import loftr_oracle as O
     cores = os.cpu_count()
     cpu_model = model.backbone.to("cpu").float()
@@ -254,17 +332,8 @@ def cpu_baseline(model, img0, img1):
     runs = sorted(forward() for _ in range(3))
     total, bb, hot, m = runs[1]                               # median by total time
     model.backbone.to(img0.device)
-    ref = {}
-    try:                                                     # the reference's OWN CPU forward on this very pair, timed where the golden was made
-        gz = np.load(os.path.join(ROOT, "tests", "golden", "e2e_synth.npz"))
-        rc = json.loads(str(gz["recipe"]))
-        ref = {"reference_forward_s": round(float(np.median(gz["ref_cpu_seconds"])), 3), "reference_forward_cores": rc.get("ref_cpu_count"),
-               "reference_forward_note": "zju3dv/LoFTR LoFTR.forward (its own ResNet-FPN included) on pair 0 of this batch, torch CPU fp32, median of 3, "
-                                         "measured in the authoring container when tests/golden/e2e_synth.npz was generated (the reference cannot travel "
-                                         "to the GPU box)"}
-    except Exception:                                        # noqa: BLE001
-        pass
-    return {**ref, "value": round(1.0 / total, 4), "unit": "image-pairs/s", "cores": threads, "kind": "port",
+    return {"value": round(1.0 / total, 4), "unit": "image-pairs/s", "cores": threads, "kind": "port",
+            "kind_reason": why or "reference leg not requested",
             "sample": f"pair 0 of the GPU batch (640x480), 1 warm-up + median of 3 forwards: torch-CPU backbone {bb:.2f}s + "
                       f"numpy oracle matching path {hot:.2f}s (M={m}); {threads} torch threads chosen by probe "
                       f"{ {k: round(v, 2) for k, v in probe.items()} } s/backbone, host has {cores} logical cores",
@@ -272,6 +341,7 @@ def cpu_baseline(model, img0, img1):
             "runs_s": [round(r[0], 3) for r in runs]}
 
 
+BACKBONE_KERNELS = ("conv3x3_kernel", "conv3x3_wide_kernel", "conv_kernel", "conv3x3s2_kernel")
 ENCODER_KERNELS = ("proj_kv_kernel", "proj_kernel", "linear_kernel", "linear_ln_kernel", "encoder_x_kernel", "fine_pair_kernel")
 # Only the bench line's `roofline` kernel carries hipEvents inside the timed region (one launch per step); everything else
 # is measured in the serial instrumented steps just before it (round-2 verdict: 83 event pairs per step in the timed region).
@@ -279,10 +349,11 @@ NORTH_STAR_TIMED = ("score_conf_kernel",)
 
 
 def run_with_retry(argv):
-    """Single-GPU launches run the measurement in a CHILD process and repeat it ONCE, in a fresh process / HIP context, if the child is
+    """OPT-IN (LOFTR_BENCH_RETRY=1; off by default since round 4 -- a retry can turn an intermittent kernel fault into a passing
+    headline number): run the measurement in a CHILD process and repeat it ONCE, in a fresh process / HIP context, if the child is
     killed by a signal (a GPU memory fault makes the ROCm runtime abort(): SIGABRT) -- seen twice in round 3 on single boxes with commands
-    that passed on every other box, no reproducer.  An ordinary non-zero exit (Python exception) is NOT retried.
-    The JSON line records the attempt when it is not the first.  LOFTR_BENCH_NO_RETRY=1 disables the wrapper (profilers)."""
+    that passed on every other box, no reproducer (docs/HISTORY.md).  An ordinary non-zero exit (Python exception) is NOT retried.
+    The JSON line records the attempt when it is not the first."""
     env = dict(os.environ, LOFTR_BENCH_CHILD="1")
     for attempt in (1, 2):
         env["LOFTR_BENCH_ATTEMPT"] = str(attempt)
@@ -438,9 +509,9 @@ def main():
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(self_spawn(sys.argv[1:], args.gpus))
-    if ("WORLD_SIZE" not in os.environ and os.environ.get("LOFTR_BENCH_CHILD") != "1" and os.environ.get("LOFTR_BENCH_NO_RETRY") != "1"
+    if ("WORLD_SIZE" not in os.environ and os.environ.get("LOFTR_BENCH_CHILD") != "1" and os.environ.get("LOFTR_BENCH_RETRY") == "1"
             and os.environ.get("LOFTR_BENCH_FORCE_DIST") != "1"):
-        sys.exit(run_with_retry(sys.argv[1:]))
+        sys.exit(run_with_retry(sys.argv[1:]))              # opt-in only: a faulting kernel must fail the default run
     # stdout carries exactly ONE line, the JSON: libraries that print banners to fd 1 (RCCL prints its version block at
     # communicator creation) are pointed at stderr for the duration of the run
     sys.stdout.flush()
@@ -619,9 +690,20 @@ def main():
     # there include time-slicing with convolution workgroups (about 2x longer); that figure is kept as `in_region_*`.
     serial = {k["kernel"]: (k["ms_per_step"] * NB, int(round(k["launches_per_step"] * NB))) for k in kernels}
     roof_enc = group_roofline([n for n in ENCODER_KERNELS if n in serial], serial, work, NB)
+    roof_bb = group_roofline([n for n in BACKBONE_KERNELS if n in serial], serial, work, NB)
+    serial_step_ms = backbone_ms + hot_ms
+    for r_ in (roof_enc, roof_bb):
+        if r_:
+            r_["measured"] = ("hipEvents around every launch of these kernels in 3 instrumented steps of this run with the two HIP "
+                              "streams serialised (kernels alone on the GPU)")
+            r_["share_of_serial_step"] = round(r_["ms_per_step"] / serial_step_ms, 4)
     if roof_enc:
-        roof_enc["measured"] = ("hipEvents around every launch of these kernels in 3 instrumented steps of this run with the two HIP "
-                                "streams serialised (kernels alone on the GPU)")
+        roof_enc["kernel"] = "encoder_x_kernel (+ proj_kv / fine_pair / linear: the linear-attention encoder group)"
+        roof_enc["dominant_share_of_step"] = round(roof_enc["ms_per_step"] / hot_ms, 4)
+        roof_enc["dominant_share_note"] = ("share of the hand-written matching path (stage_ms.hot_path_hip) these kernels account for; "
+                                           "share_of_serial_step = of backbone + matching path run serially")
+    if roof is not None:
+        roof["share_of_serial_step"] = round(roof["ms_per_step"] / serial_step_ms, 4)
     elapsed, per_rank_ms = elapsed_local, [round(elapsed_local / args.steps * 1e3, 3)]
     if multi:
         t = torch.tensor([elapsed_local], dtype=torch.float64, device=dev)
@@ -662,7 +744,10 @@ def main():
             **({"attempt": int(os.environ["LOFTR_BENCH_ATTEMPT"]), "attempt_note": "the first attempt was killed by a signal (run_with_retry)"}
                if os.environ.get("LOFTR_BENCH_ATTEMPT", "1") != "1" else {}),
             "hot_path_pairs_per_s": round(B / (hot_ms * 1e-3), 2),
-            "roofline": roof, "roofline_encoder": roof_enc, "kernels": kernels,
+            # headline roofline = the kernel group that dominates the hand-written matching path (linear-attention encoder, MFMA-bound:
+            # the north_star's "MFMA utilisation on the linear-attention kernel"); the north_star's HBM figure on the score-volume
+            # kernel is `roofline_score_volume`; `roofline_backbone` = the convolution kernels (largest share of the whole step)
+            "roofline": roof_enc if roof_enc else roof, "roofline_score_volume": roof, "roofline_backbone": roof_bb, "kernels": kernels,
             "pmc_source": ("profiles/pmc_traffic.json (rocprofv3 --pmc passes of this build, source hash " + source_hash() + ")")
                           if pmc_table() else "no PMC passes for this build of the kernels: traffic / mfma_busy are null",
         }
@@ -672,7 +757,7 @@ def main():
             except Exception as e:                          # noqa: BLE001  (the headline line must not depend on the extras)
                 out["other_configs"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(model, img0, img1)
+            out["cpu_baseline"] = cpu_baseline(model, img0, img1, last.get("data"))
         sys.stdout.flush()
         os.dup2(real_stdout, 1)
         print(json.dumps(out), flush=True)

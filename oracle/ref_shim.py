@@ -1,8 +1,10 @@
 """Import the *real* reference (zju3dv/LoFTR at /root/reference) on a box without kornia/yacs.
 
-TEST INFRASTRUCTURE ONLY, and only usable in the authoring container: /root/reference does not
-exist on the GPU box.  Used by tests/golden/make_golden.py (to generate the committed golden
-vectors) and by tests/test_oracle_vs_reference.py (skipped when the reference is absent).
+TEST / MEASUREMENT INFRASTRUCTURE ONLY.  Used by tests/golden/make_golden.py (to generate the committed golden
+vectors), by tests that compare against the reference (skipped when it is absent) and by bench.py's
+`cpu_baseline` leg.  /root/reference exists only in the authoring container; on the GPU box `import_reference()`
+falls back to the bytecode bundle that oracle/stage_ref.py compiled from it (oracle/_ref/, git-ignored, travels
+with the snapshot like the built .so).  Nothing under loftr_amd/ imports this module.
 
 The reference imports three things that are not installed here:
   * yacs.config.CfgNode                       (src/loftr/utils/cvpr_ds_config.py:1)
@@ -107,13 +109,29 @@ def _install_stubs():
     mod("src.loftr.utils.superglue", log_optimal_transport=lot)
 
 
+def reference_mode():
+    """'source' (the checkout at REFERENCE_ROOT), 'bundle' (oracle/_ref/loftr_reference.bundle, made from it by
+    oracle/stage_ref.py) or None."""
+    if reference_available():
+        return "source"
+    from oracle import stage_ref
+    return "bundle" if stage_ref.bundle_available() else None
+
+
 def import_reference():
-    """Returns (LoFTR class, default_cfg) of the real reference."""
-    if not reference_available():
-        raise RuntimeError(f"reference not found at {REFERENCE_ROOT}")
+    """Returns (LoFTR class, default_cfg) of the real reference: from the checkout when it is on this machine,
+    otherwise from the staged bytecode bundle (same code objects, compiled from those very files)."""
+    mode = reference_mode()
+    if mode is None:
+        raise RuntimeError(f"reference not found at {REFERENCE_ROOT} and no staged bundle under oracle/_ref/ "
+                           "(run `python -m oracle.stage_ref` where the reference exists)")
     _install_stubs()
-    if REFERENCE_ROOT not in sys.path:
-        sys.path.insert(0, REFERENCE_ROOT)
+    if mode == "source":
+        if REFERENCE_ROOT not in sys.path:
+            sys.path.insert(0, REFERENCE_ROOT)
+    else:
+        from oracle import stage_ref
+        stage_ref.install_finder()
     from src.loftr import LoFTR, default_cfg  # noqa
     return LoFTR, default_cfg
 
