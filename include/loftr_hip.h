@@ -38,7 +38,8 @@ typedef enum {
 
 /* 13: prepared transformer weights, RCCL entry points, scaled activations, pose estimation;
  * 14: training-side consumers (loftr_spvs_coarse / _fine, loftr_coarse_loss_sums, loftr_fine_loss_sums);
- * 16: backward of the matching heads and their losses (loftr_*_grad, loftr_dual_softmax_bwd, loftr_fine_match_bwd) */
+ * 16: backward of the matching heads and their losses (loftr_*_grad, loftr_dual_softmax_bwd, loftr_sinkhorn_bwd,
+ *     loftr_fine_match_bwd) */
 #define LOFTR_HIP_ABI_VERSION 16
 
 int loftr_hip_abi_version(void);

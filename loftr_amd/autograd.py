@@ -13,6 +13,7 @@ gradients stop at the transformer outputs (LoFTR.head_grads hands those out as l
 No CPU fallback: the nodes call loftr_amd.ops, which raises on non-GPU tensors.
 """
 import torch
+from torch.autograd.function import once_differentiable
 
 from . import ops
 
@@ -30,6 +31,7 @@ class _DualSoftmaxMatch(torch.autograd.Function):
         return r["conf_matrix"]
 
     @staticmethod
+    @once_differentiable                                   # the backward kernels' outputs are constants to autograd: no double backward
     def backward(ctx, grad_conf):
         feat_c0, feat_c1 = ctx.saved_tensors
         hw0_c, hw1_c, temperature, mask0, mask1 = ctx.meta
@@ -63,6 +65,7 @@ class _SinkhornMatch(torch.autograd.Function):
         return r["conf_matrix_with_bin"]
 
     @staticmethod
+    @once_differentiable                                   # the backward kernels' outputs are constants to autograd: no double backward
     def backward(ctx, grad_assign):
         feat_c0, feat_c1, bin_score = ctx.saved_tensors
         hw0_c, hw1_c, iters, mask0, mask1 = ctx.meta
@@ -101,6 +104,7 @@ class _FineMatch(torch.autograd.Function):
         return expec, mk1f
 
     @staticmethod
+    @once_differentiable                                   # the backward kernels' outputs are constants to autograd: no double backward
     def backward(ctx, grad_expec, _):
         feat_f0, feat_f1 = ctx.saved_tensors
         g0, g1 = ops.fine_match_bwd(feat_f0.detach().contiguous(), feat_f1.detach().contiguous(), grad_expec.contiguous())

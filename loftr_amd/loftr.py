@@ -7,16 +7,17 @@ exceptions.  Every sub-module after the backbone holds parameters only; its arit
 call into ``libloftr_hip.so`` (``loftr_amd/ops.py``).  There is no PyTorch fallback: on a box
 without the built extension or without a GPU the forward raises.
 
-Scope: forward values, plus the backward of the two matching heads.  In ``.train()`` mode CoarseMatching
+Scope: forward values, plus the backward of the matching heads.  In ``.train()`` mode CoarseMatching
 also performs the reference's random sampling / ground-truth padding of the coarse matches
-(``coarse_matching.py:200-236``, host-side index arithmetic on the kernels' outputs).  The dual-softmax
-CoarseMatching and FineMatching are autograd nodes whose backward is HIP too (``loftr_amd/autograd.py``);
-with ``LoFTR.head_grads = True`` a training step ends with d loss / d (transformer outputs).  The
-transformers, FinePreprocess, the backbone and the Sinkhorn head have no backward.
+(``coarse_matching.py:200-236``, host-side index arithmetic on the kernels' outputs).  CoarseMatching (dual-softmax
+AND Sinkhorn, incl. its ``bin_score`` parameter) and FineMatching are autograd nodes whose backward is HIP too
+(``loftr_amd/autograd.py``); with ``LoFTR.head_grads = True`` a training step ends with d loss / d (transformer
+outputs).  The transformers, FinePreprocess and the backbone have no backward.
 """
 import contextlib
 import math
 import os
+import warnings
 import weakref
 
 import torch
@@ -204,6 +205,12 @@ class CoarseMatching(nn.Module):
             if not kw["want_assign"]:
                 r.pop("conf_matrix_with_bin")
         else:
+            if self.match_type == "sinkhorn" and kw["skh_prefilter"] and autograd.wants_grad(feat_c0, feat_c1, self.bin_score):
+                # eval-mode prefilter (:136-140) rewrites conf in place inside the kernel: no graph on this path, unlike the
+                # reference, which keeps autograd through its in-place writes.  Say so instead of failing later in backward().
+                warnings.warn("CoarseMatching: eval-mode skh_prefilter=True returns conf_matrix WITHOUT an autograd graph "
+                              "(inputs require grad); use .train() or skh_prefilter=False for a differentiable Sinkhorn head",
+                              RuntimeWarning, stacklevel=2)
             r = ops.coarse_match(feat_c0, feat_c1, *hw, **kw)
         if "conf_matrix_with_bin" in r:
             data.update({"conf_matrix_with_bin": r["conf_matrix_with_bin"]})

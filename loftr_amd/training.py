@@ -6,8 +6,9 @@ Host-side mirror of the reference's interface: ``compute_supervision_coarse(data
 (src/losses/loftr_loss.py:7-192) mutate the batch dict with the same keys.  The arithmetic runs in csrc/train.hip
 behind the C-ABI (loftr_spvs_coarse, loftr_spvs_fine, loftr_coarse_loss_sums, loftr_fine_loss_sums); there is no CPU
 fallback.  Backward: when conf_matrix / expec_f carry an autograd graph (loftr_amd/autograd.py: the dual-softmax and
-FineMatching heads), LoFTRLoss is differentiable through loftr_coarse_loss_grad / loftr_fine_loss_grad; the chain ends at the
-heads' inputs (no backward for the transformers, FinePreprocess or the backbone).  The RNG-dependent
+FineMatching heads, and the Sinkhorn head with its bin_score parameter), LoFTRLoss is differentiable through
+loftr_coarse_loss_grad / loftr_fine_loss_grad; the chain ends at the heads' inputs (no backward for the transformers,
+FinePreprocess or the backbone).  The RNG-dependent
 ground-truth padding of CoarseMatching's training branch (coarse_matching.py:200-236) lives in
 loftr_amd/loftr.py:CoarseMatching._train_sample.
 
@@ -18,6 +19,7 @@ removes that one cell from the NEGATIVE term; here it stays in (1 / (N L S) rela
 import ctypes as C
 
 import torch
+from torch.autograd.function import once_differentiable
 
 from . import _lib
 from .ops import _need, _ptr, _stream, _mask_u8, workspace, _on_device
@@ -228,17 +230,19 @@ class _CoarseLossFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, conf, module, t):
         ctx.save_for_backward(conf)
-        ctx.t = t
-        return module._coarse_value(conf.detach(), t)
+        value = module._coarse_value(conf.detach(), t)
+        ctx.t = dict(t)                                  # this node's own copy (bin_count belongs to THIS forward)
+        return value
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, up):
         (conf,), t = ctx.saved_tensors, ctx.t
         c = _need(conf.detach().contiguous(), "conf")
         g = torch.empty_like(c)
         b, i, j = t["ids"]
         m0, m1 = t["masks"]
-        u = float(up)
+        u = float(up.sum())                              # upstream factor of the scalar loss (any shape broadcast to it)
         n_neg = t["bin_count"] if t["kind"] == 1 else t["n_neg"]
         with torch.cuda.device(c.device):
             lib = _lib.load()
@@ -260,6 +264,7 @@ class _FineLossFn(torch.autograd.Function):
         return value.clone()
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, up):
         expec_f, gt, sums = ctx.saved_tensors
         with_std, thr, training = ctx.args
@@ -267,6 +272,6 @@ class _FineLossFn(torch.autograd.Function):
         g = torch.empty_like(e)
         with torch.cuda.device(e.device):
             _lib.check(_lib.load().loftr_fine_loss_grad(_ptr(e), e.shape[1], _ptr(_need(gt.contiguous(), "expec_f_gt")), e.shape[0],
-                                                        int(with_std), thr, int(training), _ptr(sums), float(up), _ptr(g), _stream()),
+                                                        int(with_std), thr, int(training), _ptr(sums), float(up.sum()), _ptr(g), _stream()),
                        "loftr_fine_loss_grad")
         return g, None, None, None, None, None
