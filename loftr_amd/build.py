@@ -78,6 +78,6 @@ if __name__ == "__main__":
         i = sys.argv.index("--variant")
         name = sys.argv[i + 1]
         build(extra_flags=[a for a in sys.argv[i + 2:] if a.startswith("-")],
-              lib_path=os.path.join(HERE, f"libloftr_hip_{name}.so"))
+              lib_path=os.path.join(HERE, f"libloftr_hip_{name}.so"), obj_dir=os.path.join(CSRC, "build", f"variant_{name}"))
     else:
         build(force="--force" in sys.argv)

@@ -492,6 +492,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_kernel(Conv3Args p) {
 #undef C3_NEXT_TILE
 }
 
+#include "conv3x3_duo.h"
+
 // 3x3 convolutions whose padded output width is 7 MFMA column tiles (Cout = 196 -> 224, the FPN's middle
 // dimension: 5 of the 14 3x3 layers, among them the most expensive one).  The 128-column kernel above runs them
 // as a full tile plus a 96-column tile whose waves idle at the k-tile barrier for half of their MFMA slots and
@@ -983,7 +985,18 @@ static int conv_run(const uint32_t* x_sp, int B, int H, int W, int Cin, const vo
     static const int use_wide = []() { const char* e = getenv("LOFTR_CONV_WIDE"); return e ? atoi(e) : 1; }();
     const bool wide = use_wide && c.Coutp == 32 * c3w::NT;
     TimedLaunch tl(wide ? LOFTR_T_CONV3W : LOFTR_T_CONV3, st);
-    if (wide)
+    // round 4: two 4-wave workgroups per CU (conv3x3_duo.h).  LOFTR_CONV_DUO: 0 = off, 1 = the 128-column form only,
+    // 2 = the 224-column form only, 3 (default) = both
+    static const int use_duo = []() { const char* e = getenv("LOFTR_CONV_DUO"); return e ? atoi(e) : 3; }();
+    if ((use_duo & 1) && c.Coutp % 128 == 0) {
+      using CF = c3d::Cfg<4, 2, 4>;
+      c.tiles_y = ceil_div(H, CF::TY);
+      hipLaunchKernelGGL((conv3x3_duo_kernel<CF>), dim3(xcd_grid(B * c.tiles_x * c.tiles_y, c.Coutp / 128)), dim3(256), 0, st, c);
+    } else if ((use_duo & 2) && wide) {
+      using CF = c3d::Cfg<7, 1, 3>;
+      c.tiles_y = ceil_div(H, CF::TY);
+      hipLaunchKernelGGL((conv3x3_duo_kernel<CF>), dim3(xcd_grid(B * c.tiles_x * c.tiles_y, 1)), dim3(256), 0, st, c);
+    } else if (wide)
       hipLaunchKernelGGL(conv3x3_wide_kernel, dim3(xcd_grid(B * c.tiles_x * c.tiles_y, 1)), dim3(512), 0, st, c);
     else
       hipLaunchKernelGGL(conv3x3_kernel, dim3(shared_gpu ? xcd_grid(B * c.tiles_x * c.tiles_y, ceil_div(c.Coutp, 128))
@@ -1009,6 +1022,14 @@ static int conv_run(const uint32_t* x_sp, int B, int H, int W, int Cin, const vo
   LOFTR_CHECK_LAUNCH();
   return LOFTR_OK;
 }
+
+#ifdef LOFTR_CONV_PROBE
+// probe builds only (python -m loftr_amd.build --variant probe -DLOFTR_CONV_PROBE): where conv3x3_duo_kernel drops its time stamps
+extern "C" int loftr_conv_probe_buffer(void* buf) {
+  long long* b = (long long*)buf;
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_conv_probe), &b, sizeof(b)) == hipSuccess ? LOFTR_OK : LOFTR_ERR_LAUNCH;
+}
+#endif
 
 extern "C" int loftr_conv_prepare(const float* weight, const long* weight_strides, int Cin, int Cout, int KH, int KW,
                                   const float* bn_weight, const float* bn_bias, const float* bn_mean, const float* bn_var,

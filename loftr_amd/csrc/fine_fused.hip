@@ -18,8 +18,12 @@
 //   * Q = z (.) (elu(x Wq^T) + 1) per head pair, then message_h = KV_h^T Q_h (six MFMAs against the block-diagonal KV fragments)
 //     and at once merge: msg += Wm[:, 32 t ..] message_t  -- neither Q nor the attention output ever exist as a whole;
 //   * LayerNorm1, then per 32 hidden features hid = relu(W0 [x, msg]) -> out += W2[:, hp] hid, LayerNorm2, residual.
-// HBM traffic: both windows in (fp32), both out: 51 KB per match instead of ~770 KB.  The residual stream lives in the (hi, lo)
-// fragments (22 significant bits; the fp32 copy of round 2 is gone at this level).
+// HBM traffic: both windows in (fp32), both out, plus the fp32 residual copy below: ~100 KB per match instead of ~770 KB.
+// Residual stream in fp32 (round 4): the GEMM operands are the (hi, lo) fragments (22 significant bits), but the residual
+// `x + LayerNorm2(..)` (transformer.py:58) adds the window's fp32 rows -- every call writes its output rows to f0 / f1 in place
+// (the wave owns them) and the call that updates the window next re-reads them (L2-resident, issued ahead of the LayerNorm
+// statistics).  Round 3 rebuilt x from its fragments there: 22 bits in the residual path, measured 4.1e-4 px from the
+// reference's fp64 run on e2e_synth where the reference's own fp32 run sits at 2.5e-4 (profiles/r04_parity_margins.txt).
 #include "linear.h"
 
 namespace {
@@ -488,8 +492,16 @@ __global__ __launch_bounds__(W * 64, 1) void fine_pair_kernel(Args a) {
       FFX_BEGIN(p + 2);
       if (live) FFX_KPANEL(lds + ((p + 2) % NST) * STAGE, hh, hl, big);
     }
-    // ============ x <- x + LayerNorm2(mlp output); the second layer's results go to HBM ===================     transformer.py:55-58
+    // ============ x <- x + LayerNorm2(mlp output), in fp32; every call's rows go to HBM ======================     transformer.py:55-58
     if (live) {
+      // the window's fp32 rows (the kernel's input in the self layer, the self layer's output in the cross layer): issued here,
+      // consumed after the LayerNorm statistics
+      float* orow = ((c & 1) ? a.f1 : a.f0) + (mc * T + min(li, T - 1)) * 128;
+      f32x4 xres[16];
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) xres[4 * j + q] = *reinterpret_cast<const f32x4*>(orow + 32 * j + fq + 8 * q);
       float s = 0.f;
 #pragma unroll
       for (int j = 0; j < 4; ++j)
@@ -508,14 +520,10 @@ __global__ __launch_bounds__(W * 64, 1) void fine_pair_kernel(Args a) {
         for (int r = 0; r < 16; ++r) { const float d = big[j][r] - mean; m2 = fmaf(d, d, m2); }
       m2 += swap32(m2);
       const float rstd = rsqrtf(m2 * (1.f / 128.f) + a.ln_eps);
-      float* orow = (c == 2 ? a.f0 : a.f1) + (mc * T + min(li, T - 1)) * 128;
-      const bool store = c >= 2 && li < T;
+      const bool store = li < T;
       float y[4][16], ym = 0.f;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        float xr[16];
-        const h16x8 xfh[2] = {wah[2 * j], wah[2 * j + 1]}, xfl[2] = {wal[2 * j], wal[2 * j + 1]};
-        unpack_panel(xfh, xfl, xr);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const f32x4 ga = *reinterpret_cast<const f32x4*>(tl + T_G2 + 32 * j + fq + 8 * q);
@@ -523,7 +531,7 @@ __global__ __launch_bounds__(W * 64, 1) void fine_pair_kernel(Args a) {
           f32x4 o;
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            o[e] = fmaf(xr[4 * q + e], wa_inv, (big[j][4 * q + e] - mean) * rstd * ga[e] + be[e]);
+            o[e] = xres[4 * j + q][e] + ((big[j][4 * q + e] - mean) * rstd * ga[e] + be[e]);
             y[j][4 * q + e] = o[e];
             ym = fmaxf(ym, fabsf(o[e]));
           }

@@ -33,6 +33,10 @@ def _randomize_bn(m, g):
     (256, 256, 3, 1, 2, True, False),
     (64, 40, 3, 1, 2, True, True),
     (96, 200, 3, 1, 2, True, True),          # 7 column tiles with Cout != 196: the 224-column kernel, 3 channel groups
+    (32, 128, 3, 1, 1, True, True),          # one channel group: two half-group steps (conv3x3_duo.h)
+    (16, 128, 3, 1, 0, False, False),        # ... whose second half is all padding: nine steps in total
+    (196, 128, 3, 1, 0, False, False),       # dead last half at 128 columns
+    (200, 200, 3, 1, 1, True, False),        # 7 column tiles, live last half
 ])
 def test_conv_bn_act_vs_torch(cin, cout, k, stride, act, use_bn, use_res):
     from loftr_amd import ops
@@ -310,10 +314,26 @@ def test_conv3x3_many_tiles_per_workgroup():
             assert err <= 2e-5, (cin, cout, err)
         print("ok")
     """)
-    env = dict(os.environ, LOFTR_CONV_PERSIST="8")
+    env = dict(os.environ, LOFTR_CONV_PERSIST="8", LOFTR_CONV_DUO="0")      # the round-3 kernels (default since round 4: conv3x3_duo.h)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, "-c", code], env=env, cwd=root, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]
+
+
+def test_conv3x3_duo_ragged_tiles():
+    """conv3x3_duo_kernel (two 4-wave workgroups per CU): image sizes that leave partly filled 8 x 32 / 4 x 32 tiles on both
+    axes, several tiles per image and both column-tile counts; against fp64."""
+    from loftr_amd import ops
+    g = torch.Generator().manual_seed(11)
+    for cin, cout, (H, W) in ((64, 128, (37, 70)), (128, 256, (17, 33)), (96, 200, (9, 65)), (196, 196, (30, 40))):
+        conv = nn.Conv2d(cin, cout, 3, padding=1, bias=False)
+        conv.weight.data = torch.randn(conv.weight.shape, generator=g) * (2.0 / (cin * 9)) ** 0.5
+        x = torch.randn(3, cin, H, W, generator=g)
+        ref = F.conv2d(x.double(), conv.weight.double(), padding=1)
+        x_sp = ops.sp_from_nhwc(x.permute(0, 2, 3, 1).contiguous().cuda())
+        y = ops.conv_bn_act(x_sp, cin, conv.cuda(), None, want_sp=False, want_f32=True)[1].permute(0, 3, 1, 2).cpu().double()
+        err = (y - ref).abs().max().item() / ref.abs().max().item()
+        assert err <= 2e-5, (cin, cout, H, W, err)
 
 
 def test_backbone_chunking_is_bitwise_identical():

@@ -41,9 +41,9 @@ def main(B=16, iters=10, only=""):
             continue
         conv = nn.Conv2d(cin, cout, k, s, k // 2, bias=False).to(dev)
         bn = nn.BatchNorm2d(cout).to(dev).eval() if act or res else None
-        x = ops.sp_from_nhwc(torch.randn(B, h, w, cin, device=dev))
+        x = ops.sp_from_nhwc(torch.relu(torch.randn(B, h, w, cin, device=dev)))      # post-ReLU statistics (half zeros): power / clocks depend on the data
         ho, wo = h // s, w // s
-        r = ops.sp_from_nhwc(torch.randn(B, ho, wo, cout, device=dev)) if res else None
+        r = ops.sp_from_nhwc(torch.relu(torch.randn(B, ho, wo, cout, device=dev))) if res else None
         f = lambda: ops.conv_bn_act(x, cin, conv, bn, act=act, residual=r, want_sp=True)
         for _ in range(3):
             f()
