@@ -66,6 +66,7 @@ struct Args {
   const float *g1, *b1, *g2, *b2;
   float v_length, attn_eps, p_out_scale, ln_eps;
   int nseq, T, groups;                                  // groups of W token blocks per sequence
+  int xsplit, gpc;                                      // fewer sequences than XCDs: a sequence's groups are cut into xsplit chunks of gpc groups, one XCD each
 };
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -104,9 +105,12 @@ __device__ __forceinline__ void pack_panel(const float (&v)[16], h16x8 (&fh)[2],
 __global__ __launch_bounds__(W * 64, 1) void encoder_x_kernel(Args a) {
   __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
   // ---- workgroup -> (sequence, group of token blocks): a sequence's groups run back to back on one XCD (weights, P in its L2)
+  // (with fewer sequences than XCDs -- 1 / 2 / 4 at the outdoor configuration's batch sizes -- a sequence is cut into xsplit chunks
+  //  of groups that take one XCD each: pinned one sequence per XCD, 2 sequences used 64 of the 256 CUs)
   const int id = blockIdx.x, xcd = id % NUM_XCD, slot = id / NUM_XCD;
-  const int seq = (slot / a.groups) * NUM_XCD + xcd, grp = slot % a.groups;
-  if (seq >= a.nseq) return;
+  const int vs = (slot / a.gpc) * NUM_XCD + xcd;        // virtual sequence = (sequence, chunk)
+  const int seq = vs / a.xsplit, grp = (vs % a.xsplit) * a.gpc + slot % a.gpc;
+  if (seq >= a.nseq || grp >= a.groups) return;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 5, li = lane & 31;
   const int T = a.T;
   const int tok = (grp * W + wave) * PT + li;
@@ -821,7 +825,10 @@ int launch_encoder_x(const EncoderXArgs& p, hipStream_t st) {
   a.g1 = p.g1; a.b1 = p.b1; a.g2 = p.g2; a.b2 = p.b2;
   a.v_length = p.v_length; a.attn_eps = p.attn_eps; a.p_out_scale = p.p_out_scale; a.ln_eps = p.ln_eps;
   a.nseq = p.nseq; a.T = p.T; a.groups = ceil_div(ceil_div(p.T, efx::PT), efx::W);
-  const int grid = NUM_XCD * ceil_div(p.nseq, NUM_XCD) * a.groups;
+  a.xsplit = p.nseq < NUM_XCD ? NUM_XCD / p.nseq : 1;
+  if (a.xsplit > a.groups) a.xsplit = a.groups;
+  a.gpc = ceil_div(a.groups, a.xsplit);
+  const int grid = NUM_XCD * ceil_div(p.nseq * a.xsplit, NUM_XCD) * a.gpc;
   // Split the launch: the largest whole number of 256-workgroup rounds goes to the main kernel (a wave x 32 tokens for the whole
   // layer), the remainder to the cooperative tail kernel (a workgroup x 32 tokens) when that is the cheaper way to finish:
   // OFF by default (LOFTR_ENCODER_TAIL=1 enables it).  Measured at the bench size (tools/gpu/r3_tail.sh): a cooperative round costs
@@ -838,7 +845,7 @@ int launch_encoder_x(const EncoderXArgs& p, hipStream_t st) {
   for (int cnt = 0; g_main < grid && cnt < full; ++g_main) cnt += live(g_main);
   int tail = 0;
   for (int id = g_main; id < grid; ++id) tail += live(id);
-  const bool use_tail = tail_on && tail > 0 && ceil_div(tail * efx::W, 256) <= 1;
+  const bool use_tail = tail_on && a.xsplit == 1 && tail > 0 && ceil_div(tail * efx::W, 256) <= 1;      // (the tail kernel keeps the one-sequence-per-XCD mapping)
   if (!use_tail) g_main = grid;
   TimedLaunch tl(LOFTR_T_ENCODER_X, st);
   if (g_main > 0) hipLaunchKernelGGL(efx::encoder_x_kernel, dim3(g_main), dim3(efx::W * 64), 0, st, a);

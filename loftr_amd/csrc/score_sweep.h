@@ -68,6 +68,9 @@
 #define SWEEP_PROBE_SKEW 1       // 0: all eight waves in phase
 #endif
 namespace sweep {
+// A 16-byte vector at 4-byte alignment: global_load / store_dwordx4 take any dword-aligned address (the runtime runs the GPU in
+// unaligned access mode); rows of an [L, S] volume with S % 4 != 0 start at odd dword offsets.
+struct __attribute__((packed, aligned(4))) F4U { f32x4 v; };
 constexpr int W = 8, BR = 32 * W, PC = 32, KS = 16, STAGE = PC * 1024, NST = 4, MAXP = 32;
 constexpr int OFF_CSTAT = NST * STAGE;                    // float2 [MAXP * PC] column (max, 1/sum) of the chunk (pass B)
 constexpr int OFF_MASK = OFF_CSTAT + MAXP * PC * 8;       // uint8  [MAXP * PC] mask1 of the chunk
@@ -196,6 +199,7 @@ __global__ __launch_bounds__(512, 2) void score_sweep_kernel(Args a) {
   // ---- chunk tables -> LDS (ordinary loads and LDS stores happen only here, before any DMA is in flight)
   float2* cstat_s = reinterpret_cast<float2*>(lds + OFF_CSTAT);
   uint8_t* mask_s = reinterpret_cast<uint8_t*>(lds + OFF_MASK);
+  bool cols_dead = HAS_MASK;                       // every column of this chunk that this thread looked at is padding
   for (int t = threadIdx.x; t < np * PC; t += 512) {
     const int col = min(p0 * PC + t, S - 1);
     if (PASS == 1) {
@@ -204,7 +208,7 @@ __global__ __launch_bounds__(512, 2) void score_sweep_kernel(Args a) {
       if (LSE) reinterpret_cast<float*>(cstat_s)[t] = fmaf(-cs.x, LOG2E, __builtin_amdgcn_logf(cs.y));
       else cstat_s[t] = cs;
     }
-    if (HAS_MASK) mask_s[t] = a.mask1[(long)n * S + col];
+    if (HAS_MASK) { const uint8_t m1 = a.mask1[(long)n * S + col]; mask_s[t] = m1; cols_dead = cols_dead && m1 == 0; }
   }
   float rm = 0.f, rs = 0.f;                        // pass B: row (max, 1/sum); LSE form: rm = -log2 sum_j exp(v_ij)
   if (PASS == 1) {
@@ -213,6 +217,11 @@ __global__ __launch_bounds__(512, 2) void score_sweep_kernel(Args a) {
   }
   const float k2 = 2.f * a.scale * LOG2E;          // LSE form: conf = exp2(k2 * dot + rm + cb_j)
   const bool mrow = HAS_MASK ? (a.mask0[(long)n * L + min(row, L - 1)] != 0) : true;
+  // Padding masks (MegaDepth batches): a unit all of whose rows or all of whose columns are padding holds nothing but the fill value
+  // -1e9 (coarse_matching.py:115-118) whatever the descriptors are -- its DMA, barriers and 48 MFMAs per panel are skipped and the
+  // epilogues run on zero accumulators, which they overwrite with the fill value exactly as they would the real dot products
+  // (bit-identical results; at 840 x 840 padded from 840 x 560 that is 56 % of the units).  Block-uniform.
+  const bool dead = HAS_MASK && (__syncthreads_and(cols_dead) || __syncthreads_and(!mrow || !row_ok));
 
   // ---- DMA of one panel: 32 rows x 8 k-groups x 128 B = 32 instructions, 4 per wave (k-group = wave)
   // dword offset of this lane's 16 B inside a panel row set, per row octet: recomputed per issue (a few VALU per panel)
@@ -268,9 +277,9 @@ __global__ __launch_bounds__(512, 2) void score_sweep_kernel(Args a) {
     if (PASS == 2) {                               /* Sinkhorn: the scaled, mask-filled score itself (coarse_matching.py:123-126) */ \
       if (rows_full || row_ok) {                                                                         \
         float* co = a.conf + ((long)n * L + row) * S + col0 + 4 * g;                                     \
-        if (fullp && (S & 3) == 0) {                                                                     \
+        if (fullp) {   /* 16-byte stores; rows of an S % 4 != 0 volume (outdoor 105 x 105 grids) are only 4-byte aligned: F4U */ \
           _Pragma("unroll") for (int q = 0; q < 4; ++q)                                                  \
-            *reinterpret_cast<f32x4*>(co + 8 * q) = f32x4{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]}; \
+            reinterpret_cast<F4U*>(co + 8 * q)->v = f32x4{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]}; \
         } else {                                                                                         \
           _Pragma("unroll") for (int r = 0; r < 16; ++r) if (col0 + jr(r, g) < S) co[8 * (r >> 2) + (r & 3)] = v[r]; \
         }                                                                                                \
@@ -357,9 +366,9 @@ __global__ __launch_bounds__(512, 2) void score_sweep_kernel(Args a) {
         } else if (SWEEP_PROBE_COAL) {      /* timing probe: the store pattern of a lane = column layout (wrong data) */ \
           float* cq = a.conf + ((long)n * L + rb * BR + wave * 32) * S + col0 + li;                      \
           _Pragma("unroll") for (int r = 0; r < 16; ++r) cq[(long)jr(r, g) * S] = c[r];                  \
-        } else if (fullp && (S & 3) == 0) {                                                              \
+        } else if (fullp) {                                                                              \
           _Pragma("unroll") for (int q = 0; q < 4; ++q)                                                  \
-            *reinterpret_cast<f32x4*>(co + 8 * q) = f32x4{c[4 * q], c[4 * q + 1], c[4 * q + 2], c[4 * q + 3]}; \
+            reinterpret_cast<F4U*>(co + 8 * q)->v = f32x4{c[4 * q], c[4 * q + 1], c[4 * q + 2], c[4 * q + 3]}; \
         } else {                                                                                         \
           _Pragma("unroll") for (int r = 0; r < 16; ++r) if (col0 + jr(r, g) < S) co[8 * (r >> 2) + (r & 3)] = c[r]; \
         }                                                                                                \
@@ -393,8 +402,10 @@ __global__ __launch_bounds__(512, 2) void score_sweep_kernel(Args a) {
   // of a VGPR-destination load, and a first use inside the panel loop would drain the in-flight DMA every iteration.
   LOFTR_WAITCNT_VM(0);
   __syncthreads();                                 // tables visible; no DMA in flight yet
-  SWEEP_ISSUE(0);
-  if (np > 1) SWEEP_ISSUE(1);
+  if (!dead) {
+    SWEEP_ISSUE(0);
+    if (np > 1) SWEEP_ISSUE(1);
+  }
   // Stores a wave issues between two DMA issues (they sit between the DMA of panel p+1 and the barrier of panel p+1
   // in the in-order VMEM queue): pass A one partial store; pass B four conf stores + one partial store.  Panels that
   // take the scalar-store tail path are followed by a full drain instead.
@@ -405,12 +416,14 @@ __global__ __launch_bounds__(512, 2) void score_sweep_kernel(Args a) {
     // panel p has landed once at most {DMA of panel p+1, the epilogue stores issued after it} are outstanding (VMEM
     // operations retire in order).  The late waves have not stored anything before period 2, so the count only
     // includes the stores from there on (conservative for the early waves at p = 1).
+    if (!dead) {
     if (drain || p + 1 >= np) LOFTR_WAITCNT_VM(0);
     else if (p < 2) LOFTR_WAITCNT_VM(DMA_PER_WAVE);
     else LOFTR_WAITCNT_VM(DMA_PER_WAVE + ST);
     if (!SWEEP_PROBE_NOBAR) __builtin_amdgcn_s_barrier();   // ... for every wave; and every wave is past the MFMAs of panel p-2
     if (p + 2 < np && !SWEEP_PROBE_NODMA) SWEEP_ISSUE(p + 2);
-    drain = !((p0 + p) * PC + PC <= S && (S & 3) == 0) && PASS >= 1;
+    }
+    drain = !((p0 + p) * PC + PC <= S) && PASS >= 1;      // only the ragged last panel of the matrix takes the scalar-store path
     const char* st = lds + (p & (NST - 1)) * STAGE;
 #if SWEEP_PIPE
     // ---- 48 MFMAs in eight phases of two k-steps (one 4 KB k-group of the panel: hi / lo fragments of an even and an
@@ -482,6 +495,7 @@ __global__ __launch_bounds__(512, 2) void score_sweep_kernel(Args a) {
     if (SWEEP_PROBE_PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+    if (!dead)
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       const char* sk = st + (ks >> 1) * 4096;
