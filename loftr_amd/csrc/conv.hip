@@ -985,13 +985,22 @@ static int conv_run(const uint32_t* x_sp, int B, int H, int W, int Cin, const vo
     static const int use_wide = []() { const char* e = getenv("LOFTR_CONV_WIDE"); return e ? atoi(e) : 1; }();
     const bool wide = use_wide && c.Coutp == 32 * c3w::NT;
     TimedLaunch tl(wide ? LOFTR_T_CONV3W : LOFTR_T_CONV3, st);
-    // round 4: two 4-wave workgroups per CU (conv3x3_duo.h).  LOFTR_CONV_DUO: 0 = off, 1 = the 128-column form only,
-    // 2 = the 224-column form only, 3 (default) = both
-    static const int use_duo = []() { const char* e = getenv("LOFTR_CONV_DUO"); return e ? atoi(e) : 3; }();
-    if ((use_duo & 1) && c.Coutp % 128 == 0) {
+    // round 4: conv3x3_duo.h
+    static const int use_duo = []() { const char* e = getenv("LOFTR_CONV_DUO"); return e ? atoi(e) : 9; }();   // default: 128-column tiles on two workgroups per CU, 224-column tiles on one 8-wave workgroup (tools/gpu/r4_octo.sh)
+    // LOFTR_CONV_DUO bits: 1 = 128-column tiles on two 4-wave workgroups per CU, 4 = on one 8-wave workgroup (512 px tiles);
+    //                      2 = 224-column tiles on two 4-wave workgroups, 8 = on one 8-wave workgroup (256 px tiles); 0 = round-3 kernels
+    if ((use_duo & 4) && c.Coutp % 128 == 0) {
+      using CF = c3d::Cfg<4, 2, 4, 8, 1>;
+      c.tiles_y = ceil_div(H, CF::TY);
+      hipLaunchKernelGGL((conv3x3_duo_kernel<CF>), dim3(xcd_grid(B * c.tiles_x * c.tiles_y, c.Coutp / 128)), dim3(512), 0, st, c);
+    } else if ((use_duo & 1) && c.Coutp % 128 == 0) {
       using CF = c3d::Cfg<4, 2, 4>;
       c.tiles_y = ceil_div(H, CF::TY);
       hipLaunchKernelGGL((conv3x3_duo_kernel<CF>), dim3(xcd_grid(B * c.tiles_x * c.tiles_y, c.Coutp / 128)), dim3(256), 0, st, c);
+    } else if ((use_duo & 8) && wide) {
+      using CF = c3d::Cfg<7, 2, 4, 8, 2>;
+      c.tiles_y = ceil_div(H, CF::TY);
+      hipLaunchKernelGGL((conv3x3_duo_kernel<CF>), dim3(xcd_grid(B * c.tiles_x * c.tiles_y, 1)), dim3(512), 0, st, c);
     } else if ((use_duo & 2) && wide) {
       using CF = c3d::Cfg<7, 1, 3>;
       c.tiles_y = ceil_div(H, CF::TY);

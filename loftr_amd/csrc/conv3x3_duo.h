@@ -39,19 +39,29 @@ __device__ long long* g_conv_probe = nullptr;   // set by loftr_conv_probe_buffe
 #endif
 
 namespace c3d {
-constexpr int TX = 32, PW = TX + 2, WAVES = 4;
-template <int NT_, int RW_, int NB_>
+constexpr int TX = 32, PW = TX + 2;
+// NT column tiles per workgroup tile, RW output rows per wave, NB weight ring stages, WAVES waves of which WN share a row pair and
+// split the NT column tiles between them (wave = wn * WM + wr: waves w and w + 4 of an 8-wave workgroup sit on the same SIMD).
+//   Cfg<4, 2, 4, 4, 1>  "duo"   256 px x 128 columns, 79 KB, two workgroups per CU
+//   Cfg<7, 1, 3, 4, 1>  "duo"   128 px x 224 columns, 71 KB, two workgroups per CU
+//   Cfg<4, 2, 4, 8, 1>  "octo"  512 px x 128 columns, 111 KB, one workgroup per CU: HALF the weight DMA per MFMA
+//   Cfg<7, 2, 4, 8, 2>  "octo"  256 px x 224 columns (a wave: 2 rows x 4 or 3 tiles), 101 KB: half the weight DMA of the duo form,
+//                       whose 15 KB per 21 MFMAs and wave exceed what the global -> LDS path delivers (~14 B / clk / CU)
+template <int NT_, int RW_, int NB_, int WAVES_ = 4, int WN_ = 1>
 struct Cfg {
   static constexpr int NT = NT_, RW = RW_, NB = NB_, LA = NB_ - 1;               // LA: weight stages in flight ahead of the running step
-  static constexpr int TY = WAVES * RW, PH = TY + 2, PROWS = PW * PH;
+  static constexpr int WAVES = WAVES_, WN = WN_, WM = WAVES_ / WN_, NJ = (NT_ + WN_ - 1) / WN_;   // NJ: column tiles per wave (the last split may own NJ - 1)
+  static constexpr int TY = WM * RW, PH = TY + 2, PROWS = PW * PH;
   static constexpr int PSLOTS = (PROWS + 15) / 16, PQ = (PSLOTS + WAVES - 1) / WAVES;   // 1 KB DMA slots (16 rows) of a patch half; per wave
   static constexpr int PHALF_BYTES = PSLOTS * 1024;
   static constexpr int BROWS = NT * 32, BSLOTS = BROWS / 16, BQ = (BSLOTS + WAVES - 1) / WAVES;
   static constexpr int BSTAGE_BYTES = BSLOTS * 1024;
   static constexpr int LDS_BYTES = 2 * PHALF_BYTES + NB * BSTAGE_BYTES + 1024;    // + 1 KB scratch: destination of the unused DMA slots
-  static_assert(LDS_BYTES <= 80 * 1024, "two workgroups per CU");
+  static constexpr int WG_PER_CU = WAVES == 4 ? 2 : 1;
+  static_assert(LDS_BYTES * WG_PER_CU <= 160 * 1024, "LDS");
   static_assert(RW <= 2, "patch rows are overwritten in place: row j of the next tap column while rows 2 .. RW+1 are in use");
   static_assert(LA >= 2 && LA <= 3, "vmcnt bookkeeping below");
+  static_assert(WN == 1 || NT - (WN - 1) * NJ >= NJ - 1, "the last column split owns NJ or NJ - 1 tiles");
 };
 // Issue order of one step (see C3D_STEP): group J = 3 RW MFMAs with R reads slotted one behind each of its first MFMAs.
 template <int R, int M>
@@ -76,9 +86,10 @@ __device__ __forceinline__ void pin_groups() {
 }  // namespace c3d
 
 template <typename CF>
-__global__ __launch_bounds__(256, 2) void conv3x3_duo_kernel(Conv3Args p) {
+__global__ __launch_bounds__(CF::WAVES * 64, CF::WG_PER_CU) void conv3x3_duo_kernel(Conv3Args p) {
   using namespace c3d;
   constexpr int NT = CF::NT, RW = CF::RW, NB = CF::NB, LA = CF::LA, PQ = CF::PQ, BQ = CF::BQ;
+  constexpr int WAVES = CF::WAVES, WM = CF::WM, NJ = CF::NJ;
   typedef __attribute__((address_space(3))) void* lds_ptr_t;
   typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
   __shared__ __attribute__((aligned(16))) char lds[CF::LDS_BYTES];
@@ -97,6 +108,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_duo_kernel(Conv3Args p) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 5, tx = lane & 31;
+  const int wr = wave % WM, wn = wave / WM;                     // this wave's row pair and column split
+  const int jc0 = wn * NJ;                                      // its first column tile
+  const int nj = min(NJ, NT - jc0);                             // ... and how many it owns (wave-uniform)
   const int drow = lane >> 2, dpos = lane & 3;                  // DMA: row inside a 16-row slot, 16-B position inside the 64-B row
 
   // ---- DMA source offsets (dwords): the chunk a lane fetches is fixed by (row, position); half / group / tap are added at issue
@@ -156,33 +170,37 @@ __global__ __launch_bounds__(256, 2) void conv3x3_duo_kernel(Conv3Args p) {
   const bool odd = lane & 1;
   const int Ho = p.H, Wo = p.W;
   const float xinv = p.x_inv ? *p.x_inv : 1.f;
-  // wave-uniform: every pixel of the tile inside the image and every column of it a real channel -> no predication in the fast paths
-  const bool full = y0 + CF::TY <= Ho && x0 + TX <= Wo && n0 + NT * 32 <= p.Cout;
-  const unsigned lane_sp = (unsigned)(4 * g * p.Coutp + (odd ? 16 : 0) + (tx >> 1));     // this lane's dword inside (pixel x0 + 4 g, group of column tile 0)
-  f32x16 acc[RW][NT];
+  // wave-uniform: every pixel of the tile inside the image -> no predication of the pixel index in the fast paths (columns beyond Cout
+  // are handled by clamped table reads and a select: the padded SP row always exists)
+  const bool full = y0 + CF::TY <= Ho && x0 + TX <= Wo;
+  const int nc0 = n0 + jc0 * 32;                                // first column of this wave
+  const unsigned lane_sp = (unsigned)(4 * g * p.Coutp + (odd ? 16 : 0) + (tx >> 1));     // this lane's dword inside (pixel x0 + 4 g, group of the wave's column tile 0)
+  f32x16 acc[RW][NJ];
   if (p.residual) {
     if (full) {
 #pragma unroll
       for (int i = 0; i < RW; ++i) {
-        const sp_t* rp = p.residual + ((size_t)((b * Ho + y0 + wave * RW + i) * Wo + x0) * p.Coutp + n0);
+        const sp_t* rp = p.residual + ((size_t)((b * Ho + y0 + wr * RW + i) * Wo + x0) * p.Coutp + nc0);
 #pragma unroll
-        for (int j = 0; j < NT; ++j)
+        for (int j = 0; j < NJ; ++j)
+          if (j < nj) {
 #pragma unroll
-          for (int r = 0; r < 16; ++r)
-            acc[i][j][r] = __uint_as_float((rp + (size_t)(((r & 3) + 8 * (r >> 2)) * p.Coutp + j * 32))[lane_sp]);
+            for (int r = 0; r < 16; ++r)
+              acc[i][j][r] = __uint_as_float((rp + (size_t)(((r & 3) + 8 * (r >> 2)) * p.Coutp + j * 32))[lane_sp]);
+          }
       }
     } else {
 #pragma unroll
       for (int i = 0; i < RW; ++i) {
-        const int y = y0 + wave * RW + i;
+        const int y = y0 + wr * RW + i;
 #pragma unroll
-        for (int j = 0; j < NT; ++j) {
-          const int col = n0 + j * 32 + tx;
+        for (int j = 0; j < NJ; ++j) {
+          const int col = nc0 + j * 32 + tx;
           const int spc = (col & ~31) + (odd ? 16 : 0) + ((col & 31) >> 1);
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int x = x0 + (r & 3) + 8 * (r >> 2) + 4 * g;
-            const bool ok = y < Ho && x < Wo && col < p.Coutp;
+            const bool ok = y < Ho && x < Wo && col < p.Coutp && j < nj;
             acc[i][j][r] = __uint_as_float(ok ? p.residual[(unsigned)(((b * Ho + y) * Wo + x) * p.Coutp + spc)] : 0u);
           }
         }
@@ -192,21 +210,21 @@ __global__ __launch_bounds__(256, 2) void conv3x3_duo_kernel(Conv3Args p) {
 #pragma unroll
     for (int i = 0; i < RW; ++i)
 #pragma unroll
-      for (int j = 0; j < NT; ++j)
+      for (int j = 0; j < NJ; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   }
 
-  int bbase[NT];                                               // byte offset of this lane's hi fragment of column tile j inside a stage
+  int bbase[NJ];                                               // byte offset of this lane's hi fragment of the wave's column tile j inside a stage
 #pragma unroll
-  for (int j = 0; j < NT; ++j) {
-    const int br = j * 32 + tx;
+  for (int j = 0; j < NJ; ++j) {
+    const int br = min(jc0 + j, NT - 1) * 32 + tx;
     bbase[j] = br * 64 + ((g ^ ((br >> 2) & 3)) << 4);
   }
-  // patch pixel of this lane's output pixel in the wave's patch row jr at tap column kx: (wave * RW + jr) * PW + kx + tx
+  // patch pixel of this lane's output pixel in the wave's patch row jr at tap column kx: (wr * RW + jr) * PW + kx + tx
 #define C3D_LOAD_ROW(jr_, sP_, kx_)                                                                         \
   {                                                                                                         \
-    const int pr__ = (wave * RW + (jr_)) * PW + (kx_) + tx;                                                 \
+    const int pr__ = (wr * RW + (jr_)) * PW + (kx_) + tx;                                                 \
     const int ab__ = pr__ * 64 + ((g ^ ((pr__ >> 2) & 3)) << 4);                                            \
     fh[jr_] = *reinterpret_cast<const h16x8*>((sP_) + ab__);                                                \
     fl[jr_] = *reinterpret_cast<const h16x8*>((sP_) + (ab__ ^ 32));                                         \
@@ -235,7 +253,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_duo_kernel(Conv3Args p) {
 
   // One step = one tap x one 16-wide k-step.  Its A rows and its first B fragment are already in registers (read during the
   // previous step); the barrier of step s guarantees that weight stage s + 1 (and the patch half it may open) has landed.
-#define C3D_STEP(KX, KY)                                                                                    \
+#define C3D_STEP(KX, KY, NJ_)                                                                                  \
   {                                                                                                         \
     {   /* weight stage s + 1 has landed once only what was issued after it is outstanding: stage s + 2 (LA = 3) and a patch \
            half issued in one of the last LA - 1 steps (loads retire in order) */                           \
@@ -258,10 +276,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_duo_kernel(Conv3Args p) {
        tile j + 1 (tile 0 of the next step after the last) and, in groups 0 / 1, the patch rows the NEXT step needs (after the last \
        step: harmless reads of stale LDS).  Rows are overwritten in place: the running step reads rows KY .. KY + RW - 1. */ \
     h16x8 ch__ = bh0, cl__ = bl0;                                                                           \
-    _Pragma("unroll") for (int j = 0; j < NT; ++j) {                                                        \
+    _Pragma("unroll") for (int j = 0; j < (NJ_); ++j) {                                                     \
       h16x8 nh__, nl__;                                                                                     \
       if (!C3D_PROBE_READS) { nh__ = ch__; nl__ = cl__; }                                                   \
-      else if (j + 1 < NT) { C3D_LOAD_B(nh__, nl__, sB__, j + 1); }                                         \
+      else if (j + 1 < (NJ_)) { C3D_LOAD_B(nh__, nl__, sB__, j + 1); }                                      \
       else { C3D_LOAD_B(nh__, nl__, bring_base + nstage__ * CF::BSTAGE_BYTES, 0); }                         \
       if (C3D_PROBE_READS && j < ((KY) < 2 ? 1 : RW)) {                                                     \
         if ((KY) < 2) { C3D_LOAD_ROW((KY) + RW, sP, KX); }                                                  \
@@ -276,15 +294,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_duo_kernel(Conv3Args p) {
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[(KY) + i], ch__, acc[i][j], 0, 0, 0);         \
       ch__ = nh__; cl__ = nl__;                                                                             \
     }                                                                                                       \
-    if (C3D_PROBE_READS) c3d::pin_groups<0, NT, RW, (KY)>();                                                \
+    if (C3D_PROBE_READS) c3d::pin_groups<0, (NJ_), RW, (KY)>();                                             \
     bh0 = ch__; bl0 = cl__;                                                                                 \
     stage = nstage__;                                                                                       \
     ++s;                                                                                                    \
   }
   if (p.residual) {                                             // raw SP words -> residual / wsc (both lanes of a pair exchange halves)
 #pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      const int col = n0 + j * 32 + tx;
+    for (int j = 0; j < NJ; ++j) {
+      const int col = nc0 + j * 32 + tx;
       const float wsc = (col < p.Cout ? p.wscale[col] : 1.f) * xinv;
       const float winv = __uint_as_float(0x7F000000u - __float_as_uint(wsc));      // 1 / wsc, exact: wsc is a power of two
 #pragma unroll
@@ -298,13 +316,18 @@ __global__ __launch_bounds__(256, 2) void conv3x3_duo_kernel(Conv3Args p) {
 #endif
   __builtin_amdgcn_s_setprio(1);                               // the k-loop outranks the partner workgroup's prologue / epilogue at issue (+1.5 %)
   int s = 0;
-  for (int hq = 0; hq < nhalf; ++hq) {
-    const char* sP = patch_base + (hq & 1) * CF::PHALF_BYTES;
-    const char* sPn = patch_base + ((hq + 1) & 1) * CF::PHALF_BYTES;
-    C3D_STEP(0, 0) C3D_STEP(0, 1) C3D_STEP(0, 2)
-    C3D_STEP(1, 0) C3D_STEP(1, 1) C3D_STEP(1, 2)
-    C3D_STEP(2, 0) C3D_STEP(2, 1) C3D_STEP(2, 2)
+  // the k-loop, instantiated per number of column tiles the wave owns (no data-dependent branch inside a step)
+#define C3D_LOOP(NJ_)                                                                                       \
+  for (int hq = 0; hq < nhalf; ++hq) {                                                                      \
+    const char* sP = patch_base + (hq & 1) * CF::PHALF_BYTES;                                               \
+    const char* sPn = patch_base + ((hq + 1) & 1) * CF::PHALF_BYTES;                                        \
+    C3D_STEP(0, 0, NJ_) C3D_STEP(0, 1, NJ_) C3D_STEP(0, 2, NJ_)                                             \
+    C3D_STEP(1, 0, NJ_) C3D_STEP(1, 1, NJ_) C3D_STEP(1, 2, NJ_)                                             \
+    C3D_STEP(2, 0, NJ_) C3D_STEP(2, 1, NJ_) C3D_STEP(2, 2, NJ_)                                             \
   }
+  if (CF::WN == 1 || nj == NJ) { C3D_LOOP(NJ) }
+  else { C3D_LOOP((NJ > 1 ? NJ - 1 : 1)) }
+#undef C3D_LOOP
 #undef C3D_STEP
 #undef C3D_LOAD_B
 #undef C3D_LOAD_ROW
@@ -323,34 +346,36 @@ __global__ __launch_bounds__(256, 2) void conv3x3_duo_kernel(Conv3Args p) {
 #pragma unroll
     for (int i = 0; i < RW; ++i)
 #pragma unroll
-      for (int j = 0; j < NT; ++j) z__ += acc[i][j][0] + acc[i][j][15];
+      for (int j = 0; j < NJ; ++j) z__ += acc[i][j][0] + acc[i][j][15];
     if (z__ == 12345.678f && p.y_f32) p.y_f32[0] = z__;
   } else if (full) {
-    // fast path: uniform (SGPR) row bases + one per-lane offset, unpredicated stores
+    // fast path: uniform (SGPR) row bases + one per-lane offset, stores not predicated on the pixel
     const unsigned lane_f32 = (unsigned)(4 * g * p.Cout + tx);
 #pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      const int col = n0 + j * 32 + tx;
-      const float bia = p.bias ? p.bias[col] : 0.f;
-      const float wsc = p.wscale[col] * xinv;                                 // undo the operands' power-of-two scales
+    for (int j = 0; j < NJ; ++j) {
+      if (j >= nj) continue;
+      const int col = nc0 + j * 32 + tx, colc = min(col, p.Cout - 1);
+      const bool creal = col < p.Cout;                                        // (the SP row's pad channels are written as zeros)
+      const float bia = p.bias ? p.bias[colc] : 0.f;
+      const float wsc = p.wscale[colc] * xinv;                                // undo the operands' power-of-two scales
 #pragma unroll
       for (int i = 0; i < RW; ++i) {
-        const size_t pix0 = (size_t)((b * Ho + y0 + wave * RW + i) * Wo + x0);
+        const size_t pix0 = (size_t)((b * Ho + y0 + wr * RW + i) * Wo + x0);
         f32x16 v;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const float xv = fmaf(acc[i][j][r], wsc, bia);
-          v[r] = fmaxf(xv, slope * xv);
+          v[r] = creal ? fmaxf(xv, slope * xv) : 0.f;
         }
-        if (p.y_f32) {
-          float* op = p.y_f32 + (pix0 * p.Cout + n0 + j * 32);
+        if (p.y_f32 && creal) {
+          float* op = p.y_f32 + (pix0 * p.Cout + nc0 + j * 32);
 #pragma unroll
           for (int r = 0; r < 16; ++r) (op + (size_t)(((r & 3) + 8 * (r >> 2)) * p.Cout))[lane_f32] = v[r];
         }
         if (p.y_sp) {
           uint32_t w16[16];
           sp_words16(v, odd, w16);
-          sp_t* op = p.y_sp + (pix0 * p.Coutp + n0 + j * 32);
+          sp_t* op = p.y_sp + (pix0 * p.Coutp + nc0 + j * 32);
 #pragma unroll
           for (int r = 0; r < 16; ++r) (op + (size_t)(((r & 3) + 8 * (r >> 2)) * p.Coutp))[lane_sp] = w16[r];
         }
@@ -358,15 +383,16 @@ __global__ __launch_bounds__(256, 2) void conv3x3_duo_kernel(Conv3Args p) {
     }
   } else {
 #pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      const int col = n0 + j * 32 + tx;
+    for (int j = 0; j < NJ; ++j) {
+      if (j >= nj) continue;
+      const int col = nc0 + j * 32 + tx;
       const bool creal = col < p.Cout, cpad = col < p.Coutp;
       const float bia = (p.bias && creal) ? p.bias[col] : 0.f;
       const float wsc = (creal ? p.wscale[col] : 1.f) * xinv;
       const int spc = (col & ~31) + (odd ? 16 : 0) + ((col & 31) >> 1);       // dword of this lane inside the SP row
 #pragma unroll
       for (int i = 0; i < RW; ++i) {
-        const int y = y0 + wave * RW + i;
+        const int y = y0 + wr * RW + i;
         f32x16 v;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
