@@ -39,8 +39,9 @@ typedef enum {
 /* 13: prepared transformer weights, RCCL entry points, scaled activations, pose estimation;
  * 14: training-side consumers (loftr_spvs_coarse / _fine, loftr_coarse_loss_sums, loftr_fine_loss_sums);
  * 16: backward of the matching heads and their losses (loftr_*_grad, loftr_dual_softmax_bwd, loftr_sinkhorn_bwd,
- *     loftr_fine_match_bwd) */
-#define LOFTR_HIP_ABI_VERSION 16
+ *     loftr_fine_match_bwd);
+ * 17: loftr_head_feat_grads (the feature-gradient GEMMs of both coarse heads) */
+#define LOFTR_HIP_ABI_VERSION 17
 
 int loftr_hip_abi_version(void);
 const char* loftr_hip_status_string(int status);
@@ -322,6 +323,12 @@ int loftr_dual_softmax_bwd(const float* feat_c0, const float* feat_c1, const lof
                            const float* grad_conf, float* dsim, void* ws, size_t ws_bytes, void* stream);
 int loftr_fine_match_bwd(const float* feat_f0, const float* feat_f1, int M, int WW, int C, const float* grad_expec,
                          float* grad_f0, float* grad_f1, void* stream);
+/* The einsum behind both coarse heads in reverse (coarse_matching.py:110-114 / :122-123: sim = <feat_c0, feat_c1> * alpha):
+ *   g0 [N,L,C] = alpha * dsim . feat_c1,   g1 [N,S,C] = alpha * dsim^T . feat_c0       (either output may be null)
+ * dsim: N matrices of L x S floats with row pitch dsim_ld and batch stride dsim_bs (the Sinkhorn head hands in the interior of its
+ * [L+1, S+1] gradient); fp32 in and out, split-fp16 MFMA products with fp32 accumulation (csrc/head_grads.hip).  C % 32 == 0, C <= 256. */
+int loftr_head_feat_grads(const float* dsim, long dsim_ld, long dsim_bs, const float* feat_c0, const float* feat_c1,
+                          int N, int L, int S, int C, float alpha, float* g0, float* g1, void* stream);
 size_t loftr_sinkhorn_bwd_workspace_bytes(int N, int L, int S, int C, int iters);
 int loftr_sinkhorn_bwd(const float* feat_c0, const float* feat_c1, const loftr_coarse_params* p, float bin_score, int iters,
                        const float* grad_assign, float* z_scratch, float* dZ, float* dbin, void* ws, size_t ws_bytes, void* stream);

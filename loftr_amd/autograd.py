@@ -37,9 +37,8 @@ class _DualSoftmaxMatch(torch.autograd.Function):
         hw0_c, hw1_c, temperature, mask0, mask1 = ctx.meta
         f0, f1 = feat_c0.detach().contiguous(), feat_c1.detach().contiguous()
         dsim = ops.dual_softmax_bwd(f0, f1, grad_conf.contiguous(), hw0_c, hw1_c, temperature, mask0, mask1)
-        k = 1.0 / (f0.shape[-1] * temperature)           # sim = <feat_c0, feat_c1> / (C T): two plain library GEMMs remain
-        g0 = torch.bmm(dsim, f1).mul_(k) if ctx.needs_input_grad[0] else None
-        g1 = torch.bmm(dsim.transpose(1, 2), f0).mul_(k) if ctx.needs_input_grad[1] else None
+        k = 1.0 / (f0.shape[-1] * temperature)           # sim = <feat_c0, feat_c1> / (C T): the two GEMMs are csrc/head_grads.hip
+        g0, g1 = ops.head_feat_grads(dsim, f0, f1, k, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
         return g0, g1, None, None, None, None
 
 
@@ -76,8 +75,7 @@ class _SinkhornMatch(torch.autograd.Function):
         if mask0 is not None:                          # masked_fill_ cuts the graph at the padding (:124-127)
             dsim = dsim.masked_fill(~(mask0.bool()[..., None] & mask1.bool()[:, None]), 0.0)
         k = 1.0 / f0.shape[-1]                         # sim = <feat_c0, feat_c1> / C (no temperature, :123)
-        g0 = torch.bmm(dsim, f1).mul_(k) if ctx.needs_input_grad[0] else None
-        g1 = torch.bmm(dsim.transpose(1, 2), f0).mul_(k) if ctx.needs_input_grad[1] else None
+        g0, g1 = ops.head_feat_grads(dsim, f0, f1, k, ctx.needs_input_grad[0], ctx.needs_input_grad[1])    # a strided view: no copy
         gb = dbin.reshape(bin_score.shape).to(bin_score.dtype) if ctx.needs_input_grad[2] else None
         return g0, g1, gb, None, None, None, None
 

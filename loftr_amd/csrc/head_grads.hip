@@ -1,0 +1,252 @@
+// d loss / d feat_c0, d loss / d feat_c1 from d loss / d sim_matrix: the two GEMMs behind the backward of both coarse heads.
+//   reference: src/loftr/utils/coarse_matching.py:110-114 (dual-softmax: sim = einsum("nlc,nsc->nls", f0 / sqrt C, f1 / sqrt C) / T),
+//              :122-123 (Sinkhorn: the same without T) -- what torch.autograd does for that einsum:
+//                  g0[n] = alpha * dsim[n]   . feat_c1[n]        [L, S] x [S, C]
+//                  g1[n] = alpha * dsim[n]^T . feat_c0[n]        [S, L] x [L, C]
+// Until round 3 these were two torch.bmm calls (rocBLAS fp32 Tensile kernels, 2 x 810 us of the 3.5 ms dual-softmax backward).
+//
+// Both are fp32 x fp32 GEMMs with a LONG reduction (K = S or L = 4800) and a narrow output (C = 256 columns), and neither operand
+// exists in the SP format: dsim is produced as fp32 by the heads' backward kernels (and, for the second product, is needed
+// transposed), feat is the fp32 tensor autograd saved.  So this kernel splits on the fly: tiles travel global -> registers (fp32,
+// one k-tile ahead of the compute) -> (hi, lo) fp16 -> LDS in the fragment layout of gemm.h, and the product is the same three fp16
+// MFMAs per fp32 product with fp32 accumulation (hi*hi + hi*lo + lo*hi, csrc/gemm.h).  The transposes cost nothing: a thread
+// loads a 4-column x 4- or 8-row micro tile with 16-byte loads ALONG the contiguous dimension and writes it to LDS across it.
+//   workgroup: 4 waves, 128 output rows x all C <= 256 columns (a wave: 32 rows x C), k-tile 32; LDS 48 KB -> two workgroups per CU.
+//   Scaling (gemm.h: the lo half of |x| < 2^-3 is a subnormal fp16 number, and gradients are small): both operand tiles are staged
+//   times a power of two that keeps the tile maximum in [2^10, 2^16) -- a RUNNING pair of exponents, changed only when a tile's
+//   maximum leaves that window; when it changes the accumulators are rescaled by the exact ratio (a wave-uniform, rare branch), so
+//   one accumulator set serves the whole reduction and the result is exact in the scales.
+#include "gemm.h"
+
+namespace {
+namespace hg {
+constexpr int BM = 128, BK = 32, WAVES = 4, MAXT = 8;          // MAXT column tiles of 32 (C <= 256)
+constexpr int A_BYTES = BM * 128, B_BYTES = 256 * 128, LDS_BYTES = A_BYTES + B_BYTES + 64;     // + [2][WAVES] floats
+struct __attribute__((packed, aligned(4))) F4U { f32x4 v; };
+
+struct Args {
+  const float* a; long a_ld, a_bs;      // A source: TRANS = false: A[m][k] = a[n * a_bs + m * a_ld + k];  true: a[n * a_bs + k * a_ld + m]
+  const float* b; long b_bs;            // B[k][c] = b[n * b_bs + k * C + c]
+  float* out; long o_bs;                // out[m][c] = alpha * sum_k A[m][k] B[k][c]
+  int M, K, C, NT;                      // NT = C / 32
+  float alpha;
+  int tiles_m, N;
+};
+
+__device__ __forceinline__ float lift_exp(float absmax, float& inv) {     // power of two that lifts absmax into [2^13, 2^14), exact inverse
+  const int e = (int)((__float_as_uint(absmax) >> 23) & 0xffu) - 126;
+  int sh = 14 - e;
+  sh = (absmax > 1e-30f && absmax < 1e30f) ? sh : 0;
+  sh = sh > 60 ? 60 : (sh < -60 ? -60 : sh);
+  inv = __uint_as_float((unsigned)(127 - sh) << 23);
+  return __uint_as_float((unsigned)(127 + sh) << 23);
+}
+
+template <bool TRANS>
+__global__ __launch_bounds__(WAVES * 64, 2) void head_grad_kernel(Args p) {
+  __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
+  char* const sA = lds;
+  char* const sB = lds + A_BYTES;
+  float* const smax = reinterpret_cast<float*>(lds + A_BYTES + B_BYTES);     // [2][WAVES] per-wave |A|, |B| maxima of the tile being staged
+  int tm, tn_;
+  if (!xcd_tile(p.tiles_m * p.N, 1, tm, tn_)) return;
+  (void)tn_;
+  const int n = tm / p.tiles_m, m0 = (tm - n * p.tiles_m) * BM;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 5, li = lane & 31;
+  const float* A = p.a + (long)n * p.a_bs;
+  const float* B = p.b + (long)n * p.b_bs;
+  const int M = p.M, K = p.K, C = p.C, NT = p.NT;
+  const int nk = ceil_div(K, BK);
+
+  // ---- staging registers: A 16 floats, B 32 floats per thread and k-tile
+  //   A, plain:      thread = (row tid >> 1, k half tid & 1): 16 consecutive k of one row
+  //   A, transposed: thread = (4 rows m = 4 (tid & 31) .., 4 k = 4 (tid >> 5) ..): 4 loads of 4 consecutive m
+  //   B:             thread = (4 columns c = 4 (tid & 63) .., 8 k = 8 (tid >> 6) ..): 8 loads of 4 consecutive c
+  f32x4 ra[4], rb[8];
+  const bool a_vec = TRANS ? (m0 + BM <= M) : true;
+  auto load_tile = [&](int kt) {
+    const int k0 = kt * BK;
+    if (!TRANS) {
+      const int row = min(m0 + (tid >> 1), M - 1), kb = k0 + (tid & 1) * 16;
+      const float* src = A + (long)row * p.a_ld + kb;
+      if (kb + 16 <= K) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) ra[q] = reinterpret_cast<const F4U*>(src + 4 * q)->v;
+      } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) ra[q][e] = kb + 4 * q + e < K ? src[4 * q + e] : 0.f;
+      }
+    } else {
+      const int mb = m0 + 4 * (tid & 31), kb = k0 + 4 * (tid >> 5);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int k = kb + q;
+        const float* src = A + (long)min(k, K - 1) * p.a_ld + mb;
+        if (a_vec) ra[q] = reinterpret_cast<const F4U*>(src)->v;
+        else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) ra[q][e] = src[min(mb + e, M - 1) - mb];
+        }
+        if (k >= K) ra[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+    const int cb = 4 * (tid & 63), kb2 = k0 + 8 * (tid >> 6);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int k = kb2 + q;
+      rb[q] = (cb < C && k < K) ? *reinterpret_cast<const f32x4*>(B + (long)k * C + cb) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  // registers -> (hi, lo) halves -> LDS rows of 128 B (chunks 0..3 hi, 4..7 lo; 16-B chunk c of row r at slot c ^ ((r >> 1) & 7))
+  auto store_tile = [&](float a_sc, float b_sc) {
+    if (!TRANS) {
+      const int r = tid >> 1, c0 = (tid & 1) * 2;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const float v[8] = {ra[2 * h][0] * a_sc, ra[2 * h][1] * a_sc, ra[2 * h][2] * a_sc, ra[2 * h][3] * a_sc,
+                            ra[2 * h + 1][0] * a_sc, ra[2 * h + 1][1] * a_sc, ra[2 * h + 1][2] * a_sc, ra[2 * h + 1][3] * a_sc};
+        u32x4 hi, lo;
+        uint32_t hw[4], lw[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) sp_pack2(v[2 * e], v[2 * e + 1], hw[e], lw[e]);
+        hi = u32x4{hw[0], hw[1], hw[2], hw[3]}; lo = u32x4{lw[0], lw[1], lw[2], lw[3]};
+        *reinterpret_cast<u32x4*>(sA + lds_chunk_off(r, c0 + h)) = hi;
+        *reinterpret_cast<u32x4*>(sA + lds_chunk_off(r, 4 + c0 + h)) = lo;
+      }
+    } else {
+      const int rb0 = 4 * (tid & 31), kq = tid >> 5;             // rows rb0 .. +3, k = 4 kq .. +3: half of chunk kq >> 1
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        uint32_t h0, l0, h1, l1;
+        sp_pack2(ra[0][e] * a_sc, ra[1][e] * a_sc, h0, l0);
+        sp_pack2(ra[2][e] * a_sc, ra[3][e] * a_sc, h1, l1);
+        const int r = rb0 + e;
+        *reinterpret_cast<uint2*>(sA + lds_chunk_off(r, kq >> 1) + (kq & 1) * 8) = uint2{h0, h1};
+        *reinterpret_cast<uint2*>(sA + lds_chunk_off(r, 4 + (kq >> 1)) + (kq & 1) * 8) = uint2{l0, l1};
+      }
+    }
+    const int cb = 4 * (tid & 63), kc = tid >> 6;                // columns cb .. +3 (rows of the B tile), k = 8 kc .. +7: chunk kc
+    if (cb < C) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        uint32_t hw[4], lw[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) sp_pack2(rb[2 * q][e] * b_sc, rb[2 * q + 1][e] * b_sc, hw[q], lw[q]);
+        const int r = cb + e;
+        *reinterpret_cast<u32x4*>(sB + lds_chunk_off(r, kc)) = u32x4{hw[0], hw[1], hw[2], hw[3]};
+        *reinterpret_cast<u32x4*>(sB + lds_chunk_off(r, 4 + kc)) = u32x4{lw[0], lw[1], lw[2], lw[3]};
+      }
+    }
+  };
+  auto tile_absmax = [&](float& mb) {
+    float m = 0.f;
+    mb = 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) m = fmaxf(m, fabsf(ra[q][e]));
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) mb = fmaxf(mb, fabsf(rb[q][e]));
+    mb = half_max(mb); mb = fmaxf(mb, swap32(mb));
+    m = half_max(m);
+    return fmaxf(m, swap32(m));
+  };
+
+  f32x16 acc[MAXT];
+#pragma unroll
+  for (int j = 0; j < MAXT; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+  const int arow = wave * 32 + li;
+  float a_sc = 1.f, a_inv = 1.f, b_sc = 1.f, b_inv = 1.f;      // running operand scales (powers of two) and their inverses
+  load_tile(0);
+  { float wmb; const float wma = tile_absmax(wmb); if (lane == 0) { smax[wave] = wma; smax[WAVES + wave] = wmb; } }
+  for (int kt = 0; kt < nk; ++kt) {
+    __syncthreads();                                     // every wave is done reading the previous tile; the staged tile's maxima are visible
+    const float ma = fmaxf(fmaxf(smax[0], smax[1]), fmaxf(smax[2], smax[3]));
+    const float mb = fmaxf(fmaxf(smax[4], smax[5]), fmaxf(smax[6], smax[7]));
+    // keep a running scale while it holds the tile maximum in [2^10, 2^16); otherwise re-lift to [2^13, 2^14) and carry the exact
+    // ratio into the accumulators (block-uniform branch)
+    const bool a_bad = !(ma * a_sc >= 1024.f && ma * a_sc < 65000.f) && ma > 1e-30f;
+    const bool b_bad = !(mb * b_sc >= 1024.f && mb * b_sc < 65000.f) && mb > 1e-30f;
+    if (a_bad || b_bad) {
+      float na_sc = a_sc, na_inv = a_inv, nb_sc = b_sc, nb_inv = b_inv;
+      if (a_bad) na_sc = lift_exp(ma, na_inv);
+      if (b_bad) nb_sc = lift_exp(mb, nb_inv);
+      const float ratio = (na_sc * a_inv) * (nb_sc * b_inv);     // new / old, a power of two
+      if (kt > 0) {
+#pragma unroll
+        for (int j = 0; j < MAXT; ++j)
+          if (j < NT) acc[j] *= ratio;
+      }
+      a_sc = na_sc; a_inv = na_inv; b_sc = nb_sc; b_inv = nb_inv;
+    }
+    store_tile(a_sc, b_sc);
+    __syncthreads();
+    if (kt + 1 < nk) load_tile(kt + 1);                  // in flight under the MFMAs below
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const h16x8 ah = *reinterpret_cast<const h16x8*>(sA + lds_chunk_off(arow, 2 * ks + g));
+      const h16x8 al = *reinterpret_cast<const h16x8*>(sA + lds_chunk_off(arow, 4 + 2 * ks + g));
+#pragma unroll
+      for (int j = 0; j < MAXT; ++j) {
+        if (j < NT) {
+          const int br = j * 32 + li;
+          const h16x8 bh = *reinterpret_cast<const h16x8*>(sB + lds_chunk_off(br, 2 * ks + g));
+          const h16x8 bl = *reinterpret_cast<const h16x8*>(sB + lds_chunk_off(br, 4 + 2 * ks + g));
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[j], 0, 0, 0);
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[j], 0, 0, 0);
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[j], 0, 0, 0);
+        }
+      }
+    }
+    if (kt + 1 < nk) {                                   // maxima of the tile just loaded (every wave read the previous ones before the barrier above)
+      float wmb;
+      const float wma = tile_absmax(wmb);
+      if (lane == 0) { smax[wave] = wma; smax[WAVES + wave] = wmb; }
+    }
+  }
+  const float undo = a_inv * b_inv * p.alpha;
+  // ---- out[m][c] = alpha * acc: lane = column, 16 rows per register set
+  float* O = p.out + (long)n * p.o_bs;
+#pragma unroll
+  for (int j = 0; j < MAXT; ++j) {
+    if (j >= NT) continue;
+    const int c = j * 32 + li;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
+      if (m < M) O[(long)m * C + c] = acc[j][r] * undo;
+    }
+  }
+}
+}  // namespace hg
+}  // namespace
+
+// g0 [N,L,C] = alpha * dsim . feat_c1,  g1 [N,S,C] = alpha * dsim^T . feat_c0 (either may be null).  dsim: [N] matrices of L x S with row
+// pitch dsim_ld and batch stride dsim_bs (floats): the Sinkhorn head hands in the interior of its [L+1, S+1] gradient.
+extern "C" int loftr_head_feat_grads(const float* dsim, long dsim_ld, long dsim_bs, const float* feat_c0, const float* feat_c1,
+                                     int N, int L, int S, int C, float alpha, float* g0, float* g1, void* stream) {
+  LOFTR_CHECK_ARG(dsim && feat_c0 && feat_c1 && (g0 || g1) && N >= 0 && L > 0 && S > 0 && C > 0 && dsim_ld >= S);
+  if (C % 32 != 0 || C > 32 * hg::MAXT) return LOFTR_ERR_UNSUPPORTED;
+  if (N == 0) return LOFTR_OK;
+  hipStream_t st = (hipStream_t)stream;
+  hg::Args a{};
+  a.C = C; a.NT = C / 32; a.alpha = alpha; a.N = N;
+  if (g0) {
+    a.a = dsim; a.a_ld = dsim_ld; a.a_bs = dsim_bs; a.b = feat_c1; a.b_bs = (long)S * C; a.out = g0; a.o_bs = (long)L * C;
+    a.M = L; a.K = S; a.tiles_m = ceil_div(L, hg::BM);
+    hipLaunchKernelGGL((hg::head_grad_kernel<false>), dim3(xcd_grid(a.tiles_m * N, 1)), dim3(hg::WAVES * 64), 0, st, a);
+  }
+  if (g1) {
+    a.a = dsim; a.a_ld = dsim_ld; a.a_bs = dsim_bs; a.b = feat_c0; a.b_bs = (long)L * C; a.out = g1; a.o_bs = (long)S * C;
+    a.M = S; a.K = L; a.tiles_m = ceil_div(S, hg::BM);
+    hipLaunchKernelGGL((hg::head_grad_kernel<true>), dim3(xcd_grid(a.tiles_m * N, 1)), dim3(hg::WAVES * 64), 0, st, a);
+  }
+  LOFTR_CHECK_LAUNCH();
+  return LOFTR_OK;
+}

@@ -333,6 +333,23 @@ def dual_softmax_bwd(feat_c0, feat_c1, grad_conf, hw0_c, hw1_c, temperature, mas
 
 
 @_on_device
+def head_feat_grads(dsim, feat_c0, feat_c1, alpha, want0=True, want1=True):
+    """(alpha * dsim @ feat_c1, alpha * dsim^T @ feat_c0): the einsum of coarse_matching.py:110-114 / :122-123 in reverse.
+    dsim [N,L,S] fp32, possibly a strided view (last stride 1): the interior of the Sinkhorn head's [N,L+1,S+1] gradient."""
+    _need(feat_c0, "feat_c0"); _need(feat_c1, "feat_c1")
+    N, L, Cc = feat_c0.shape
+    S = feat_c1.shape[1]
+    if not (dsim.is_cuda and dsim.dtype == torch.float32 and tuple(dsim.shape) == (N, L, S) and dsim.stride(2) == 1):
+        raise _lib.LoftrHipError("head_feat_grads: dsim must be a float32 GPU tensor [N,L,S] with unit last stride")
+    g0 = torch.empty_like(feat_c0) if want0 else None
+    g1 = torch.empty_like(feat_c1) if want1 else None
+    if want0 or want1:
+        check(_lib.load().loftr_head_feat_grads(_ptr(dsim), dsim.stride(1), dsim.stride(0), _ptr(feat_c0), _ptr(feat_c1), N, L, S, Cc,
+                                                float(alpha), _ptr(g0), _ptr(g1), _stream()), "loftr_head_feat_grads")
+    return g0, g1
+
+
+@_on_device
 def sinkhorn_bwd(feat_c0, feat_c1, grad_assign, hw0_c, hw1_c, bin_score, iters, mask0=None, mask1=None):
     """(dL/d couplings [N,L+1,S+1], dL/d bin_score [1]) from dL/d conf_matrix_with_bin (coarse_matching.py:121-143)."""
     _need(feat_c0, "feat_c0"); _need(feat_c1, "feat_c1"); _need(grad_assign, "grad_assign")

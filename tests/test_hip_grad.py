@@ -183,3 +183,29 @@ def test_sinkhorn_backward_full_size():
     for got, ref in ((a.grad, a64.grad), (b.grad, b64.grad), (bin_score.grad, s64.grad)):
         err = (got.double() - ref).abs().max().item() / ref.abs().max().item()
         assert err <= 5e-4, err
+
+
+@pytest.mark.parametrize("N,L,S,C,strided", [(2, 300, 173, 256, False), (1, 129, 640, 128, True), (3, 48, 48, 256, False), (1, 4800, 4800, 256, False)])
+def test_head_feat_grads_vs_fp64(N, L, S, C, strided):
+    """loftr_head_feat_grads (csrc/head_grads.hip): g0 = a dsim f1, g1 = a dsim^T f0 against float64 matmuls -- ragged tiles on every
+    axis, the strided view the Sinkhorn head hands in, gradient magnitudes that vary by 1e6 across the matrix (running tile scales)."""
+    from loftr_amd import ops
+    g = torch.Generator().manual_seed(N * 1000 + L + S)
+    f0 = torch.randn(N, L, C, generator=g)
+    f1 = torch.randn(N, S, C, generator=g)
+    full = torch.randn(N, L + 1, S + 1, generator=g) * torch.exp(-14.0 * torch.rand(N, L + 1, 1, generator=g)) * 1e-2
+    dsim = full[:, :L, :S] if strided else full[:, :L, :S].contiguous()
+    a = 0.0390625
+    r0 = a * torch.bmm(dsim.double(), f1.double())
+    r1 = a * torch.bmm(dsim.double().transpose(1, 2), f0.double())
+    d = dsim.cuda() if not strided else full.cuda()[:, :L, :S]
+    g0, g1 = ops.head_feat_grads(d, f0.cuda(), f1.cuda(), a)
+    for got, ref in ((g0, r0), (g1, r1)):
+        err = (got.cpu().double() - ref).abs().max().item() / ref.abs().max().item()
+        assert err <= 2e-6, (N, L, S, C, strided, err)
+    # row-wise: a row of tiny gradients keeps its own relative accuracy (per-tile scaling, not per-tensor)
+    rows = r0.abs().amax(-1)
+    rel = ((g0.cpu().double() - r0).abs().amax(-1) / rows.clamp_min(1e-300)).max().item()
+    assert rel <= 2e-4, rel
+    only0, none1 = ops.head_feat_grads(d, f0.cuda(), f1.cuda(), a, want1=False)
+    assert none1 is None and torch.equal(only0, g0)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Duration of the heads' backward at the bench's sizes (N pairs of 4800 x 4800 cells, M fine windows).
 
-    python tools/micro/grad_bench.py [N=8] [M=7700] [reps=5]
+    python tools/micro/grad_bench.py [N=8] [M=7700] [reps=5] [with_bmm=0]
 """
 import sys
 import time
@@ -21,7 +21,7 @@ def timed(fn, reps):
     return (time.perf_counter() - t) / reps * 1e3
 
 
-def main(N=8, M=7700, reps=5):
+def main(N=8, M=7700, reps=5, with_bmm=0):
     dev = torch.device("cuda", 0)
     torch.manual_seed(0)
     h, w = 60, 80
@@ -34,7 +34,9 @@ def main(N=8, M=7700, reps=5):
         G[n, idx[n], torch.randint(L, (900,), device=dev)] = 1.0
     t_dsim = timed(lambda: ops.dual_softmax_bwd(f0, f1, G, (h, w), (h, w), 0.1), reps)
     dsim = ops.dual_softmax_bwd(f0, f1, G, (h, w), (h, w), 0.1)
-    t_gemm = timed(lambda: (torch.bmm(dsim, f1), torch.bmm(dsim.transpose(1, 2), f0)), reps)
+    # what round 3 ran (rocBLAS fp32): only on request, so that the profile of this script shows the product's kernels only
+    t_gemm = timed(lambda: (torch.bmm(dsim, f1), torch.bmm(dsim.transpose(1, 2), f0)), reps) if with_bmm else float('nan')
+    t_own = timed(lambda: ops.head_feat_grads(dsim, f0, f1, 1.0 / 25.6), reps)                    # csrc/head_grads.hip
     Gd = torch.randn(N, L, L, device=dev)
     t_dense = timed(lambda: ops.dual_softmax_bwd(f0, f1, Gd, (h, w), (h, w), 0.1), reps)
     kw = dict(thr=0.2, border_rm=2, scale=8.0, match_type="dual_softmax", temperature=0.1, want_conf=True)
@@ -51,7 +53,7 @@ def main(N=8, M=7700, reps=5):
     t_ffwd = timed(lambda: ops.fine_match(a, b, z2, zb, 2.0), reps)
     t_fbwd = timed(lambda: ops.fine_match_bwd(a, b, ge), reps)
     print(f"N={N} L=S={L}: coarse match forward {t_fwd:.3f} ms | dual-softmax backward: dsim {t_dsim:.3f} ms (sparse G) / {t_dense:.3f} ms (dense G), "
-          f"+ 2 fp32 bmm {t_gemm:.3f} ms | Sinkhorn (3 iterations): forward {t_otf:.3f} ms, backward {t_ot:.3f} ms (+ the same 2 bmm) | M={M}: fine match forward {t_ffwd:.3f} ms, backward {t_fbwd:.3f} ms")
+          f"+ the two feature-gradient GEMMs {t_own:.3f} ms (csrc/head_grads.hip; torch.bmm fp32: {t_gemm:.3f} ms) | Sinkhorn (3 iterations): forward {t_otf:.3f} ms, backward {t_ot:.3f} ms (+ the same two GEMMs) | M={M}: fine match forward {t_ffwd:.3f} ms, backward {t_fbwd:.3f} ms")
 
 
 if __name__ == "__main__":
