@@ -41,6 +41,8 @@ def bench_name(full):
         return "score_stats_kernel"         # pass A: shared-reference variant + exact variant
     if "score_sweep_kernel<2" in full:
         return "score_store_kernel"         # Sinkhorn: score store on the sweep
+    if "conv3x3_duo_kernel" in full:        # round 4: the 3x3 stride-1 convolutions; timed under the ids of the kernels they replaced
+        return "conv3x3_wide_kernel" if "Cfg<7" in full else "conv3x3_kernel"
     if "rowsweep_kernel<0" in full:
         return "proj_kernel"                # coarse q projection (timed under LOFTR_T_PROJ)
     if "rowsweep_kernel<1" in full:
