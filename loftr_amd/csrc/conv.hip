@@ -997,6 +997,10 @@ static int conv_run(const uint32_t* x_sp, int B, int H, int W, int Cin, const vo
       using CF = c3d::Cfg<4, 2, 4>;
       c.tiles_y = ceil_div(H, CF::TY);
       hipLaunchKernelGGL((conv3x3_duo_kernel<CF>), dim3(xcd_grid(B * c.tiles_x * c.tiles_y, c.Coutp / 128)), dim3(256), 0, st, c);
+    } else if ((use_duo & 8) && c.Coutp == 192) {        // six column tiles (3 + 3 per wave pair)
+      using CF = c3d::Cfg<6, 2, 4, 8, 2>;
+      c.tiles_y = ceil_div(H, CF::TY);
+      hipLaunchKernelGGL((conv3x3_duo_kernel<CF>), dim3(xcd_grid(B * c.tiles_x * c.tiles_y, 1)), dim3(512), 0, st, c);
     } else if ((use_duo & 8) && wide) {
       using CF = c3d::Cfg<7, 2, 4, 8, 2>;
       c.tiles_y = ceil_div(H, CF::TY);

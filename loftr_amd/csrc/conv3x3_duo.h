@@ -37,6 +37,9 @@ __device__ long long* g_conv_probe = nullptr;   // set by loftr_conv_probe_buffe
 #ifndef C3D_PROBE_EPI
 #define C3D_PROBE_EPI 1
 #endif
+#ifndef C3D_BDIST
+#define C3D_BDIST 1               // column tiles the B-fragment reads run ahead of their MFMAs (2: +8 registers)
+#endif
 
 namespace c3d {
 constexpr int TX = 32, PW = TX + 2;
@@ -244,12 +247,14 @@ __global__ __launch_bounds__(CF::WAVES * 64, CF::WG_PER_CU) void conv3x3_duo_ker
   bool patch_m1 = false, patch_m2 = false;                     // a patch half was issued one / two steps ago
   h16x8 fh[RW + 2], fl[RW + 2];                                // A fragments of the wave's patch rows at the running tap column
   h16x8 bh0, bl0;                                              // B fragment of column tile 0 of the running step
+  [[maybe_unused]] h16x8 bh1, bl1;                             // C3D_BDIST 2: ... and of column tile 1
   // pipeline fill: patch half 0 and weight stage 0 have landed once only stages 1 .. LA-1 are in flight
   LOFTR_WAITCNT_VM((LA - 1) * BQ);
   __builtin_amdgcn_s_barrier();
 #pragma unroll
   for (int jr = 0; jr < RW; ++jr) C3D_LOAD_ROW(jr, patch_base, 0);
   C3D_LOAD_B(bh0, bl0, bring_base, 0);
+  if (C3D_BDIST == 2) { C3D_LOAD_B(bh1, bl1, bring_base, (NJ > 1 ? 1 : 0)); }
 
   // One step = one tap x one 16-wide k-step.  Its A rows and its first B fragment are already in registers (read during the
   // previous step); the barrier of step s guarantees that weight stage s + 1 (and the patch half it may open) has landed.
@@ -276,11 +281,12 @@ __global__ __launch_bounds__(CF::WAVES * 64, CF::WG_PER_CU) void conv3x3_duo_ker
        tile j + 1 (tile 0 of the next step after the last) and, in groups 0 / 1, the patch rows the NEXT step needs (after the last \
        step: harmless reads of stale LDS).  Rows are overwritten in place: the running step reads rows KY .. KY + RW - 1. */ \
     h16x8 ch__ = bh0, cl__ = bl0;                                                                           \
+    [[maybe_unused]] h16x8 dh__ = bh1, dl__ = bl1;             /* C3D_BDIST 2: the fragment after the running one */ \
     _Pragma("unroll") for (int j = 0; j < (NJ_); ++j) {                                                     \
       h16x8 nh__, nl__;                                                                                     \
       if (!C3D_PROBE_READS) { nh__ = ch__; nl__ = cl__; }                                                   \
-      else if (j + 1 < (NJ_)) { C3D_LOAD_B(nh__, nl__, sB__, j + 1); }                                      \
-      else { C3D_LOAD_B(nh__, nl__, bring_base + nstage__ * CF::BSTAGE_BYTES, 0); }                         \
+      else if (j + C3D_BDIST < (NJ_)) { C3D_LOAD_B(nh__, nl__, sB__, j + C3D_BDIST); }                      \
+      else { C3D_LOAD_B(nh__, nl__, bring_base + nstage__ * CF::BSTAGE_BYTES, (j + C3D_BDIST - (NJ_)) % (NJ_)); } \
       if (C3D_PROBE_READS && j < ((KY) < 2 ? 1 : RW)) {                                                     \
         if ((KY) < 2) { C3D_LOAD_ROW((KY) + RW, sP, KX); }                                                  \
         else if ((KX) < 2) { C3D_LOAD_ROW(j, sP, (KX) + 1); }                                               \
@@ -292,10 +298,12 @@ __global__ __launch_bounds__(CF::WAVES * 64, CF::WG_PER_CU) void conv3x3_duo_ker
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[(KY) + i], cl__, acc[i][j], 0, 0, 0);         \
       _Pragma("unroll") for (int i = 0; i < RW; ++i)                                                        \
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[(KY) + i], ch__, acc[i][j], 0, 0, 0);         \
-      ch__ = nh__; cl__ = nl__;                                                                             \
+      if (C3D_BDIST == 2) { ch__ = dh__; cl__ = dl__; dh__ = nh__; dl__ = nl__; }                           \
+      else { ch__ = nh__; cl__ = nl__; }                                                                    \
     }                                                                                                       \
     if (C3D_PROBE_READS) c3d::pin_groups<0, (NJ_), RW, (KY)>();                                             \
     bh0 = ch__; bl0 = cl__;                                                                                 \
+    if (C3D_BDIST == 2) { bh1 = dh__; bl1 = dl__; }                                                         \
     stage = nstage__;                                                                                       \
     ++s;                                                                                                    \
   }
