@@ -247,7 +247,7 @@ __global__ __launch_bounds__(CF::WAVES * 64, CF::WG_PER_CU) void conv3x3_duo_ker
   bool patch_m1 = false, patch_m2 = false;                     // a patch half was issued one / two steps ago
   h16x8 fh[RW + 2], fl[RW + 2];                                // A fragments of the wave's patch rows at the running tap column
   h16x8 bh0, bl0;                                              // B fragment of column tile 0 of the running step
-  [[maybe_unused]] h16x8 bh1, bl1;                             // C3D_BDIST 2: ... and of column tile 1
+  [[maybe_unused]] h16x8 bh1 = {}, bl1 = {};                   // C3D_BDIST 2: ... and of column tile 1
   // pipeline fill: patch half 0 and weight stage 0 have landed once only stages 1 .. LA-1 are in flight
   LOFTR_WAITCNT_VM((LA - 1) * BQ);
   __builtin_amdgcn_s_barrier();
