@@ -40,8 +40,9 @@ typedef enum {
  * 14: training-side consumers (loftr_spvs_coarse / _fine, loftr_coarse_loss_sums, loftr_fine_loss_sums);
  * 16: backward of the matching heads and their losses (loftr_*_grad, loftr_dual_softmax_bwd, loftr_sinkhorn_bwd,
  *     loftr_fine_match_bwd);
- * 17: loftr_head_feat_grads (the feature-gradient GEMMs of both coarse heads) */
-#define LOFTR_HIP_ABI_VERSION 17
+ * 17: loftr_head_feat_grads (the feature-gradient GEMMs of both coarse heads);
+ * 18: loftr_encoder_layer_bwd */
+#define LOFTR_HIP_ABI_VERSION 18
 
 int loftr_hip_abi_version(void);
 const char* loftr_hip_status_string(int status);
@@ -91,6 +92,20 @@ size_t loftr_encoder_workspace_bytes(int nb, int L, int S, int C);
 int loftr_encoder_layer_fwd(const float* x, const float* source, const uint8_t* x_mask,
                             const uint8_t* source_mask, const loftr_layer_weights* w, float* out,
                             int nb, int L, int S, int C, int H, void* ws, size_t ws_bytes,
+                            void* stream);
+
+/* Backward of loftr_encoder_layer_fwd (what torch.autograd derives from transformer.py:35-58 + linear_attention.py:20-47):
+ * from grad_out = dL/d out [nb,L,C]:  grad_x [nb,L,C], grad_source [nb,S,C] (WRITTEN, not accumulated: a self layer's caller adds
+ * the two) and the gradients of the ten weight tensors (written into the caller's buffers, shapes as loftr_layer_weights).
+ * The layer is recomputed from (x, source) in the workspace; C in {128, 256}, head dimension 16 or 32. */
+typedef struct {
+  float* q_proj; float* k_proj; float* v_proj; float* merge; float* mlp0; float* mlp2;
+  float* norm1_w; float* norm1_b; float* norm2_w; float* norm2_b;
+} loftr_layer_grads;
+size_t loftr_encoder_layer_bwd_workspace_bytes(int nb, int L, int S, int C, int H);
+int loftr_encoder_layer_bwd(const float* x, const float* source, const uint8_t* x_mask, const uint8_t* source_mask,
+                            const loftr_layer_weights* w, const float* grad_out, float* grad_x, float* grad_source,
+                            const loftr_layer_grads* gw, int nb, int L, int S, int C, int H, void* ws, size_t ws_bytes,
                             void* stream);
 
 /* Replaces: LocalFeatureTransformer.forward (transformer.py:80-101), in place on feat0/feat1.

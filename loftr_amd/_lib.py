@@ -49,6 +49,8 @@ SIGNATURES = {
     "loftr_pos_encode_flatten": (_i, [C.POINTER(FMap), _p, _i, _i, _p, _i, _i, _p]),
     "loftr_encoder_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "loftr_encoder_layer_fwd": (_i, [_p, _p, _p, _p, C.POINTER(LayerWeights), _p, _i, _i, _i, _i, _i, _p, _sz, _p]),
+    "loftr_encoder_layer_bwd_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
+    "loftr_encoder_layer_bwd": (_i, [_p, _p, _p, _p, C.POINTER(LayerWeights), _p, _p, _p, C.POINTER(LayerWeights), _i, _i, _i, _i, _i, _p, _sz, _p]),
     "loftr_transformer_fwd": (_i, [_p, _p, _p, _p, C.POINTER(LayerWeights), C.POINTER(_i), _i, _i, _i, _i, _i, _i,
                                    _p, _sz, _p, _sz, _p]),
     "loftr_transformer_prepared_bytes": (_sz, [_i, _i]),
@@ -103,7 +105,7 @@ SIGNATURES = {
     "loftr_linear_fwd": (_i, [_p, _p, _p, _i, _i, _i, _p, _sz, _p]),
 }
 
-ABI_VERSION = 17
+ABI_VERSION = 18
 _lib = None
 
 

@@ -6,9 +6,10 @@ inputs, for the dual-softmax configuration (the Sinkhorn one swaps the first nod
     feat_c0, feat_c1 --CoarseMatching (coarse_matching.py:105-119)--> conf_matrix --LoFTRLoss (loftr_loss.py:22-99)---> loss_c
     feat_f0, feat_f1 --FineMatching   (fine_matching.py:43-57)-----> expec_f     --LoFTRLoss (loftr_loss.py:108-157)-> loss_f
 
-The loss nodes are loftr_amd.training.LoFTRLoss (same mechanism).  Nothing upstream of the heads has a backward: the
-gradients stop at the transformer outputs (LoFTR.head_grads hands those out as leaves).  The Sinkhorn head
-(coarse_matching.py:121-143, conf_matrix_with_bin, the bin_score parameter) has its backward too: _SinkhornMatch.
+The loss nodes are loftr_amd.training.LoFTRLoss (same mechanism).  The Sinkhorn head (coarse_matching.py:121-143,
+conf_matrix_with_bin, the bin_score parameter) has its backward too: _SinkhornMatch.  Round 4: LoFTREncoderLayer is a node as well
+(_EncoderLayer, csrc/encoder_bwd.hip), so both LocalFeatureTransformers are differentiable in their inputs and weights when they
+run layer by layer (LocalFeatureTransformer.forward does that whenever a gradient is wanted); FinePreprocess and the backbone are not.
 
 No CPU fallback: the nodes call loftr_amd.ops, which raises on non-GPU tensors.
 """
@@ -111,6 +112,39 @@ class _FineMatch(torch.autograd.Function):
 
 def fine_match(feat_f0, feat_f1, mkpts1_c, b_ids, scale, scale1=None):
     return _FineMatch.apply(feat_f0, feat_f1, mkpts1_c, b_ids, scale, scale1)
+
+
+class _EncoderLayer(torch.autograd.Function):
+    """One LoFTREncoderLayer (transformer.py:35-58): forward = the fused inference kernels (ops.encoder_layer), backward =
+    loftr_encoder_layer_bwd (csrc/encoder_bwd.hip: recomputes the layer from (x, source), then differentiates it).  Differentiable
+    in x, source and the ten weight tensors."""
+    FIELDS = ("q_proj", "k_proj", "v_proj", "merge", "mlp0", "mlp2", "norm1_w", "norm1_b", "norm2_w", "norm2_b")
+
+    @staticmethod
+    def forward(ctx, x, source, x_mask, source_mask, nhead, *weights):
+        w = dict(zip(_EncoderLayer.FIELDS, (t.detach() for t in weights)))
+        out = ops.encoder_layer(x.detach().contiguous(), source.detach().contiguous(), ops.layer_weights_struct(w), nhead, x_mask, source_mask)
+        ctx.save_for_backward(x, source, *weights)
+        ctx.meta = (x_mask, source_mask, nhead)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_out):
+        x, source, *weights = ctx.saved_tensors
+        x_mask, source_mask, nhead = ctx.meta
+        w = dict(zip(_EncoderLayer.FIELDS, (t.detach().contiguous() for t in weights)))
+        gx, gs, gw = ops.encoder_layer_bwd(x.detach().contiguous(), source.detach().contiguous(), w, grad_out.contiguous(), nhead,
+                                           x_mask, source_mask)
+        need = ctx.needs_input_grad
+        return ((gx if need[0] else None), (gs if need[1] else None), None, None, None,
+                *[(gw[f] if need[5 + i] else None) for i, f in enumerate(_EncoderLayer.FIELDS)])
+
+
+def encoder_layer(x, source, weights, nhead, x_mask=None, source_mask=None):
+    """weights: dict(field -> tensor) (LoFTREncoderLayer.weight_tensors()).  The same tensor may be passed as x and source (self
+    attention): autograd adds the two gradients."""
+    return _EncoderLayer.apply(x, source, x_mask, source_mask, nhead, *[weights[f] for f in _EncoderLayer.FIELDS])
 
 
 def wants_grad(*tensors):

@@ -1,0 +1,6 @@
+// Internal launcher of the on-the-fly-split GEMM of head_grads.hip (used by the coarse heads' backward and by the weight
+// gradients of encoder_bwd.hip): out[n][m][c] = alpha * sum_k A[n](m, k) * B[n][k][c], fp32 in / out, C % 32 == 0, C <= 256.
+#pragma once
+#include "common.h"
+int launch_head_grad(const float* a, long a_ld, long a_bs, bool trans, const float* b, long b_ld, long b_bs, float* out, long o_ld,
+                     long o_bs, int M, int K, int ktot, int C, int nbatch, float alpha, hipStream_t st);

@@ -17,6 +17,7 @@
 //   maximum leaves that window; when it changes the accumulators are rescaled by the exact ratio (a wave-uniform, rare branch), so
 //   one accumulator set serves the whole reduction and the result is exact in the scales.
 #include "gemm.h"
+#include "head_grads.h"
 
 namespace {
 namespace hg {
@@ -26,9 +27,10 @@ struct __attribute__((packed, aligned(4))) F4U { f32x4 v; };
 
 struct Args {
   const float* a; long a_ld, a_bs;      // A source: TRANS = false: A[m][k] = a[n * a_bs + m * a_ld + k];  true: a[n * a_bs + k * a_ld + m]
-  const float* b; long b_bs;            // B[k][c] = b[n * b_bs + k * C + c]
-  float* out; long o_bs;                // out[m][c] = alpha * sum_k A[m][k] B[k][c]
-  int M, K, C, NT;                      // NT = C / 32
+  const float* b; long b_ld, b_bs;      // B[k][c] = b[n * b_bs + k * b_ld + c]
+  float* out; long o_ld, o_bs;          // out[m][c] = alpha * sum_k A[m][k] B[k][c] at out[n * o_bs + m * o_ld + c]
+  int M, K, C, NT;                      // NT = C / 32; K = reduction length of a batch element ...
+  int Ktot;                             // ... except the last one when the batch is a split of ONE reduction of Ktot (0 = not a split)
   float alpha;
   int tiles_m, N;
 };
@@ -55,7 +57,8 @@ __global__ __launch_bounds__(WAVES * 64, 2) void head_grad_kernel(Args p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 5, li = lane & 31;
   const float* A = p.a + (long)n * p.a_bs;
   const float* B = p.b + (long)n * p.b_bs;
-  const int M = p.M, K = p.K, C = p.C, NT = p.NT;
+  const int M = p.M, C = p.C, NT = p.NT;
+  const int K = p.Ktot ? min(p.K, p.Ktot - n * p.K) : p.K;          // split-K batches: the last chunk is shorter
   const int nk = ceil_div(K, BK);
 
   // ---- staging registers: A 16 floats, B 32 floats per thread and k-tile
@@ -96,7 +99,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void head_grad_kernel(Args p) {
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
       const int k = kb2 + q;
-      rb[q] = (cb < C && k < K) ? *reinterpret_cast<const f32x4*>(B + (long)k * C + cb) : f32x4{0.f, 0.f, 0.f, 0.f};
+      rb[q] = (cb < C && k < K) ? *reinterpret_cast<const f32x4*>(B + (long)k * p.b_ld + cb) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
   };
   // registers -> (hi, lo) halves -> LDS rows of 128 B (chunks 0..3 hi, 4..7 lo; 16-B chunk c of row r at slot c ^ ((r >> 1) & 7))
@@ -220,12 +223,26 @@ __global__ __launch_bounds__(WAVES * 64, 2) void head_grad_kernel(Args p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int m = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
-      if (m < M) O[(long)m * C + c] = acc[j][r] * undo;
+      if (m < M) O[(long)m * p.o_ld + c] = acc[j][r] * undo;
     }
   }
 }
 }  // namespace hg
 }  // namespace
+
+// Internal launcher (head_grads.h): out[n] = alpha * op(A[n]) . B[n] for nbatch batch elements; trans: A is read as [k][m].  ktot > 0:
+// the batch is a split of ONE reduction of length ktot into chunks of K (split-K: the caller sums the nbatch partial outputs).
+int launch_head_grad(const float* a, long a_ld, long a_bs, bool trans, const float* b, long b_ld, long b_bs, float* out, long o_ld,
+                     long o_bs, int M, int K, int ktot, int C, int nbatch, float alpha, hipStream_t st) {
+  if (C % 32 != 0 || C > 32 * hg::MAXT || (b_ld & 3) || M <= 0 || K <= 0 || nbatch <= 0) return LOFTR_ERR_UNSUPPORTED;
+  hg::Args g{};
+  g.a = a; g.a_ld = a_ld; g.a_bs = a_bs; g.b = b; g.b_ld = b_ld; g.b_bs = b_bs; g.out = out; g.o_ld = o_ld; g.o_bs = o_bs;
+  g.M = M; g.K = K; g.Ktot = ktot; g.C = C; g.NT = C / 32; g.alpha = alpha; g.N = nbatch; g.tiles_m = ceil_div(M, hg::BM);
+  if (trans) hipLaunchKernelGGL((hg::head_grad_kernel<true>), dim3(xcd_grid(g.tiles_m * nbatch, 1)), dim3(hg::WAVES * 64), 0, st, g);
+  else hipLaunchKernelGGL((hg::head_grad_kernel<false>), dim3(xcd_grid(g.tiles_m * nbatch, 1)), dim3(hg::WAVES * 64), 0, st, g);
+  LOFTR_CHECK_LAUNCH();
+  return LOFTR_OK;
+}
 
 // g0 [N,L,C] = alpha * dsim . feat_c1,  g1 [N,S,C] = alpha * dsim^T . feat_c0 (either may be null).  dsim: [N] matrices of L x S with row
 // pitch dsim_ld and batch stride dsim_bs (floats): the Sinkhorn head hands in the interior of its [L+1, S+1] gradient.
@@ -235,18 +252,9 @@ extern "C" int loftr_head_feat_grads(const float* dsim, long dsim_ld, long dsim_
   if (C % 32 != 0 || C > 32 * hg::MAXT) return LOFTR_ERR_UNSUPPORTED;
   if (N == 0) return LOFTR_OK;
   hipStream_t st = (hipStream_t)stream;
-  hg::Args a{};
-  a.C = C; a.NT = C / 32; a.alpha = alpha; a.N = N;
-  if (g0) {
-    a.a = dsim; a.a_ld = dsim_ld; a.a_bs = dsim_bs; a.b = feat_c1; a.b_bs = (long)S * C; a.out = g0; a.o_bs = (long)L * C;
-    a.M = L; a.K = S; a.tiles_m = ceil_div(L, hg::BM);
-    hipLaunchKernelGGL((hg::head_grad_kernel<false>), dim3(xcd_grid(a.tiles_m * N, 1)), dim3(hg::WAVES * 64), 0, st, a);
-  }
-  if (g1) {
-    a.a = dsim; a.a_ld = dsim_ld; a.a_bs = dsim_bs; a.b = feat_c0; a.b_bs = (long)L * C; a.out = g1; a.o_bs = (long)S * C;
-    a.M = S; a.K = L; a.tiles_m = ceil_div(S, hg::BM);
-    hipLaunchKernelGGL((hg::head_grad_kernel<true>), dim3(xcd_grid(a.tiles_m * N, 1)), dim3(hg::WAVES * 64), 0, st, a);
-  }
-  LOFTR_CHECK_LAUNCH();
-  return LOFTR_OK;
+  int rc = LOFTR_OK;
+  if (g0) rc = launch_head_grad(dsim, dsim_ld, dsim_bs, false, feat_c1, C, (long)S * C, g0, C, (long)L * C, L, S, 0, C, N, alpha, st);
+  if (rc == LOFTR_OK && g1)
+    rc = launch_head_grad(dsim, dsim_ld, dsim_bs, true, feat_c0, C, (long)L * C, g1, C, (long)S * C, S, L, 0, C, N, alpha, st);
+  return rc;
 }

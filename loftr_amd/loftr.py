@@ -73,11 +73,14 @@ class LoFTREncoderLayer(nn.Module):
         self.norm1 = nn.LayerNorm(d_model)
         self.norm2 = nn.LayerNorm(d_model)
 
+    def weight_tensors(self):
+        return {"q_proj": self.q_proj.weight, "k_proj": self.k_proj.weight, "v_proj": self.v_proj.weight,
+                "merge": self.merge.weight, "mlp0": self.mlp[0].weight, "mlp2": self.mlp[2].weight,
+                "norm1_w": self.norm1.weight, "norm1_b": self.norm1.bias,
+                "norm2_w": self.norm2.weight, "norm2_b": self.norm2.bias}
+
     def weight_struct(self):
-        sd = {"q_proj": self.q_proj.weight, "k_proj": self.k_proj.weight, "v_proj": self.v_proj.weight,
-              "merge": self.merge.weight, "mlp0": self.mlp[0].weight, "mlp2": self.mlp[2].weight,
-              "norm1_w": self.norm1.weight, "norm1_b": self.norm1.bias,
-              "norm2_w": self.norm2.weight, "norm2_b": self.norm2.bias}
+        sd = self.weight_tensors()
         for k, v in sd.items():
             if not v.is_contiguous() or v.dtype != torch.float32 or not v.is_cuda:
                 raise ops._lib.LoftrHipError(f"{k}: parameters must be contiguous float32 GPU tensors "
@@ -85,6 +88,9 @@ class LoFTREncoderLayer(nn.Module):
         return ops.layer_weights_struct(sd)
 
     def forward(self, x, source, x_mask=None, source_mask=None):
+        if autograd.wants_grad(x, source, *self.parameters()):
+            self.weight_struct()                                  # (dtype / device checks)
+            return autograd.encoder_layer(x, source, self.weight_tensors(), self.nhead, x_mask, source_mask)
         return ops.encoder_layer(x.contiguous(), source.contiguous(), self.weight_struct(), self.nhead,
                                  x_mask, source_mask)
 
@@ -122,6 +128,17 @@ class LocalFeatureTransformer(nn.Module):
         for name in self.layer_names:
             if name not in ("self", "cross"):
                 raise KeyError
+        if autograd.wants_grad(feat0, feat1, *self.parameters()):
+            # differentiable form: the reference's own layer loop (transformer.py:91-99) over autograd nodes whose forward and
+            # backward are the HIP kernels (loftr_amd/autograd.py:_EncoderLayer)
+            for layer, name in zip(self.layers, self.layer_names):
+                if name == "self":
+                    feat0 = layer(feat0, feat0, mask0, mask0)
+                    feat1 = layer(feat1, feat1, mask1, mask1)
+                else:
+                    feat0 = layer(feat0, feat1, mask0, mask1)
+                    feat1 = layer(feat1, feat0, mask1, mask0)
+            return feat0, feat1
         structs = [layer.weight_struct() for layer in self.layers]
         return ops.transformer(feat0.contiguous(), feat1.contiguous(), structs, self.layer_names, self.nhead,
                                mask0, mask1, inplace=inplace, prepared=self._prepared(structs, feat0.device))

@@ -155,6 +155,30 @@ def encoder_layer(x, source, w_struct, nhead, x_mask=None, source_mask=None, out
     return out
 
 
+GRAD_FIELD_SHAPES = lambda Cc: {"q_proj": (Cc, Cc), "k_proj": (Cc, Cc), "v_proj": (Cc, Cc), "merge": (Cc, Cc), "mlp0": (2 * Cc, 2 * Cc),
+                                "mlp2": (Cc, 2 * Cc), "norm1_w": (Cc,), "norm1_b": (Cc,), "norm2_w": (Cc,), "norm2_b": (Cc,)}
+
+
+@_on_device
+def encoder_layer_bwd(x, source, weights, grad_out, nhead, x_mask=None, source_mask=None):
+    """Backward of one LoFTREncoderLayer (transformer.py:35-58 under autograd): weights = dict(field -> tensor) as for
+    layer_weights_struct.  Returns (grad_x [nb,L,C], grad_source [nb,S,C], dict(field -> weight gradient))."""
+    _need(x, "x"); _need(source, "source"); _need(grad_out, "grad_out")
+    nb, L, Cc = x.shape
+    S = source.shape[1]
+    assert tuple(grad_out.shape) == (nb, L, Cc)
+    xm, sm = _mask_u8(x_mask, "x_mask"), _mask_u8(source_mask, "source_mask")
+    dev = x.device
+    gx, gs = torch.empty_like(x), torch.empty_like(source)
+    grads = {k: torch.empty(shp, device=dev, dtype=torch.float32) for k, shp in GRAD_FIELD_SHAPES(Cc).items()}
+    lib = _lib.load()
+    ws = workspace(lib.loftr_encoder_layer_bwd_workspace_bytes(nb, L, S, Cc, nhead), dev)
+    wst, gst = layer_weights_struct(weights), layer_weights_struct(grads)
+    check(lib.loftr_encoder_layer_bwd(_ptr(x), _ptr(source), _ptr(xm), _ptr(sm), C.byref(wst), _ptr(grad_out), _ptr(gx), _ptr(gs),
+                                      C.byref(gst), nb, L, S, Cc, nhead, _ptr(ws), ws.numel(), _stream()), "loftr_encoder_layer_bwd")
+    return gx, gs, grads
+
+
 def stacked_halves(a, b):
     """The tensor [a; b] WITHOUT a copy when a and b already are the two batch halves of one buffer
     (e.g. ``x.split(n)`` of a stacked pair batch, or the outputs of pos_encode_flatten / fine_preprocess);

@@ -11,6 +11,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+GOLD = os.path.join(HERE, "golden")
 _spec = importlib.util.spec_from_file_location("make_golden_grad", os.path.join(HERE, "golden", "make_golden_grad.py"))
 MG = importlib.util.module_from_spec(_spec)
 _spec.loader.exec_module(MG)
@@ -209,3 +210,70 @@ def test_head_feat_grads_vs_fp64(N, L, S, C, strided):
     assert rel <= 2e-4, rel
     only0, none1 = ops.head_feat_grads(d, f0.cuda(), f1.cuda(), a, want1=False)
     assert none1 is None and torch.equal(only0, g0)
+
+
+def _layer_golden(name):
+    spec = importlib.util.spec_from_file_location("make_golden_layer_grad", os.path.join(GOLD, "make_golden_layer_grad.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    g = np.load(os.path.join(GOLD, f"{name}.npz"))
+    rc = json.loads(str(g["recipe"]))
+    return mod, rc, mod.build(rc), g
+
+
+def _check_weight_grad(mod, g, key, got, tol=1e-3):
+    """A weight gradient against its golden digest (make_golden_layer_grad.digest): whole vectors; sub-matrix, row and column sums of matrices."""
+    got = got.detach().cpu().numpy()
+    if f"{key}/sub" not in g:
+        ref = g[key]
+        assert np.abs(got - ref).max() <= tol * max(np.abs(ref).max(), 1e-6), key
+        return
+    d = mod.digest(key, got)
+    scale = float(g[f"{key}/absmax"])
+    assert np.abs(d[f"{key}/sub"] - g[f"{key}/sub"]).max() <= tol * scale, key
+    for part in ("rowsum", "colsum"):
+        ref = g[f"{key}/{part}"]
+        assert np.abs(d[f"{key}/{part}"] - ref).max() <= tol * max(np.abs(ref).max(), scale), (key, part)
+
+
+@pytest.mark.parametrize("name", ["glayer_self", "glayer_cross_mask", "glayer_fine"])
+def test_encoder_layer_backward_against_reference_autograd(name):
+    """loftr_encoder_layer_bwd (csrc/encoder_bwd.hip) vs the gradients torch.autograd derives from the reference's own LoFTREncoderLayer
+    (tests/golden/make_golden_layer_grad.py): d x, d source and the ten weight gradients, 1e-3 relative."""
+    from loftr_amd import ops
+    mod, rc, inp, g = _layer_golden(name)
+    dev = "cuda:0"
+    t = lambda a: None if a is None else torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    w = {f: t(inp["w"][n]) for f, n in mod.FIELDS}
+    x, s = t(inp["x"]), t(inp["source"])
+    out = ops.encoder_layer(x, s, ops.layer_weights_struct(w), rc["H"], t(inp["x_mask"]), t(inp["source_mask"]))
+    assert np.abs(out.cpu().numpy() - g["out"]).max() <= 2e-4 * np.abs(g["out"]).max()
+    gx, gs, gw = ops.encoder_layer_bwd(x, s, w, t(inp["G"]), rc["H"], t(inp["x_mask"]), t(inp["source_mask"]))
+    for got, key in ((gx, "grad_x"), (gs, "grad_source")):
+        assert np.abs(got.cpu().numpy() - g[key]).max() <= 1e-3 * np.abs(g[key]).max(), key
+    for f, _ in mod.FIELDS:
+        _check_weight_grad(mod, g, f"grad_{f}", gw[f])
+
+
+def test_transformer_backward_against_reference_autograd():
+    """The whole coarse LocalFeatureTransformer under autograd (layer nodes: loftr_amd/autograd.py:_EncoderLayer): leaves = both inputs
+    and every weight, against the reference's own module (gtf_coarse: self / cross x 2, padding masks, L != S)."""
+    from loftr_amd.loftr import LocalFeatureTransformer
+    mod, rc, inp, g = _layer_golden("gtf_coarse")
+    dev = "cuda:0"
+    t = lambda a: None if a is None else torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    tf = LocalFeatureTransformer(dict(d_model=rc["C"], nhead=rc["H"], layer_names=rc["layers"], attention="linear")).to(dev).train()
+    tf.load_state_dict({f"layers.{i}.{k}": t(v) for i, w in enumerate(inp["w"]) for k, v in w.items()}, strict=True)
+    f0, f1 = t(inp["feat0"]).requires_grad_(True), t(inp["feat1"]).requires_grad_(True)
+    o0, o1 = tf(f0, f1, t(inp["mask0"]), t(inp["mask1"]))
+    for got, key in ((o0, "out0"), (o1, "out1")):
+        assert np.abs(got.detach().cpu().numpy() - g[key]).max() <= 3e-4 * np.abs(g[key]).max(), key
+    ((o0 * t(inp["G0"])).sum() + (o1 * t(inp["G1"])).sum()).backward()
+    for got, key in ((f0.grad, "grad_feat0"), (f1.grad, "grad_feat1")):
+        assert np.abs(got.cpu().numpy() - g[key]).max() <= 1e-3 * np.abs(g[key]).max(), key
+    names = {"q_proj": "q_proj.weight", "k_proj": "k_proj.weight", "v_proj": "v_proj.weight", "merge": "merge.weight", "mlp0": "mlp.0.weight",
+             "mlp2": "mlp.2.weight", "norm1_w": "norm1.weight", "norm1_b": "norm1.bias", "norm2_w": "norm2.weight", "norm2_b": "norm2.bias"}
+    for i, layer in enumerate(tf.layers):
+        params = dict(layer.named_parameters())
+        for f, n in names.items():
+            _check_weight_grad(mod, g, f"grad_l{i}_{f}", params[n].grad)
