@@ -41,8 +41,9 @@ typedef enum {
  * 16: backward of the matching heads and their losses (loftr_*_grad, loftr_dual_softmax_bwd, loftr_sinkhorn_bwd,
  *     loftr_fine_match_bwd);
  * 17: loftr_head_feat_grads (the feature-gradient GEMMs of both coarse heads);
- * 18: loftr_encoder_layer_bwd */
-#define LOFTR_HIP_ABI_VERSION 18
+ * 18: loftr_encoder_layer_bwd;
+ * 19: loftr_fine_preprocess_bwd */
+#define LOFTR_HIP_ABI_VERSION 19
 
 int loftr_hip_abi_version(void);
 const char* loftr_hip_status_string(int status);
@@ -189,6 +190,17 @@ int loftr_fine_preprocess(const loftr_fmap* feat_f0, const loftr_fmap* feat_f1,
                           const float* down_w, const float* down_b, const float* merge_w,
                           const float* merge_b, float* out0, float* out1, void* ws,
                           size_t ws_bytes, void* stream);
+
+/* Backward of loftr_fine_preprocess (fine_preprocess.py:29-59 under autograd) from grad_out0 / grad_out1 [M, W*W, Cf].
+ *   grad_f0 / grad_f1 (maps laid out like feat_f0 / feat_f1), grad_c0 [N,L,Cc], grad_c1 [N,S,Cc]: ADDED TO (zero-fill them first:
+ *   windows overlap and a cell may carry several matches; float atomics).  The four parameter gradients are written. */
+size_t loftr_fine_preprocess_bwd_workspace_bytes(int M, int W, int Cf, int Cc);
+int loftr_fine_preprocess_bwd(const loftr_fmap* feat_f0, const loftr_fmap* feat_f1, const float* feat_c0, const float* feat_c1,
+                              int L, int S, int Cc, const int64_t* b_ids, const int64_t* i_ids, const int64_t* j_ids, int M,
+                              int w0c, int w1c, int stride, int W, int Cf, const float* down_w, const float* down_b,
+                              const float* merge_w, const float* grad_out0, const float* grad_out1, const loftr_fmap* grad_f0,
+                              const loftr_fmap* grad_f1, float* grad_c0, float* grad_c1, float* grad_down_w, float* grad_down_b,
+                              float* grad_merge_w, float* grad_merge_b, void* ws, size_t ws_bytes, void* stream);
 
 /* ---- FineMatching ---------------------------------------------------------------------------
  * Replaces: FineMatching.forward + get_fine_match (src/loftr/utils/fine_matching.py:15-74).

@@ -62,6 +62,9 @@ SIGNATURES = {
     "loftr_fine_preprocess_workspace_bytes": (_sz, [_i, _i, _i]),
     "loftr_fine_preprocess": (_i, [C.POINTER(FMap), C.POINTER(FMap), _p, _p, _i, _i, _i, _p, _p, _p, _i, _i, _i, _i,
                                    _i, _i, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
+    "loftr_fine_preprocess_bwd_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    "loftr_fine_preprocess_bwd": (_i, [C.POINTER(FMap), C.POINTER(FMap), _p, _p, _i, _i, _i, _p, _p, _p, _i, _i, _i, _i, _i, _i,
+                                       _p, _p, _p, _p, _p, C.POINTER(FMap), C.POINTER(FMap), _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
     "loftr_fine_match": (_i, [_p, _p, _i, _i, _i, _p, _p, _f, _p, _p, _p, _p]),
     "loftr_conv_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "loftr_conv_bn_act": (_i, [_p, _i, _i, _i, _i, _p, C.POINTER(_l), _i, _i, _i, _i, _i, _p, _p, _p, _p, _f, _i, _p, _p, _p, _p, _sz, _p, _p]),
@@ -105,7 +108,7 @@ SIGNATURES = {
     "loftr_linear_fwd": (_i, [_p, _p, _p, _i, _i, _i, _p, _sz, _p]),
 }
 
-ABI_VERSION = 18
+ABI_VERSION = 19
 _lib = None
 
 

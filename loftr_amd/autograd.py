@@ -147,5 +147,42 @@ def encoder_layer(x, source, weights, nhead, x_mask=None, source_mask=None):
     return _EncoderLayer.apply(x, source, x_mask, source_mask, nhead, *[weights[f] for f in _EncoderLayer.FIELDS])
 
 
+class _FinePreprocess(torch.autograd.Function):
+    """FinePreprocess (fine_preprocess.py:29-59): forward ops.fine_preprocess, backward loftr_fine_preprocess_bwd (csrc/fine_bwd.hip).
+    Differentiable in the two fine maps, the two coarse token tensors and the four parameters; the two outputs are returned as ONE
+    stacked tensor [2M, WW, Cf] (the fine transformer runs on its halves)."""
+
+    @staticmethod
+    def forward(ctx, feat_f0, feat_f1, feat_c0, feat_c1, down_w, down_b, merge_w, merge_b, ids, geo):
+        b_ids, i_ids, j_ids = ids
+        hw0_c, hw1_c, W, stride = geo
+        o0, o1 = ops.fine_preprocess(feat_f0.detach(), feat_f1.detach(), feat_c0.detach(), feat_c1.detach(), b_ids, i_ids, j_ids, hw0_c, hw1_c,
+                                     W, stride, down_w=down_w.detach(), down_b=down_b.detach(), merge_w=merge_w.detach(),
+                                     merge_b=merge_b.detach())
+        ctx.save_for_backward(feat_f0, feat_f1, feat_c0, feat_c1, down_w, down_b, merge_w)
+        ctx.meta = (ids, geo)
+        stacked = ops.stacked_halves(o0, o1)
+        return stacked if stacked is not None else torch.cat([o0, o1], 0)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad):
+        feat_f0, feat_f1, feat_c0, feat_c1, down_w, down_b, merge_w = ctx.saved_tensors
+        (b_ids, i_ids, j_ids), (hw0_c, hw1_c, W, stride) = ctx.meta
+        M = b_ids.shape[0]
+        g = grad.contiguous()
+        r = ops.fine_preprocess_bwd(feat_f0.detach(), feat_f1.detach(), feat_c0.detach().contiguous(), feat_c1.detach().contiguous(), b_ids,
+                                    i_ids, j_ids, hw0_c, hw1_c, W, stride, down_w.detach(), down_b.detach(), merge_w.detach(), g[:M], g[M:])
+        need = ctx.needs_input_grad
+        return tuple(r[k] if need[k] else None for k in range(8)) + (None, None)
+
+
+def fine_preprocess(feat_f0, feat_f1, feat_c0, feat_c1, ids, geo, down_w, down_b, merge_w, merge_b):
+    """-> (feat_f0_unfold, feat_f1_unfold) [M, WW, Cf] with the graph."""
+    st = _FinePreprocess.apply(feat_f0, feat_f1, feat_c0, feat_c1, down_w, down_b, merge_w, merge_b, ids, geo)
+    M = ids[0].shape[0]
+    return st[:M], st[M:]
+
+
 def wants_grad(*tensors):
     return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)

@@ -21,7 +21,6 @@ extern "C" int loftr_linear_fwd(const float* a, const float* w, float* out, int 
 namespace {
 namespace eb {
 constexpr int MAXD = 32;            // head dimension (coarse 32, fine 16)
-constexpr int KCHUNK = 512;         // split-K chunk of the weight gradients (tokens per partial)
 
 __device__ __forceinline__ float elu1d(float x) { return x > 0.f ? 1.f : __expf(x); }      // d/dx (elu(x) + 1)
 
@@ -221,14 +220,6 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
     part[((long)blockIdx.x * 2 + 1) * C + c] = (red[0][1][c] + red[1][1][c]) + (red[2][1][c] + red[3][1][c]);
   }
 }
-// out[i] = sum_p part[p * stride + i]   (ascending p: deterministic)
-__global__ void reduce_partials_kernel(const float* __restrict__ part, float* __restrict__ out, int P, long stride, long n) {
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  float s = 0.f;
-  for (int p = 0; p < P; ++p) s += part[(long)p * stride + i];
-  out[i] = s;
-}
 // hcat[t] = [x[t], m[t]]
 __global__ void concat_kernel(const float* __restrict__ x, const float* __restrict__ m, float* __restrict__ out, long rows, int C) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -284,7 +275,7 @@ Ws carve(WsAlloc& wa, int nb, int L, int S, int C, int H) {
   w.t0 = wa.take<float>(Tm * C); w.t1 = wa.take<float>(Tm * C);
   w.wqT = wa.take<float>((size_t)C * C); w.wkT = wa.take<float>((size_t)C * C); w.wvT = wa.take<float>((size_t)C * C);
   w.wmT = wa.take<float>((size_t)C * C); w.w0T = wa.take<float>((size_t)4 * C * C); w.w2T = wa.take<float>((size_t)2 * C * C);
-  w.wpart = wa.take<float>((size_t)ceil_div((int)Tm, KCHUNK) * 4 * C * C);
+  w.wpart = wa.take<float>(wgrad_part_floats((long)Tm, 2 * C, 2 * C));
   w.lnpart = wa.take<float>((size_t)ceil_div((int)T, LN_ROWS_PB) * 2 * C);
   w.st1 = wa.take<float2>(T); w.st2 = wa.take<float2>(T);
   w.lin_bytes = loftr_linear_workspace_bytes((int)Tm, 2 * C, 2 * C);
@@ -299,18 +290,6 @@ size_t ws_bytes_needed(int nb, int L, int S, int C, int H) {
 }
 inline dim3 g1d(long n) { return dim3((unsigned)((n + 255) / 256)); }
 
-// dW [O][I] = dy^T act  (dy [T, O], act [T, I]) as a split-K batch + ordered sum; I in column blocks of <= 256
-int wgrad(const float* dy, int O, const float* act, int I, long T, float* dW, float* part, hipStream_t st) {
-  const int ns = ceil_div((int)T, KCHUNK);
-  for (int c0 = 0; c0 < I; c0 += 256) {
-    const int cw = I - c0 < 256 ? I - c0 : 256;
-    const int rc = launch_head_grad(dy, O, (long)KCHUNK * O, true, act + c0, I, (long)KCHUNK * I, part + c0, I, (long)O * I, O, KCHUNK, (int)T,
-                                    cw, ns, 1.f, st);
-    if (rc) return rc;
-  }
-  hipLaunchKernelGGL(reduce_partials_kernel, g1d((long)O * I), dim3(256), 0, st, part, dW, ns, (long)O * I, (long)O * I);
-  return LOFTR_OK;
-}
 }  // namespace eb
 }  // namespace
 
@@ -363,26 +342,26 @@ extern "C" int loftr_encoder_layer_bwd(const float* x, const float* source, cons
   // ---- backward: out = x + LN2(m3)
   const int nlb = ceil_div((int)T, LN_ROWS_PB);
   hipLaunchKernelGGL(ln_bwd_kernel, dim3(nlb), dim3(256), 0, st, grad_out, a.m3, a.st2, w->norm2_w, T, C, a.dm3, a.lnpart);
-  hipLaunchKernelGGL(reduce_partials_kernel, g1d(C), dim3(256), 0, st, a.lnpart, gw->norm2_w, nlb, (long)2 * C, (long)C);
-  hipLaunchKernelGGL(reduce_partials_kernel, g1d(C), dim3(256), 0, st, a.lnpart + C, gw->norm2_b, nlb, (long)2 * C, (long)C);
+  launch_reduce_partials(a.lnpart, gw->norm2_w, nlb, (long)2 * C, (long)C, st);
+  launch_reduce_partials(a.lnpart + C, gw->norm2_b, nlb, (long)2 * C, (long)C, st);
   // m3 = h1 W2^T
   transpose(w->mlp2, a.w2T, C, C2);                                    // [C, 2C] -> [2C, C]
   LIN(a.dm3, a.w2T, a.dh1, T, C2, C);                                  // dh1 = dm3 W2
-  if ((rc = wgrad(a.dm3, C, a.h1, C2, T, gw->mlp2, a.wpart, st))) return rc;
+  if ((rc = launch_wgrad(a.dm3, C, a.h1, C2, T, gw->mlp2, a.wpart, st))) return rc;
   hipLaunchKernelGGL(relu_bwd_kernel, g1d(T * C2), dim3(256), 0, st, a.dh1, a.h1, T * C2);
   // h1 = relu(hcat W0^T)
   transpose(w->mlp0, a.w0T, C2, C2);
   LIN(a.dh1, a.w0T, a.dhcat, T, C2, C2);
-  if ((rc = wgrad(a.dh1, C2, a.hcat, C2, T, gw->mlp0, a.wpart, st))) return rc;
+  if ((rc = launch_wgrad(a.dh1, C2, a.hcat, C2, T, gw->mlp0, a.wpart, st))) return rc;
   hipLaunchKernelGGL(slice_cols_kernel, g1d(T * C), dim3(256), 0, st, a.dhcat + C, (long)C2, a.dm2, T, C);
   // m2 = LN1(m1)
   hipLaunchKernelGGL(ln_bwd_kernel, dim3(nlb), dim3(256), 0, st, a.dm2, a.m1, a.st1, w->norm1_w, T, C, a.dm1, a.lnpart);
-  hipLaunchKernelGGL(reduce_partials_kernel, g1d(C), dim3(256), 0, st, a.lnpart, gw->norm1_w, nlb, (long)2 * C, (long)C);
-  hipLaunchKernelGGL(reduce_partials_kernel, g1d(C), dim3(256), 0, st, a.lnpart + C, gw->norm1_b, nlb, (long)2 * C, (long)C);
+  launch_reduce_partials(a.lnpart, gw->norm1_w, nlb, (long)2 * C, (long)C, st);
+  launch_reduce_partials(a.lnpart + C, gw->norm1_b, nlb, (long)2 * C, (long)C, st);
   // m1 = msg0 Wm^T
   transpose(w->merge, a.wmT, C, C);
   LIN(a.dm1, a.wmT, a.dmsg0, T, C, C);
-  if ((rc = wgrad(a.dm1, C, a.msg0, C, T, gw->merge, a.wpart, st))) return rc;
+  if ((rc = launch_wgrad(a.dm1, C, a.msg0, C, T, gw->merge, a.wpart, st))) return rc;
   // linear attention
   if (D == 32)
     hipLaunchKernelGGL((attn_q_kernel<true, 32>), dim3(ceil_div(L, 256), nb * H), dim3(256), 0, st, a.q, x_mask, a.KV, a.Ksum, vlen, attn_eps,
@@ -404,9 +383,9 @@ extern "C" int loftr_encoder_layer_bwd(const float* x, const float* source, cons
   LIN(a.dk, a.wkT, a.t0, Ts, C, C);
   LIN(a.dv, a.wvT, a.t1, Ts, C, C);
   hipLaunchKernelGGL(add_rows_kernel, g1d(Ts * C), dim3(256), 0, st, a.t0, a.t1, (long)C, (const float*)nullptr, grad_source, Ts, C);
-  if ((rc = wgrad(a.dq, C, x, C, T, gw->q_proj, a.wpart, st))) return rc;
-  if ((rc = wgrad(a.dk, C, source, C, Ts, gw->k_proj, a.wpart, st))) return rc;
-  if ((rc = wgrad(a.dv, C, source, C, Ts, gw->v_proj, a.wpart, st))) return rc;
+  if ((rc = launch_wgrad(a.dq, C, x, C, T, gw->q_proj, a.wpart, st))) return rc;
+  if ((rc = launch_wgrad(a.dk, C, source, C, Ts, gw->k_proj, a.wpart, st))) return rc;
+  if ((rc = launch_wgrad(a.dv, C, source, C, Ts, gw->v_proj, a.wpart, st))) return rc;
 #undef LIN
   LOFTR_CHECK_LAUNCH();
   return LOFTR_OK;

@@ -244,6 +244,54 @@ int launch_head_grad(const float* a, long a_ld, long a_bs, bool trans, const flo
   return LOFTR_OK;
 }
 
+// ---- shared by the layer backward passes (encoder_bwd.hip, fine_bwd.hip) -----------------------------------------------------------
+namespace {
+// out[i] = sum_p part[p * stride + i]   (ascending p: deterministic)
+__global__ void reduce_partials_kernel(const float* __restrict__ part, float* __restrict__ out, int P, long stride, long n) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float s = 0.f;
+  for (int p = 0; p < P; ++p) s += part[(long)p * stride + i];
+  out[i] = s;
+}
+// part[block][c] = sum over the block's WG_ROWS rows of x[row][c]   (column sums, stage 1; ascending rows)
+constexpr int COLSUM_ROWS = 256;
+__global__ void colsum_part_kernel(const float* __restrict__ x, long rows, int C, float* __restrict__ part) {
+  const long r0 = (long)blockIdx.x * COLSUM_ROWS;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float s = 0.f;
+    for (long r = r0; r < r0 + COLSUM_ROWS && r < rows; ++r) s += x[r * C + c];
+    part[(long)blockIdx.x * C + c] = s;
+  }
+}
+}  // namespace
+constexpr int WGRAD_KCHUNK = 512;      // tokens per split-K partial
+size_t wgrad_part_floats(long T, int O, int I) { return (size_t)ceil_div((int)T, WGRAD_KCHUNK) * O * I; }
+// dW [O][I] = dy^T act  (dy [T, O], act [T, I]): a split-K batch of launch_head_grad + an ordered sum of the partials; I in column
+// blocks of <= 256.  part: wgrad_part_floats(T, O, I) floats of scratch.
+int launch_wgrad(const float* dy, int O, const float* act, int I, long T, float* dW, float* part, hipStream_t st) {
+  const int ns = ceil_div((int)T, WGRAD_KCHUNK);
+  for (int c0 = 0; c0 < I; c0 += 256) {
+    const int cw = I - c0 < 256 ? I - c0 : 256;
+    const int rc = launch_head_grad(dy, O, (long)WGRAD_KCHUNK * O, true, act + c0, I, (long)WGRAD_KCHUNK * I, part + c0, I, (long)O * I, O,
+                                    WGRAD_KCHUNK, (int)T, cw, ns, 1.f, st);
+    if (rc) return rc;
+  }
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)(((long)O * I + 255) / 256)), dim3(256), 0, st, part, dW, ns, (long)O * I, (long)O * I);
+  return LOFTR_OK;
+}
+int launch_reduce_partials(const float* part, float* out, int P, long stride, long n, hipStream_t st) {
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, part, out, P, stride, n);
+  return LOFTR_OK;
+}
+size_t colsum_part_floats(long rows, int C) { return (size_t)((rows + COLSUM_ROWS - 1) / COLSUM_ROWS) * C; }
+// out[c] = sum_rows x[row][c]  (fixed order)
+int launch_colsum(const float* x, long rows, int C, float* out, float* part, hipStream_t st) {
+  const int nb = (int)((rows + COLSUM_ROWS - 1) / COLSUM_ROWS);
+  hipLaunchKernelGGL(colsum_part_kernel, dim3(nb), dim3(256), 0, st, x, rows, C, part);
+  return launch_reduce_partials(part, out, nb, C, C, st);
+}
+
 // g0 [N,L,C] = alpha * dsim . feat_c1,  g1 [N,S,C] = alpha * dsim^T . feat_c0 (either may be null).  dsim: [N] matrices of L x S with row
 // pitch dsim_ld and batch stride dsim_bs (floats): the Sinkhorn head hands in the interior of its [L+1, S+1] gradient.
 extern "C" int loftr_head_feat_grads(const float* dsim, long dsim_ld, long dsim_bs, const float* feat_c0, const float* feat_c1,

@@ -308,6 +308,9 @@ class FinePreprocess(nn.Module):
         if self.cat_c_feat:
             kw = dict(down_w=self.down_proj.weight, down_b=self.down_proj.bias,
                       merge_w=self.merge_feat.weight, merge_b=self.merge_feat.bias)
+        if self.cat_c_feat and autograd.wants_grad(feat_f0, feat_f1, feat_c0, feat_c1, *self.parameters()):
+            return autograd.fine_preprocess(feat_f0, feat_f1, feat_c0, feat_c1, (data["b_ids"], data["i_ids"], data["j_ids"]),
+                                            (tuple(data["hw0_c"]), tuple(data["hw1_c"]), W, stride), **kw)
         return ops.fine_preprocess(feat_f0, feat_f1, feat_c0, feat_c1, data["b_ids"], data["i_ids"], data["j_ids"],
                                    tuple(data["hw0_c"]), tuple(data["hw1_c"]), W, stride, **kw)
 

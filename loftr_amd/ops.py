@@ -320,6 +320,33 @@ def fine_preprocess(feat_f0, feat_f1, feat_c0, feat_c1, b_ids, i_ids, j_ids, hw0
 
 
 @_on_device
+def fine_preprocess_bwd(feat_f0, feat_f1, feat_c0, feat_c1, b_ids, i_ids, j_ids, hw0_c, hw1_c, W, stride, down_w, down_b, merge_w,
+                        grad_out0, grad_out1):
+    """Backward of fine_preprocess (fine_preprocess.py:29-59 under autograd).  Returns (grad_feat_f0, grad_feat_f1 [laid out like the
+    inputs], grad_feat_c0, grad_feat_c1, grad_down_w, grad_down_b, grad_merge_w, grad_merge_b)."""
+    _need(feat_c0, "feat_c0"); _need(feat_c1, "feat_c1"); _need(grad_out0, "grad_out0"); _need(grad_out1, "grad_out1")
+    M = b_ids.shape[0]
+    Cf, Cc = feat_f0.shape[1], feat_c0.shape[2]
+    dev = feat_f0.device
+    gf0, gf1 = torch.zeros_like(feat_f0), torch.zeros_like(feat_f1)             # (preserve_format: same strides as the inputs)
+    gc0, gc1 = torch.zeros_like(feat_c0), torch.zeros_like(feat_c1)
+    gdw, gdb = torch.zeros_like(down_w), torch.zeros_like(down_b)
+    gmw, gmb = torch.zeros(Cf, 2 * Cf, device=dev), torch.zeros(Cf, device=dev)
+    if M == 0:
+        return gf0, gf1, gc0, gc1, gdw, gdb, gmw, gmb
+    lib = _lib.load()
+    ws = workspace(lib.loftr_fine_preprocess_bwd_workspace_bytes(M, int(W), Cf, Cc), dev)
+    f0, f1, g0, g1 = _fmap(feat_f0), _fmap(feat_f1), _fmap(gf0), _fmap(gf1)
+    check(lib.loftr_fine_preprocess_bwd(C.byref(f0), C.byref(f1), _ptr(feat_c0), _ptr(feat_c1), feat_c0.shape[1], feat_c1.shape[1], Cc,
+                                        _ptr(_need(b_ids, "b_ids", torch.int64)), _ptr(_need(i_ids, "i_ids", torch.int64)),
+                                        _ptr(_need(j_ids, "j_ids", torch.int64)), M, hw0_c[1], hw1_c[1], int(stride), int(W), Cf,
+                                        _ptr(_need(down_w, "down_w")), _ptr(_need(down_b, "down_b")), _ptr(_need(merge_w, "merge_w")),
+                                        _ptr(grad_out0), _ptr(grad_out1), C.byref(g0), C.byref(g1), _ptr(gc0), _ptr(gc1), _ptr(gdw), _ptr(gdb),
+                                        _ptr(gmw), _ptr(gmb), _ptr(ws), ws.numel(), _stream()), "loftr_fine_preprocess_bwd")
+    return gf0, gf1, gc0, gc1, gdw, gdb, gmw, gmb
+
+
+@_on_device
 def fine_match(feat_f0, feat_f1, mkpts1_c, b_ids, scale, scale1=None):
     """FineMatching for M > 0.  Returns (expec_f [M,3], mkpts1_f [M,2])."""
     _need(feat_f0, "feat_f0"); _need(feat_f1, "feat_f1")

@@ -21,6 +21,8 @@ CASES = {
     "glayer_self": dict(seed=31, kind="layer", nb=2, L=48, S=48, C=256, H=8, masks=False),
     "glayer_cross_mask": dict(seed=32, kind="layer", nb=2, L=40, S=56, C=256, H=8, masks=True),
     "glayer_fine": dict(seed=33, kind="layer", nb=5, L=25, S=25, C=128, H=8, masks=False),
+    # FinePreprocess (fine_preprocess.py:29-59): border cells (clipped windows), a cell matched twice, unequal maps
+    "gfpre": dict(seed=35, kind="fpre", N=2, hc0=(6, 8), hc1=(5, 9), Cf=128, Cc=256, W=5, stride=4, M=40),
     "gtf_coarse": dict(seed=34, kind="tf", N=2, L=48, S=35, C=256, H=8, masks=True, layers=["self", "cross", "self", "cross"]),
 }
 FIELDS = (("q_proj", "q_proj.weight"), ("k_proj", "k_proj.weight"), ("v_proj", "v_proj.weight"), ("merge", "merge.weight"),
@@ -50,6 +52,22 @@ def layer_weights(rng, C):
 
 def build(rc):
     rng = np.random.default_rng(rc["seed"])
+    if rc["kind"] == "fpre":
+        N, (h0, w0), (h1, w1), Cf, Cc, st, M = rc["N"], rc["hc0"], rc["hc1"], rc["Cf"], rc["Cc"], rc["stride"], rc["M"]
+        b = np.sort(rng.integers(0, N, M)).astype(np.int64)
+        i = rng.integers(0, h0 * w0, M).astype(np.int64)
+        j = rng.integers(0, h1 * w1, M).astype(np.int64)
+        i[:4] = [0, w0 - 1, (h0 - 1) * w0, h0 * w0 - 1]                      # the four corner cells: windows clipped on two sides
+        b[:4] = 0
+        i[5], b[5], j[5] = i[4], b[4], (j[4] + 1) % (h1 * w1)                # cell (b, i) carries two matches
+        kai = lambda o, ii: (rng.standard_normal((o, ii)) * np.sqrt(2.0 / o)).astype(np.float32)
+        return dict(feat_f0=rng.standard_normal((N, Cf, h0 * st, w0 * st)).astype(np.float32),
+                    feat_f1=rng.standard_normal((N, Cf, h1 * st, w1 * st)).astype(np.float32),
+                    feat_c0=rng.standard_normal((N, h0 * w0, Cc)).astype(np.float32), feat_c1=rng.standard_normal((N, h1 * w1, Cc)).astype(np.float32),
+                    b_ids=b, i_ids=i, j_ids=j, G0=rng.standard_normal((M, rc["W"] ** 2, Cf)).astype(np.float32),
+                    G1=rng.standard_normal((M, rc["W"] ** 2, Cf)).astype(np.float32),
+                    w={"down_proj.weight": kai(Cf, Cc), "down_proj.bias": (0.1 * rng.standard_normal(Cf)).astype(np.float32),
+                       "merge_feat.weight": kai(Cf, 2 * Cf), "merge_feat.bias": (0.1 * rng.standard_normal(Cf)).astype(np.float32)})
     C = rc["C"]
     if rc["kind"] == "layer":
         nb, L, S = rc["nb"], rc["L"], rc["S"]
@@ -81,7 +99,20 @@ def make(name):
     inp = build(rc)
     t = lambda a: None if a is None else torch.from_numpy(np.ascontiguousarray(a))
     store = dict(recipe=np.array(json.dumps(rc)))
-    if rc["kind"] == "layer":
+    if rc["kind"] == "fpre":
+        fpm = importlib.import_module("src.loftr.loftr_module.fine_preprocess")
+        cfg = {"fine_concat_coarse_feat": True, "fine_window_size": rc["W"], "coarse": {"d_model": rc["Cc"]}, "fine": {"d_model": rc["Cf"]}}
+        fp = fpm.FinePreprocess(cfg)
+        fp.load_state_dict({k: t(v) for k, v in inp["w"].items()}, strict=True)
+        leaf = {k: t(inp[k]).requires_grad_(True) for k in ("feat_f0", "feat_f1", "feat_c0", "feat_c1")}
+        (h0, w0), (h1, w1), stp = rc["hc0"], rc["hc1"], rc["stride"]
+        data = {"hw0_f": (h0 * stp, w0 * stp), "hw0_c": (h0, w0), "b_ids": t(inp["b_ids"]), "i_ids": t(inp["i_ids"]), "j_ids": t(inp["j_ids"])}
+        o0, o1 = fp(leaf["feat_f0"], leaf["feat_f1"], leaf["feat_c0"], leaf["feat_c1"], data)
+        ((o0 * t(inp["G0"])).sum() + (o1 * t(inp["G1"])).sum()).backward()
+        store.update(out0=o0.detach().numpy(), out1=o1.detach().numpy(), **{f"grad_{k}": v.grad.numpy() for k, v in leaf.items()})
+        for n, prm in fp.named_parameters():
+            store.update(digest("grad_" + n.replace(".", "_"), prm.grad.numpy()))
+    elif rc["kind"] == "layer":
         layer = tfm.LoFTREncoderLayer(rc["C"], rc["H"], "linear")
         layer.load_state_dict({k: t(v) for k, v in inp["w"].items()}, strict=True)
         x, s = t(inp["x"]).requires_grad_(True), t(inp["source"]).requires_grad_(True)

@@ -277,3 +277,32 @@ def test_transformer_backward_against_reference_autograd():
         params = dict(layer.named_parameters())
         for f, n in names.items():
             _check_weight_grad(mod, g, f"grad_l{i}_{f}", params[n].grad)
+
+
+def test_fine_preprocess_backward_against_reference_autograd():
+    """loftr_fine_preprocess_bwd (csrc/fine_bwd.hip) through the autograd node vs the reference's own FinePreprocess under torch.autograd
+    (gfpre: clipped windows at the corners, a cell with two matches, maps of unequal size): d feat_f0/1, d feat_c0/1 and the four
+    parameter gradients."""
+    from loftr_amd.loftr import FinePreprocess
+    mod, rc, inp, g = _layer_golden("gfpre")
+    dev = "cuda:0"
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    cfg = {"fine_concat_coarse_feat": True, "fine_window_size": rc["W"], "coarse": {"d_model": rc["Cc"]}, "fine": {"d_model": rc["Cf"]}}
+    fp = FinePreprocess(cfg).to(dev).train()
+    fp.load_state_dict({k: t(v) for k, v in inp["w"].items()}, strict=True)
+    for memory_format in (torch.contiguous_format, torch.channels_last):            # the backbone hands over channels-last maps
+        fp.zero_grad()
+        leaf = {k: t(inp[k]).requires_grad_(True) for k in ("feat_c0", "feat_c1")}
+        leaf.update({k: t(inp[k]).contiguous(memory_format=memory_format).requires_grad_(True) for k in ("feat_f0", "feat_f1")})
+        (h0, w0), (h1, w1), stp = rc["hc0"], rc["hc1"], rc["stride"]
+        data = {"hw0_f": (h0 * stp, w0 * stp), "hw0_c": (h0, w0), "hw1_c": (h1, w1), "b_ids": t(inp["b_ids"]), "i_ids": t(inp["i_ids"]),
+                "j_ids": t(inp["j_ids"])}
+        o0, o1 = fp(leaf["feat_f0"], leaf["feat_f1"], leaf["feat_c0"], leaf["feat_c1"], data)
+        for got, key in ((o0, "out0"), (o1, "out1")):
+            assert np.abs(got.detach().cpu().numpy() - g[key]).max() <= 2e-4 * np.abs(g[key]).max(), key
+        ((o0 * t(inp["G0"])).sum() + (o1 * t(inp["G1"])).sum()).backward()
+        for k, v in leaf.items():
+            ref = g[f"grad_{k}"]
+            assert np.abs(v.grad.cpu().numpy() - ref).max() <= 1e-3 * np.abs(ref).max(), (k, str(memory_format))
+        for n, prm in fp.named_parameters():
+            _check_weight_grad(mod, g, "grad_" + n.replace(".", "_"), prm.grad)
