@@ -184,5 +184,25 @@ def fine_preprocess(feat_f0, feat_f1, feat_c0, feat_c1, ids, geo, down_w, down_b
     return st[:M], st[M:]
 
 
+class _PosEncodeFlatten(torch.autograd.Function):
+    """(x + pe) rearranged 'n c h w -> n (h w) c' (position_encoding.py:37-42, loftr.py:58-59): the gradient is the upstream gradient
+    in the input's layout (a view, no arithmetic)."""
+
+    @staticmethod
+    def forward(ctx, x, pe):
+        ctx.shape = x.shape
+        return ops.pos_encode_flatten(x.detach(), pe)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad):
+        n, c, h, w = ctx.shape
+        return grad.view(n, h, w, c).permute(0, 3, 1, 2), None
+
+
+def pos_encode_flatten(x, pe):
+    return _PosEncodeFlatten.apply(x, pe)
+
+
 def wants_grad(*tensors):
     return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)

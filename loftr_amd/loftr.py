@@ -7,12 +7,14 @@ exceptions.  Every sub-module after the backbone holds parameters only; its arit
 call into ``libloftr_hip.so`` (``loftr_amd/ops.py``).  There is no PyTorch fallback: on a box
 without the built extension or without a GPU the forward raises.
 
-Scope: forward values, plus the backward of the matching heads.  In ``.train()`` mode CoarseMatching
+Scope: forward values, plus the backward of everything after the backbone.  In ``.train()`` mode CoarseMatching
 also performs the reference's random sampling / ground-truth padding of the coarse matches
-(``coarse_matching.py:200-236``, host-side index arithmetic on the kernels' outputs).  CoarseMatching (dual-softmax
-AND Sinkhorn, incl. its ``bin_score`` parameter) and FineMatching are autograd nodes whose backward is HIP too
-(``loftr_amd/autograd.py``); with ``LoFTR.head_grads = True`` a training step ends with d loss / d (transformer
-outputs).  The transformers, FinePreprocess and the backbone have no backward.
+(``coarse_matching.py:200-236``, host-side index arithmetic on the kernels' outputs).  Every node after the backbone is an
+autograd node whose forward AND backward are HIP kernels (``loftr_amd/autograd.py``): position encoding, the encoder
+layers of both transformers (round 4, ``csrc/encoder_bwd.hip``), CoarseMatching (dual-softmax and Sinkhorn incl.
+``bin_score``), FinePreprocess (round 4, ``csrc/fine_bwd.hip``) and FineMatching.  ``LoFTR.full_grads = True``:
+``loss.backward()`` fills ``.grad`` of every parameter like the reference's training step (the backbone trains as the
+PyTorch module: its HIP convolutions have no backward); ``LoFTR.head_grads = True`` stops at the heads' inputs.
 """
 import contextlib
 import math
@@ -49,6 +51,8 @@ class PositionEncodingSine(nn.Module):
 
     def forward(self, x):
         """x [N,C,H,W] -> (x + pe) flattened to [N, H*W, C] (fuses loftr.py:58-59's rearrange)."""
+        if autograd.wants_grad(x):
+            return autograd.pos_encode_flatten(x, self.pe[0])
         return ops.pos_encode_flatten(x, self.pe[0])
 
 
@@ -363,6 +367,12 @@ class LoFTR(nn.Module):
         # with a graph, so that LoFTRLoss(...)(data); data['loss'].backward() leaves d loss / d (transformer outputs) in
         # their .grad -- the part of the reference's backward pass this library provides (loftr_amd/autograd.py).
         self.head_grads = False
+        # .train() only, round 4: run the WHOLE matcher with a graph -- every node after the backbone is an autograd node whose
+        # forward and backward are HIP kernels (loftr_amd/autograd.py: position encoding, encoder layers of both transformers, both
+        # matching heads, FinePreprocess, FineMatching); the backbone trains as the PyTorch module (its HIP convolutions have no
+        # backward).  LoFTRLoss(...)(data); data['loss'].backward() then fills .grad of every parameter, as the reference's
+        # training step does (src/lightning/lightning_loftr.py:112-133).
+        self.full_grads = False
         self.pos_encoding = PositionEncodingSine(config["coarse"]["d_model"],
                                                  temp_bug_fix=config["coarse"]["temp_bug_fix"])
         self.loftr_coarse = LocalFeatureTransformer(config["coarse"])
@@ -428,7 +438,8 @@ class LoFTR(nn.Module):
         if not late and getattr(self, "_fine_join", None) is not None:
             torch.cuda.current_stream(feat_f0.device).wait_stream(self._fine_join)
             self._fine_join = None
-        grads = self.training and self.head_grads
+        full = self.training and self.full_grads
+        grads = self.training and self.head_grads and not full
         if grads:
             feat_c0, feat_c1 = feat_c0.detach().requires_grad_(True), feat_c1.detach().requires_grad_(True)
             data["_head_inputs"] = {"feat_c0": feat_c0, "feat_c1": feat_c1}
@@ -446,13 +457,16 @@ class LoFTR(nn.Module):
         with torch.enable_grad() if grads else contextlib.nullcontext():
             self.fine_matching(feat_f0_unfold, feat_f1_unfold, data)
 
-    @torch.no_grad()
     def forward(self, data):
         """Updates `data` in place exactly like the reference (loftr.py:29-75).
 
         data: image0, image1 [N,1,H,W] float; optional mask0/mask1 [N,H/8,W/8] ('0' = padded),
-        scale0/scale1 [N,2].
+        scale0/scale1 [N,2].  Runs without a graph unless .train() and `full_grads` (see __init__).
         """
+        with torch.enable_grad() if (self.training and self.full_grads) else torch.no_grad():
+            return self._forward(data)
+
+    def _forward(self, data):
         dev = data["image0"].device
         if data["image1"].device != dev:
             raise ops._lib.LoftrHipError(f"image0 on {dev} but image1 on {data['image1'].device}")

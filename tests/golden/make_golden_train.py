@@ -318,6 +318,46 @@ def make_step_grads(name):
     finally:
         torch.randint = real
     data["loss"].backward()
+    # Round 4: the gradient of EVERY parameter of the reference's training step (lightning_loftr.py:112-133 back-propagates batch['loss'] into
+    # the whole matcher) -> tests/golden/tfull_*.npz, as digests (make_golden_layer_grad.digest: vectors whole; matrices / filters as a
+    # strided sub-matrix plus all row and column sums of their 2-D view).
+    from tests.golden.make_golden_layer_grad import digest
+    full = dict(recipe=np.array(json.dumps(dict(rc, **gc))), losses=np.array(json.dumps({k: float(v) for k, v in data["loss_scalars"].items()})))
+    for pname, prm in model.named_parameters():
+        gnp = (prm.grad if prm.grad is not None else torch.zeros_like(prm)).numpy()
+        full.update(digest("grad/" + pname, gnp.reshape(gnp.shape[0], -1) if gnp.ndim > 2 else gnp))
+    # ... and the same step in float64 (same seeds, same sampled matches): |fp32 - fp64| per tensor is the reference's OWN rounding noise, the
+    # yardstick the test holds the HIP path to (some gradients -- BatchNorm shifts, the fine-level q / k projections behind the attention
+    # normaliser -- are sums with heavy cancellation: 1e-3 relative is not what float32 autograd itself delivers there).
+    m64 = RefLoFTR(copy.deepcopy(cfg))
+    m64.load_state_dict(e2e_state_dict(m64, cfg, 0.3, gc["coarse_gain"], gc["fine_gain"]), strict=True)
+    m64 = m64.double().train()
+    d64 = {"dataset_name": ["scannet"] * geo["N"], "pair_names": [["a"] * geo["N"], ["b"] * geo["N"]],
+           **{k: (t(v).double() if t(v).is_floating_point() else t(v)) for k, v in batch.items()}}
+    torch.randint = det_randint
+    try:
+        with torch.no_grad():
+            sup.spvs_coarse(d64, C)
+        m64(d64)
+        with torch.no_grad():
+            sup.spvs_fine(d64, C)
+        LoFTRLoss(step_loss_cfg(rc)).train()(d64)
+    finally:
+        torch.randint = real
+    same = all(torch.equal(d64[k], data[k]) for k in ("b_ids", "i_ids", "j_ids"))
+    d64["loss"].backward()
+    noise = {}
+    for (pname, prm), (_, p64) in zip(model.named_parameters(), m64.named_parameters()):
+        a = (prm.grad if prm.grad is not None else torch.zeros_like(prm)).double()
+        b_ = p64.grad if p64.grad is not None else torch.zeros_like(p64)
+        noise[pname] = float((a - b_).abs().max() / max(float(b_.abs().max()), 1e-300))
+    full["ref_noise"] = np.array(json.dumps(noise))
+    full["ref64_same_matches"] = np.array(same)
+    print("reference fp32 vs fp64 (same match set: %s): worst relative gradient deviations" % same,
+          sorted(noise.items(), key=lambda kv: -kv[1])[:6])
+    np.savez_compressed(os.path.join(HERE, name.replace("tgrad", "tfull") + ".npz"), **full)
+    print(name.replace("tgrad", "tfull"), "%d parameter tensors, %.0f kB" % (len(list(model.parameters())),
+          os.path.getsize(os.path.join(HERE, name.replace("tgrad", "tfull") + ".npz")) / 1e3))
     # d loss / d conf_matrix and d loss / d expec_f are now known.  The heads' OWN backward, cut from the rest of the graph
     # (the final feat_*1 of a transformer is computed from the final feat_*0, so feat_*0.grad of the full graph also contains
     # the transformer's share): re-run each head on detached copies of its inputs and back-propagate the node gradient.

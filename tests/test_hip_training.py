@@ -289,6 +289,96 @@ def test_training_step_head_gradients_against_reference(name, monkeypatch):
         assert abs(got - float(g["grad_bin_score"])) <= 2e-3 * abs(float(g["grad_bin_score"])), (got, g["grad_bin_score"])
 
 
+@pytest.mark.parametrize("name", ["tfull_ds", "tfull_ot"])
+def test_training_step_full_backward_against_reference(name, monkeypatch):
+    """The WHOLE training step's backward (round 4, LoFTR.full_grads): supervision -> matcher in .train() mode -> losses ->
+    data['loss'].backward(), every node after the backbone an autograd node whose forward and backward are HIP kernels (position
+    encoding, 8 + 2 encoder layers, CoarseMatching, FinePreprocess, FineMatching, both losses), the backbone the PyTorch mirror on
+    the CPU in train mode (its autograd, the reference's own arithmetic).  Compared: the gradient of EVERY parameter (160 / 161
+    tensors) with the reference's own training step under torch.autograd (tests/golden/tfull_*.npz, digests)."""
+    import copy
+    import importlib.util
+    import os
+    from _cases import GOLDEN_DIR
+    from loftr_amd import LoFTR
+    from loftr_amd.training import LoFTRLoss, compute_supervision_coarse, compute_supervision_fine
+
+    def load_mod(fname):
+        spec = importlib.util.spec_from_file_location(fname, os.path.join(GOLDEN_DIR, fname + ".py"))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        return mod
+    E2E, LG = load_mod("make_golden_e2e"), load_mod("make_golden_layer_grad")
+    dev = torch.device("cuda", 0)
+    g = dict(np.load(os.path.join(GOLDEN_DIR, f"{name}.npz")))
+    rc = json.loads(str(g["recipe"]))
+    batch, geo = MG.step_batch(rc)
+    N = geo["N"]
+    cfg = MG.step_matcher_cfg(rc)
+    cpu = LoFTR(copy.deepcopy(cfg))
+    sd = E2E.e2e_state_dict(cpu, cfg, 0.3, rc["coarse_gain"], rc["fine_gain"])
+    cpu.load_state_dict(sd, strict=True)
+    cpu.train()
+    fc, ff = cpu.backbone(torch.from_numpy(np.concatenate([batch["image0"], batch["image1"]], 0)))       # WITH its graph
+    model = LoFTR(copy.deepcopy(cfg))
+    model.load_state_dict(sd, strict=True)
+    model = model.to(dev).train()
+    model.full_grads = True
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    data = {"dataset_name": ["scannet"] * N, **{k: t(v) for k, v in batch.items()}}
+    monkeypatch.setattr(torch, "randint", MG.det_randint)
+    compute_supervision_coarse(data, CFG)
+    data.update({"bs": N, "hw0_i": data["image0"].shape[2:], "hw1_i": data["image1"].shape[2:]})
+    with torch.enable_grad():
+        model.match_from_features(fc[:N].to(dev), fc[N:].to(dev), ff[:N].to(dev), ff[N:].to(dev), data)
+    compute_supervision_fine(data, CFG)
+    LoFTRLoss(MG.step_loss_cfg(rc)).train()(data)
+    want = json.loads(str(g["losses"]))
+    for k in ("loss_c", "loss_f", "loss"):
+        assert abs(float(data["loss_scalars"][k]) - want[k]) <= 2e-4 * max(1.0, abs(want[k])), (k, data["loss_scalars"], want)
+    data["loss"].backward()
+    torch.cuda.synchronize()
+    params = {"backbone." + n: p for n, p in cpu.backbone.named_parameters()}
+    params.update({n: p for n, p in model.named_parameters() if not n.startswith("backbone.")})
+    names = sorted({k.split("/")[1] for k in g if k.startswith("grad/")})
+    assert set(names) == set(params), set(names) ^ set(params)
+    worst = {}
+    for n in names:
+        key = "grad/" + n
+        got = params[n].grad
+        got = (got if got is not None else torch.zeros_like(params[n])).detach().cpu().numpy()
+        got = got.reshape(got.shape[0], -1) if got.ndim > 2 else got
+        if key in g:                                             # vectors (and scalars): stored whole
+            ref = g[key]
+            err = np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-12)
+        else:
+            d = LG.digest(key, got)
+            scale = max(float(g[key + "/absmax"]), 1e-12)
+            err = max(np.abs(d[key + "/sub"] - g[key + "/sub"]).max() / scale,
+                      max(np.abs(d[key + "/" + s_] - g[key + "/" + s_]).max() / max(np.abs(g[key + "/" + s_]).max(), scale) for s_ in ("rowsum", "colsum")))
+        worst[n] = float(err)
+    # Bar per tensor, relative to its largest entry: 6e-3, or 3 x the reference's OWN float32 rounding noise on that tensor -- |its fp32
+    # gradient - its fp64 gradient| of the same step, stored in the golden -- where that is larger.  Why not the 2e-3 of the heads' gradients
+    # above: those start from identical head inputs; here the upstream gradients already carry the forward's differences (features ~1e-5
+    # from the reference's) through ten more nodes, and BatchNorm shifts, the stride-2 block of layer2 and the fine-level q projections
+    # (behind the attention normaliser) are sums with heavy cancellation -- the reference itself is off by up to 3.4e-2 there, and two
+    # float32 evaluations can differ by twice their common noise.  Measured: matcher tensors <= 4.7e-3 (138 / 154 of the 160 / 161 tensors
+    # within 2e-3), backbone tensors at the reference's own noise (1.60e-2 vs 1.60e-2, 5.1e-3 vs 5.2e-3).
+    noise = json.loads(str(g["ref_noise"]))
+    assert bool(g["ref64_same_matches"])
+    tol = {n: max(6e-3, 3.0 * noise[n]) for n in worst}
+    hip = {n: e for n, e in worst.items() if not n.startswith("backbone.")}
+    bb = {n: e for n, e in worst.items() if n.startswith("backbone.")}
+    rep = os.path.join(os.path.dirname(GOLDEN_DIR), "..", "gpurun_out")
+    os.makedirs(rep, exist_ok=True)
+    with open(os.path.join(rep, "full_backward_margins.txt"), "a") as fh:
+        fh.write(f"{name}: {len(hip)} matcher tensors, worst {max(hip.values()):.2e} ({max(hip, key=hip.get)}; reference fp32-vs-fp64 there "
+                 f"{noise[max(hip, key=hip.get)]:.2e}); {len(bb)} backbone tensors, worst {max(bb.values()):.2e} ({max(bb, key=bb.get)}; reference "
+                 f"{noise[max(bb, key=bb.get)]:.2e}); tensors above 2e-3: {sum(e > 2e-3 for e in worst.values())}\n")
+    bad = {n: (e, tol[n]) for n, e in worst.items() if e > tol[n]}
+    assert not bad, (sorted(bad.items(), key=lambda kv: -kv[1][0])[:8], len(bad), len(worst))
+
+
 @pytest.mark.parametrize("match_type", ["dual_softmax", "sinkhorn"])
 def test_train_mode_forward_from_images_with_head_grads(match_type, monkeypatch):
     """LoFTR.forward(data) in .train() mode with head_grads straight from images, then LoFTRLoss and loss.backward(): the four
