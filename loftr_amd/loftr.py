@@ -92,7 +92,7 @@ class LoFTREncoderLayer(nn.Module):
         return ops.layer_weights_struct(sd)
 
     def forward(self, x, source, x_mask=None, source_mask=None):
-        if autograd.wants_grad(x, source, *self.parameters()):
+        if self.training and autograd.wants_grad(x, source, *self.parameters()):      # .eval(): the inference kernels, no graph
             self.weight_struct()                                  # (dtype / device checks)
             return autograd.encoder_layer(x, source, self.weight_tensors(), self.nhead, x_mask, source_mask)
         return ops.encoder_layer(x.contiguous(), source.contiguous(), self.weight_struct(), self.nhead,
@@ -132,7 +132,7 @@ class LocalFeatureTransformer(nn.Module):
         for name in self.layer_names:
             if name not in ("self", "cross"):
                 raise KeyError
-        if autograd.wants_grad(feat0, feat1, *self.parameters()):
+        if self.training and autograd.wants_grad(feat0, feat1, *self.parameters()):
             # differentiable form: the reference's own layer loop (transformer.py:91-99) over autograd nodes whose forward and
             # backward are the HIP kernels (loftr_amd/autograd.py:_EncoderLayer)
             for layer, name in zip(self.layers, self.layer_names):
@@ -312,7 +312,7 @@ class FinePreprocess(nn.Module):
         if self.cat_c_feat:
             kw = dict(down_w=self.down_proj.weight, down_b=self.down_proj.bias,
                       merge_w=self.merge_feat.weight, merge_b=self.merge_feat.bias)
-        if self.cat_c_feat and autograd.wants_grad(feat_f0, feat_f1, feat_c0, feat_c1, *self.parameters()):
+        if self.training and self.cat_c_feat and autograd.wants_grad(feat_f0, feat_f1, feat_c0, feat_c1, *self.parameters()):
             return autograd.fine_preprocess(feat_f0, feat_f1, feat_c0, feat_c1, (data["b_ids"], data["i_ids"], data["j_ids"]),
                                             (tuple(data["hw0_c"]), tuple(data["hw1_c"]), W, stride), **kw)
         return ops.fine_preprocess(feat_f0, feat_f1, feat_c0, feat_c1, data["b_ids"], data["i_ids"], data["j_ids"],

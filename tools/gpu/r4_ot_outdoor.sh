@@ -1,0 +1,10 @@
+#!/bin/bash
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
+O=$R/gpurun_out; mkdir -p $O; cd $R
+python -c 'import torch' 2> /dev/null
+timeout 120 python tools/micro/outdoor_bench.py 2 5 sinkhorn 2>&1 | grep outdoor
+export TMPDIR=/tmp; cd /tmp
+timeout -k 5 180 rocprofv3 --kernel-trace --stats -d $O/prof_oot -o p -- python $R/tools/micro/outdoor_bench.py 2 3 sinkhorn > /dev/null 2> $O/prof_oot.err
+cd $R
+python tools/rocpd_summary.py $(find $O/prof_oot -name '*.db' | head -1) 2>&1 | head -16 | cut -c1-170
+rm -rf $O/prof_oot
