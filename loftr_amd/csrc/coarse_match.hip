@@ -778,15 +778,26 @@ extern "C" int loftr_coarse_match_dual_softmax(const float* feat_c0, const float
 namespace {
 // Work decomposition of the Sinkhorn iteration passes (a function of the geometry only) and the iteration loop itself, shared
 // by the forward and by the backward's re-creation of (u_t, v_t).
-struct OtPlan { bool rowstream, fused; int wgs, rpws, wgp, rpw, cpt; };
+// wide rows (up to 12 x 1024 columns): ONE workgroup per CU, one row per round, the next row prefetched.  Measured at 2 x 11025^2
+// (936 MB per pass): iteration 272 us with 512 threads, 321 with 1024; last pass (reads + writes) 786 / 575 us.
+#ifndef OT_WIDE_NT
+#define OT_WIDE_NT 512
+#endif
+#ifndef OT_WIDE_NT_FINAL
+#define OT_WIDE_NT_FINAL 1024
+#endif
+struct OtPlan { bool rowstream, fused, wide, aligned; int wgs, rpws, wgp, rpw, cpt; };
 OtPlan ot_plan(const Geometry& g) {
   OtPlan p{};
-  // row-streaming passes (otp::ot_pass_kernel): aligned rows and at most 5 x 1024 columns incl. the dustbin (indoor)
-  p.rowstream = (g.S & 3) == 0 && g.S + 1 <= 4 * 256 * 5;
+  // row-streaming passes (otp::ot_pass_kernel): at most 5 x 1024 columns incl. the dustbin with 256 threads (indoor), 6 x 2048 with
+  // 512 (outdoor 105 x 105); rows of any alignment
+  p.rowstream = g.S + 1 <= 4 * 512 * 6;
+  p.wide = g.S + 1 > 4 * 256 * 5;
+  p.aligned = (g.S & 3) == 0;
   if (p.rowstream) {
-    constexpr int R = 2;
+    const int R = p.wide ? 1 : 2;
     const int capP = [&] { const int a = ceil_div(g.L, 256) * 8; const int c = a > g.PI ? a : g.PI; return c < OT_RCH ? c : OT_RCH; }();
-    int wgs = 768 / g.N;                                   // ~3 workgroups (of 4 waves) per CU over the batch
+    int wgs = (p.wide ? 256 : 768) / g.N;                  // ~3 workgroups of 4 waves per CU over the batch (wide: one)
     wgs = wgs < 1 ? 1 : (wgs > capP ? capP : wgs);
     if (wgs > ceil_div(g.L, R)) wgs = ceil_div(g.L, R);
     p.rpws = ceil_div(ceil_div(g.L, wgs), R) * R;
@@ -803,6 +814,19 @@ OtPlan ot_plan(const Geometry& g) {
   p.wgp = ceil_div(g.L, p.rpw);
   return p;
 }
+// one row-streaming pass in the variant the plan names
+template <bool FINAL>
+void ot_pass_launch(const OtPlan& pl, const Geometry& g, hipStream_t st, float* z, float bin_score, float norm, const float* v, float* u,
+                    float2* part, const uint8_t* rk, const uint8_t* ck, float* assign, float2* rowmax_part, float* colmax_part) {
+  const dim3 grid(pl.wgs, g.N);
+  constexpr int WNT = FINAL ? OT_WIDE_NT_FINAL : OT_WIDE_NT;
+#define OT_PASS(NT_, G4_, R_, AL_, PF_)                                                                                        \
+  hipLaunchKernelGGL((otp::ot_pass_kernel<NT_, G4_, R_, FINAL, AL_, PF_>), grid, dim3(NT_), 0, st, z, g, bin_score, norm, v, u, part, \
+                     pl.rpws, rk, ck, assign, rowmax_part, colmax_part)
+  if (!pl.wide) { if (pl.aligned) OT_PASS(256, 5, 2, true, false); else OT_PASS(256, 5, 2, false, false); }
+  else { if (pl.aligned) OT_PASS(WNT, 12 * 256 / WNT, 1, true, true); else OT_PASS(WNT, 12 * 256 / WNT, 1, false, true); }
+#undef OT_PASS
+}
 // u = v = 0, then `iters` iterations on z (the scaled, mask-filled scores) in w.ot_u / w.ot_v.  save_u [iters][N (L+1)] /
 // save_v [iters + 1][N (S+1)] (or null): the potentials after every iteration (save_v[0] = 0), for the backward.
 void ot_iterate(const Geometry& g, const OtPlan& pl, float* z, const MatchWs& w, float bin_score, float norm, int iters, hipStream_t st,
@@ -814,8 +838,7 @@ void ot_iterate(const Geometry& g, const OtPlan& pl, float* z, const MatchWs& w,
   const long cols = (long)g.N * (g.S + 1);
   for (int it = 0; it < iters; ++it) {
     if (pl.rowstream) {
-      hipLaunchKernelGGL((otp::ot_pass_kernel<5, 2, false>), dim3(pl.wgs, g.N), dim3(256), 0, st, z, g, bin_score, norm, w.ot_v, w.ot_u,
-                         w.ot_part, pl.rpws, nullptr, nullptr, nullptr, nullptr, nullptr);
+      ot_pass_launch<false>(pl, g, st, z, bin_score, norm, w.ot_v, w.ot_u, w.ot_part, nullptr, nullptr, nullptr, nullptr, nullptr);
       hipLaunchKernelGGL(ot_col_merge2_kernel, dim3(ceil_div((int)cols, 256)), dim3(256), 0, st, w.ot_part, g, bin_score, norm, pl.wgs, w.ot_u, w.ot_v);
     } else if (pl.fused) {
       if (pl.cpt <= 19) hipLaunchKernelGGL((ot_iter_kernel<19, 4>), dim3(pl.wgp, g.N), dim3(256), 0, st, z, g, bin_score, norm, w.ot_v, w.ot_u, w.ot_part, pl.rpw);
@@ -864,7 +887,7 @@ extern "C" int loftr_coarse_match_sinkhorn(const float* feat_c0, const float* fe
   const OtPlan plan = ot_plan(g);
   ot_iterate(g, plan, conf_out, w, bin_score, norm, iters, st, nullptr, nullptr);
   const bool rowstream = plan.rowstream;
-  const int wgs = plan.wgs, rpws = plan.rpws;
+  const int wgs = plan.wgs;
   const uint8_t *rk = nullptr, *ck = nullptr;
   if (prefilter) {
     hipLaunchKernelGGL(ot_rowkill_kernel, dim3(ceil_div(g.L, 4), g.N), dim3(256), 0, st, conf_out, g, bin_score, w.ot_u, w.ot_v, w.rowkill);
@@ -874,8 +897,7 @@ extern "C" int loftr_coarse_match_sinkhorn(const float* feat_c0, const float* fe
   if (assign_out)
     hipLaunchKernelGGL(ot_assign_bins_kernel, dim3(ceil_div((g.L > g.S ? g.L : g.S) + 1, 256), g.N), dim3(256), 0, st, g, bin_score, norm, w.ot_u, w.ot_v, assign_out);
   if (rowstream) {
-    hipLaunchKernelGGL((otp::ot_pass_kernel<5, 2, true>), dim3(wgs, g.N), dim3(256), 0, st, conf_out, g, bin_score, norm, w.ot_v, w.ot_u,
-                       nullptr, rpws, rk, ck, assign_out, w.rowmax_part, w.colmax_part);
+    ot_pass_launch<true>(plan, g, st, conf_out, bin_score, norm, w.ot_v, w.ot_u, nullptr, rk, ck, assign_out, w.rowmax_part, w.colmax_part);
     LOFTR_CHECK_LAUNCH();
     Geometry gs = g;
     gs.PJ = 1; gs.PI = wgs;                                // one row partial per row, one column-maximum partial per workgroup

@@ -338,20 +338,24 @@ __device__ __forceinline__ void best_merge(float& b, int& w, float ob, int ow) {
   w = (take ? jo : jb) | tie;
 }
 
-#ifndef OTP_PREFETCH
-#define OTP_PREFETCH 0           // 1: second register set for the next round's rows (256 VGPRs, 2 workgroups / SIMD set) -- A/B
-#endif
-template <int G4, int R, bool FINAL>
-__global__ __launch_bounds__(256, OTP_PREFETCH ? 2 : 3) void ot_pass_kernel(float* __restrict__ z, Geometry g, float alpha, float norm,
+// NT threads (NW = NT / 64 waves), G4 column groups of four per thread: 4 NT G4 >= S + 1.  AL: rows are 16-byte aligned
+// (S % 4 == 0); otherwise the groups are loaded / stored as 4-byte aligned dwordx4 (sweep::F4U) and the ragged last group
+// (S % 4 columns, then the dustbin) element by element, so that nothing is read beyond the volume.  PF: a second register
+// set holds the next round's rows while this round is processed (one workgroup per CU: no neighbour hides the latency).
+//   <256, 5, 2, ., ., false>, 3 workgroups / CU: S + 1 <= 5120 (indoor 60 x 80);  <512, 6, 2, ., ., true>, 1 / CU: S + 1 <= 12288
+//   (outdoor 105 x 105).
+template <int NT, int G4, int R, bool FINAL, bool AL, bool PF>
+__global__ __launch_bounds__(NT, PF ? 1 : (NT == 256 ? 3 : 2)) void ot_pass_kernel(float* __restrict__ z, Geometry g, float alpha, float norm,
                                                       const float* __restrict__ v, float* __restrict__ u,
                                                       float2* __restrict__ part, int rows_per_wg,
                                                       const uint8_t* __restrict__ rowkill, const uint8_t* __restrict__ colkill,
                                                       float* __restrict__ assign, float2* __restrict__ rowmax_part,
                                                       float* __restrict__ colmax_part) {
-  __shared__ float red_a[2][R][4], red_b[2][R][4];
-  __shared__ int red_w[2][R][4];
+  constexpr int NW = NT / 64;
+  __shared__ float red_a[2][R][NW], red_b[2][R][NW];
+  __shared__ int red_w[2][R][NW];
   const int n = blockIdx.y, t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const int S = g.S, L = g.L, S4 = S >> 2;
+  const int S = g.S, L = g.L, S4 = S >> 2, rem = AL ? 0 : (S & 3);
   const float* vn = v + (long)n * (S + 1);
   f32x4 vk[G4], ca[G4], cb[G4];         // column constants; ITER: running (reference, sum);  FINAL: ca = running column maximum
   unsigned kill = 0;                    // FINAL: bit 4 k + e set: the prefilter zeroes this column
@@ -359,7 +363,7 @@ __global__ __launch_bounds__(256, OTP_PREFETCH ? 2 : 3) void ot_pass_kernel(floa
   for (int k = 0; k < G4; ++k) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const int j = 4 * (t + 256 * k) + e;
+      const int j = 4 * (t + NT * k) + e;
       const float x = j <= S ? vn[j] : 0.f;
       vk[k][e] = x;
       if (FINAL && colkill && j < S && colkill[(long)n * S + j]) kill |= 1u << (4 * k + e);
@@ -369,29 +373,30 @@ __global__ __launch_bounds__(256, OTP_PREFETCH ? 2 : 3) void ot_pass_kernel(floa
   const int r0 = blockIdx.x * rows_per_wg, r1 = min(r0 + rows_per_wg, L);
   if (r0 >= r1) return;                 // (never: the host sizes the grid to the rows)
   f32x4 zc[R][G4];
-#if OTP_PREFETCH
-  f32x4 zn[R][G4];
-#endif
+  f32x4 zn[PF ? R : 1][PF ? G4 : 1];
+  // the group that holds the dustbin: S % 4 scores (read one by one), alpha, padding
+  auto tail_group = [&](const float* zr) {
+    f32x4 x{SENTINEL, SENTINEL, SENTINEL, SENTINEL};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) x[e] = e < rem ? zr[4 * S4 + e] : (e == rem ? alpha : SENTINEL);
+    return x;
+  };
 #define OTP_LOAD(dst_, rb_)                                                                              \
   _Pragma("unroll") for (int r = 0; r < R; ++r) {                                                        \
     const float* zr__ = z + ((long)n * L + min((rb_) + r, L - 1)) * S;                                   \
     _Pragma("unroll") for (int k = 0; k < G4; ++k) {                                                     \
-      const int q__ = t + 256 * k;                                                                       \
-      dst_[r][k] = q__ < S4 ? *reinterpret_cast<const f32x4*>(zr__ + 4 * q__)                            \
-                            : (q__ == S4 ? f32x4{alpha, SENTINEL, SENTINEL, SENTINEL} : f32x4{SENTINEL, SENTINEL, SENTINEL, SENTINEL}); \
+      const int q__ = t + NT * k;                                                                        \
+      if (q__ < S4) dst_[r][k] = AL ? *reinterpret_cast<const f32x4*>(zr__ + 4 * q__) : reinterpret_cast<const sweep::F4U*>(zr__ + 4 * q__)->v; \
+      else if (q__ == S4) dst_[r][k] = tail_group(zr__);                                                 \
+      else dst_[r][k] = f32x4{SENTINEL, SENTINEL, SENTINEL, SENTINEL};                                   \
     }                                                                                                    \
   }
-#if OTP_PREFETCH
-  OTP_LOAD(zc, r0)
-#endif
+  if constexpr (PF) { OTP_LOAD(zc, r0) }
   int par = 0;
   for (int rb = r0; rb < r1; rb += R, par ^= 1) {
-#if OTP_PREFETCH
     const bool more = rb + R < r1;                       // block-uniform
-    if (more) OTP_LOAD(zn, rb + R)
-#else
-    OTP_LOAD(zc, rb)                                     // latency is hidden by the other workgroups of the CU (3 x 4 waves)
-#endif
+    if constexpr (PF) { if (more) { OTP_LOAD(zn, rb + R) } }
+    else { OTP_LOAD(zc, rb) }                            // latency is hidden by the other workgroups of the CU (3 x 4 waves)
     if (!FINAL) {
       // ---- u_i = log_mu - LSE_j(Z_ij + v_j): block maximum, then block sum of exponentials
       float rmx[R], ui[R];
@@ -409,7 +414,10 @@ __global__ __launch_bounds__(256, OTP_PREFETCH ? 2 : 3) void ot_pass_kernel(floa
       __syncthreads();
 #pragma unroll
       for (int r = 0; r < R; ++r) {
-        rmx[r] = fmaxf(fmaxf(red_a[par][r][0], red_a[par][r][1]), fmaxf(red_a[par][r][2], red_a[par][r][3]));
+        float m = red_a[par][r][0];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) m = fmaxf(m, red_a[par][r][w]);
+        rmx[r] = m;
         float sm = 0.f;
 #pragma unroll
         for (int k = 0; k < G4; ++k) {
@@ -423,7 +431,11 @@ __global__ __launch_bounds__(256, OTP_PREFETCH ? 2 : 3) void ot_pass_kernel(floa
       __syncthreads();
 #pragma unroll
       for (int r = 0; r < R; ++r) {
-        const float ssum = (red_b[par][r][0] + red_b[par][r][1]) + (red_b[par][r][2] + red_b[par][r][3]);
+        float ssum;
+        if (NW == 4) ssum = (red_b[par][r][0] + red_b[par][r][1]) + (red_b[par][r][2] + red_b[par][r][3]);
+        else { ssum = 0.f;
+#pragma unroll
+          for (int w = 0; w < NW; w += 2) ssum += red_b[par][r][w] + red_b[par][r][w + 1]; }
         ui[r] = norm - (rmx[r] + logf(ssum));            // log_mu = norm for the real rows
         if (t == 0 && rb + r < r1) u[(long)n * (L + 1) + rb + r] = ui[r];
         if (rb + r >= r1) ui[r] = SENTINEL;              // rows beyond the range: y = SENTINEL below, contribute nothing
@@ -456,20 +468,25 @@ __global__ __launch_bounds__(256, OTP_PREFETCH ? 2 : 3) void ot_pass_kernel(floa
         float best = -1.f; int bw = 0;
 #pragma unroll
         for (int k = 0; k < G4; ++k) {
-          const int q = t + 256 * k;
+          const int q = t + NT * k;
           f32x4 c;
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             float x = ex(((zc[r][k][e] + ub) + vk[k][e]) - norm);
             if (rk || ((kill >> (4 * k + e)) & 1u)) x = 0.f;       // skh_prefilter: coarse_matching.py:136-140
-            c[e] = (q < S4 && valid) ? x : -1.f;
+            c[e] = ((AL ? q < S4 : 4 * q + e < S) && valid) ? x : -1.f;
           }
           if (q < S4 && valid) {
-            *reinterpret_cast<f32x4*>(zr + 4 * q) = c;
+            if (AL) *reinterpret_cast<f32x4*>(zr + 4 * q) = c;
+            else reinterpret_cast<sweep::F4U*>(zr + 4 * q)->v = c;
             // conf_matrix is a VIEW of assign_matrix in the reference (:133): the prefilter zeroing is visible there too
             // (row pitch S + 1: only 4-byte aligned.  Scalar stores: +147 us for the 737 MB at N = 8, i.e. 5 TB/s -- already the HBM
             //  write rate; one unaligned dwordx4 per group measured 40 % slower, a separate aligned fill kernel re-reading conf 120 us slower)
             if (ar) { ar[4 * q] = c[0]; ar[4 * q + 1] = c[1]; ar[4 * q + 2] = c[2]; ar[4 * q + 3] = c[3]; }
+          } else if (!AL && q == S4 && valid) {
+#pragma unroll
+            for (int e = 0; e < 3; ++e)
+              if (e < rem) { zr[4 * q + e] = c[e]; if (ar) ar[4 * q + e] = c[e]; }
           }
 #pragma unroll
           for (int e = 0; e < 4; ++e) {                  // this thread's columns ascend with (k, e): > keeps the first
@@ -490,24 +507,31 @@ __global__ __launch_bounds__(256, OTP_PREFETCH ? 2 : 3) void ot_pass_kernel(floa
       if (t < R && rb + t < r1) {
         float b = red_a[par][t][0]; int w = red_w[par][t][0];
 #pragma unroll
-        for (int k = 1; k < 4; ++k) best_merge(b, w, red_a[par][t][k], red_w[par][t][k]);
+        for (int k = 1; k < NW; ++k) best_merge(b, w, red_a[par][t][k], red_w[par][t][k]);
         rowmax_part[(long)n * L + rb + t] = make_float2(b, __int_as_float(w));       // PJ = 1
       }
     }
-#if OTP_PREFETCH
-    if (more) {
+    if constexpr (PF) {
+      if (more) {
 #pragma unroll
-      for (int r = 0; r < R; ++r)
+        for (int r = 0; r < R; ++r)
 #pragma unroll
-        for (int k = 0; k < G4; ++k) zc[r][k] = zn[r][k];
+          for (int k = 0; k < G4; ++k) zc[r][k] = zn[r][k];
+      }
     }
-#endif
   }
 #undef OTP_LOAD
   if (FINAL) {
     float* cp = colmax_part + ((long)n * gridDim.x + blockIdx.x) * S;
 #pragma unroll
-    for (int k = 0; k < G4; ++k) if (t + 256 * k < S4) *reinterpret_cast<f32x4*>(cp + 4 * (t + 256 * k)) = ca[k];
+    for (int k = 0; k < G4; ++k) {
+      const int q = t + NT * k;
+      if (AL) { if (q < S4) *reinterpret_cast<f32x4*>(cp + 4 * q) = ca[k]; }
+      else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) if (4 * q + e < S) cp[4 * q + e] = ca[k][e];
+      }
+    }
     return;
   }
   float2* pn = part + ((long)n * gridDim.x + blockIdx.x) * (S + 1);
@@ -515,7 +539,7 @@ __global__ __launch_bounds__(256, OTP_PREFETCH ? 2 : 3) void ot_pass_kernel(floa
   for (int k = 0; k < G4; ++k)
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const int j = 4 * (t + 256 * k) + e;
+      const int j = 4 * (t + NT * k) + e;
       if (j <= S) pn[j] = make_float2(ca[k][e], cb[k][e]);
     }
   if (blockIdx.x == 0) {               // u of the dustbin row: log(S) + norm - LSE_j(alpha + v_j), j = 0 .. S
@@ -524,21 +548,29 @@ __global__ __launch_bounds__(256, OTP_PREFETCH ? 2 : 3) void ot_pass_kernel(floa
 #pragma unroll
     for (int k = 0; k < G4; ++k)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) if (4 * (t + 256 * k) + e <= S) m = fmaxf(m, alpha + vk[k][e]);
+      for (int e = 0; e < 4; ++e) if (4 * (t + NT * k) + e <= S) m = fmaxf(m, alpha + vk[k][e]);
     m = wave_max(m);
     if (lane == 0) red_a[0][0][wave] = m;
     __syncthreads();
-    m = fmaxf(fmaxf(red_a[0][0][0], red_a[0][0][1]), fmaxf(red_a[0][0][2], red_a[0][0][3]));
+    m = red_a[0][0][0];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) m = fmaxf(m, red_a[0][0][w]);
     float sm = 0.f;
 #pragma unroll
     for (int k = 0; k < G4; ++k)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) if (4 * (t + 256 * k) + e <= S) sm += expf(alpha + vk[k][e] - m);
+      for (int e = 0; e < 4; ++e) if (4 * (t + NT * k) + e <= S) sm += expf(alpha + vk[k][e] - m);
     sm = wave_sum(sm);
     if (lane == 0) red_b[0][0][wave] = sm;
     __syncthreads();
-    if (t == 0)
-      u[(long)n * (L + 1) + L] = logf((float)S) + norm - (m + logf((red_b[0][0][0] + red_b[0][0][1]) + (red_b[0][0][2] + red_b[0][0][3])));
+    if (t == 0) {
+      float ssum;
+      if (NW == 4) ssum = (red_b[0][0][0] + red_b[0][0][1]) + (red_b[0][0][2] + red_b[0][0][3]);
+      else { ssum = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; w += 2) ssum += red_b[0][0][w] + red_b[0][0][w + 1]; }
+      u[(long)n * (L + 1) + L] = logf((float)S) + norm - (m + logf(ssum));
+    }
   }
 }
 }  // namespace otp

@@ -235,11 +235,14 @@ def test_single_encoder_layer_vs_oracle(C, L, S, masked):
 
 
 @pytest.mark.parametrize("hw0,hw1,C,masked,prefilter", [((7, 9), (9, 7), 256, False, False), ((7, 9), (5, 7), 256, True, True),
-                                                         ((6, 8), (8, 6), 128, False, False), ((9, 12), (12, 9), 256, True, False)])
+                                                         ((6, 8), (8, 6), 128, False, False), ((9, 12), (12, 9), 256, True, False),
+                                                         ((5, 7), (75, 91), 256, True, False), ((6, 6), (72, 96), 256, False, True),
+                                                         ((4, 5), (105, 105), 256, False, False)])
 def test_sinkhorn_paths_vs_oracle(hw0, hw1, C, masked, prefilter):
     """Sinkhorn coarse matching against the numpy oracle on the shapes the goldens do not reach: rows that are not
-    16-byte aligned (S % 4 != 0: the round-1 iteration / finalize kernels), another descriptor width (tiled score store),
-    and the row-streaming passes (S % 4 == 0) with masks on unequal grids."""
+    16-byte aligned (S % 4 != 0: unaligned 16-byte groups and a ragged last group in the row-streaming passes), another
+    descriptor width (tiled score store), masks on unequal grids, and rows wider than 5119 columns (the 512-thread variant
+    of the passes: the outdoor 105 x 105 grid and an aligned one)."""
     import torch
     from oracle import loftr_oracle as O
     from loftr_amd import ops
@@ -248,7 +251,8 @@ def test_sinkhorn_paths_vs_oracle(hw0, hw1, C, masked, prefilter):
     f0 = rng.standard_normal((N, L, C)).astype(np.float32) * 2
     f1 = rng.standard_normal((N, S, C)).astype(np.float32) * 2
     k = min(L, S)
-    f1[:, :k] += 1.5 * f0[:, rng.permutation(L)[:k]]
+    cols = np.arange(k) if S < 1000 else np.sort(rng.permutation(S)[:k])       # (wide grids: the first k cells are all border cells)
+    f1[:, cols] += 1.5 * f0[:, rng.permutation(L)[:k]]
     m0 = m1 = None
     if masked:
         m0 = np.ones((N,) + hw0, bool); m0[1, hw0[0] - 2:] = False
