@@ -102,12 +102,12 @@ __device__ __forceinline__ void pack_panel(const float (&v)[16], h16x8 (&fh)[2],
   }
 }
 
-__global__ __launch_bounds__(W * 64, 1) void encoder_x_kernel(Args a) {
-  __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
+// One workgroup of the layer: `id` is its index inside the job `a` (= blockIdx.x when the launch holds one job)
+__device__ __forceinline__ void encoder_x_body(const Args& a, const int id, char* const lds) {
   // ---- workgroup -> (sequence, group of token blocks): a sequence's groups run back to back on one XCD (weights, P in its L2)
   // (with fewer sequences than XCDs -- 1 / 2 / 4 at the outdoor configuration's batch sizes -- a sequence is cut into xsplit chunks
   //  of groups that take one XCD each: pinned one sequence per XCD, 2 sequences used 64 of the 256 CUs)
-  const int id = blockIdx.x, xcd = id % NUM_XCD, slot = id / NUM_XCD;
+  const int xcd = id % NUM_XCD, slot = id / NUM_XCD;
   const int vs = (slot / a.gpc) * NUM_XCD + xcd;        // virtual sequence = (sequence, chunk)
   const int seq = vs / a.xsplit, grp = (vs % a.xsplit) * a.gpc + slot % a.gpc;
   if (seq >= a.nseq || grp >= a.groups) return;
@@ -523,6 +523,24 @@ __global__ __launch_bounds__(W * 64, 1) void encoder_x_kernel(Args a) {
   }
 }
 
+__global__ __launch_bounds__(W * 64, 1) void encoder_x_kernel(Args a) {
+  __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
+  encoder_x_body(a, blockIdx.x, lds);
+}
+
+// TWO jobs in one launch.  A call's time is set by whole rounds of 256 workgroups (one per CU: tools/gpu/r4_enc_sweep.sh -- 256
+// workgroups 116 us, 300: 201 us, 512: 242 us), and the cross-attention calls of the batch-8 configuration are 304: the 208 slots
+// their second round leaves idle take workgroups of the NEXT self-attention call on the other image (it depends on the same
+// predecessor).  Workgroups [0, n0) are job 0's [off0, off0 + n0), the rest job 1's from off1 on; offsets are multiples of the XCD
+// count, so that a workgroup's XCD (blockIdx % 8) is the one its index inside the job names.  Results do not depend on the split.
+struct Args2 { Args j[2]; int n0, off0, off1; };
+__global__ __launch_bounds__(W * 64, 1) void encoder_x2_kernel(Args2 m) {
+  __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
+  const bool second = (int)blockIdx.x >= m.n0;          // workgroup-uniform
+  const Args* a = second ? &m.j[1] : &m.j[0];           // (one copy of the body: its arguments come from a uniform kernarg offset)
+  encoder_x_body(*a, second ? (int)blockIdx.x - m.n0 + m.off1 : (int)blockIdx.x + m.off0, lds);
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // The TAIL of a launch.  encoder_x_kernel's unit of work is one wave x 32 tokens for the whole layer (~110 us): a call with
 // 1200 blocks on the 1024 SIMDs costs two rounds although it holds 1.17 rounds of work.  The blocks beyond the last full
@@ -816,9 +834,10 @@ static bool fused_enabled() {
   return on;
 }
 
-int launch_encoder_x(const EncoderXArgs& p, hipStream_t st) {
-  if (!fused_enabled() || p.C != 256 || p.nseq <= 0 || p.T <= 0 || !p.wq_s || !p.w0_s || !p.w2_s || !p.kv) return LOFTR_ERR_UNSUPPORTED;
-  efx::Args a{};
+// the job's kernel arguments and its number of workgroups (0: not a shape the fused kernel takes)
+static int make_job(const EncoderXArgs& p, efx::Args& a) {
+  if (!fused_enabled() || p.C != 256 || p.nseq <= 0 || p.T <= 0 || !p.wq_s || !p.w0_s || !p.w2_s || !p.kv) return 0;
+  a = efx::Args{};
   a.x_sp = p.x_sp; a.x_f32 = p.x_f32; a.out_f32 = p.out_f32; a.out_sp = p.out_sp;
   a.wq = p.wq; a.pm = p.pm; a.pm_seq_stride = p.pm_seq_stride; a.w0 = p.w0; a.w2 = p.w2;
   a.wq_s = p.wq_s; a.w0_s = p.w0_s; a.w2_s = p.w2_s; a.kv = p.kv; a.mask = p.mask;
@@ -828,7 +847,34 @@ int launch_encoder_x(const EncoderXArgs& p, hipStream_t st) {
   a.xsplit = p.nseq < NUM_XCD ? NUM_XCD / p.nseq : 1;
   if (a.xsplit > a.groups) a.xsplit = a.groups;
   a.gpc = ceil_div(a.groups, a.xsplit);
-  const int grid = NUM_XCD * ceil_div(p.nseq * a.xsplit, NUM_XCD) * a.gpc;
+  return NUM_XCD * ceil_div(p.nseq * a.xsplit, NUM_XCD) * a.gpc;
+}
+
+int encoder_x_workgroups(const EncoderXArgs& p) {
+  efx::Args a;
+  return make_job(p, a);
+}
+
+// workgroups [off0, off0 + n0) of job p0 followed by [off1, off1 + n1) of job p1 in ONE launch (encoder_x2_kernel); n1 == 0: p0 only
+int launch_encoder_x2(const EncoderXArgs& p0, int off0, int n0, const EncoderXArgs& p1, int off1, int n1, hipStream_t st) {
+  efx::Args2 m;
+  const int g0 = make_job(p0, m.j[0]);
+  const int g1 = n1 > 0 ? make_job(p1, m.j[1]) : 0;
+  if (g0 == 0 || (n1 > 0 && g1 == 0)) return LOFTR_ERR_UNSUPPORTED;
+  if (off0 < 0 || n0 <= 0 || off0 + n0 > g0 || off0 % NUM_XCD || n0 % NUM_XCD || n1 < 0) return LOFTR_ERR_BAD_ARG;
+  if (n1 > 0 && (off1 < 0 || off1 + n1 > g1 || off1 % NUM_XCD)) return LOFTR_ERR_BAD_ARG;
+  if (n1 == 0) m.j[1] = m.j[0];
+  m.n0 = n0; m.off0 = off0; m.off1 = off1;
+  TimedLaunch tl(LOFTR_T_ENCODER_X, st);
+  hipLaunchKernelGGL(efx::encoder_x2_kernel, dim3(n0 + n1), dim3(efx::W * 64), 0, st, m);
+  LOFTR_CHECK_LAUNCH();
+  return LOFTR_OK;
+}
+
+int launch_encoder_x(const EncoderXArgs& p, hipStream_t st) {
+  efx::Args a;
+  const int grid = make_job(p, a);
+  if (grid == 0) return LOFTR_ERR_UNSUPPORTED;
   // Split the launch: the largest whole number of 256-workgroup rounds goes to the main kernel (a wave x 32 tokens for the whole
   // layer), the remainder to the cooperative tail kernel (a workgroup x 32 tokens) when that is the cheaper way to finish:
   // OFF by default (LOFTR_ENCODER_TAIL=1 enables it).  Measured at the bench size (tools/gpu/r3_tail.sh): a cooperative round costs

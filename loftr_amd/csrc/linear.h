@@ -97,6 +97,10 @@ struct EncoderXArgs {
   float v_length, attn_eps, p_out_scale, ln_eps;
 };
 int launch_encoder_x(const EncoderXArgs& p, hipStream_t st);
+// Workgroups of the job (0: not a shape the fused kernel takes), and a launch of workgroups [off0, off0 + n0) of job p0 followed by
+// [off1, off1 + n1) of job p1 (offsets / n0 multiples of 8; n1 == 0: p0 alone): two independent calls share rounds of 256 workgroups
+int encoder_x_workgroups(const EncoderXArgs& p);
+int launch_encoder_x2(const EncoderXArgs& p0, int off0, int n0, const EncoderXArgs& p1, int off1, int n1, hipStream_t st);
 
 // The whole fine-level transformer (layers [self, cross]) on M window pairs of T <= 32 tokens, C = 128, in one launch
 // (fine_fused.hip).  [l] = layer 0 (self) / 1 (cross).  LOFTR_ERR_UNSUPPORTED for any other shape.

@@ -26,6 +26,7 @@ struct EncoderWs {
   float *k, *v;                  // [rows_s, C]  fp32
   sp_t *msg, *msgn, *hid;        // [rows_l, C] (fine only), [rows_l, C], [rows_l, 2C]
   void* attn; size_t attn_bytes;
+  void* attn2;                   // a second block of the same size: two calls' KV / P alive at once (scheduled coarse transformer)
   bool ok;
 };
 
@@ -39,7 +40,7 @@ size_t encoder_ws_bytes(int nb, int L, int S, int C) {
   b += 3 * align_up(rows_l * C * 4, 256);          // q, msg, msgn
   b += 2 * align_up(rows_s * C * 4, 256);          // k, v
   b += align_up(rows_l * 2 * C * 4, 256);          // hidden
-  b += attention_workspace_bytes(nb, S, C);
+  b += 2 * align_up(attention_workspace_bytes(nb, S, C), 256);
   return b + 2048;
 }
 
@@ -54,6 +55,7 @@ EncoderWs carve(WsAlloc& wa, int nb, int L, int S, int C) {
   e.hid = wa.take<sp_t>(rows_l * 2 * C);
   e.attn_bytes = attention_workspace_bytes(nb, S, C);
   e.attn = wa.take<char>(e.attn_bytes);
+  e.attn2 = wa.take<char>(e.attn_bytes);
   e.ok = wa.ok();
   return e;
 }
@@ -93,6 +95,83 @@ LayerSp stage_layer(const loftr_layer_weights& w, sp_t* dst, int C, SpJobs& jobs
   l.merge_f32 = w.merge;
   l.n1w = w.norm1_w; l.n1b = w.norm1_b; l.n2w = w.norm2_w; l.n2b = w.norm2_b;
   return l;
+}
+
+// ---- coarse level (C = 256), the two halves of a layer call as separate steps ------------------------------------------------
+// K / V projections of the source with the KV / Ksum reduction in their epilogue (K, V never reach HBM), then the finalize:
+// sum of the row-tile partials + P (KV folded into merge).  Results live in the attention block `attn`.
+int coarse_kv(const sp_t* src_sp, const uint8_t* src_mask, const LayerSp& w, int nb, int S, int C, int H, void* attn, size_t attn_bytes,
+              const float** kv, const sp_t** pm, hipStream_t st) {
+  float* part = attention_part_buffer(attn, attn_bytes, nb, S);
+  if (!part) return LOFTR_ERR_WORKSPACE;
+  int rc;
+  ProjKVArgs pkv{src_sp, S, C, nb, w.kv, src_mask, 1.f / (float)S, part, ceil_div(S, 128), w.kv_s};
+  if ((rc = launch_proj_kv(pkv, st))) return rc;
+  return launch_attention_finalize(w.merge_f32, nb, S, C, H, attn, attn_bytes, kv, pm, st);
+}
+// everything on the x side of the layer (encoder_fused.hip), in place
+EncoderXArgs coarse_x(float* x_f32, sp_t* x_sp, const uint8_t* x_mask, const LayerSp& w, int nb, int L, int S, int C, const float* kv,
+                      const sp_t* pm) {
+  return EncoderXArgs{x_sp, x_f32, x_f32, x_sp, nb, L, C, w.q, pm, (long)C * C, w.mlp0, w.mlp2, w.q_s, w.mlp0_s, w.mlp2_s,
+                      kv, x_mask, w.n1w, w.n1b, w.n2w, w.n2b, (float)S, 1e-6f, 1.f / ATTN_P_SCALE, 1e-5f};
+}
+
+// LocalFeatureTransformer with layers [self, cross] * P at C = 256 (transformer.py:80-101) as a schedule of launches.
+// Calls: A_i = self(feat0), B_i = self(feat1), C_i = cross(feat0 <- feat1), D_i = cross(feat1 <- updated feat0).  The reference's
+// order A B C D is a chain C_i -> D_i -> B_i+1 -> C_i+1 with A_i+1 hanging off C_i: A_i+1 needs nothing D_i or B_i+1 produce, and
+// writes only feat0, which they read through the K V summary taken BEFORE the launch.  A call's time is whole rounds of 256
+// workgroups (encoder_fused.hip: Args2) and a cross call of the batch-8 configuration is 304, so A_i+1 rides in the idle slots
+// of D_i's last round and the rest of it next to B_i+1:
+//     [A_0 B_0]  { [C_i]  [D_i + head of A_i+1]  [B_i+1 + tail of A_i+1] } ...  [C_P-1] [D_P-1]
+// 25 rounds instead of 28 at batch 8.  Every workgroup computes what it computed before: results are bit-identical to the call-by-
+// call order.  LOFTR_ENCODER_SCHEDULE=0 keeps that order (A/B).  Returns LOFTR_ERR_UNSUPPORTED when the shapes are not the fused kernel's.
+int coarse_transformer_scheduled(float* feat0, float* feat1, sp_t* sp0, sp_t* sp1, const uint8_t* mask0, const uint8_t* mask1,
+                                 const LayerSp* lw, int P, bool stacked, int N, int L, int S, int C, int H, const EncoderWs& e,
+                                 hipStream_t st) {
+  int rc;
+  const float* kvA; const sp_t* pmA; const float* kvB; const sp_t* pmB;
+  {
+    // does the fused kernel take these shapes at all?  (probe with dummy summaries: only shapes are looked at)
+    EncoderXArgs probe = coarse_x(feat0, sp0, mask0, lw[0], N, L, L, C, reinterpret_cast<const float*>(e.attn), reinterpret_cast<const sp_t*>(e.attn));
+    if (encoder_x_workgroups(probe) == 0) return LOFTR_ERR_UNSUPPORTED;
+  }
+  // ---- A_0, B_0
+  if (stacked) {
+    if ((rc = coarse_kv(sp0, mask0, lw[0], 2 * N, L, C, H, e.attn, e.attn_bytes, &kvA, &pmA, st))) return rc;
+    if ((rc = launch_encoder_x(coarse_x(feat0, sp0, mask0, lw[0], 2 * N, L, L, C, kvA, pmA), st))) return rc;
+  } else {
+    if ((rc = coarse_kv(sp0, mask0, lw[0], N, L, C, H, e.attn, e.attn_bytes, &kvA, &pmA, st))) return rc;
+    if ((rc = coarse_kv(sp1, mask1, lw[0], N, S, C, H, e.attn2, e.attn_bytes, &kvB, &pmB, st))) return rc;
+    const EncoderXArgs a = coarse_x(feat0, sp0, mask0, lw[0], N, L, L, C, kvA, pmA), b = coarse_x(feat1, sp1, mask1, lw[0], N, S, S, C, kvB, pmB);
+    if ((rc = launch_encoder_x2(a, 0, encoder_x_workgroups(a), b, 0, encoder_x_workgroups(b), st))) return rc;
+  }
+  for (int i = 0; i < P; ++i) {
+    const LayerSp& wc = lw[2 * i + 1];
+    // ---- C_i: feat0 attends to feat1
+    if ((rc = coarse_kv(sp1, mask1, wc, N, S, C, H, e.attn, e.attn_bytes, &kvA, &pmA, st))) return rc;
+    if ((rc = launch_encoder_x(coarse_x(feat0, sp0, mask0, wc, N, L, S, C, kvA, pmA), st))) return rc;
+    // ---- D_i: feat1 attends to the UPDATED feat0 (transformer.py:96-97) ...
+    if ((rc = coarse_kv(sp0, mask0, wc, N, L, C, H, e.attn, e.attn_bytes, &kvA, &pmA, st))) return rc;
+    const EncoderXArgs d = coarse_x(feat1, sp1, mask1, wc, N, S, L, C, kvA, pmA);
+    const int nd = encoder_x_workgroups(d);
+    if (i + 1 == P) {
+      if ((rc = launch_encoder_x(d, st))) return rc;
+      break;
+    }
+    // ---- ... with the head of A_i+1 (self on the same updated feat0) in the slots its last round leaves idle
+    const LayerSp& ws = lw[2 * i + 2];
+    if ((rc = coarse_kv(sp0, mask0, ws, N, L, C, H, e.attn2, e.attn_bytes, &kvB, &pmB, st))) return rc;
+    const EncoderXArgs a = coarse_x(feat0, sp0, mask0, ws, N, L, L, C, kvB, pmB);
+    const int na = encoder_x_workgroups(a);
+    int head = (256 - nd % 256) % 256 / 8 * 8;
+    if (head > na) head = na;
+    if ((rc = launch_encoder_x2(d, 0, nd, a, 0, head, st))) return rc;
+    // ---- B_i+1 (self on feat1, which D_i has just finished) + the tail of A_i+1
+    if ((rc = coarse_kv(sp1, mask1, ws, N, S, C, H, e.attn, e.attn_bytes, &kvA, &pmA, st))) return rc;
+    const EncoderXArgs b = coarse_x(feat1, sp1, mask1, ws, N, S, S, C, kvA, pmA);
+    if ((rc = launch_encoder_x2(b, 0, encoder_x_workgroups(b), a, head, na - head, st))) return rc;
+  }
+  return LOFTR_OK;
 }
 
 int encoder_layer(const float* x_f32, const sp_t* x_sp, const sp_t* src_sp, bool self,
@@ -297,6 +376,16 @@ extern "C" int loftr_transformer_fwd(float* feat0, float* feat1, const uint8_t* 
     if (weights_ready) {
       if ((rc = launch_sp_convert(jobs, st))) return rc;
     } else if ((rc = convert_layers(layers, n_layers, C, w_sp, jobs, lw, st))) return rc;
+  }
+  {
+    // coarse level with the stock layer pattern: the scheduled form (bit-identical results, fewer rounds of workgroups)
+    static const bool sched_on = []() { const char* v = getenv("LOFTR_ENCODER_SCHEDULE"); return !(v && atoi(v) == 0); }();
+    bool pattern = C == 256 && n_layers >= 2 && n_layers % 2 == 0;
+    for (int i = 0; pattern && i < n_layers; ++i) pattern = (layer_is_cross[i] != 0) == ((i & 1) != 0);
+    if (sched_on && pattern) {
+      rc = coarse_transformer_scheduled(feat0, feat1, sp0, sp1, mask0, mask1, lw, n_layers / 2, stacked, N, L, S, C, H, e, st);
+      if (rc != LOFTR_ERR_UNSUPPORTED) return rc;
+    }
   }
   for (int i = 0; i < n_layers; ++i) {
     if (!layer_is_cross[i]) {

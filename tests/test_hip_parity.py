@@ -303,3 +303,22 @@ def test_dual_softmax_paths_vs_oracle(hw0, hw1, C, masked):
     got = set(zip(r["b_ids"].tolist(), r["i_ids"].tolist(), r["j_ids"].tolist()))
     want = set(zip(sel["b_ids"].tolist(), sel["i_ids"].tolist(), sel["j_ids"].tolist()))
     assert len(got ^ want) <= 1 and len(want) > 10, sorted(got ^ want)
+
+
+@pytest.mark.parametrize("shape", [("8", "4800", "4800"), ("3", "300", "300"), ("2", "700", "500", "mask")])
+def test_scheduled_transformer_is_bit_identical_to_call_order(shape, tmp_path):
+    """The coarse transformer runs as a schedule of two-job launches (csrc/transformer.hip: coarse_transformer_scheduled -- the next
+    self-attention call on image 0 rides in the idle slots of the cross call on image 1); LOFTR_ENCODER_SCHEDULE=0 keeps the
+    reference's call order (transformer.py:92-97).  Both must give the same bits: full batch-8 size (a split self call), fewer
+    sequences than XCDs, unequal masked grids.  (The switch is read once per process: two subprocesses.)"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = os.path.join(root, "tools", "micro", "encoder_ab.py")
+    env = dict(os.environ, LOFTR_AB_DIR=str(tmp_path))
+    r0 = subprocess.run([sys.executable, script, "callwise", *shape], env=dict(env, LOFTR_ENCODER_SCHEDULE="0"), capture_output=True, text=True, timeout=300)
+    assert r0.returncode == 0, r0.stderr[-2000:]
+    r1 = subprocess.run([sys.executable, script, "scheduled", *shape], env=dict(env, LOFTR_ENCODER_SCHEDULE="1"), capture_output=True, text=True, timeout=300)
+    assert r1.returncode == 0, r1.stderr[-2000:]
+    assert "bit-identical" in r1.stdout and "finite=True" in r1.stdout and "DIFFERENT" not in r1.stdout, r1.stdout[-2000:]
