@@ -44,19 +44,25 @@ __global__ void transpose_kernel(const float* __restrict__ w, float* __restrict_
 //   KV / Ksum:   a = k, b = v, bscale = 1 / S, mask_b, w = null (1)            (linear_attention.py:41-43)
 //   dKV / dKsum: a = q, b = dA, bscale = 1, w = dDen                            (their gradients)
 // grid (nb * H), 256 threads; thread i owns entries i, i + 256, .. of the D x D matrix.  Fixed summation order.
+// gridDim.y > 1: block (., y) sums tokens [y chunk, (y + 1) chunk) into partial y (mat / vec then point at the partial buffers,
+// [gridDim.y][nb * H][D * D] and [gridDim.y][nb * H][D]; outer_reduce_kernel adds them in order): nb * H blocks alone are 16 .. 32
+// workgroups on 256 CUs (408 us per call at 4 x 4800 tokens, 30 % of the matcher's backward).
 __global__ __launch_bounds__(256) void outer_accum_kernel(const float* __restrict__ a, const float* __restrict__ b,
                                                           const uint8_t* __restrict__ mask, int mask_b, const float* __restrict__ w,
-                                                          float bscale, int Tn, int C, int H, int D, float* __restrict__ mat,
+                                                          float bscale, int Tn, int C, int H, int D, int chunk, float* __restrict__ mat,
                                                           float* __restrict__ vec) {
   __shared__ float As[64][MAXD + 1], Bs[64][MAXD + 1], Ws[64];
   const int n = blockIdx.x / H, h = blockIdx.x % H, tid = threadIdx.x;
   float acc[4] = {0.f, 0.f, 0.f, 0.f}, vacc = 0.f;
   const int DD = D * D;
-  for (int t0 = 0; t0 < Tn; t0 += 64) {
+  const int tb = blockIdx.y * chunk, te = min(Tn, tb + chunk);
+  mat += (long)blockIdx.y * gridDim.x * DD;
+  vec += (long)blockIdx.y * gridDim.x * D;
+  for (int t0 = tb; t0 < te; t0 += 64) {
     for (int i = tid; i < 64 * D; i += 256) {
       const int tt = i / D, d = i - tt * D, t = t0 + tt;
       float av = 0.f, bv = 0.f;
-      if (t < Tn) {
+      if (t < te) {
         const long off = ((long)n * Tn + t) * C + h * D + d;
         const float mk = mask ? (mask[(long)n * Tn + t] ? 1.f : 0.f) : 1.f;
         av = elu1(a[off]) * mk;
@@ -64,7 +70,7 @@ __global__ __launch_bounds__(256) void outer_accum_kernel(const float* __restric
       }
       As[tt][d] = av; Bs[tt][d] = bv;
     }
-    if (tid < 64) { const int t = t0 + tid; Ws[tid] = t < Tn ? (w ? w[((long)n * Tn + t) * H + h] : 1.f) : 0.f; }
+    if (tid < 64) { const int t = t0 + tid; Ws[tid] = t < te ? (w ? w[((long)n * Tn + t) * H + h] : 1.f) : 0.f; }
     __syncthreads();
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -82,6 +88,33 @@ __global__ __launch_bounds__(256) void outer_accum_kernel(const float* __restric
 #pragma unroll
   for (int u = 0; u < 4; ++u) { const int idx = tid + u * 256; if (idx < DD) mat[(long)blockIdx.x * DD + idx] = acc[u]; }
   if (tid < D) vec[(long)blockIdx.x * D + tid] = vacc;
+}
+
+// out[i] = part[0][i] + part[1][i] + ...  (fixed order)
+__global__ void outer_reduce_kernel(const float* __restrict__ part, int np, long n, float* __restrict__ out) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float s = part[i];
+  for (int p = 1; p < np; ++p) s += part[(long)p * n + i];
+  out[i] = s;
+}
+// tokens split over up to 16 chunks of >= 512 when the scratch holds the partials (scratch_floats), else one block per (pair, head)
+void launch_outer_accum(const float* a, const float* b, const uint8_t* mask, int mask_b, const float* w, float bscale, int Tn, int C, int H, int D,
+                        int nb, float* mat, float* vec, float* scratch, size_t scratch_floats, hipStream_t st) {
+  int splits = Tn > 1024 ? ceil_div(Tn, 512) : 1;
+  if (splits > 16) splits = 16;
+  const long nm = (long)nb * H * D * D, nv = (long)nb * H * D;
+  if ((size_t)splits * (size_t)(nm + nv) > scratch_floats) splits = 1;
+  if (splits == 1) {
+    hipLaunchKernelGGL(outer_accum_kernel, dim3(nb * H), dim3(256), 0, st, a, b, mask, mask_b, w, bscale, Tn, C, H, D, Tn, mat, vec);
+    return;
+  }
+  const int chunk = ceil_div(ceil_div(Tn, splits), 64) * 64;
+  splits = ceil_div(Tn, chunk);
+  float* pm = scratch; float* pv = scratch + (size_t)splits * nm;
+  hipLaunchKernelGGL(outer_accum_kernel, dim3(nb * H, splits), dim3(256), 0, st, a, b, mask, mask_b, w, bscale, Tn, C, H, D, chunk, pm, pv);
+  hipLaunchKernelGGL(outer_reduce_kernel, dim3((unsigned)ceil_div((int)nm, 256)), dim3(256), 0, st, pm, splits, nm, mat);
+  hipLaunchKernelGGL(outer_reduce_kernel, dim3((unsigned)ceil_div((int)nv, 256)), dim3(256), 0, st, pv, splits, nv, vec);
 }
 
 // Per (token l, head h):  Q = (elu(q)+1) mq;  A = Q KV;  Z = 1 / (Q . Ksum + eps);  msg0 = A Z S            (linear_attention.py:44-45)
@@ -313,6 +346,7 @@ extern "C" int loftr_encoder_layer_bwd(const float* x, const float* source, cons
   if (!a.ok) return LOFTR_ERR_WORKSPACE;
   const int D = C / H, C2 = 2 * C;
   const long T = (long)nb * L, Ts = (long)nb * S;
+  const size_t wpart_floats = wgrad_part_floats(T > Ts ? T : Ts, 2 * C, 2 * C);      // (a.wpart also holds the K V partials: not alive together)
   const float vlen = (float)S, inv_s = 1.f / (float)S, attn_eps = 1e-6f, ln_eps = 1e-5f;      // linear_attention.py:26,41; nn.LayerNorm default
   int rc;
 #define LIN(A_, W_, OUT_, M_, N_, K_) if ((rc = loftr_linear_fwd(A_, W_, OUT_, (int)(M_), N_, K_, a.lin, a.lin_bytes, stream))) return rc
@@ -324,7 +358,7 @@ extern "C" int loftr_encoder_layer_bwd(const float* x, const float* source, cons
   LIN(x, w->q_proj, a.q, T, C, C);
   LIN(source, w->k_proj, a.k, Ts, C, C);
   LIN(source, w->v_proj, a.v, Ts, C, C);
-  hipLaunchKernelGGL(outer_accum_kernel, dim3(nb * H), dim3(256), 0, st, a.k, a.v, source_mask, 1, nullptr, inv_s, S, C, H, D, a.KV, a.Ksum);
+  launch_outer_accum(a.k, a.v, source_mask, 1, nullptr, inv_s, S, C, H, D, nb, a.KV, a.Ksum, a.wpart, wpart_floats, st);
   if (D == 32)
     hipLaunchKernelGGL((attn_q_kernel<false, 32>), dim3(ceil_div(L, 256), nb * H), dim3(256), 0, st, a.q, x_mask, a.KV, a.Ksum, vlen, attn_eps,
                        L, C, H, a.msg0, (const float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr);
@@ -369,7 +403,7 @@ extern "C" int loftr_encoder_layer_bwd(const float* x, const float* source, cons
   else
     hipLaunchKernelGGL((attn_q_kernel<true, 16>), dim3(ceil_div(L, 256), nb * H), dim3(256), 0, st, a.q, x_mask, a.KV, a.Ksum, vlen, attn_eps,
                        L, C, H, (float*)nullptr, (const float*)a.dmsg0, a.dA, a.dDen, a.dq);
-  hipLaunchKernelGGL(outer_accum_kernel, dim3(nb * H), dim3(256), 0, st, a.q, a.dA, x_mask, 0, a.dDen, 1.f, L, C, H, D, a.dKV, a.dKsum);
+  launch_outer_accum(a.q, a.dA, x_mask, 0, a.dDen, 1.f, L, C, H, D, nb, a.dKV, a.dKsum, a.wpart, wpart_floats, st);
   if (D == 32)
     hipLaunchKernelGGL((attn_kv_bwd_kernel<32>), dim3(ceil_div(S, 256), nb * H), dim3(256), 0, st, a.k, a.v, source_mask, a.dKV, a.dKsum, inv_s,
                        S, C, H, a.dk, a.dv);

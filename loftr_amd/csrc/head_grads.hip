@@ -254,6 +254,22 @@ __global__ void reduce_partials_kernel(const float* __restrict__ part, float* __
   for (int p = 0; p < P; ++p) s += part[(long)p * stride + i];
   out[i] = s;
 }
+// the same for P >> n: 32 columns x 8 lanes per block, lane l adds p = l, l + 8, ... (ascending), then the 8 lane sums in order
+__global__ __launch_bounds__(256) void reduce_partials_tall_kernel(const float* __restrict__ part, float* __restrict__ out, int P, long stride, long n) {
+  __shared__ float red[8][32];
+  const int c = threadIdx.x & 31, l = threadIdx.x >> 5;
+  const long i = (long)blockIdx.x * 32 + c;
+  float s = 0.f;
+  if (i < n) for (int p = l; p < P; p += 8) s += part[(long)p * stride + i];
+  red[l][c] = s;
+  __syncthreads();
+  if (l == 0 && i < n) {
+    float t = red[0][c];
+#pragma unroll
+    for (int k = 1; k < 8; ++k) t += red[k][c];
+    out[i] = t;
+  }
+}
 // part[block][c] = sum over the block's WG_ROWS rows of x[row][c]   (column sums, stage 1; ascending rows)
 constexpr int COLSUM_ROWS = 256;
 __global__ void colsum_part_kernel(const float* __restrict__ x, long rows, int C, float* __restrict__ part) {
@@ -265,23 +281,44 @@ __global__ void colsum_part_kernel(const float* __restrict__ x, long rows, int C
   }
 }
 }  // namespace
-constexpr int WGRAD_KCHUNK = 512;      // tokens per split-K partial
-size_t wgrad_part_floats(long T, int O, int I) { return (size_t)ceil_div((int)T, WGRAD_KCHUNK) * O * I; }
+// Tokens per split-K partial: enough partials to put ~256 workgroups on the chip (one 128-row tile of dW per workgroup and partial),
+// between 128 and 512 tokens, a multiple of the k-tile.  (A fixed 512 left a 256 x 256 gradient over 9600 tokens on 38 workgroups.)
+static int wgrad_chunk(long T, int O) {
+  const int tiles = ceil_div(O, 128);
+  const int target = tiles >= 256 ? 1 : 256 / tiles;
+  long c = (T + target - 1) / target;
+  c = (c + 31) / 32 * 32;
+  return (int)(c < 128 ? 128 : (c > 512 ? 512 : c));
+}
+// scratch of launch_wgrad for any O' <= O (callers size one buffer for their largest matrix and reuse it)
+size_t wgrad_part_floats(long T, int O, int I) {
+  size_t best = 0;
+  for (int o = 128;; o += 128) {
+    const int oo = o < O ? o : O;
+    const size_t v = (size_t)ceil_div((int)T, wgrad_chunk(T, oo)) * oo * I;
+    best = v > best ? v : best;
+    if (o >= O) break;
+  }
+  return best;
+}
 // dW [O][I] = dy^T act  (dy [T, O], act [T, I]): a split-K batch of launch_head_grad + an ordered sum of the partials; I in column
 // blocks of <= 256.  part: wgrad_part_floats(T, O, I) floats of scratch.
 int launch_wgrad(const float* dy, int O, const float* act, int I, long T, float* dW, float* part, hipStream_t st) {
-  const int ns = ceil_div((int)T, WGRAD_KCHUNK);
+  const int kch = wgrad_chunk(T, O);
+  const int ns = ceil_div((int)T, kch);
   for (int c0 = 0; c0 < I; c0 += 256) {
     const int cw = I - c0 < 256 ? I - c0 : 256;
-    const int rc = launch_head_grad(dy, O, (long)WGRAD_KCHUNK * O, true, act + c0, I, (long)WGRAD_KCHUNK * I, part + c0, I, (long)O * I, O,
-                                    WGRAD_KCHUNK, (int)T, cw, ns, 1.f, st);
+    const int rc = launch_head_grad(dy, O, (long)kch * O, true, act + c0, I, (long)kch * I, part + c0, I, (long)O * I, O,
+                                    kch, (int)T, cw, ns, 1.f, st);
     if (rc) return rc;
   }
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)(((long)O * I + 255) / 256)), dim3(256), 0, st, part, dW, ns, (long)O * I, (long)O * I);
-  return LOFTR_OK;
+  return launch_reduce_partials(part, dW, ns, (long)O * I, (long)O * I, st);
 }
 int launch_reduce_partials(const float* part, float* out, int P, long stride, long n, hipStream_t st) {
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, part, out, P, stride, n);
+  if (P >= 16)                   // many partials (split-K weight gradients, LayerNorm weight gradients: one partial per 64 rows): 8 lanes share the walk over P
+    hipLaunchKernelGGL(reduce_partials_tall_kernel, dim3((unsigned)((n + 31) / 32)), dim3(256), 0, st, part, out, P, stride, n);
+  else
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, part, out, P, stride, n);
   return LOFTR_OK;
 }
 size_t colsum_part_floats(long rows, int C) { return (size_t)((rows + COLSUM_ROWS - 1) / COLSUM_ROWS) * C; }

@@ -9,7 +9,7 @@ O=$R/gpurun_out
 mkdir -p $O; export TMPDIR=/tmp; cd $R
 python -c 'import torch' 2> /dev/null
 rm -f $O/parity_e2e.txt
-timeout 1500 python -m pytest tests -m gpu -q --timeout 600 2>&1 | tail -3 | tee $O/${T}_pytest_gpu.txt
+timeout 1500 python -m pytest tests -m gpu -q --timeout 600 > $O/${T}_pytest_full.txt 2>&1; grep -E "passed|failed|error" $O/${T}_pytest_full.txt | tail -3 | tee $O/${T}_pytest_gpu.txt
 { echo "# parity margins of the HIP path, library of $(date -u +%FT%TZ), source hash $(python -c 'import bench; print(bench.source_hash())')";
   echo "# (1) hot path from the reference's backbone features (tools/parity_margins.py)"; timeout 600 python tools/parity_margins.py 2>&1 | grep -v "amdgpu.ids\|^W2026";
   echo "# (2) full forward from images, both backbones (tests/test_e2e_golden.py; max and RMS distances to the reference's fp64 forward, next to the reference's own fp32 forward)";
@@ -28,9 +28,10 @@ timeout -k 5 180 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/pmc_write_$T -o
 timeout -k 5 180 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -d $O/pmc_sq_$T -o p -- $B --steps 2 > /dev/null 2> $O/${T}_pmc_sq.err
 [ $? -eq 0 ] || fail "$O/pmc_sq_$T" $O/${T}_pmc_sq.err
 timeout -k 5 200 rocprofv3 --kernel-trace -d $O/prof_cov_$T -o p -- $B --steps 12 > /dev/null 2> $O/${T}_cov.err
-timeout -k 5 200 rocprofv3 --kernel-trace --stats -d $O/prof_out_$T -o p -- python $R/tools/micro/outdoor_bench.py 2 5 > $O/${T}_outdoor_n2.txt 2>&1
+timeout -k 5 200 rocprofv3 --kernel-trace --stats -d $O/prof_out_$T -o p -- python $R/tools/micro/outdoor_bench.py 2 5 2>&1 | grep "^outdoor" > $O/${T}_outdoor_n2.txt
 timeout -k 5 200 rocprofv3 --kernel-trace --stats -d $O/prof_ot_$T -o p -- $B --match-type sinkhorn --steps 5 --no-overlap > /dev/null 2> $O/${T}_ot.err
 timeout -k 5 200 rocprofv3 --kernel-trace --stats -d $O/prof_bwd_$T -o p -- python $R/tools/micro/grad_bench.py 8 7700 3 > $O/${T}_grad_bench.txt 2> $O/${T}_grad_bench.err
+timeout -k 5 200 rocprofv3 --kernel-trace --stats -d $O/prof_ts_$T -o p -- python $R/tools/micro/train_step_bench.py 2 3 2>&1 | grep -v "amdgpu.ids\|^W2026\|^E2026" > $O/${T}_train_step.txt
 cd $R
 db() { find $1 -name '*.db' | head -1; }
 python tools/rocpd_summary.py $(db $O/prof_$T) > $O/${T}_kernel_stats.txt 2>&1
@@ -40,9 +41,13 @@ python tools/rocpd_summary.py $(db $O/prof_cov_$T) | grep "^# " > $O/${T}_covera
 python tools/rocpd_summary.py $(db $O/prof_out_$T) > $O/${T}_kernel_stats_outdoor.txt 2>&1
 python tools/rocpd_summary.py $(db $O/prof_ot_$T) > $O/${T}_kernel_stats_ot.txt 2>&1
 python tools/rocpd_summary.py $(db $O/prof_bwd_$T) > $O/${T}_kernel_stats_backward.txt 2>&1
+python tools/rocpd_summary.py $(db $O/prof_ts_$T) > $O/${T}_kernel_stats_train_step.txt 2>&1
 cp $O/pmc_traffic.json $R/profiles/pmc_traffic.json
-rm -rf $O/prof_$T $O/profs_$T $O/pmc_fetch_$T $O/pmc_write_$T $O/pmc_sq_$T $O/prof_cov_$T $O/prof_out_$T $O/prof_ot_$T $O/prof_bwd_$T
+rm -rf $O/prof_$T $O/profs_$T $O/pmc_fetch_$T $O/pmc_write_$T $O/pmc_sq_$T $O/prof_cov_$T $O/prof_out_$T $O/prof_ot_$T $O/prof_bwd_$T $O/prof_ts_$T
 for n in 1 2 4; do timeout 120 python tools/micro/outdoor_bench.py $n 5 2>&1 | grep outdoor; done | tee -a $O/${T}_outdoor_n2.txt
+for m in 2 4; do timeout 120 python tools/micro/outdoor_bench.py $m 5 sinkhorn 2>&1 | grep outdoor; done | tee -a $O/${T}_outdoor_n2.txt
+[ -x tools/micro/dma_probe ] && timeout 60 tools/micro/dma_probe > $O/${T}_dma_probe.txt 2>&1
+bash tools/gpu/r4_enc_sweep.sh > $O/${T}_encoder_rounds.txt 2>&1
 timeout 300 python tools/micro/conv_layers.py 16 10 2>&1 | grep -v "amdgpu.ids\|^W2026" > $O/${T}_conv_layers.txt
 head -14 $O/${T}_kernel_stats_serial.txt | cut -c1-160; head -20 $O/${T}_pmc_traffic.txt | cut -c1-200; cat $O/${T}_coverage.txt
 # the bench line as the driver runs it (with the PMC table of THIS build in place)

@@ -43,6 +43,8 @@ def bench_name(full):
         return "score_store_kernel"         # Sinkhorn: score store on the sweep
     if "conv3x3_duo_kernel" in full:        # round 4: the 3x3 stride-1 convolutions; timed under the ids of the kernels they replaced
         return "conv3x3_wide_kernel" if "Cfg<7" in full else "conv3x3_kernel"
+    if "encoder_x2_kernel" in full:         # round 4: two-job launches of the same kernel body, timed under LOFTR_T_ENCODER_X
+        return "encoder_x_kernel"
     if "rowsweep_kernel<0" in full:
         return "proj_kernel"                # coarse q projection (timed under LOFTR_T_PROJ)
     if "rowsweep_kernel<1" in full:
