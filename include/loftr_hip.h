@@ -42,8 +42,9 @@ typedef enum {
  *     loftr_fine_match_bwd);
  * 17: loftr_head_feat_grads (the feature-gradient GEMMs of both coarse heads);
  * 18: loftr_encoder_layer_bwd;
- * 19: loftr_fine_preprocess_bwd */
-#define LOFTR_HIP_ABI_VERSION 19
+ * 19: loftr_fine_preprocess_bwd;
+ * 20: loftr_conv_wgrad (backbone training: weight gradient of a convolution) */
+#define LOFTR_HIP_ABI_VERSION 20
 
 int loftr_hip_abi_version(void);
 const char* loftr_hip_status_string(int status);
@@ -356,6 +357,15 @@ int loftr_fine_match_bwd(const float* feat_f0, const float* feat_f1, int M, int 
  * [L+1, S+1] gradient); fp32 in and out, split-fp16 MFMA products with fp32 accumulation (csrc/head_grads.hip).  C % 32 == 0, C <= 256. */
 int loftr_head_feat_grads(const float* dsim, long dsim_ld, long dsim_bs, const float* feat_c0, const float* feat_c1,
                           int N, int L, int S, int C, float alpha, float* g0, float* g1, void* stream);
+/* Weight gradient of a bias-free convolution (what autograd computes for every nn.Conv2d of resnet_fpn.py in a training step):
+ *   dw_taps[ky * KW + kx][co][ci] = sum_{b,y,x} dy[b,y,x,co] * x[b, y stride + ky - pad, x stride + kx - pad, ci]   (zero outside the map)
+ * dy [B,Ho,Wo,Cout], x [B,H,W,Cin] fp32 channels-last; the caller permutes dw_taps [KH*KW, Cout, Cin] to [Cout,Cin,KH,KW].  Per tap a
+ * split-K product over the output pixels on the split-fp16 MFMA path with fp32 accumulation and an ordered sum of the partials
+ * (deterministic).  Cin % 4 == 0, Cin <= 256 (the one-channel stem: hand in the 7 x 7 patches as a 52-channel 1 x 1 problem).
+ * The input gradient is loftr_conv_bn_act on the flipped, transposed filter (stride 2: on the zero-interleaved dy). */
+size_t loftr_conv_wgrad_workspace_bytes(int B, int Ho, int Wo, int Cin, int Cout);
+int loftr_conv_wgrad(const float* dy, const float* x, int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
+                     float* dw_taps, void* ws, size_t ws_bytes, void* stream);
 size_t loftr_sinkhorn_bwd_workspace_bytes(int N, int L, int S, int C, int iters);
 int loftr_sinkhorn_bwd(const float* feat_c0, const float* feat_c1, const loftr_coarse_params* p, float bin_score, int iters,
                        const float* grad_assign, float* z_scratch, float* dZ, float* dbin, void* ws, size_t ws_bytes, void* stream);

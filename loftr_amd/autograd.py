@@ -206,3 +206,86 @@ def pos_encode_flatten(x, pe):
 
 def wants_grad(*tensors):
     return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)
+
+
+# ---- backbone training: nn.Conv2d(bias=False) with HIP forward, input gradient and weight gradient -------------------------------------
+class _Conv2d(torch.autograd.Function):
+    """F.conv2d(x, weight, None, stride, padding) of the backbone's bias-free convolutions (resnet_fpn.py:5-13, :52, :58-77) as an
+    autograd node on the HIP convolutions.
+      forward:  x -> channels-last -> scaled SP -> loftr_conv_bn_act (no BatchNorm folded) -> fp32;
+      dL/dx:    the same kernels on the flipped, transposed filter (stride 2: on dy with zeros interleaved; 1 x 1 stride 2: the
+                low-resolution product scattered to the even pixels);
+      dL/dw:    loftr_conv_wgrad (split-K over the output pixels, ordered partial sums).
+    BatchNorm (batch statistics), activations, the residual / FPN adds and the bilinear upsampling stay PyTorch autograd."""
+    calls = 0                                                  # forward applications (tests check that the node is the one that ran)
+
+    @staticmethod
+    def forward(ctx, x, weight, stride, pad):
+        _Conv2d.calls += 1
+        Cout, Cin, KH, KW = weight.shape
+        xn = x.detach().permute(0, 2, 3, 1).contiguous()
+        if Cin % 4:                                            # the one-channel stem: its KH x KW patches as channels (1 x 1 problem)
+            assert Cin == 1
+            cols = torch.nn.functional.unfold(x.detach(), (KH, KW), padding=pad, stride=stride)       # [B, KH*KW, Ho*Wo]
+            B, _, H, W = x.shape
+            Ho, Wo = (H + 2 * pad - KH) // stride + 1, (W + 2 * pad - KW) // stride + 1
+            kk = (KH * KW + 3) // 4 * 4
+            xn = torch.zeros(B, Ho, Wo, kk, dtype=x.dtype, device=x.device)
+            xn[..., :KH * KW] = cols.transpose(1, 2).reshape(B, Ho, Wo, KH * KW)
+            w1 = torch.zeros(Cout, kk, 1, 1, dtype=weight.dtype, device=weight.device)
+            w1[:, :KH * KW, 0, 0] = weight.detach().reshape(Cout, KH * KW)
+            xs, inv = ops.sp_from_nhwc(xn, scaled=True)
+            y = ops.conv_raw(xs, kk, w1, 1, 0, x_inv_scale=inv)
+            ctx.stem = (KH, KW, kk)
+        else:
+            xs, inv = ops.sp_from_nhwc(xn, scaled=True)
+            y = ops.conv_raw(xs, Cin, weight.detach().contiguous(), stride, pad, x_inv_scale=inv)
+            ctx.stem = None
+        ctx.save_for_backward(xn, weight)
+        ctx.geom = (stride, pad, tuple(x.shape))
+        return y.permute(0, 3, 1, 2)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        xn, weight = ctx.saved_tensors
+        stride, pad, xshape = ctx.geom
+        Cout, Cin, KH, KW = weight.shape
+        dyn = dy.permute(0, 2, 3, 1).contiguous()
+        B, Ho, Wo, _ = dyn.shape
+        dw = dx = None
+        if ctx.needs_input_grad[1]:
+            if ctx.stem is not None:
+                kk = ctx.stem[2]
+                dw = ops.conv_wgrad(dyn, xn, 1, 1, 1, 0)[:, :KH * KW, 0, 0].reshape(Cout, 1, KH, KW).contiguous()
+            else:
+                dw = ops.conv_wgrad(dyn, xn, KH, KW, stride, pad)
+        if ctx.needs_input_grad[0]:
+            if ctx.stem is not None:
+                raise RuntimeError("the stem's input gradient is not implemented (images are leaves without gradients)")
+            H, W = xshape[2], xshape[3]
+            wt = weight.detach().flip(2, 3).transpose(0, 1).contiguous()                  # [Cin, Cout, KH, KW], taps reversed
+            if stride == 1:
+                ds, inv = ops.sp_from_nhwc(dyn, scaled=True)
+                dxn = ops.conv_raw(ds, Cout, wt, 1, KH - 1 - pad, x_inv_scale=inv)
+            elif KH == 1 and KW == 1 and pad == 0:
+                ds, inv = ops.sp_from_nhwc(dyn, scaled=True)
+                low = ops.conv_raw(ds, Cout, wt, 1, 0, x_inv_scale=inv)
+                dxn = torch.zeros(B, H, W, Cin, dtype=dyn.dtype, device=dyn.device)
+                dxn[:, 0:stride * Ho:stride, 0:stride * Wo:stride] = low
+            else:
+                # transposed convolution = stride-1 convolution of dy with stride - 1 zeros between its pixels (and the rows / columns
+                # the forward never reached appended), filter flipped, padding K - 1 - pad
+                Hz, Wz = H + 2 * pad - KH + 1, W + 2 * pad - KW + 1
+                dz = torch.zeros(B, Hz, Wz, Cout, dtype=dyn.dtype, device=dyn.device)
+                dz[:, 0:stride * Ho:stride, 0:stride * Wo:stride] = dyn
+                ds, inv = ops.sp_from_nhwc(dz, scaled=True)
+                dxn = ops.conv_raw(ds, Cout, wt, 1, KH - 1 - pad, x_inv_scale=inv)
+            assert tuple(dxn.shape) == (B, H, W, Cin), (dxn.shape, xshape)
+            dx = dxn.permute(0, 3, 1, 2)
+        return dx, dw, None, None
+
+
+def conv2d(x, weight, stride=1, padding=0):
+    """Differentiable bias-free convolution on the HIP kernels (see _Conv2d)."""
+    return _Conv2d.apply(x, weight, int(stride), int(padding))

@@ -13,6 +13,10 @@ Two execution paths over the same parameters:
                         launch of the library's split-fp16 MFMA core (csrc/conv.hip), the FPN
                         upsample+add one more kernel, the 1-channel 7x7 stem a direct convolution.
 ``LoFTR`` uses ``forward_hip`` on the GPU in eval mode (``backbone_impl='hip'``).
+
+Training (``.train()``, gradients wanted): ``forward`` with every convolution an autograd node on the HIP kernels
+(``Conv2d`` below -> ``autograd.conv2d``: forward, input gradient, weight gradient); BatchNorm with batch statistics,
+the activations, the adds and the bilinear upsampling stay PyTorch autograd.
 """
 import os
 
@@ -20,18 +24,34 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import ops
+from . import autograd, ops
 
 # A/B switch: LOFTR_FUSE_TOPDOWN=0 runs the lateral conv and the upsample-add as two launches
 FUSE_TOPDOWN = os.environ.get("LOFTR_FUSE_TOPDOWN", "1") != "0"
 
 
+# LOFTR_TRAIN_CONV=0: training runs the convolutions through PyTorch (MIOpen) instead of the HIP autograd node (A/B)
+TRAIN_CONV_HIP = os.environ.get("LOFTR_TRAIN_CONV", "1") != "0"
+
+
+class Conv2d(nn.Conv2d):
+    """nn.Conv2d(bias=False) of the backbone.  In .train() mode on the GPU, with gradients wanted, it is the HIP autograd node
+    (autograd.conv2d: forward, input gradient and weight gradient on the library's convolutions); everywhere else the stock
+    module (the inference path does not go through forward() at all: forward_hip reads the weights)."""
+
+    def forward(self, x):
+        if (TRAIN_CONV_HIP and self.training and x.is_cuda and x.dtype == torch.float32 and torch.is_grad_enabled()
+                and (x.requires_grad or self.weight.requires_grad)):
+            return autograd.conv2d(x, self.weight, self.stride[0], self.padding[0])
+        return super().forward(x)
+
+
 def _c1(cin, cout, stride=1):
-    return nn.Conv2d(cin, cout, kernel_size=1, stride=stride, padding=0, bias=False)
+    return Conv2d(cin, cout, kernel_size=1, stride=stride, padding=0, bias=False)
 
 
 def _c3(cin, cout, stride=1):
-    return nn.Conv2d(cin, cout, kernel_size=3, stride=stride, padding=1, bias=False)
+    return Conv2d(cin, cout, kernel_size=3, stride=stride, padding=1, bias=False)
 
 
 class BasicBlock(nn.Module):
@@ -132,7 +152,7 @@ class ResNetFPN_8_2(_ResNetFPN):
         d0 = config["initial_dim"]
         d1, d2, d3 = config["block_dims"]
         self.in_planes = d0
-        self.conv1 = nn.Conv2d(1, d0, kernel_size=7, stride=2, padding=3, bias=False)
+        self.conv1 = Conv2d(1, d0, kernel_size=7, stride=2, padding=3, bias=False)
         self.bn1 = nn.BatchNorm2d(d0)
         self.relu = nn.ReLU(inplace=True)
         self.layer1 = self._stage(d1, 1)     # 1/2
@@ -192,7 +212,7 @@ class ResNetFPN_16_4(_ResNetFPN):
         d0 = config["initial_dim"]
         d1, d2, d3, d4 = config["block_dims"]
         self.in_planes = d0
-        self.conv1 = nn.Conv2d(1, d0, kernel_size=7, stride=2, padding=3, bias=False)
+        self.conv1 = Conv2d(1, d0, kernel_size=7, stride=2, padding=3, bias=False)
         self.bn1 = nn.BatchNorm2d(d0)
         self.relu = nn.ReLU(inplace=True)
         self.layer1 = self._stage(d1, 1)     # 1/2

@@ -421,7 +421,9 @@ class LoFTR(nn.Module):
         """Steps 2-5 of forward (loftr.py:51-75): THE hot path.  `data` needs bs, hw0_i, hw1_i."""
         data.update({"hw0_c": feat_c0.shape[2:], "hw1_c": feat_c1.shape[2:],
                      "hw0_f": feat_f0.shape[2:], "hw1_f": feat_f1.shape[2:]})
-        both = ops.stacked_halves(feat_c0, feat_c1) if feat_c0.shape == feat_c1.shape else None
+        # (not with a graph: as_strided's backward only reaches the FIRST half's tensor, the second half's gradient would be dropped)
+        both = (ops.stacked_halves(feat_c0, feat_c1)
+                if feat_c0.shape == feat_c1.shape and not autograd.wants_grad(feat_c0, feat_c1) else None)
         if both is not None:         # the two coarse maps are halves of one backbone batch: one launch, one buffer
             feat_c0, feat_c1 = self.pos_encoding(both).split(feat_c0.shape[0])
         else:

@@ -523,6 +523,40 @@ def conv_bn_act(x_sp, Cin, conv, bn=None, act=0, residual=None, want_sp=True, wa
 
 
 @_on_device
+def conv_raw(x_sp, Cin, weight, stride, pad, x_inv_scale=None):
+    """Bias-free convolution of an SP activation with a filter given as a TENSOR [Cout,Cin,KH,KW] (no BatchNorm folded, no
+    activation, filter encoded per call): the training forward and the input-gradient convolutions.  -> fp32 [B,Ho,Wo,Cout]."""
+    _need(weight, "weight")
+    Cout, Cin_w, KH, KW = weight.shape
+    assert Cin_w == Cin
+    B, H, W, Cp = x_sp.shape
+    assert Cp == ceil32(Cin) and x_sp.dtype == torch.int32 and x_sp.is_contiguous()
+    Ho, Wo = (H + 2 * pad - KH) // stride + 1, (W + 2 * pad - KW) // stride + 1
+    lib = _lib.load()
+    ws = workspace(lib.loftr_conv_workspace_bytes(Cin, Cout, KH, KW), x_sp.device)
+    y = torch.empty(B, Ho, Wo, Cout, dtype=torch.float32, device=x_sp.device)
+    wst = (C.c_long * 4)(*weight.stride())
+    check(lib.loftr_conv_bn_act(_ptr(x_sp), B, H, W, Cin, _ptr(weight), wst, Cout, KH, KW, stride, pad, None, None, None, None, 0.0, 0,
+                                None, None, _ptr(y), _ptr(ws), ws.numel(), _ptr(x_inv_scale), _stream()), "loftr_conv_bn_act")
+    return y
+
+
+@_on_device
+def conv_wgrad(dy_nhwc, x_nhwc, KH, KW, stride, pad):
+    """dL/dweight [Cout,Cin,KH,KW] of a bias-free convolution from dy [B,Ho,Wo,Cout] and its input x [B,H,W,Cin] (fp32, channels last)."""
+    _need(dy_nhwc, "dy_nhwc"); _need(x_nhwc, "x_nhwc")
+    B, H, W, Cin = x_nhwc.shape
+    _, Ho, Wo, Cout = dy_nhwc.shape
+    assert Ho == (H + 2 * pad - KH) // stride + 1 and Wo == (W + 2 * pad - KW) // stride + 1 and dy_nhwc.shape[0] == B
+    lib = _lib.load()
+    ws = workspace(lib.loftr_conv_wgrad_workspace_bytes(B, Ho, Wo, Cin, Cout), x_nhwc.device)
+    taps = torch.empty(KH * KW, Cout, Cin, dtype=torch.float32, device=x_nhwc.device)
+    check(lib.loftr_conv_wgrad(_ptr(dy_nhwc), _ptr(x_nhwc), B, H, W, Cin, Cout, KH, KW, stride, pad, _ptr(taps), _ptr(ws), ws.numel(),
+                               _stream()), "loftr_conv_wgrad")
+    return taps.view(KH, KW, Cout, Cin).permute(2, 3, 0, 1).contiguous()
+
+
+@_on_device
 def stem_conv_bn_relu(x, conv, bn):
     """conv1 (7x7, stride 2, one input channel) + eval bn1 + relu -> SP int32 [B,Ho,Wo,ceil32(C0)]."""
     if not x.is_cuda or x.dtype != torch.float32 or x.shape[1] != 1:

@@ -186,10 +186,13 @@ def test_sinkhorn_backward_full_size():
         assert err <= 5e-4, err
 
 
-@pytest.mark.parametrize("N,L,S,C,strided", [(2, 300, 173, 256, False), (1, 129, 640, 128, True), (3, 48, 48, 256, False), (1, 4800, 4800, 256, False)])
+@pytest.mark.parametrize("N,L,S,C,strided", [(2, 300, 173, 256, False), (1, 129, 640, 128, True), (3, 48, 48, 256, False), (1, 4800, 4800, 256, False),
+                                             (8, 4800, 4800, 256, False)])
 def test_head_feat_grads_vs_fp64(N, L, S, C, strided):
     """loftr_head_feat_grads (csrc/head_grads.hip): g0 = a dsim f1, g1 = a dsim^T f0 against float64 matmuls -- ragged tiles on every
-    axis, the strided view the Sinkhorn head hands in, gradient magnitudes that vary by 1e6 across the matrix (running tile scales)."""
+    axis, the strided view the Sinkhorn head hands in, gradient magnitudes that vary by 1e6 across the matrix (running tile scales),
+    and the batch-8 size: 304 workgroups, more than one per CU (round 4: two co-resident workgroups of this kernel corrupted each
+    other -- every test before that launched fewer than 256)."""
     from loftr_amd import ops
     g = torch.Generator().manual_seed(N * 1000 + L + S)
     f0 = torch.randn(N, L, C, generator=g)
@@ -197,13 +200,13 @@ def test_head_feat_grads_vs_fp64(N, L, S, C, strided):
     full = torch.randn(N, L + 1, S + 1, generator=g) * torch.exp(-14.0 * torch.rand(N, L + 1, 1, generator=g)) * 1e-2
     dsim = full[:, :L, :S] if strided else full[:, :L, :S].contiguous()
     a = 0.0390625
-    r0 = a * torch.bmm(dsim.double(), f1.double())
-    r1 = a * torch.bmm(dsim.double().transpose(1, 2), f0.double())
     d = dsim.cuda() if not strided else full.cuda()[:, :L, :S]
+    r0 = (a * torch.bmm(d.double(), f1.cuda().double())).cpu()
+    r1 = (a * torch.bmm(d.double().transpose(1, 2), f0.cuda().double())).cpu()
     g0, g1 = ops.head_feat_grads(d, f0.cuda(), f1.cuda(), a)
     for got, ref in ((g0, r0), (g1, r1)):
         err = (got.cpu().double() - ref).abs().max().item() / ref.abs().max().item()
-        assert err <= 2e-6, (N, L, S, C, strided, err)
+        assert err <= (3e-6 if N * L > 20000 else 2e-6), (N, L, S, C, strided, err)      # (38 400-term sums at batch 8)
     # row-wise: a row of tiny gradients keeps its own relative accuracy (per-tile scaling, not per-tensor)
     rows = r0.abs().amax(-1)
     rel = ((g0.cpu().double() - r0).abs().amax(-1) / rows.clamp_min(1e-300)).max().item()
@@ -306,3 +309,38 @@ def test_fine_preprocess_backward_against_reference_autograd():
             assert np.abs(v.grad.cpu().numpy() - ref).max() <= 1e-3 * np.abs(ref).max(), (k, str(memory_format))
         for n, prm in fp.named_parameters():
             _check_weight_grad(mod, g, "grad_" + n.replace(".", "_"), prm.grad)
+
+
+@pytest.mark.parametrize("cfg", [(128, 196, 1, 1, 0, 160, 160), (128, 128, 3, 1, 1, 120, 160), (1, 128, 7, 2, 3, 40, 56), (128, 128, 3, 1, 1, 20, 28), (128, 196, 3, 2, 1, 20, 28), (128, 196, 1, 2, 0, 21, 27),
+                                 (196, 196, 3, 1, 1, 10, 14), (196, 256, 3, 2, 1, 21, 27), (256, 256, 1, 1, 0, 9, 13), (196, 256, 1, 1, 0, 12, 16),
+                                 (256, 196, 3, 1, 1, 12, 16), (196, 128, 3, 1, 1, 24, 32)])
+def test_conv2d_node_vs_float64(cfg):
+    """autograd.conv2d (HIP forward, input gradient, weight gradient: the backbone's training convolutions, resnet_fpn.py:5-13,
+    :52, :58-77) against F.conv2d in float64 on every (Cin, Cout, kernel, stride, padding) the backbone has, odd map sizes under
+    stride 2 included, and two training-size maps (the weight gradient's split-K grid exceeds one workgroup per CU there).  Tolerance: 4 x float32's own distance to float64 on the same problem (+ 1e-6 of the tensor's scale)."""
+    import torch
+    import torch.nn.functional as F
+    from loftr_amd import autograd
+    Cin, Cout, K, s, p, H, W = cfg
+    g = torch.Generator().manual_seed(Cin * 7 + Cout + K + s)
+    x = torch.randn(3, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, K, K, generator=g) / (Cin * K * K) ** 0.5
+    x[:, :, :2] *= 30.0                                          # uneven magnitudes: the per-tensor operand scale must cope
+    gy = None
+    outs = {}
+    for name, dt, fn in (("f64", torch.float64, None), ("f32", torch.float32, None), ("hip", torch.float32, autograd.conv2d)):
+        xx = x.to("cuda", dt).requires_grad_(Cin > 1)
+        ww = w.to("cuda", dt).requires_grad_(True)
+        y = fn(xx, ww, s, p) if fn else F.conv2d(xx, ww, None, s, p)
+        if gy is None:
+            gy = torch.randn(y.shape, generator=g) * 1e-3       # gradients are small numbers
+        y.backward(gy.to("cuda", dt))
+        outs[name] = (y.detach().double().cpu(), None if xx.grad is None else xx.grad.double().cpu(), ww.grad.double().cpu())
+    for i, what in enumerate(("y", "dx", "dw")):
+        ref = outs["f64"][i]
+        if ref is None:
+            continue
+        scale = float(ref.abs().max())
+        noise = float((outs["f32"][i] - ref).abs().max())
+        err = float((outs["hip"][i] - ref).abs().max())
+        assert err <= 4 * noise + 1e-6 * scale, (cfg, what, err, noise, scale)

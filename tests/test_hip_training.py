@@ -289,13 +289,15 @@ def test_training_step_head_gradients_against_reference(name, monkeypatch):
         assert abs(got - float(g["grad_bin_score"])) <= 2e-3 * abs(float(g["grad_bin_score"])), (got, g["grad_bin_score"])
 
 
-@pytest.mark.parametrize("name", ["tfull_ds", "tfull_ot"])
-def test_training_step_full_backward_against_reference(name, monkeypatch):
+@pytest.mark.parametrize("name,backbone_on", [("tfull_ds", "cpu"), ("tfull_ot", "cpu"), ("tfull_ds", "hip"), ("tfull_ot", "hip")])
+def test_training_step_full_backward_against_reference(name, backbone_on, monkeypatch):
     """The WHOLE training step's backward (round 4, LoFTR.full_grads): supervision -> matcher in .train() mode -> losses ->
     data['loss'].backward(), every node after the backbone an autograd node whose forward and backward are HIP kernels (position
     encoding, 8 + 2 encoder layers, CoarseMatching, FinePreprocess, FineMatching, both losses), the backbone the PyTorch mirror on
     the CPU in train mode (its autograd, the reference's own arithmetic).  Compared: the gradient of EVERY parameter (160 / 161
-    tensors) with the reference's own training step under torch.autograd (tests/golden/tfull_*.npz, digests)."""
+    tensors) with the reference's own training step under torch.autograd (tests/golden/tfull_*.npz, digests).
+    backbone_on = "hip": the backbone runs on the GPU in train mode as well, every convolution the HIP autograd node (autograd.conv2d:
+    forward, input gradient, weight gradient), BatchNorm / activations / adds / upsampling PyTorch autograd on the GPU."""
     import copy
     import importlib.util
     import os
@@ -319,11 +321,19 @@ def test_training_step_full_backward_against_reference(name, monkeypatch):
     sd = E2E.e2e_state_dict(cpu, cfg, 0.3, rc["coarse_gain"], rc["fine_gain"])
     cpu.load_state_dict(sd, strict=True)
     cpu.train()
-    fc, ff = cpu.backbone(torch.from_numpy(np.concatenate([batch["image0"], batch["image1"]], 0)))       # WITH its graph
     model = LoFTR(copy.deepcopy(cfg))
     model.load_state_dict(sd, strict=True)
     model = model.to(dev).train()
     model.full_grads = True
+    images = torch.from_numpy(np.concatenate([batch["image0"], batch["image1"]], 0))
+    if backbone_on == "hip":
+        from loftr_amd import autograd as AG
+        calls0 = AG._Conv2d.calls
+        with torch.enable_grad():
+            fc, ff = model.backbone(images.to(dev))                                                          # WITH its graph, on the HIP convolutions
+        assert AG._Conv2d.calls - calls0 == sum(isinstance(m, torch.nn.Conv2d) for m in model.backbone.modules()), "HIP convolution nodes not used"
+    else:
+        fc, ff = cpu.backbone(images)                                                                        # WITH its graph
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
     data = {"dataset_name": ["scannet"] * N, **{k: t(v) for k, v in batch.items()}}
     monkeypatch.setattr(torch, "randint", MG.det_randint)
@@ -338,7 +348,7 @@ def test_training_step_full_backward_against_reference(name, monkeypatch):
         assert abs(float(data["loss_scalars"][k]) - want[k]) <= 2e-4 * max(1.0, abs(want[k])), (k, data["loss_scalars"], want)
     data["loss"].backward()
     torch.cuda.synchronize()
-    params = {"backbone." + n: p for n, p in cpu.backbone.named_parameters()}
+    params = {"backbone." + n: p for n, p in (model if backbone_on == "hip" else cpu).backbone.named_parameters()}
     params.update({n: p for n, p in model.named_parameters() if not n.startswith("backbone.")})
     names = sorted({k.split("/")[1] for k in g if k.startswith("grad/")})
     assert set(names) == set(params), set(names) ^ set(params)
@@ -372,9 +382,10 @@ def test_training_step_full_backward_against_reference(name, monkeypatch):
     rep = os.path.join(os.path.dirname(GOLDEN_DIR), "..", "gpurun_out")
     os.makedirs(rep, exist_ok=True)
     with open(os.path.join(rep, "full_backward_margins.txt"), "a") as fh:
-        fh.write(f"{name}: {len(hip)} matcher tensors, worst {max(hip.values()):.2e} ({max(hip, key=hip.get)}; reference fp32-vs-fp64 there "
+        fh.write(f"{name} (backbone on {backbone_on}): {len(hip)} matcher tensors, worst {max(hip.values()):.2e} ({max(hip, key=hip.get)}; reference fp32-vs-fp64 there "
                  f"{noise[max(hip, key=hip.get)]:.2e}); {len(bb)} backbone tensors, worst {max(bb.values()):.2e} ({max(bb, key=bb.get)}; reference "
-                 f"{noise[max(bb, key=bb.get)]:.2e}); tensors above 2e-3: {sum(e > 2e-3 for e in worst.values())}\n")
+                 f"{noise[max(bb, key=bb.get)]:.2e}); tensors above 2e-3: {sum(e > 2e-3 for e in worst.values())}; top: "
+                 + ", ".join(f"{n} {e:.1e}" for n, e in sorted(worst.items(), key=lambda kv: -kv[1])[:4]) + "\n")
     bad = {n: (e, tol[n]) for n, e in worst.items() if e > tol[n]}
     assert not bad, (sorted(bad.items(), key=lambda kv: -kv[1][0])[:8], len(bad), len(worst))
 
