@@ -22,15 +22,15 @@
 namespace {
 namespace hg {
 constexpr int BM = 128, BK = 32, WAVES = 4, MAXT = 8;          // MAXT column tiles of 32 (C <= 256)
-// ONE workgroup per CU, enforced through the LDS footprint (HG_LDS_PAD): two co-resident workgroups of this kernel corrupt each
-// other's results -- found in round 4 at the first grids of more than 256 workgroups (loftr_conv_wgrad, loftr_head_feat_grads at
-// N = 8: up to 10 % error in the tiles that shared a CU, different from run to run; tools/micro/conv_wgrad_debug.py names the
-// partials).  Ruled out on the GPU: LDS overlap (a 30 KB gap between the two footprints changes nothing), the register budget
-// (launch_bounds(256, 3) fails alike), the running operand scales, the cross-lane reductions.  Root cause open (open items);
-// with one workgroup per CU every partial is right (0 of 150 / 512 bad in repeated runs).
-#ifndef HG_EXP
-#define HG_EXP 0
-#endif
+// ONE workgroup per CU, enforced through the LDS footprint (HG_LDS_PAD; -DHG_LDS_PAD=0 -DHG_MINWG=2 rebuilds the two-per-CU form).
+// Two co-resident workgroups of this kernel corrupt each other's results -- found in round 4 at the first grids of more than 256
+// workgroups (loftr_conv_wgrad, loftr_head_feat_grads at N = 8: up to 10 % error in the tiles that shared a CU, different from run
+// to run).  What the GPU said (tools/micro/conv_wgrad_debug.py): with CONSTANT operands a bad partial misses exactly 1 .. 5 of its 128
+// k-terms in some rows or columns (an operand element that is zero when the MFMA reads it); not LDS overlap (a 30 KB gap between
+// the two footprints changes nothing), not the register budget (launch_bounds(256, 3) fails alike), not the running operand scales
+// (fixed scales fail alike), not the cross-lane reductions (ds_bpermute instead of permlane swaps fails alike), not barrier
+// visibility (s_waitcnt 0 + fence + double barrier fails alike).  Root cause open; with one workgroup per CU every partial is
+// right (0 of 150 / 512 bad in repeated runs, tests at batch 8 and training-size maps).
 #ifndef HG_LDS_PAD
 #define HG_LDS_PAD 40960
 #endif
@@ -185,14 +185,9 @@ __global__ __launch_bounds__(WAVES * 64, HG_MINWG) void head_grad_kernel(Args p)
     for (int q = 0; q < 8; ++q)
 #pragma unroll
       for (int e = 0; e < 4; ++e) mb = fmaxf(mb, fabsf(rb[q][e]));
-#if HG_EXP == 3
-    for (int o = 32; o >= 1; o >>= 1) { mb = fmaxf(mb, __shfl_xor(mb, o, 64)); m = fmaxf(m, __shfl_xor(m, o, 64)); }
-    return m;
-#else
     mb = half_max(mb); mb = fmaxf(mb, swap32(mb));
     m = half_max(m);
     return fmaxf(m, swap32(m));
-#endif
   };
 
   f32x16 acc[MAXT];
@@ -210,12 +205,8 @@ __global__ __launch_bounds__(WAVES * 64, HG_MINWG) void head_grad_kernel(Args p)
     const float mb = fmaxf(fmaxf(smax[4], smax[5]), fmaxf(smax[6], smax[7]));
     // keep a running scale while it holds the tile maximum in [2^10, 2^16); otherwise re-lift to [2^13, 2^14) and carry the exact
     // ratio into the accumulators (block-uniform branch)
-#if HG_EXP == 2
-    const bool a_bad = kt == 0, b_bad = kt == 0;
-#else
     const bool a_bad = !(ma * a_sc >= 1024.f && ma * a_sc < 65000.f) && ma > 1e-30f;
     const bool b_bad = !(mb * b_sc >= 1024.f && mb * b_sc < 65000.f) && mb > 1e-30f;
-#endif
     if (a_bad || b_bad) {
       float na_sc = a_sc, na_inv = a_inv, nb_sc = b_sc, nb_inv = b_inv;
       if (a_bad) na_sc = lift_exp(ma, na_inv);
