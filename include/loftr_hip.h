@@ -359,11 +359,11 @@ int loftr_head_feat_grads(const float* dsim, long dsim_ld, long dsim_bs, const f
                           int N, int L, int S, int C, float alpha, float* g0, float* g1, void* stream);
 /* Weight gradient of a bias-free convolution (what autograd computes for every nn.Conv2d of resnet_fpn.py in a training step):
  *   dw_taps[ky * KW + kx][co][ci] = sum_{b,y,x} dy[b,y,x,co] * x[b, y stride + ky - pad, x stride + kx - pad, ci]   (zero outside the map)
- * dy [B,Ho,Wo,Cout], x [B,H,W,Cin] fp32 channels-last; the caller permutes dw_taps [KH*KW, Cout, Cin] to [Cout,Cin,KH,KW].  Per tap a
- * split-K product over the output pixels on the split-fp16 MFMA path with fp32 accumulation and an ordered sum of the partials
+ * dy [B,Ho,Wo,Cout], x [B,H,W,Cin] fp32 channels-last; the caller permutes dw_taps [KH*KW, Cout, Cin] to [Cout,Cin,KH,KW].  All taps in
+ * one launch, each a split-K product over the output pixels on the split-fp16 MFMA path with fp32 accumulation and an ordered sum of the partials
  * (deterministic).  Cin % 4 == 0, Cin <= 256 (the one-channel stem: hand in the 7 x 7 patches as a 52-channel 1 x 1 problem).
  * The input gradient is loftr_conv_bn_act on the flipped, transposed filter (stride 2: on the zero-interleaved dy). */
-size_t loftr_conv_wgrad_workspace_bytes(int B, int Ho, int Wo, int Cin, int Cout);
+size_t loftr_conv_wgrad_workspace_bytes(int B, int Ho, int Wo, int Cin, int Cout, int KH, int KW);
 int loftr_conv_wgrad(const float* dy, const float* x, int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
                      float* dw_taps, void* ws, size_t ws_bytes, void* stream);
 size_t loftr_sinkhorn_bwd_workspace_bytes(int N, int L, int S, int C, int iters);

@@ -80,7 +80,7 @@ SIGNATURES = {
     "loftr_coarse_loss_sums": (_i, [_p, _i, _i, _i, _i, _p, _p, _p, _l, _p, _p, _f, _f, _p, _p, _sz, _p]),
     "loftr_fine_loss_sums": (_i, [_p, _i, _p, _l, _i, _f, _p, _p, _sz, _p]),
     "loftr_coarse_loss_grad": (_i, [_p, _i, _i, _i, _i, _p, _p, _p, _l, _p, _p, _f, _f, C.c_double, C.c_double, _p, _p, _sz, _p]),
-    "loftr_conv_wgrad_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
+    "loftr_conv_wgrad_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i, _i]),
     "loftr_conv_wgrad": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p, _sz, _p]),
     "loftr_head_feat_grads": (_i, [_p, C.c_long, C.c_long, _p, _p, _i, _i, _i, _i, _f, _p, _p, _p]),
     "loftr_sinkhorn_bwd_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),

@@ -49,6 +49,9 @@ struct Args {
   // B rows through a convolution tap (gHo > 0; split-K batches only: reduction index t = n * K + k is output pixel (b, y, x) of a
   // [., gHo, gWo] map and B's row is input pixel (b, y gs + gdy, x gs + gdx) of the [., gH, gW] map b points at, or zero outside it)
   int gHo, gWo, gH, gW, gs, gdy, gdx;
+  // ... all taps of a KH x KW filter in ONE launch (gtaps = KH KW > 1): batch element nb = tap * gns + n is chunk n of the reduction
+  // seen through tap (ky, kx) = (tap / gKW, tap % gKW), i.e. gdy = ky - gpad, gdx = kx - gpad; its output is out[nb]
+  int gtaps, gns, gKW, gpad;
 };
 
 __device__ __forceinline__ float lift_exp(float absmax, float& inv) {     // power of two that lifts absmax into [2^13, 2^14), exact inverse
@@ -72,7 +75,13 @@ __global__ __launch_bounds__(WAVES * 64, HG_MINWG) void head_grad_kernel(Args p)
   int tm, tn_;
   if (!xcd_tile(p.tiles_m * p.N, 1, tm, tn_)) return;
   (void)tn_;
-  const int n = tm / p.tiles_m, m0 = (tm - n * p.tiles_m) * BM;
+  const int nb = tm / p.tiles_m, m0 = (tm - nb * p.tiles_m) * BM;
+  int n = nb, gdy = p.gdy, gdx = p.gdx;
+  if (p.gtaps > 1) {
+    const int tap = nb / p.gns;
+    n = nb - tap * p.gns;
+    gdy = tap / p.gKW - p.gpad; gdx = tap % p.gKW - p.gpad;
+  }
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 5, li = lane & 31;
   const float* A = p.a + (long)n * p.a_bs;
   const float* B = p.b + (long)n * p.b_bs;
@@ -124,7 +133,7 @@ __global__ __launch_bounds__(WAVES * 64, HG_MINWG) void head_grad_kernel(Args p)
           const long t = (long)n * p.K + k;
           const int hw = p.gHo * p.gWo, bb = (int)(t / hw), rem = (int)(t - (long)bb * hw);
           const int y = rem / p.gWo, x = rem - y * p.gWo;
-          const int iy = y * p.gs + p.gdy, ix = x * p.gs + p.gdx;
+          const int iy = y * p.gs + gdy, ix = x * p.gs + gdx;
           if ((unsigned)iy < (unsigned)p.gH && (unsigned)ix < (unsigned)p.gW) brow = p.b + ((long)(bb * p.gH + iy) * p.gW + ix) * p.b_ld;
         } else {
           brow = B + (long)k * p.b_ld;
@@ -246,7 +255,7 @@ __global__ __launch_bounds__(WAVES * 64, HG_MINWG) void head_grad_kernel(Args p)
   }
   const float undo = a_inv * b_inv * p.alpha;
   // ---- out[m][c] = alpha * acc: lane = column, 16 rows per register set
-  float* O = p.out + (long)n * p.o_bs;
+  float* O = p.out + (long)nb * p.o_bs;
 #pragma unroll
   for (int j = 0; j < MAXT; ++j) {
     if (j >= NT) continue;
@@ -384,10 +393,21 @@ extern "C" int loftr_head_feat_grads(const float* dsim, long dsim_ld, long dsim_
 // dW[tap][co][ci] = sum over output pixels (b, y, x) of dy[b, y, x, co] * x[b, y stride + ky - pad, x stride + kx - pad, ci]: per tap the
 // split-K product of launch_wgrad with B's rows gathered through the tap (hg::Args::gHo ..).   what torch.autograd does for
 // F.conv2d's weight (resnet_fpn.py: every nn.Conv2d of the backbone, bias-free)
-static size_t conv_wgrad_part_floats(long T, int Cout, int Cin) { return wgrad_part_floats(T, Cout, Cin); }
-extern "C" size_t loftr_conv_wgrad_workspace_bytes(int B, int Ho, int Wo, int Cin, int Cout) {
-  if (B <= 0 || Ho <= 0 || Wo <= 0 || Cin <= 0 || Cout <= 0) return 0;
-  return conv_wgrad_part_floats((long)B * Ho * Wo, Cout, Cin) * sizeof(float) + 1024;
+// Tokens per partial for the convolution: all KH KW taps go in one launch, so the reduction is cut only as far as it takes to put
+// ~512 workgroups (two rounds of one per CU) on the chip -- at least 128 pixels per partial, a multiple of the k-tile.
+static int conv_wgrad_chunk(long T, int Cout, int taps) {
+  static const int forced = []() { const char* e = getenv("LOFTR_WGRAD_CHUNK"); return e ? atoi(e) : 0; }();      // (debug: tools/micro/conv_wgrad_debug.py)
+  if (forced > 0) return forced;
+  const int per = ceil_div(Cout, hg::BM) * taps;
+  const int target = per >= 512 ? 1 : 512 / per;
+  long c = (T + target - 1) / target;
+  c = (c + 31) / 32 * 32;
+  return (int)(c < 128 ? 128 : c);
+}
+extern "C" size_t loftr_conv_wgrad_workspace_bytes(int B, int Ho, int Wo, int Cin, int Cout, int KH, int KW) {
+  if (B <= 0 || Ho <= 0 || Wo <= 0 || Cin <= 0 || Cout <= 0 || KH <= 0 || KW <= 0) return 0;
+  const long T = (long)B * Ho * Wo;
+  return (size_t)ceil_div((int)T, conv_wgrad_chunk(T, Cout, KH * KW)) * KH * KW * Cout * Cin * sizeof(float) + 1024;
 }
 extern "C" int loftr_conv_wgrad(const float* dy, const float* x, int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
                                 float* dw_taps, void* ws, size_t ws_bytes, void* stream) {
@@ -396,28 +416,27 @@ extern "C" int loftr_conv_wgrad(const float* dy, const float* x, int B, int H, i
   const int Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
   if (Ho <= 0 || Wo <= 0) return LOFTR_ERR_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
-  if (B == 0) { (void)hipMemsetAsync(dw_taps, 0, sizeof(float) * KH * KW * Cout * Cin, st); return LOFTR_OK; }
+  const int taps = KH * KW;
+  if (B == 0) { (void)hipMemsetAsync(dw_taps, 0, sizeof(float) * taps * Cout * Cin, st); return LOFTR_OK; }
   const long T = (long)B * Ho * Wo;
   if (T >= (1L << 31)) return LOFTR_ERR_UNSUPPORTED;
   LOFTR_CHECK_ARG(ws != nullptr);
-  if (ws_bytes < loftr_conv_wgrad_workspace_bytes(B, Ho, Wo, Cin, Cout)) return LOFTR_ERR_WORKSPACE;
+  if (ws_bytes < loftr_conv_wgrad_workspace_bytes(B, Ho, Wo, Cin, Cout, KH, KW)) return LOFTR_ERR_WORKSPACE;
   float* part = reinterpret_cast<float*>(ws);
-  const int kch = wgrad_chunk(T, Cout), ns = ceil_div((int)T, kch);
-  for (int ky = 0; ky < KH; ++ky)
-    for (int kx = 0; kx < KW; ++kx) {
-      hg::Args g{};
-      g.a = dy; g.a_ld = Cout; g.a_bs = (long)kch * Cout;
-      g.b = x; g.b_ld = Cin; g.b_bs = 0;
-      g.out = part; g.o_ld = Cin; g.o_bs = (long)Cout * Cin;
-      g.M = Cout; g.K = kch; g.Ktot = (int)T; g.C = ceil_div(Cin, 32) * 32; g.NT = g.C / 32; g.Cr = Cin; g.alpha = 1.f; g.N = ns;
-      g.tiles_m = ceil_div(Cout, hg::BM);
-      g.gHo = Ho; g.gWo = Wo; g.gH = H; g.gW = W; g.gs = stride; g.gdy = ky - pad; g.gdx = kx - pad;
-      static const int no_gather = []() { const char* e = getenv("LOFTR_WGRAD_NOGATHER"); return e ? atoi(e) : 0; }();      // (debug)
-      if (no_gather && KH == 1 && KW == 1 && stride == 1 && pad == 0) { g.gHo = 0; g.b_bs = (long)kch * Cin; }
-      hipLaunchKernelGGL((hg::head_grad_kernel<true>), dim3(xcd_grid(g.tiles_m * ns, 1)), dim3(hg::WAVES * 64), 0, st, g);
-      const int rc = launch_reduce_partials(part, dw_taps + (size_t)(ky * KW + kx) * Cout * Cin, ns, (long)Cout * Cin, (long)Cout * Cin, st);
-      if (rc) return rc;
-    }
+  const int kch = conv_wgrad_chunk(T, Cout, taps), ns = ceil_div((int)T, kch);
+  hg::Args g{};
+  g.a = dy; g.a_ld = Cout; g.a_bs = (long)kch * Cout;
+  g.b = x; g.b_ld = Cin; g.b_bs = 0;
+  g.out = part; g.o_ld = Cin; g.o_bs = (long)Cout * Cin;
+  g.M = Cout; g.K = kch; g.Ktot = (int)T; g.C = ceil_div(Cin, 32) * 32; g.NT = g.C / 32; g.Cr = Cin; g.alpha = 1.f; g.N = taps * ns;
+  g.tiles_m = ceil_div(Cout, hg::BM);
+  g.gHo = Ho; g.gWo = Wo; g.gH = H; g.gW = W; g.gs = stride; g.gdy = -pad; g.gdx = -pad;
+  g.gtaps = taps; g.gns = ns; g.gKW = KW; g.gpad = pad;
+  hipLaunchKernelGGL((hg::head_grad_kernel<true>), dim3(xcd_grid(g.tiles_m * g.N, 1)), dim3(hg::WAVES * 64), 0, st, g);
+  for (int t = 0; t < taps; ++t) {
+    const int rc = launch_reduce_partials(part + (size_t)t * ns * Cout * Cin, dw_taps + (size_t)t * Cout * Cin, ns, (long)Cout * Cin, (long)Cout * Cin, st);
+    if (rc) return rc;
+  }
   LOFTR_CHECK_LAUNCH();
   return LOFTR_OK;
 }

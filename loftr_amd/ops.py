@@ -549,7 +549,7 @@ def conv_wgrad(dy_nhwc, x_nhwc, KH, KW, stride, pad):
     _, Ho, Wo, Cout = dy_nhwc.shape
     assert Ho == (H + 2 * pad - KH) // stride + 1 and Wo == (W + 2 * pad - KW) // stride + 1 and dy_nhwc.shape[0] == B
     lib = _lib.load()
-    ws = workspace(lib.loftr_conv_wgrad_workspace_bytes(B, Ho, Wo, Cin, Cout), x_nhwc.device)
+    ws = workspace(lib.loftr_conv_wgrad_workspace_bytes(B, Ho, Wo, Cin, Cout, KH, KW), x_nhwc.device)
     taps = torch.empty(KH * KW, Cout, Cin, dtype=torch.float32, device=x_nhwc.device)
     check(lib.loftr_conv_wgrad(_ptr(dy_nhwc), _ptr(x_nhwc), B, H, W, Cin, Cout, KH, KW, stride, pad, _ptr(taps), _ptr(ws), ws.numel(),
                                _stream()), "loftr_conv_wgrad")

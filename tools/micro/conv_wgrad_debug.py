@@ -16,7 +16,7 @@ for (B, H, W, Cin, Cout) in [(4, 60, 80, 256, 256), (1, 256, 256, 128, 256)]:
         x.fill_(1.0); dy.fill_(1e-3)
     if os.environ.get("CONST") == "2":                       # x constant per pixel-chunk: partial n = known multiple
         x.fill_(1.0); dy.copy_((torch.arange(T, device="cuda") // chunk + 1).float().view(B, H, W, 1).expand(B, H, W, Cout) * 1e-3)
-    nbytes = lib.loftr_conv_wgrad_workspace_bytes(B, H, W, Cin, Cout)
+    nbytes = lib.loftr_conv_wgrad_workspace_bytes(B, H, W, Cin, Cout, 1, 1)
     for fill in (0.0, 7.0):
         ws = torch.full((nbytes // 4 + 16,), fill, dtype=torch.float32, device="cuda")
         taps = torch.empty(1, Cout, Cin, device="cuda")
