@@ -29,8 +29,11 @@ constexpr int BM = 128, BK = 32, WAVES = 4, MAXT = 8;          // MAXT column ti
 // k-terms in some rows or columns (an operand element that is zero when the MFMA reads it); not LDS overlap (a 30 KB gap between
 // the two footprints changes nothing), not the register budget (launch_bounds(256, 3) fails alike), not the running operand scales
 // (fixed scales fail alike), not the cross-lane reductions (ds_bpermute instead of permlane swaps fails alike), not barrier
-// visibility (s_waitcnt 0 + fence + double barrier fails alike).  Root cause open; with one workgroup per CU every partial is
-// right (0 of 150 / 512 bad in repeated runs, tests at batch 8 and training-size maps).
+// visibility (s_waitcnt 0 + fence + double barrier fails alike), not the 8-byte LDS stores (volatile 4-byte stores fail alike), not
+// the unaligned 16-byte loads.  The affected elements belong to the LAST lanes of a staging instruction (rows 64 .. 127 of the
+// transposed A tile, columns 192 .. 255 of B: lanes 16-31 / 48-63), as if a tile were read before its last writes were visible.
+// Root cause open; with one workgroup per CU -- by LDS footprint, or by a 372-register build (launch_bounds(256) alone) -- every
+// partial is right (0 of 150 / 512 bad in repeated runs, tests at batch 8 and training-size maps).
 #ifndef HG_LDS_PAD
 #define HG_LDS_PAD 40960
 #endif
