@@ -326,21 +326,23 @@ def test_training_step_full_backward_against_reference(name, backbone_on, monkey
     model = model.to(dev).train()
     model.full_grads = True
     images = torch.from_numpy(np.concatenate([batch["image0"], batch["image1"]], 0))
-    if backbone_on == "hip":
-        from loftr_amd import autograd as AG
-        calls0 = AG._Conv2d.calls
-        with torch.enable_grad():
-            fc, ff = model.backbone(images.to(dev))                                                          # WITH its graph, on the HIP convolutions
-        assert AG._Conv2d.calls - calls0 == sum(isinstance(m, torch.nn.Conv2d) for m in model.backbone.modules()), "HIP convolution nodes not used"
-    else:
+    if backbone_on != "hip":
         fc, ff = cpu.backbone(images)                                                                        # WITH its graph
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
     data = {"dataset_name": ["scannet"] * N, **{k: t(v) for k, v in batch.items()}}
     monkeypatch.setattr(torch, "randint", MG.det_randint)
     compute_supervision_coarse(data, CFG)
-    data.update({"bs": N, "hw0_i": data["image0"].shape[2:], "hw1_i": data["image1"].shape[2:]})
-    with torch.enable_grad():
-        model.match_from_features(fc[:N].to(dev), fc[N:].to(dev), ff[:N].to(dev), ff[N:].to(dev), data)
+    if backbone_on == "hip":
+        # the user's training step: LoFTR.forward(data) itself -- backbone in train mode on the stacked image batch (every convolution the
+        # HIP node), its two halves straight into the matcher (lightning_loftr.py:112-133: supervision, matcher, fine supervision, loss)
+        from loftr_amd import autograd as AG
+        calls0 = AG._Conv2d.calls
+        model(data)
+        assert AG._Conv2d.calls - calls0 == sum(isinstance(m, torch.nn.Conv2d) for m in model.backbone.modules()), "HIP convolution nodes not used"
+    else:
+        data.update({"bs": N, "hw0_i": data["image0"].shape[2:], "hw1_i": data["image1"].shape[2:]})
+        with torch.enable_grad():
+            model.match_from_features(fc[:N].to(dev), fc[N:].to(dev), ff[:N].to(dev), ff[N:].to(dev), data)
     compute_supervision_fine(data, CFG)
     LoFTRLoss(MG.step_loss_cfg(rc)).train()(data)
     want = json.loads(str(g["losses"]))

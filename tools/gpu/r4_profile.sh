@@ -2,7 +2,8 @@
 # Round-4 profile set, all from the library as built: (1) the whole GPU test suite, (2) parity margins (hot-path goldens + image-level goldens with
 # the fp64 distances), (3) rocprofv3 kernel-trace stats of the default (two-stream) and the serial bench, (4) three PMC passes -> pmc_traffic.json,
 # (5) coverage, (6) outdoor / Sinkhorn / backward kernel stats, per-layer convolution table, (7) the bench line as the driver runs it.
-#   bash tools/gpu/r4_profile.sh [tag=r04]  ->  gpurun_out/<tag>_*   (copy what is to be judged into profiles/)
+#   bash tools/gpu/r4_profile.sh [tag=r04]  ->  gpurun_out/<tag>_* and gpurun_out/pmc_traffic.json: copy what is to be judged into profiles/ -- pmc_traffic.json ALWAYS
+#   (gpurun only merges gpurun_out/ back; the copy into profiles/ below happens on the GPU box, for the bench line of that run)
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 T=${1:-r04}
 O=$R/gpurun_out
