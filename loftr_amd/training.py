@@ -7,8 +7,9 @@ Host-side mirror of the reference's interface: ``compute_supervision_coarse(data
 behind the C-ABI (loftr_spvs_coarse, loftr_spvs_fine, loftr_coarse_loss_sums, loftr_fine_loss_sums); there is no CPU
 fallback.  Backward: when conf_matrix / expec_f carry an autograd graph (loftr_amd/autograd.py: the dual-softmax and
 FineMatching heads, and the Sinkhorn head with its bin_score parameter), LoFTRLoss is differentiable through
-loftr_coarse_loss_grad / loftr_fine_loss_grad; the chain ends at the heads' inputs (no backward for the transformers,
-FinePreprocess or the backbone).  The RNG-dependent
+loftr_coarse_loss_grad / loftr_fine_loss_grad.  With ``LoFTR.head_grads`` the chain ends at the heads' inputs; with
+``LoFTR.full_grads`` it runs through the whole model (autograd.py: transformers, FinePreprocess, position encoding and the
+backbone's convolutions), and ``trainval_inference`` below is the reference's training step.  The RNG-dependent
 ground-truth padding of CoarseMatching's training branch (coarse_matching.py:200-236) lives in
 loftr_amd/loftr.py:CoarseMatching._train_sample.
 
@@ -99,6 +100,17 @@ def compute_supervision_fine(data, config):
         spvs_fine(data, config)
     else:
         raise NotImplementedError
+
+
+def trainval_inference(matcher, loss, batch, config):
+    """PL_LoFTR._trainval_inference (src/lightning/lightning_loftr.py:76-91) without the Lightning module around it: coarse
+    supervision -> matcher -> fine supervision -> loss, all on the batch dict; returns ``batch['loss']`` (with its graph when the
+    matcher is in ``.train()`` mode with ``full_grads`` / ``head_grads``: ``training_step`` is this + ``.backward()`` + the optimiser)."""
+    compute_supervision_coarse(batch, config)
+    matcher(batch)
+    compute_supervision_fine(batch, config)
+    loss(batch)
+    return batch["loss"]
 
 
 class LoFTRLoss(torch.nn.Module):

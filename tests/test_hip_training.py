@@ -331,20 +331,22 @@ def test_training_step_full_backward_against_reference(name, backbone_on, monkey
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
     data = {"dataset_name": ["scannet"] * N, **{k: t(v) for k, v in batch.items()}}
     monkeypatch.setattr(torch, "randint", MG.det_randint)
-    compute_supervision_coarse(data, CFG)
     if backbone_on == "hip":
-        # the user's training step: LoFTR.forward(data) itself -- backbone in train mode on the stacked image batch (every convolution the
-        # HIP node), its two halves straight into the matcher (lightning_loftr.py:112-133: supervision, matcher, fine supervision, loss)
+        # the user's training step (training.trainval_inference = lightning_loftr.py:76-91): supervision, LoFTR.forward(data) itself --
+        # backbone in train mode on the stacked image batch, every convolution the HIP node, its two halves straight into the matcher --
+        # fine supervision, loss
         from loftr_amd import autograd as AG
+        from loftr_amd.training import trainval_inference
         calls0 = AG._Conv2d.calls
-        model(data)
+        trainval_inference(model, LoFTRLoss(MG.step_loss_cfg(rc)).train(), data, CFG)
         assert AG._Conv2d.calls - calls0 == sum(isinstance(m, torch.nn.Conv2d) for m in model.backbone.modules()), "HIP convolution nodes not used"
     else:
+        compute_supervision_coarse(data, CFG)
         data.update({"bs": N, "hw0_i": data["image0"].shape[2:], "hw1_i": data["image1"].shape[2:]})
         with torch.enable_grad():
             model.match_from_features(fc[:N].to(dev), fc[N:].to(dev), ff[:N].to(dev), ff[N:].to(dev), data)
-    compute_supervision_fine(data, CFG)
-    LoFTRLoss(MG.step_loss_cfg(rc)).train()(data)
+        compute_supervision_fine(data, CFG)
+        LoFTRLoss(MG.step_loss_cfg(rc)).train()(data)
     want = json.loads(str(g["losses"]))
     for k in ("loss_c", "loss_f", "loss"):
         assert abs(float(data["loss_scalars"][k]) - want[k]) <= 2e-4 * max(1.0, abs(want[k])), (k, data["loss_scalars"], want)
