@@ -51,3 +51,26 @@ def test_hip_forward_matches_reference_backbone(name):
         ref = g[f"{name}_{key}"]
         assert tuple(got.shape) == ref.shape
         assert np.abs(got.cpu().numpy() - ref).max() <= 2e-5 * np.abs(ref).max()      # fp32-class (split-fp16 MFMA) vs fp32 CPU
+
+
+def test_training_conv_module_is_plain_conv_off_the_gpu():
+    """backbone.Conv2d (the module whose .train()-mode GPU forward is the HIP autograd node) must be nn.Conv2d everywhere else:
+    same parameters and state-dict keys as the reference's conv1x1 / conv3x3 (resnet_fpn.py:5-13), the stock forward on the CPU in
+    both modes with gradients, and a loud error -- not a silent fallback -- if the node were asked to run on CPU tensors."""
+    import torch.nn as nn
+    from loftr_amd import autograd, backbone
+    c = backbone._c3(4, 8, stride=2)
+    ref = nn.Conv2d(4, 8, kernel_size=3, stride=2, padding=1, bias=False)
+    assert isinstance(c, nn.Conv2d) and list(c.state_dict().keys()) == list(ref.state_dict().keys()) == ["weight"]
+    ref.load_state_dict(c.state_dict())
+    x = torch.randn(2, 4, 9, 11, requires_grad=True)
+    for mode in (True, False):
+        c.train(mode)
+        y = c(x)
+        assert torch.equal(y, ref(x)) and y.grad_fn is not None
+    calls = autograd._Conv2d.calls
+    c.train()
+    c(x).sum().backward()
+    assert autograd._Conv2d.calls == calls and c.weight.grad is not None          # the HIP node did not run on the CPU
+    with pytest.raises(Exception):
+        autograd.conv2d(x, c.weight, 2, 1)                                         # CPU tensors: the ops raise (no fallback)
