@@ -101,3 +101,20 @@ def test_single_gpu_launch_retries_once_after_a_signal(monkeypatch, capsys):
     calls.clear()
     monkeypatch.setattr(subprocess, "run", fake([P(-11, b""), P(-6, b"")]))
     assert bench.run_with_retry([]) == 134 and len(calls) == 2         # out of attempts: 128 + signal
+
+
+def test_pmc_kernel_families_follow_the_timing_table():
+    """tools/rocpd_pmc.py pools rocprofv3's kernel names into the families bench.py's timing table knows: the two-job launches of the
+    encoder kernel (round 4) and the round-4 3x3 convolution templates must land on the ids they are timed under, or the encoder
+    group's traffic / mfma_busy silently lose half their launches."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("rocpd_pmc", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "rocpd_pmc.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    f = mod.bench_name
+    assert f("(anonymous namespace)::efx::encoder_x2_kernel((anonymous namespace)::efx::Args2)") == "encoder_x_kernel"
+    assert f("(anonymous namespace)::efx::encoder_x_kernel((anonymous namespace)::efx::Args)") == "encoder_x_kernel"
+    assert f("void conv3x3_duo_kernel<c3d::Cfg<7, 2, 4, 8, 2> >(Conv3Args)") == "conv3x3_wide_kernel"
+    assert f("void conv3x3_duo_kernel<c3d::Cfg<4, 2, 4, 4, 1> >(Conv3Args)") == "conv3x3_kernel"
+    assert f("void (anonymous namespace)::sweep::score_sweep_kernel<1, false, false, false>((anonymous namespace)::sweep::Args)") == "score_conf_kernel"
