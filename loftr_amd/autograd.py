@@ -1,4 +1,5 @@
-"""torch.autograd nodes for the two matching heads: forward AND backward are the HIP kernels behind the C-ABI.
+"""torch.autograd nodes of the model: forward AND backward are the HIP kernels behind the C-ABI (heads, losses' inputs, encoder
+layers, FinePreprocess, position encoding, and -- at the end of this file -- the backbone's convolutions).
 
 What the reference gets from autograd between ``batch['loss']`` (src/lightning/lightning_loftr.py:112-133) and the heads'
 inputs, for the dual-softmax configuration (the Sinkhorn one swaps the first node):
@@ -9,7 +10,8 @@ inputs, for the dual-softmax configuration (the Sinkhorn one swaps the first nod
 The loss nodes are loftr_amd.training.LoFTRLoss (same mechanism).  The Sinkhorn head (coarse_matching.py:121-143,
 conf_matrix_with_bin, the bin_score parameter) has its backward too: _SinkhornMatch.  Round 4: LoFTREncoderLayer is a node as well
 (_EncoderLayer, csrc/encoder_bwd.hip), so both LocalFeatureTransformers are differentiable in their inputs and weights when they
-run layer by layer (LocalFeatureTransformer.forward does that whenever a gradient is wanted); FinePreprocess and the backbone are not.
+run layer by layer (LocalFeatureTransformer.forward does that whenever a gradient is wanted); so are FinePreprocess
+(_FinePreprocess), the position encoding (_PosEncodeFlatten) and every convolution of the backbone (_Conv2d).
 
 No CPU fallback: the nodes call loftr_amd.ops, which raises on non-GPU tensors.
 """

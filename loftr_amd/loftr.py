@@ -7,14 +7,15 @@ exceptions.  Every sub-module after the backbone holds parameters only; its arit
 call into ``libloftr_hip.so`` (``loftr_amd/ops.py``).  There is no PyTorch fallback: on a box
 without the built extension or without a GPU the forward raises.
 
-Scope: forward values, plus the backward of everything after the backbone.  In ``.train()`` mode CoarseMatching
+Scope: forward values, plus the backward of the whole model.  In ``.train()`` mode CoarseMatching
 also performs the reference's random sampling / ground-truth padding of the coarse matches
 (``coarse_matching.py:200-236``, host-side index arithmetic on the kernels' outputs).  Every node after the backbone is an
 autograd node whose forward AND backward are HIP kernels (``loftr_amd/autograd.py``): position encoding, the encoder
 layers of both transformers (round 4, ``csrc/encoder_bwd.hip``), CoarseMatching (dual-softmax and Sinkhorn incl.
 ``bin_score``), FinePreprocess (round 4, ``csrc/fine_bwd.hip``) and FineMatching.  ``LoFTR.full_grads = True``:
-``loss.backward()`` fills ``.grad`` of every parameter like the reference's training step (the backbone trains as the
-PyTorch module: its HIP convolutions have no backward); ``LoFTR.head_grads = True`` stops at the heads' inputs.
+``loss.backward()`` fills ``.grad`` of every parameter like the reference's training step (the backbone runs as the
+PyTorch module whose convolutions are autograd nodes on the HIP kernels too, ``backbone.Conv2d``; its BatchNorm with batch
+statistics and elementwise glue stay PyTorch autograd); ``LoFTR.head_grads = True`` stops at the heads' inputs.
 """
 import contextlib
 import math
@@ -369,9 +370,9 @@ class LoFTR(nn.Module):
         self.head_grads = False
         # .train() only, round 4: run the WHOLE matcher with a graph -- every node after the backbone is an autograd node whose
         # forward and backward are HIP kernels (loftr_amd/autograd.py: position encoding, encoder layers of both transformers, both
-        # matching heads, FinePreprocess, FineMatching); the backbone trains as the PyTorch module (its HIP convolutions have no
-        # backward).  LoFTRLoss(...)(data); data['loss'].backward() then fills .grad of every parameter, as the reference's
-        # training step does (src/lightning/lightning_loftr.py:112-133).
+        # matching heads, FinePreprocess, FineMatching); the backbone runs as the PyTorch module with its convolutions as HIP
+        # autograd nodes (backbone.Conv2d).  LoFTRLoss(...)(data); data['loss'].backward() then fills .grad of every parameter, as
+        # the reference's training step does (src/lightning/lightning_loftr.py:112-133; training.trainval_inference).
         self.full_grads = False
         self.pos_encoding = PositionEncodingSine(config["coarse"]["d_model"],
                                                  temp_bug_fix=config["coarse"]["temp_bug_fix"])
