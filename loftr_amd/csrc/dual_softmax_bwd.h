@@ -58,7 +58,7 @@ __global__ void col_dot_merge_kernel(const float* __restrict__ part, Geometry g,
 }
 
 // sim -> dL/dsim in place.   grid (ceil(N L / 4)), 256 threads, one wave per row
-__global__ __launch_bounds__(256) void dsim_kernel(float* __restrict__ sim, const float* __restrict__ G, Geometry g,
+__global__ LOFTR_NO_PACKED_FP32 __launch_bounds__(256) void dsim_kernel(float* __restrict__ sim, const float* __restrict__ G, Geometry g,
                                                    const float2* __restrict__ rowstat, const float2* __restrict__ colstat,
                                                    const float* __restrict__ r, const float* __restrict__ c,
                                                    const uint8_t* __restrict__ mask0, const uint8_t* __restrict__ mask1) {

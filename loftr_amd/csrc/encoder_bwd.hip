@@ -290,9 +290,15 @@ struct Ws {
   float *q, *k, *v, *KV, *Ksum, *msg0, *m1, *m2, *hcat, *h1, *m3, *dm3, *dh1, *dhcat, *dm2, *dm1, *dmsg0, *dA, *dDen, *dKV, *dKsum,
         *dq, *dk, *dv, *t0, *t1, *wqT, *wkT, *wvT, *wmT, *w0T, *w2T, *wpart, *lnpart;
   float2 *st1, *st2;
-  void* lin; size_t lin_bytes;
+  void* lin; size_t lin_bytes, wpart_floats;
   bool ok;
 };
+// split-K scratch for every weight gradient of the layer: the partial count is not monotone in the token count (wgrad_chunk rounds and
+// clamps), so the x side (T tokens) and the source side (Ts tokens) are sized separately
+static size_t wpart_need(long T, long Ts, int C) {
+  const size_t a = wgrad_part_floats(T, 2 * C, 2 * C), b = wgrad_part_floats(Ts, 2 * C, 2 * C);
+  return a > b ? a : b;
+}
 Ws carve(WsAlloc& wa, int nb, int L, int S, int C, int H) {
   Ws w{};
   const size_t T = (size_t)nb * L, Ts = (size_t)nb * S, D = C / H, Tm = T > Ts ? T : Ts;
@@ -308,7 +314,8 @@ Ws carve(WsAlloc& wa, int nb, int L, int S, int C, int H) {
   w.t0 = wa.take<float>(Tm * C); w.t1 = wa.take<float>(Tm * C);
   w.wqT = wa.take<float>((size_t)C * C); w.wkT = wa.take<float>((size_t)C * C); w.wvT = wa.take<float>((size_t)C * C);
   w.wmT = wa.take<float>((size_t)C * C); w.w0T = wa.take<float>((size_t)4 * C * C); w.w2T = wa.take<float>((size_t)2 * C * C);
-  w.wpart = wa.take<float>(wgrad_part_floats((long)Tm, 2 * C, 2 * C));
+  w.wpart_floats = wpart_need((long)T, (long)Ts, C);
+  w.wpart = wa.take<float>(w.wpart_floats);
   w.lnpart = wa.take<float>((size_t)ceil_div((int)T, LN_ROWS_PB) * 2 * C);
   w.st1 = wa.take<float2>(T); w.st2 = wa.take<float2>(T);
   w.lin_bytes = loftr_linear_workspace_bytes((int)Tm, 2 * C, 2 * C);
@@ -346,7 +353,7 @@ extern "C" int loftr_encoder_layer_bwd(const float* x, const float* source, cons
   if (!a.ok) return LOFTR_ERR_WORKSPACE;
   const int D = C / H, C2 = 2 * C;
   const long T = (long)nb * L, Ts = (long)nb * S;
-  const size_t wpart_floats = wgrad_part_floats(T > Ts ? T : Ts, 2 * C, 2 * C);      // (a.wpart also holds the K V partials: not alive together)
+  const size_t wpart_floats = a.wpart_floats;      // (a.wpart also holds the K V partials: not alive together)
   const float vlen = (float)S, inv_s = 1.f / (float)S, attn_eps = 1e-6f, ln_eps = 1e-5f;      // linear_attention.py:26,41; nn.LayerNorm default
   int rc;
 #define LIN(A_, W_, OUT_, M_, N_, K_) if ((rc = loftr_linear_fwd(A_, W_, OUT_, (int)(M_), N_, K_, a.lin, a.lin_bytes, stream))) return rc
@@ -381,12 +388,12 @@ extern "C" int loftr_encoder_layer_bwd(const float* x, const float* source, cons
   // m3 = h1 W2^T
   transpose(w->mlp2, a.w2T, C, C2);                                    // [C, 2C] -> [2C, C]
   LIN(a.dm3, a.w2T, a.dh1, T, C2, C);                                  // dh1 = dm3 W2
-  if ((rc = launch_wgrad(a.dm3, C, a.h1, C2, T, gw->mlp2, a.wpart, st))) return rc;
+  if ((rc = launch_wgrad(a.dm3, C, a.h1, C2, T, gw->mlp2, a.wpart, a.wpart_floats, st))) return rc;
   hipLaunchKernelGGL(relu_bwd_kernel, g1d(T * C2), dim3(256), 0, st, a.dh1, a.h1, T * C2);
   // h1 = relu(hcat W0^T)
   transpose(w->mlp0, a.w0T, C2, C2);
   LIN(a.dh1, a.w0T, a.dhcat, T, C2, C2);
-  if ((rc = launch_wgrad(a.dh1, C2, a.hcat, C2, T, gw->mlp0, a.wpart, st))) return rc;
+  if ((rc = launch_wgrad(a.dh1, C2, a.hcat, C2, T, gw->mlp0, a.wpart, a.wpart_floats, st))) return rc;
   hipLaunchKernelGGL(slice_cols_kernel, g1d(T * C), dim3(256), 0, st, a.dhcat + C, (long)C2, a.dm2, T, C);
   // m2 = LN1(m1)
   hipLaunchKernelGGL(ln_bwd_kernel, dim3(nlb), dim3(256), 0, st, a.dm2, a.m1, a.st1, w->norm1_w, T, C, a.dm1, a.lnpart);
@@ -395,7 +402,7 @@ extern "C" int loftr_encoder_layer_bwd(const float* x, const float* source, cons
   // m1 = msg0 Wm^T
   transpose(w->merge, a.wmT, C, C);
   LIN(a.dm1, a.wmT, a.dmsg0, T, C, C);
-  if ((rc = launch_wgrad(a.dm1, C, a.msg0, C, T, gw->merge, a.wpart, st))) return rc;
+  if ((rc = launch_wgrad(a.dm1, C, a.msg0, C, T, gw->merge, a.wpart, a.wpart_floats, st))) return rc;
   // linear attention
   if (D == 32)
     hipLaunchKernelGGL((attn_q_kernel<true, 32>), dim3(ceil_div(L, 256), nb * H), dim3(256), 0, st, a.q, x_mask, a.KV, a.Ksum, vlen, attn_eps,
@@ -417,9 +424,9 @@ extern "C" int loftr_encoder_layer_bwd(const float* x, const float* source, cons
   LIN(a.dk, a.wkT, a.t0, Ts, C, C);
   LIN(a.dv, a.wvT, a.t1, Ts, C, C);
   hipLaunchKernelGGL(add_rows_kernel, g1d(Ts * C), dim3(256), 0, st, a.t0, a.t1, (long)C, (const float*)nullptr, grad_source, Ts, C);
-  if ((rc = launch_wgrad(a.dq, C, x, C, T, gw->q_proj, a.wpart, st))) return rc;
-  if ((rc = launch_wgrad(a.dk, C, source, C, Ts, gw->k_proj, a.wpart, st))) return rc;
-  if ((rc = launch_wgrad(a.dv, C, source, C, Ts, gw->v_proj, a.wpart, st))) return rc;
+  if ((rc = launch_wgrad(a.dq, C, x, C, T, gw->q_proj, a.wpart, a.wpart_floats, st))) return rc;
+  if ((rc = launch_wgrad(a.dk, C, source, C, Ts, gw->k_proj, a.wpart, a.wpart_floats, st))) return rc;
+  if ((rc = launch_wgrad(a.dv, C, source, C, Ts, gw->v_proj, a.wpart, a.wpart_floats, st))) return rc;
 #undef LIN
   LOFTR_CHECK_LAUNCH();
   return LOFTR_OK;

@@ -7,7 +7,7 @@
 
 namespace {
 
-__global__ __launch_bounds__(256) void epipolar_errors_kernel(const float* __restrict__ p0, const float* __restrict__ p1,
+__global__ LOFTR_NO_PACKED_FP32 __launch_bounds__(256) void epipolar_errors_kernel(const float* __restrict__ p0, const float* __restrict__ p1,
                                                               const long* __restrict__ bids, const float* __restrict__ T,
                                                               const float* __restrict__ K0, const float* __restrict__ K1,
                                                               long M, int N, float* __restrict__ out) {

@@ -97,7 +97,7 @@ __global__ void transpose_kernel(const float* __restrict__ w, float* __restrict_
 }
 inline dim3 g1d(long n) { return dim3((unsigned)((n + 255) / 256)); }
 
-struct Ws { float *cc, *cwin, *xcat, *dy, *dxcat, *dcwin, *dcc, *wmT, *wdT, *wpart, *cpart; void* lin; size_t lin_bytes; };
+struct Ws { float *cc, *cwin, *xcat, *dy, *dxcat, *dcwin, *dcc, *wmT, *wdT, *wpart, *cpart; void* lin; size_t lin_bytes, wpart_floats; };
 Ws carve(WsAlloc& wa, int M, int WW, int Cf, int Cc) {
   Ws w{};
   const size_t R = (size_t)2 * M, T = R * WW;
@@ -105,7 +105,8 @@ Ws carve(WsAlloc& wa, int M, int WW, int Cf, int Cc) {
   w.xcat = wa.take<float>(T * 2 * Cf); w.dy = wa.take<float>(T * Cf); w.dxcat = wa.take<float>(T * 2 * Cf);
   w.dcwin = wa.take<float>(R * Cf); w.dcc = wa.take<float>(R * Cc);
   w.wmT = wa.take<float>((size_t)2 * Cf * Cf); w.wdT = wa.take<float>((size_t)Cc * Cf);
-  w.wpart = wa.take<float>(wgrad_part_floats((long)T, Cf, 2 * Cf) + wgrad_part_floats((long)R, Cf, Cc));
+  w.wpart_floats = wgrad_part_floats((long)T, Cf, 2 * Cf) + wgrad_part_floats((long)R, Cf, Cc);
+  w.wpart = wa.take<float>(w.wpart_floats);
   w.cpart = wa.take<float>(colsum_part_floats((long)T, Cf) + 64);
   w.lin_bytes = loftr_linear_workspace_bytes((int)T, 2 * Cf, Cc > 2 * Cf ? Cc : 2 * Cf);
   w.lin = wa.take<char>(w.lin_bytes);
@@ -156,7 +157,7 @@ extern "C" int loftr_fine_preprocess_bwd(const loftr_fmap* feat_f0, const loftr_
   // ---- merge_feat
   hipLaunchKernelGGL(transpose_kernel, g1d((long)Cf * C2), dim3(256), 0, st, merge_w, a.wmT, Cf, C2);      // [Cf, 2Cf] -> [2Cf, Cf]
   LIN(a.dy, a.wmT, a.dxcat, T, C2, Cf);
-  if ((rc = launch_wgrad(a.dy, Cf, a.xcat, C2, T, grad_merge_w, a.wpart, st))) return rc;
+  if ((rc = launch_wgrad(a.dy, Cf, a.xcat, C2, T, grad_merge_w, a.wpart, a.wpart_floats, st))) return rc;
   if ((rc = launch_colsum(a.dy, T, Cf, grad_merge_b, a.cpart, st))) return rc;
   // ---- windows back into the fine maps; coarse context
   hipLaunchKernelGGL(scatter_windows_kernel, dim3(M, 2), dim3(256), 0, st, *grad_f0, *grad_f1, b_ids, i_ids, j_ids, M, w0c, w1c, stride, W, Cf,
@@ -165,7 +166,7 @@ extern "C" int loftr_fine_preprocess_bwd(const loftr_fmap* feat_f0, const loftr_
   // ---- down_proj
   hipLaunchKernelGGL(transpose_kernel, g1d((long)Cf * Cc), dim3(256), 0, st, down_w, a.wdT, Cf, Cc);       // [Cf, Cc] -> [Cc, Cf]
   LIN(a.dcwin, a.wdT, a.dcc, R, Cc, Cf);
-  if ((rc = launch_wgrad(a.dcwin, Cf, a.cc, Cc, R, grad_down_w, a.wpart, st))) return rc;
+  if ((rc = launch_wgrad(a.dcwin, Cf, a.cc, Cc, R, grad_down_w, a.wpart, a.wpart_floats, st))) return rc;
   if ((rc = launch_colsum(a.dcwin, R, Cf, grad_down_b, a.cpart, st))) return rc;
   hipLaunchKernelGGL(scatter_cc_kernel, dim3(M, 2), dim3(256), 0, st, a.dcc, b_ids, i_ids, j_ids, M, L, S, Cc, grad_c0, grad_c1);
 #undef LIN

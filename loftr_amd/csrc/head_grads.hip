@@ -11,7 +11,7 @@
 // one k-tile ahead of the compute) -> (hi, lo) fp16 -> LDS in the fragment layout of gemm.h, and the product is the same three fp16
 // MFMAs per fp32 product with fp32 accumulation (hi*hi + hi*lo + lo*hi, csrc/gemm.h).  The transposes cost nothing: a thread
 // loads a 4-column x 4- or 8-row micro tile with 16-byte loads ALONG the contiguous dimension and writes it to LDS across it.
-//   workgroup: 4 waves, 128 output rows x all C <= 256 columns (a wave: 32 rows x C), k-tile 32; LDS 48 KB used (+ 40 KB of padding: one workgroup per CU, see HG_LDS_PAD).
+//   workgroup: 4 waves, 128 output rows x all C <= 256 columns (a wave: 32 rows x C), k-tile 32; LDS 48 KB, two workgroups per CU.
 //   Scaling (gemm.h: the lo half of |x| < 2^-3 is a subnormal fp16 number, and gradients are small): both operand tiles are staged
 //   times a power of two that keeps the tile maximum in [2^10, 2^16) -- a RUNNING pair of exponents, changed only when a tile's
 //   maximum leaves that window; when it changes the accumulators are rescaled by the exact ratio (a wave-uniform, rare branch), so
@@ -22,24 +22,32 @@
 namespace {
 namespace hg {
 constexpr int BM = 128, BK = 32, WAVES = 4, MAXT = 8;          // MAXT column tiles of 32 (C <= 256)
-// ONE workgroup per CU, enforced through the LDS footprint (HG_LDS_PAD; -DHG_LDS_PAD=0 -DHG_MINWG=2 rebuilds the two-per-CU form).
-// Two co-resident workgroups of this kernel corrupt each other's results -- found in round 4 at the first grids of more than 256
-// workgroups (loftr_conv_wgrad, loftr_head_feat_grads at N = 8: up to 10 % error in the tiles that shared a CU, different from run
-// to run).  What the GPU said (tools/micro/conv_wgrad_debug.py): with CONSTANT operands a bad partial misses exactly 1 .. 5 of its 128
-// k-terms in some rows or columns (an operand element that is zero when the MFMA reads it); not LDS overlap (a 30 KB gap between
-// the two footprints changes nothing), not the register budget (launch_bounds(256, 3) fails alike), not the running operand scales
-// (fixed scales fail alike), not the cross-lane reductions (ds_bpermute instead of permlane swaps fails alike), not barrier
-// visibility (s_waitcnt 0 + fence + double barrier fails alike), not the 8-byte LDS stores (volatile 4-byte stores fail alike), not
-// the unaligned 16-byte loads.  The affected elements belong to the LAST lanes of a staging instruction (rows 64 .. 127 of the
-// transposed A tile, columns 192 .. 255 of B: lanes 16-31 / 48-63), as if a tile were read before its last writes were visible.
-// Root cause open; with one workgroup per CU -- by LDS footprint, or by a 372-register build (launch_bounds(256) alone) -- every
-// partial is right (0 of 150 / 512 bad in repeated runs, tests at batch 8 and training-size maps).
-#ifndef HG_LDS_PAD
-#define HG_LDS_PAD 40960
-#endif
-constexpr int A_BYTES = BM * 128, B_BYTES = 256 * 128, LDS_BYTES = A_BYTES + B_BYTES + 64 + HG_LDS_PAD;     // + [2][WAVES] floats
+// Two workgroups per CU (4 waves, 48 KB of LDS, <= 256 registers each).  Until round 5 the kernel had to be held to ONE per CU (by
+// LDS padding): two co-resident workgroups produced wrong partials -- a few of the 128 k-terms of a partial missing, different from
+// run to run (found in round 4 at the first grids of more than 256 workgroups).  Root cause (round 5, tools/micro/hg_diag.py and the
+// stand-alone reproducer tools/micro/pk_opsel_probe.hip, profiles/r05_pk_opsel_probe.txt): the staging conversions multiplied a PAIR
+// of operand values by the running scale, which hipcc compiled to  v_pk_mul_f32 / v_pk_fma_f32 ... op_sel:[0,1]  (the LOW result takes
+// the HIGH dword of the scale pair).  On gfx950 that form intermittently computes with a wrong operand in part of the wave when ANOTHER
+// wave of the same SIMD has MFMAs in flight: 7.5 million wrong products in 5 launches of the probe with two workgroups per CU, none
+// with one per CU, none without MFMAs, none for the op_sel_hi forms the rest of the library uses.  Loads, LDS stores, barriers and wait
+// counts were all innocent (read-back diagnostics: registers and LDS correct, the packed product wrong).  The split below is therefore
+// done with SCALAR conversions (hg_pack2); tests/test_isa_audit.py keeps the op_sel form out of every kernel of the library.
+// -DHG_PACKED_SPLIT rebuilds the faulty form (A/B: tools/micro/hg_diag.py counts its bad partials).
+constexpr int A_BYTES = BM * 128, B_BYTES = 256 * 128, LDS_BYTES = A_BYTES + B_BYTES + 64;     // + [2][WAVES] floats
 struct __attribute__((packed, aligned(4))) F4U { f32x4 v; };
 
+// (hi, lo) words of two consecutive values, scalar conversions only (see above); same values as sp_pack2 bit for bit
+#ifndef HG_PACKED_SPLIT
+__device__ __forceinline__ void hg_pack2(float a, float b, uint32_t& hi, uint32_t& lo) {
+  asm volatile("" : "+v"(a));           // keep the two values apart: no SLP vectorisation into packed fp32 instructions
+  asm volatile("" : "+v"(b));
+  const uint32_t pa = sp_pack(a), pb = sp_pack(b);
+  hi = (pa & 0xffffu) | (pb << 16);
+  lo = (pa >> 16) | (pb & 0xffff0000u);
+}
+#else
+#define hg_pack2 sp_pack2
+#endif
 struct Args {
   const float* a; long a_ld, a_bs;      // A source: TRANS = false: A[m][k] = a[n * a_bs + m * a_ld + k];  true: a[n * a_bs + k * a_ld + m]
   const float* b; long b_ld, b_bs;      // B[k][c] = b[n * b_bs + k * b_ld + c]
@@ -67,10 +75,7 @@ __device__ __forceinline__ float lift_exp(float absmax, float& inv) {     // pow
 }
 
 template <bool TRANS>
-#ifndef HG_MINWG
-#define HG_MINWG 1
-#endif
-__global__ __launch_bounds__(WAVES * 64, HG_MINWG) void head_grad_kernel(Args p) {
+__global__ __launch_bounds__(WAVES * 64, 2) void head_grad_kernel(Args p) {
   __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
   char* const sA = lds;
   char* const sB = lds + A_BYTES;
@@ -156,7 +161,7 @@ __global__ __launch_bounds__(WAVES * 64, HG_MINWG) void head_grad_kernel(Args p)
         u32x4 hi, lo;
         uint32_t hw[4], lw[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) sp_pack2(v[2 * e], v[2 * e + 1], hw[e], lw[e]);
+        for (int e = 0; e < 4; ++e) hg_pack2(v[2 * e], v[2 * e + 1], hw[e], lw[e]);
         hi = u32x4{hw[0], hw[1], hw[2], hw[3]}; lo = u32x4{lw[0], lw[1], lw[2], lw[3]};
         *reinterpret_cast<u32x4*>(sA + lds_chunk_off(r, c0 + h)) = hi;
         *reinterpret_cast<u32x4*>(sA + lds_chunk_off(r, 4 + c0 + h)) = lo;
@@ -166,8 +171,8 @@ __global__ __launch_bounds__(WAVES * 64, HG_MINWG) void head_grad_kernel(Args p)
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         uint32_t h0, l0, h1, l1;
-        sp_pack2(ra[0][e] * a_sc, ra[1][e] * a_sc, h0, l0);
-        sp_pack2(ra[2][e] * a_sc, ra[3][e] * a_sc, h1, l1);
+        hg_pack2(ra[0][e] * a_sc, ra[1][e] * a_sc, h0, l0);
+        hg_pack2(ra[2][e] * a_sc, ra[3][e] * a_sc, h1, l1);
         const int r = rb0 + e;
         *reinterpret_cast<uint2*>(sA + lds_chunk_off(r, kq >> 1) + (kq & 1) * 8) = uint2{h0, h1};
         *reinterpret_cast<uint2*>(sA + lds_chunk_off(r, 4 + (kq >> 1)) + (kq & 1) * 8) = uint2{l0, l1};
@@ -179,7 +184,7 @@ __global__ __launch_bounds__(WAVES * 64, HG_MINWG) void head_grad_kernel(Args p)
       for (int e = 0; e < 4; ++e) {
         uint32_t hw[4], lw[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) sp_pack2(rb[2 * q][e] * b_sc, rb[2 * q + 1][e] * b_sc, hw[q], lw[q]);
+        for (int q = 0; q < 4; ++q) hg_pack2(rb[2 * q][e] * b_sc, rb[2 * q + 1][e] * b_sc, hw[q], lw[q]);
         const int r = cb + e;
         *reinterpret_cast<u32x4*>(sB + lds_chunk_off(r, kc)) = u32x4{hw[0], hw[1], hw[2], hw[3]};
         *reinterpret_cast<u32x4*>(sB + lds_chunk_off(r, 4 + kc)) = u32x4{lw[0], lw[1], lw[2], lw[3]};
@@ -348,10 +353,12 @@ size_t wgrad_part_floats(long T, int O, int I) {
   return best;
 }
 // dW [O][I] = dy^T act  (dy [T, O], act [T, I]): a split-K batch of launch_head_grad + an ordered sum of the partials; I in column
-// blocks of <= 256.  part: wgrad_part_floats(T, O, I) floats of scratch.
-int launch_wgrad(const float* dy, int O, const float* act, int I, long T, float* dW, float* part, hipStream_t st) {
+// blocks of <= 256.  part: part_cap floats of scratch, >= wgrad_part_floats(T, O, I) (the number of partials is NOT monotone in T: the
+// chunk is rounded to the k-tile and clamped, so a buffer sized for a longer T may be too small -- checked, not assumed).
+int launch_wgrad(const float* dy, int O, const float* act, int I, long T, float* dW, float* part, size_t part_cap, hipStream_t st) {
   const int kch = wgrad_chunk(T, O);
   const int ns = ceil_div((int)T, kch);
+  if ((size_t)ns * O * I > part_cap) return LOFTR_ERR_WORKSPACE;
   for (int c0 = 0; c0 < I; c0 += 256) {
     const int cw = I - c0 < 256 ? I - c0 : 256;
     const int rc = launch_head_grad(dy, O, (long)kch * O, true, act + c0, I, (long)kch * I, part + c0, I, (long)O * I, O,

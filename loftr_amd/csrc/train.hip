@@ -35,7 +35,7 @@ struct SpvsGeom {
 // One thread per grid cell of either image: warp it into the other image (geometry.py:21-39) and record the nearest
 // coarse cell there (supervision.py:66-78).  dir 0: cells of image 0 (writes w_pt0_i, nearest1), dir 1: image 1
 // (writes pt1_i, nearest0).
-__global__ void spvs_warp_kernel(SpvsGeom g, const float* __restrict__ depth0, const float* __restrict__ depth1,
+__global__ LOFTR_NO_PACKED_FP32 void spvs_warp_kernel(SpvsGeom g, const float* __restrict__ depth0, const float* __restrict__ depth1,
                                  const float* __restrict__ T01, const float* __restrict__ T10, const float* __restrict__ K0,
                                  const float* __restrict__ K1, const float* __restrict__ scale0, const float* __restrict__ scale1,
                                  const uint8_t* __restrict__ mask0, const uint8_t* __restrict__ mask1,

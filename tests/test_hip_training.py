@@ -328,6 +328,11 @@ def test_training_step_full_backward_against_reference(name, backbone_on, monkey
     images = torch.from_numpy(np.concatenate([batch["image0"], batch["image1"]], 0))
     if backbone_on != "hip":
         fc, ff = cpu.backbone(images)                                                                        # WITH its graph
+        eps = float(os.environ.get("LOFTR_TEST_PERTURB_FEATURES", "0"))      # sensitivity experiment (tools/gpu/r5_bwd_sensitivity.sh): how far do the
+        if eps > 0:                                                          # gradients move when the features move by eps (relative, Gaussian)?
+            gp = torch.Generator().manual_seed(11)
+            fc = fc * (1 + eps * torch.randn(fc.shape, generator=gp))
+            ff = ff * (1 + eps * torch.randn(ff.shape, generator=gp))
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
     data = {"dataset_name": ["scannet"] * N, **{k: t(v) for k, v in batch.items()}}
     monkeypatch.setattr(torch, "randint", MG.det_randint)
@@ -371,16 +376,27 @@ def test_training_step_full_backward_against_reference(name, backbone_on, monkey
             err = max(np.abs(d[key + "/sub"] - g[key + "/sub"]).max() / scale,
                       max(np.abs(d[key + "/" + s_] - g[key + "/" + s_]).max() / max(np.abs(g[key + "/" + s_]).max(), scale) for s_ in ("rowsum", "colsum")))
         worst[n] = float(err)
-    # Bar per tensor, relative to its largest entry: 6e-3, or 3 x the reference's OWN float32 rounding noise on that tensor -- |its fp32
-    # gradient - its fp64 gradient| of the same step, stored in the golden -- where that is larger.  Why not the 2e-3 of the heads' gradients
-    # above: those start from identical head inputs; here the upstream gradients already carry the forward's differences (features ~1e-5
-    # from the reference's) through ten more nodes, and BatchNorm shifts, the stride-2 block of layer2 and the fine-level q projections
-    # (behind the attention normaliser) are sums with heavy cancellation -- the reference itself is off by up to 3.4e-2 there, and two
-    # float32 evaluations can differ by twice their common noise.  Measured: matcher tensors <= 4.7e-3 (138 / 154 of the 160 / 161 tensors
-    # within 2e-3), backbone tensors at the reference's own noise (1.60e-2 vs 1.60e-2, 5.1e-3 vs 5.2e-3).
+    # Bar per tensor, relative to its largest entry: 3e-3 (round-4 verdict; was 6e-3), or 3 x the reference's OWN float32 rounding noise on
+    # that tensor -- |its fp32 gradient - its fp64 gradient| of the same step, stored in the golden -- where that is larger (BatchNorm
+    # shifts and the stride-2 block of layer2 are sums with heavy cancellation: the reference itself is off by up to 3.4e-2 there, and two
+    # float32 evaluations can differ by twice their common noise).
+    # Three named exceptions at 8e-3, measured and explained in profiles/r05_backward_sensitivity.txt (tools/gpu/r5_bwd_sensitivity.sh):
+    #   * the fine-level q projections (behind the attention normaliser of 25-token windows): ill-conditioned -- perturbing the backbone
+    #     features by a RELATIVE 1e-6 moves loftr_fine.layers.1.q_proj.weight's gradient from 3.7e-3 to 5.8e-3 of its scale (to 3.0e-3 at
+    #     1e-5): any two float32 forwards differ by more than that, the reference's same-input noise (7e-4) does not measure it;
+    #   * loftr_coarse.layers.7.mlp.0.weight with the HIP backbone (5.6e-3; 3.5e-5 = the reference's noise with identical features): the
+    #     layer next to the loss sees gradients on few tokens, and a ReLU unit whose pre-activation changes sign under the 1e-5 forward
+    #     difference switches its whole contribution on or off -- the same experiment moves mlp.0 gradients of other layers by 24 x their
+    #     noise (5.6e-4); the match set, the sampled ids and both losses are identical to 7 digits in the two variants (full_backward_all.txt).
     noise = json.loads(str(g["ref_noise"]))
     assert bool(g["ref64_same_matches"])
-    tol = {n: max(6e-3, 3.0 * noise[n]) for n in worst}
+    loose = {"loftr_fine.layers.0.q_proj.weight": 8e-3, "loftr_fine.layers.1.q_proj.weight": 8e-3}
+    if backbone_on == "hip":
+        loose["loftr_coarse.layers.7.mlp.0.weight"] = 8e-3
+    # BatchNorm shifts of the backbone: the plain sum of the feature gradient over every pixel of the batch (cancellation): 4e-3
+    # (measured 3.06e-3 on backbone.layer1.1.bn2.bias with the CPU mirror, where the reference's own noise is 7.4e-4)
+    is_shift = lambda n: n.startswith("backbone.") and n.endswith(".bias")
+    tol = {n: max(loose.get(n, 4e-3 if is_shift(n) else 3e-3), 3.0 * noise[n]) for n in worst}
     hip = {n: e for n, e in worst.items() if not n.startswith("backbone.")}
     bb = {n: e for n, e in worst.items() if n.startswith("backbone.")}
     rep = os.path.join(os.path.dirname(GOLDEN_DIR), "..", "gpurun_out")
@@ -390,6 +406,12 @@ def test_training_step_full_backward_against_reference(name, backbone_on, monkey
                  f"{noise[max(hip, key=hip.get)]:.2e}); {len(bb)} backbone tensors, worst {max(bb.values()):.2e} ({max(bb, key=bb.get)}; reference "
                  f"{noise[max(bb, key=bb.get)]:.2e}); tensors above 2e-3: {sum(e > 2e-3 for e in worst.values())}; top: "
                  + ", ".join(f"{n} {e:.1e}" for n, e in sorted(worst.items(), key=lambda kv: -kv[1])[:4]) + "\n")
+    with open(os.path.join(rep, "full_backward_all.txt"), "a") as fh:          # every tensor: distance, the reference's own fp32 noise, ratio
+        ids = torch.stack([data["b_ids"], data["i_ids"], data["j_ids"]], 1).cpu().numpy().astype(np.int64)
+        import hashlib
+        fh.write(f"== {name} (backbone on {backbone_on}); training matches M = {len(ids)}, sha1 of (b, i, j) {hashlib.sha1(ids.tobytes()).hexdigest()[:12]}, "
+                 f"loss_c {float(data['loss_scalars']['loss_c']):.7f} loss_f {float(data['loss_scalars']['loss_f']):.7f}\n" + "".join(f"{n:52s} {e:.2e}  ref noise {noise[n]:.2e}  x{e / max(noise[n], 1e-12):7.1f}\n"
+                                                                         for n, e in sorted(worst.items(), key=lambda kv: -kv[1])))
     bad = {n: (e, tol[n]) for n, e in worst.items() if e > tol[n]}
     assert not bad, (sorted(bad.items(), key=lambda kv: -kv[1][0])[:8], len(bad), len(worst))
 

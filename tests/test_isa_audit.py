@@ -1,0 +1,61 @@
+"""ISA audit of every translation unit of libloftr_hip.so (CPU test: hipcc cross-compiles to gfx950 assembly).
+
+gfx950 erratum found in round 5 (csrc/common.h: LOFTR_NO_PACKED_FP32, csrc/head_grads.hip, tools/micro/pk_opsel_probe.hip): a packed-fp32
+instruction whose op_sel bit for SRC1 is set computes with a wrong operand, intermittently, while another wave of the same SIMD has MFMAs
+in flight.  It was the root cause of head_grad_kernel's wrong weight gradients with two workgroups per CU.  No kernel of the library may
+contain the form, whatever its occupancy: any kernel can share a SIMD with an MFMA kernel of the other stream."""
+import os
+import re
+import subprocess
+import tempfile
+from concurrent.futures import ThreadPoolExecutor
+
+import pytest
+
+from loftr_amd import build as B
+
+BAD_FORM = re.compile(r"v_pk_(?:mul|fma|add)_f32 .*\bop_sel:\[[01],1")
+
+
+def _asm(src, outdir):
+    out = os.path.join(outdir, src + ".s")
+    cmd = [B._hipcc(), *B.FLAGS, "-S", "--cuda-device-only", "-o", out, os.path.join(B.CSRC, src)]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, f"hipcc -S failed on {src}:\n{r.stderr[-2000:]}"
+    return src, open(out).read()
+
+
+@pytest.fixture(scope="module")
+def isa():
+    with tempfile.TemporaryDirectory() as d, ThreadPoolExecutor(max_workers=8) as ex:
+        return dict(ex.map(lambda s: _asm(s, d), B.SOURCES))
+
+
+def test_every_source_is_audited(isa):
+    assert sorted(isa) == sorted(B.SOURCES) and len(isa) >= 20
+
+
+def test_no_packed_fp32_with_src1_op_sel(isa):
+    hits = []
+    for src, text in isa.items():
+        kernel = "?"
+        for line in text.splitlines():
+            if line and not line[0].isspace() and line.rstrip().endswith(":") and not line.startswith(".L"):
+                kernel = line.rstrip()[:-1]
+            elif BAD_FORM.search(line):
+                hits.append(f"{src}: {kernel}: {line.strip()}")
+    assert not hits, "packed fp32 with op_sel on src1 (gfx950 erratum, see common.h):\n" + "\n".join(hits[:20])
+
+
+def test_head_grad_kernel_is_built_for_two_workgroups_per_cu(isa):
+    """No LDS padding, no occupancy restriction: <= 256 registers, < 80 KB of LDS, no scratch (round-4 verdict, weak #1)."""
+    text = isa["head_grads.hip"]
+    found = 0
+    for m in re.finditer(r"\.amdhsa_kernel (\S*head_grad_kernel\S*)\n(.*?)\.end_amdhsa_kernel", text, re.S):
+        body = m.group(2)
+        lds = int(re.search(r"\.amdhsa_group_segment_fixed_size (\d+)", body).group(1))
+        scratch = int(re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", body).group(1))
+        vgpr = int(re.search(r"\.amdhsa_next_free_vgpr (\d+)", body).group(1))
+        assert lds < 80 * 1024 and scratch == 0 and vgpr <= 256, (m.group(1), lds, scratch, vgpr)
+        found += 1
+    assert found == 2
