@@ -61,8 +61,8 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F16_PEAK_TF = 2500.0      # MI355X_MICROARCH.md: dense fp16/bf16 MFMA peak
 MFMA_F32_PEAK_TF = 157.3       # MI355X_MICROARCH.md: fp32-input MFMA = fp32 vector peak (for context only)
 SPLIT_FACTOR = 3               # every fp32 product = 3 fp16 MFMAs (hi*hi + hi*lo + lo*hi), csrc/gemm.h
-GEMM_KERNELS = ("proj_kernel", "proj_kv_kernel", "linear_kernel", "linear_ln_kernel", "score_stats_kernel", "score_conf_kernel",
-                "conv_kernel", "conv3x3_kernel", "conv3x3_wide_kernel", "encoder_x_kernel", "fine_pair_kernel")
+GEMM_KERNELS = ("proj_kernel", "proj_kv_kernel", "linear_kernel", "linear_ln_kernel", "score_sweep_kernel<0>", "score_sweep_kernel<1>",
+                "conv_kernel", "conv3x3_duo_kernel<Cfg<4,2,4,4,1>>", "conv3x3_duo_kernel<Cfg<7,2,4,8,2>>", "encoder_x_kernel", "fine_pair_kernel")
 
 K_IDS = {}
 
@@ -122,16 +122,16 @@ def algorithmic_work(B, L, S, M, C_=256, Cf=128, WW=25, fused=True, fused_fine=T
     w["linear_kernel"] = (w["linear_kernel"][0] + fp_f, w["linear_kernel"][1] + fp_b)
     nl = n_self + n_cross
     w["proj_kv_kernel"] = (nl * (2 * rows_c * C_ * 2 * C_ + 2 * rows_c * C_ * 32), nl * 4 * (rows_c * C_ + 2 * C_ * C_))
-    w["score_stats_kernel"] = (2 * B * L * S * C_, 4 * B * (L + S) * C_)
-    w["score_conf_kernel"] = (2 * B * L * S * C_, 4 * B * ((L + S) * C_ + L * S))
+    w["score_sweep_kernel<0>"] = (2 * B * L * S * C_, 4 * B * (L + S) * C_)
+    w["score_sweep_kernel<1>"] = (2 * B * L * S * C_, 4 * B * ((L + S) * C_ + L * S))
     w["gather_windows_kernel"] = (0, 2 * 4 * 2 * M * WW * Cf)
     # backbone convolutions on the same GEMM core (conv.hip): ResNetFPN_8_2 over 2B images of 480x640
     # 3x3 stride-1 layers run the patch-in-LDS kernels (the 224-column one when ceil32(Cout) == 224)
-    acc = {"conv_kernel": [0, 0], "conv3x3_kernel": [0, 0], "conv3x3_wide_kernel": [0, 0]}
+    acc = {"conv_kernel": [0, 0], "conv3x3_duo_kernel<Cfg<4,2,4,4,1>>": [0, 0], "conv3x3_duo_kernel<Cfg<7,2,4,8,2>>": [0, 0]}
     for (cin, cout, k, stride, hin, win) in backbone_convs(H_IMG, W_IMG):
         ho, wo = hin // stride, win // stride
         patch = k == 3 and stride == 1
-        a = acc[("conv3x3_wide_kernel" if (cout + 31) // 32 == 7 else "conv3x3_kernel") if patch else "conv_kernel"]
+        a = acc[("conv3x3_duo_kernel<Cfg<7,2,4,8,2>>" if (cout + 31) // 32 == 7 else "conv3x3_duo_kernel<Cfg<4,2,4,4,1>>") if patch else "conv_kernel"]
         a[0] += 2 * 2 * B * ho * wo * cout * cin * k * k
         a[1] += 4 * 2 * B * (hin * win * cin + ho * wo * cout) + 4 * cout * cin * k * k
     for name, (fl, by) in acc.items():
@@ -256,25 +256,39 @@ def reference_cpu_forward(model, img0, img1, gpu_data):
         h0.remove(); h1.remove()
     runs = sorted(runs[1:])
     total, bbt = runs[1]
-    # live parity of the GPU forward (last timed step, pair 0) against this reference forward
+    # live parity of the GPU forward (last timed step) against this reference forward: pair 0 (the timed sample) and the LAST pair of the
+    # batch (one more reference forward; a batch-position mistake on the GPU side would show there and not on pair 0)
     g = gpu_data
-    sel = (g["b_ids"] == 0).nonzero().squeeze(1)
-    msel = (g["m_bids"] == 0).nonzero().squeeze(1)
-    gi, gj = g["i_ids"][sel].cpu().numpy(), g["j_ids"][sel].cpu().numpy()
-    ri, rj = data["i_ids"].numpy(), data["j_ids"].numpy()
-    rk = {k: n for n, k in enumerate(zip(ri.tolist(), rj.tolist()))}
-    com = [(n, rk[k]) for n, k in enumerate(zip(gi.tolist(), gj.tolist())) if k in rk]
-    ia, ib = [c[0] for c in com], [c[1] for c in com]
-    par = {"pair": 0, "matches_gpu": int(len(gi)), "matches_reference": int(len(ri)), "common": len(com)}
-    if com:
-        gm = {k: g[k][msel].cpu().numpy() for k in ("mconf", "mkpts0_f", "mkpts1_f")}
-        par.update(d_mconf=float(np.abs(gm["mconf"][ia] - data["mconf"].numpy()[ib]).max()),
-                   d_mkpts0_f_px=float(np.abs(gm["mkpts0_f"][ia] - data["mkpts0_f"].numpy()[ib]).max()),
-                   d_mkpts1_f_px=float(np.abs(gm["mkpts1_f"][ia] - data["mkpts1_f"].numpy()[ib]).max()))
-    if "conf_matrix" in g and g["conf_matrix"] is not None:
-        par["d_conf_matrix"] = float((g["conf_matrix"][0].cpu() - data["conf_matrix"][0]).abs().max())
-    par["note"] = ("GPU forward (HIP backbone + HIP matching path) vs the reference's fp32 CPU forward on the same pair and weights in this run; "
-                   "match sets can differ by near-tie flips at thr 0 with random weights (the goldens pin this against the reference's fp64 run)")
+
+    def pair_parity(b, rd):
+        sel = (g["b_ids"] == b).nonzero().squeeze(1)
+        msel = (g["m_bids"] == b).nonzero().squeeze(1)
+        gi, gj = g["i_ids"][sel].cpu().numpy(), g["j_ids"][sel].cpu().numpy()
+        ri, rj = rd["i_ids"].numpy(), rd["j_ids"].numpy()
+        rk = {k: n for n, k in enumerate(zip(ri.tolist(), rj.tolist()))}
+        com = [(n, rk[k]) for n, k in enumerate(zip(gi.tolist(), gj.tolist())) if k in rk]
+        ia, ib = [c[0] for c in com], [c[1] for c in com]
+        par = {"pair": int(b), "matches_gpu": int(len(gi)), "matches_reference": int(len(ri)), "common": len(com)}
+        if com:
+            gm = {k: g[k][msel].cpu().numpy() for k in ("mconf", "mkpts0_f", "mkpts1_f")}
+            par.update(d_mconf=float(np.abs(gm["mconf"][ia] - rd["mconf"].numpy()[ib]).max()),
+                       d_mkpts0_f_px=float(np.abs(gm["mkpts0_f"][ia] - rd["mkpts0_f"].numpy()[ib]).max()),
+                       d_mkpts1_f_px=float(np.abs(gm["mkpts1_f"][ia] - rd["mkpts1_f"].numpy()[ib]).max()))
+        if "conf_matrix" in g and g["conf_matrix"] is not None:
+            par["d_conf_matrix"] = float((g["conf_matrix"][b].cpu() - rd["conf_matrix"][0]).abs().max())
+        return par
+    ri = data["i_ids"].numpy()
+    pars = [pair_parity(0, data)]
+    last = int(img0.shape[0]) - 1
+    if last > 0:
+        dl = {"image0": img0[last:last + 1].cpu().clone(), "image1": img1[last:last + 1].cpu().clone()}
+        with torch.no_grad():
+            ref(dl)
+        pars.append(pair_parity(last, dl))
+    par = {"pairs": pars,
+           "note": "GPU forward (HIP backbone + HIP matching path) vs the reference's fp32 CPU forward on the same pair and weights in this run, for the "
+                   "first and the last pair of the batch; match sets can differ by near-tie flips at thr 0 with random weights (the goldens pin this "
+                   "against the reference's fp64 run: profiles/r05_parity_margins.txt)"}
     out = {"value": round(1.0 / total, 4), "unit": "image-pairs/s", "cores": threads, "kind": "reference", "reference_import": mode,
            "reference_forward_s": round(total, 3), "reference_backbone_s": round(bbt, 3), "reference_hot_path_s": round(total - bbt, 3),
            "sample": f"pair 0 of the GPU batch (640x480), zju3dv/LoFTR LoFTR.forward (eval, no_grad, fp32, torch CPU), the GPU model's weights: "
@@ -341,11 +355,26 @@ def cpu_baseline(model, img0, img1, gpu_data=None):
             "runs_s": [round(r[0], 3) for r in runs]}
 
 
-BACKBONE_KERNELS = ("conv3x3_kernel", "conv3x3_wide_kernel", "conv_kernel", "conv3x3s2_kernel")
+BACKBONE_KERNELS = ("conv3x3_duo_kernel<Cfg<4,2,4,4,1>>", "conv3x3_duo_kernel<Cfg<7,2,4,8,2>>", "conv_kernel", "conv3x3s2_kernel")
 ENCODER_KERNELS = ("proj_kv_kernel", "proj_kernel", "linear_kernel", "linear_ln_kernel", "encoder_x_kernel", "fine_pair_kernel")
 # Only the bench line's `roofline` kernel carries hipEvents inside the timed region (one launch per step); everything else
 # is measured in the serial instrumented steps just before it (round-2 verdict: 83 event pairs per step in the timed region).
-NORTH_STAR_TIMED = ("score_conf_kernel",)
+NORTH_STAR_TIMED = ("score_sweep_kernel<1>",)
+# The library times kernel FAMILIES (one hipEvent slot per family, csrc/common.h: LoftrTimedKernel); a slot is named after the kernel the
+# default path launches, and these are the names `rocprofv3 --kernel-trace --stats` prints for everything pooled in it.
+POOLED_FROM = {
+    "score_sweep_kernel<0>": ["sweep::score_sweep_kernel<0, false, true>", "sweep::score_sweep_kernel<0, false, false>", "sweep::score_sweep_kernel<0, true, false>",
+                              "(C != 256: score_stats_kernel)"],
+    "score_sweep_kernel<1>": ["sweep::score_sweep_kernel<1, false, false, false>", "sweep::score_sweep_kernel<1, false, false, true>",
+                              "sweep::score_sweep_kernel<1, true, false, true>", "(C != 256: score_conf_kernel)"],
+    "score_sweep_kernel<2>": ["sweep::score_sweep_kernel<2, false>", "sweep::score_sweep_kernel<2, true>", "(C != 256: score_store_kernel)"],
+    "conv3x3_duo_kernel<Cfg<4,2,4,4,1>>": ["conv3x3_duo_kernel<c3d::Cfg<4, 2, 4, 4, 1> >", "(Cout not a multiple of 128: conv3x3_kernel)"],
+    "conv3x3_duo_kernel<Cfg<7,2,4,8,2>>": ["conv3x3_duo_kernel<c3d::Cfg<7, 2, 4, 8, 2> >"],
+    "encoder_x_kernel": ["efx::encoder_x_kernel", "efx::encoder_x2_kernel"],
+    "fine_pair_kernel": ["ffx::fine_pair_kernel"],
+    "conv_kernel": ["conv_kernel<GemmCfg<...>, false> (strided 3x3, 1x1)", "conv_kernel<GemmCfg<...>, true> (FPN top-down: 1x1 + bilinear x2 + add)"],
+    "proj_kernel": ["proj_kernel", "rowsweep_kernel<0>"], "linear_ln_kernel": ["linear_ln_kernel", "rowsweep_kernel<1>"],
+}
 
 
 def run_with_retry(argv):
@@ -430,7 +459,7 @@ def other_configs(lib, ids, dev, sd, backbone, steps=5, warmup=2):
         e1.record(); torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / steps
         M = int(d["mconf"].shape[0])
-        names = [n for n in ("score_conf_kernel", "score_stats_kernel", "score_store_kernel", "encoder_x_kernel", "fine_pair_kernel") if n in ids]
+        names = [n for n in ("score_sweep_kernel<1>", "score_sweep_kernel<0>", "score_sweep_kernel<2>", "encoder_x_kernel", "fine_pair_kernel") if n in ids]
         mask = 0
         for n in names:
             mask |= 1 << ids[n]; read_timing(lib, ids[n])
@@ -448,9 +477,9 @@ def other_configs(lib, ids, dev, sd, backbone, steps=5, warmup=2):
             if c:
                 kt[n] = round(t / c * 1e3, 1)
         ent["kernel_avg_us"] = kt
-        if "score_conf_kernel" in kt:                       # dual-softmax pass B against the HBM roof at THIS L
+        if "score_sweep_kernel<1>" in kt:                       # dual-softmax pass B against the HBM roof at THIS L
             by = 4 * n_pairs * (2 * L * 256 + L * L)
-            gbs = by / (kt["score_conf_kernel"] * 1e-6) / 1e9
+            gbs = by / (kt["score_sweep_kernel<1>"] * 1e-6) / 1e9
             ent["score_conf_roofline"] = {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                           "frac": round(gbs / HBM_PEAK_GBS, 4), "algorithmic_bytes": by}
         out[tag] = ent
@@ -461,15 +490,15 @@ def other_configs(lib, ids, dev, sd, backbone, steps=5, warmup=2):
     N = 2
     cfg = get_cfg(thr=0.0, border_rm=2)
     cfg["coarse"]["temp_bug_fix"] = False                    # configs/loftr/outdoor/buggy_pos_enc/loftr_ds.py:3-4 (outdoor_ds.ckpt)
-    g = torch.Generator().manual_seed(1234)
-    i0 = torch.rand(N, 1, 840, 840, generator=g)
-    i1 = (i0.roll((8, 16), (2, 3)) + 0.02 * torch.rand(N, 1, 840, 840, generator=g)).clamp(0, 1)
+    o0, o1 = make_images(1234, N, 840, 840)               # the images of tests/golden/e2e_outdoor_840.npz (pinned there against the reference from images)
+    i0, i1 = torch.from_numpy(o0), torch.from_numpy(o1)
     i0[:, :, 560:] = 0; i1[:, :, 560:] = 0
     mask = torch.zeros(N, 105, 105, dtype=torch.bool); mask[:, :70] = True
     fixed = {"image0": i0.to(dev), "image1": i1.to(dev), "mask0": mask.to(dev), "mask1": mask.to(dev),
              "scale0": torch.full((N, 2), 1.9).to(dev), "scale1": torch.full((N, 2), 1.9).to(dev)}
     run("outdoor_840_masked", cfg, lambda: dict(fixed), N, 105 * 105,
-        {"workload": "BASELINE configs[3]: 2 pairs 840x840 (valid 840x560, zero-padded), mask0/1 [2,105,105], scale 1.9, dual-softmax, thr 0.0"})
+        {"workload": "BASELINE configs[3]: 2 pairs 840x840 (valid 840x560, zero-padded), mask0/1 [2,105,105], scale 1.9, dual-softmax, thr 0.0",
+         "parity": "this exact batch is pinned against the reference's forward from images: tests/golden/e2e_outdoor_840.npz (tests/test_e2e_golden.py)"})
     del fixed
     # ---- configs[4]: indoor_ot
     B = 8
@@ -501,7 +530,7 @@ def main():
                     help="sinkhorn = BASELINE configs[4] (indoor_ot); not the headline")
     ap.add_argument("--backbone", default="hip", choices=["hip", "torch"],
                     help="hip: implicit-GEMM convolutions of this library (default; image-level parity with the reference held at "
-                         "1e-4 / 1e-3 px, profiles/r02_parity_margins.txt); torch: PyTorch-ROCm / MIOpen fp32")
+                         "1e-4 / 1e-3 px, profiles/r05_parity_margins.txt); torch: PyTorch-ROCm / MIOpen fp32")
     ap.add_argument("--collective", default="auto", choices=["auto", "cabi", "torch"],
                     help="count all-gather transport: the library's C-ABI RCCL call, or torch.distributed (also RCCL); auto = cabi, "
                          "falling back to torch if the communicator cannot be created (recorded in the JSON)")
@@ -657,6 +686,8 @@ def main():
             if e:
                 e["traffic"] = pmc_traffic(name)
                 e["mfma_busy"] = pmc_mfma_busy(name)
+                if name in POOLED_FROM:
+                    e["pooled_from"] = POOLED_FROM[name]
                 kernels.append(e)
     model.overlap_fine_branch = not args.no_overlap
     kernels.sort(key=lambda k: -k["ms_per_step"])
@@ -682,12 +713,30 @@ def main():
         ms, cnt = read_timing(lib, ids[n])
         if cnt:
             timing[n] = (ms, cnt)
+    # ---- the encoder group INSIDE the two-stream step (after the timed region, same step function): its launches share the CUs with the
+    # FPN fine branch's convolution workgroups there, so an event-bracketed launch is longer than alone -- reported as in_region_*
+    in_region = {}
+    if model.overlap_fine_branch:
+        enc_ids = [n for n in ENCODER_KERNELS if n in ids]
+        m2 = 0
+        for n in enc_ids:
+            m2 |= 1 << ids[n]
+            read_timing(lib, ids[n])
+        lib.loftr_hip_timing_enable(m2)
+        for _ in range(NB):
+            step()
+        torch.cuda.synchronize()
+        lib.loftr_hip_timing_enable(0)
+        for n in enc_ids:
+            ms, cnt = read_timing(lib, ids[n])
+            if cnt:
+                in_region[n] = (ms, cnt)
     roof = None
-    if "score_conf_kernel" in timing:
-        ms, cnt = timing["score_conf_kernel"]
-        roof = roofline_entry("score_conf_kernel", ms, cnt, work["score_conf_kernel"][0], work["score_conf_kernel"][1], args.steps)
+    if "score_sweep_kernel<1>" in timing:
+        ms, cnt = timing["score_sweep_kernel<1>"]
+        roof = roofline_entry("score_sweep_kernel<1>", ms, cnt, work["score_sweep_kernel<1>"][0], work["score_sweep_kernel<1>"][1], args.steps)
         roof["bound"], roof["achieved"], roof["peak"], roof["unit"], roof["frac"] = "hbm", roof["alg_GB_s"], HBM_PEAK_GBS, "GB/s", roof["hbm_frac"]
-        roof["traffic"] = pmc_traffic("score_conf_kernel")
+        roof["traffic"] = pmc_traffic("score_sweep_kernel<1>")
         roof["note"] = ("north_star score-volume kernel (dual-softmax pass B: recompute the score tile on MFMA, write conf_matrix "
                         "once): algorithmic bytes = descriptors + conf_matrix (DESIGN.md §4) / in-region hipEvent launch time")
     # Encoder group: from the serial instrumented steps (same process, just before the timed region).  In the timed region
@@ -702,8 +751,16 @@ def main():
             r_["measured"] = ("hipEvents around every launch of these kernels in 3 instrumented steps of this run with the two HIP "
                               "streams serialised (kernels alone on the GPU)")
             r_["share_of_serial_step"] = round(r_["ms_per_step"] / serial_step_ms, 4)
+    if roof_enc and in_region:
+        r2 = group_roofline([n for n in ENCODER_KERNELS if n in in_region], in_region, work, NB)
+        if r2:
+            roof_enc["in_region_frac"] = r2["frac"]
+            roof_enc["in_region_ms_per_step"] = r2["ms_per_step"]
+            roof_enc["in_region_note"] = ("the same kernels event-bracketed inside the two-stream step (3 steps after the timed region): launches time-slice "
+                                          "the CUs with the fine branch's convolutions; `frac` / `achieved` above are the kernels alone on the GPU")
     if roof_enc:
         roof_enc["kernel"] = "encoder_x_kernel (+ proj_kv / fine_pair / linear: the linear-attention encoder group)"
+        roof_enc["pooled_from"] = sorted({x for n in ENCODER_KERNELS for x in POOLED_FROM.get(n, [n])})
         roof_enc["dominant_share_of_step"] = round(roof_enc["ms_per_step"] / hot_ms, 4)
         roof_enc["dominant_share_note"] = ("share of the hand-written matching path (stage_ms.hot_path_hip) these kernels account for; "
                                            "share_of_serial_step = of backbone + matching path run serially")
@@ -739,7 +796,7 @@ def main():
                        "thr_note": "stock thr 0.2 gives 0 matches with random weights; thr 0.0 keeps the fine stage loaded",
                        "conf_matrix_materialised": not args.no_conf, "match_type": args.match_type, "matches_per_pair": round(m_total / (world * B), 1),
                        "global_batch": world * B, "parallelism": f"dp{world} (pairs sharded; RCCL all-gather of match counts)",
-                       "parity": "image-level goldens of the reference forward, both backbones: profiles/r02_parity_margins.txt"},
+                       "parity": "image-level goldens of the reference forward, both backbones (incl. a 3-pair batch and the 840 x 840 masked outdoor batch): profiles/r05_parity_margins.txt"},
             "per_rank_ms_per_step": per_rank_ms,
             "collective": {"transport": transport, "ranks_in_communicator": (rccl.ranks_seen if rccl is not None else world) if multi else 1},
             "stage_ms": {"backbone": round(backbone_ms, 3), "backbone_impl": args.backbone, "hot_path_hip": round(hot_ms, 3),
@@ -763,6 +820,7 @@ def main():
                 out["other_configs"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(model, img0, img1, last.get("data"))
+            out["cpu_baseline_kind"] = out["cpu_baseline"].get("kind")       # top level: "reference" (the reference's own forward) or "port" -- never to be mixed
         sys.stdout.flush()
         os.dup2(real_stdout, 1)
         print(json.dumps(out), flush=True)

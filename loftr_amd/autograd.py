@@ -199,7 +199,7 @@ class _PosEncodeFlatten(torch.autograd.Function):
     @once_differentiable
     def backward(ctx, grad):
         n, c, h, w = ctx.shape
-        return grad.view(n, h, w, c).permute(0, 3, 1, 2), None
+        return grad.reshape(n, h, w, c).permute(0, 3, 1, 2), None      # (reshape: the incoming gradient need not be contiguous)
 
 
 def pos_encode_flatten(x, pe):

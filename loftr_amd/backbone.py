@@ -40,8 +40,9 @@ class Conv2d(nn.Conv2d):
     module (the inference path does not go through forward() at all: forward_hip reads the weights)."""
 
     def forward(self, x):
+        # (in_channels > 256: loftr_conv_wgrad's column limit -- custom block_dims above 256 train through PyTorch's convolution)
         if (TRAIN_CONV_HIP and self.training and x.is_cuda and x.dtype == torch.float32 and torch.is_grad_enabled()
-                and (x.requires_grad or self.weight.requires_grad)):
+                and self.in_channels <= 256 and (x.requires_grad or self.weight.requires_grad)):
             return autograd.conv2d(x, self.weight, self.stride[0], self.padding[0])
         return super().forward(x)
 

@@ -63,7 +63,11 @@ def _build(force, verbose, extra_flags):
 
     with ThreadPoolExecutor(max_workers=min(8, len(SOURCES))) as ex:
         objs = list(ex.map(compile_one, SOURCES))
-    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH, *objs, "-ldl"],
+    # export the C ABI only (include/loftr_hip.h: loftr_*); the C++ launch helpers shared between translation units stay internal
+    vs = os.path.join(OBJ_DIR, "exports.map")
+    with open(vs, "w") as fh:
+        fh.write("{ global: loftr_*; local: *; };\n")
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", f"-Wl,--version-script={vs}", "-o", LIB_PATH, *objs, "-ldl"],
                        capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stderr}")

@@ -494,6 +494,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_kernel(Conv3Args p) {
 
 #include "conv3x3_duo.h"
 
+#ifdef LOFTR_LEGACY_CONV   // round-3 kernel for the 224-column layers, superseded by conv3x3_duo_kernel<Cfg<7, 2, 4, 8, 2>> (round 4); kept for A/B builds only:
+                           // python -m loftr_amd.build --variant legacy -DLOFTR_LEGACY_CONV, then LOFTR_CONV_DUO=0
 // 3x3 convolutions whose padded output width is 7 MFMA column tiles (Cout = 196 -> 224, the FPN's middle
 // dimension: 5 of the 14 3x3 layers, among them the most expensive one).  The 128-column kernel above runs them
 // as a full tile plus a 96-column tile whose waves idle at the k-tile barrier for half of their MFMA slots and
@@ -712,6 +714,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wide_kernel(Conv3Args p) {
 #undef C3W_FINISH
 #undef C3W_RES_LOAD
 }
+#endif  // LOFTR_LEGACY_CONV
 
 // Weight preparation: fold eval-mode BN, transpose to tap-major, pad channels, encode as SP.
 //   w [Cout, Cin, KH, KW] -> wsp [Cout, KH*KW*Cp];  bias[co] = beta - mean * scale,  scale = gamma / sqrt(var + eps)
@@ -983,7 +986,7 @@ static int conv_run(const uint32_t* x_sp, int B, int H, int W, int Cin, const vo
     c.tiles_x = ceil_div(W, c3::TX); c.tiles_y = ceil_div(H, c3::TY);
     // LOFTR_CONV_WIDE=0: run 7-column-tile outputs as 128 + 96 columns on the generic kernel (A/B experiments)
     static const int use_wide = []() { const char* e = getenv("LOFTR_CONV_WIDE"); return e ? atoi(e) : 1; }();
-    const bool wide = use_wide && c.Coutp == 32 * c3w::NT;
+    const bool wide = use_wide && c.Coutp == 32 * 7;
     TimedLaunch tl(wide ? LOFTR_T_CONV3W : LOFTR_T_CONV3, st);
     // round 4: conv3x3_duo.h
     static const int use_duo = []() { const char* e = getenv("LOFTR_CONV_DUO"); return e ? atoi(e) : 9; }();   // default: 128-column tiles on two workgroups per CU, 224-column tiles on one 8-wave workgroup (tools/gpu/r4_octo.sh)
@@ -1009,9 +1012,12 @@ static int conv_run(const uint32_t* x_sp, int B, int H, int W, int Cin, const vo
       using CF = c3d::Cfg<7, 1, 3>;
       c.tiles_y = ceil_div(H, CF::TY);
       hipLaunchKernelGGL((conv3x3_duo_kernel<CF>), dim3(xcd_grid(B * c.tiles_x * c.tiles_y, 1)), dim3(256), 0, st, c);
-    } else if (wide)
+    }
+#ifdef LOFTR_LEGACY_CONV
+    else if (wide)
       hipLaunchKernelGGL(conv3x3_wide_kernel, dim3(xcd_grid(B * c.tiles_x * c.tiles_y, 1)), dim3(512), 0, st, c);
-    else
+#endif
+    else                          // any other Cout (not a multiple of 128, not 192 / 224): the generic patch kernel, column tiles of 128
       hipLaunchKernelGGL(conv3x3_kernel, dim3(shared_gpu ? xcd_grid(B * c.tiles_x * c.tiles_y, ceil_div(c.Coutp, 128))
                                                          : persistent_grid(xcd_grid(B * c.tiles_x * c.tiles_y, ceil_div(c.Coutp, 128)))),
                          dim3(512), 0, st, c);

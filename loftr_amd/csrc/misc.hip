@@ -64,10 +64,10 @@ struct TimingSlot {
   double total_ms; long long launches;
 };
 TimingSlot g_slots[LOFTR_T_COUNT];
-const char* const T_NAMES[LOFTR_T_COUNT] = {"score_stats_kernel", "score_conf_kernel", "proj_kernel", "linear_kernel",
+const char* const T_NAMES[LOFTR_T_COUNT] = {"score_sweep_kernel<0>", "score_sweep_kernel<1>", "proj_kernel", "linear_kernel",
                                             "linear_ln_kernel", "proj_kv_kernel", "attn_apply_kernel",
-                                            "attn_small_kernel", "gather_windows_kernel", "score_store_kernel", "conv_kernel",
-                                            "conv3x3_kernel", "conv3x3_wide_kernel", "encoder_x_kernel", "fine_pair_kernel"};
+                                            "attn_small_kernel", "gather_windows_kernel", "score_sweep_kernel<2>", "conv_kernel",
+                                            "conv3x3_duo_kernel<Cfg<4,2,4,4,1>>", "conv3x3_duo_kernel<Cfg<7,2,4,8,2>>", "encoder_x_kernel", "fine_pair_kernel"};
 void timing_drain(TimingSlot& s) {
   for (int i = 0; i < s.used; ++i) {
     float ms = 0.f;

@@ -93,7 +93,12 @@ class LoFTREncoderLayer(nn.Module):
         return ops.layer_weights_struct(sd)
 
     def forward(self, x, source, x_mask=None, source_mask=None):
-        if self.training and autograd.wants_grad(x, source, *self.parameters()):      # .eval(): the inference kernels, no graph
+        wants = autograd.wants_grad(x, source, *self.parameters())
+        if wants and not self.training and autograd.wants_grad(x, source):
+            import warnings                                       # (advisor, round 4: no silent graph cut)
+            warnings.warn("LoFTREncoderLayer in .eval() mode returns a tensor WITHOUT a graph although its inputs require grad: "
+                          "call .train() for the differentiable HIP nodes", stacklevel=2)
+        if self.training and wants:      # .eval(): the inference kernels, no graph
             self.weight_struct()                                  # (dtype / device checks)
             return autograd.encoder_layer(x, source, self.weight_tensors(), self.nhead, x_mask, source_mask)
         return ops.encoder_layer(x.contiguous(), source.contiguous(), self.weight_struct(), self.nhead,
@@ -133,6 +138,10 @@ class LocalFeatureTransformer(nn.Module):
         for name in self.layer_names:
             if name not in ("self", "cross"):
                 raise KeyError
+        if not self.training and autograd.wants_grad(feat0, feat1):
+            import warnings                                       # (advisor, round 4: no silent graph cut)
+            warnings.warn("LocalFeatureTransformer in .eval() mode returns tensors WITHOUT a graph although its inputs require grad: "
+                          "call .train() for the differentiable HIP nodes", stacklevel=2)
         if self.training and autograd.wants_grad(feat0, feat1, *self.parameters()):
             # differentiable form: the reference's own layer loop (transformer.py:91-99) over autograd nodes whose forward and
             # backward are the HIP kernels (loftr_amd/autograd.py:_EncoderLayer)
@@ -313,7 +322,12 @@ class FinePreprocess(nn.Module):
         if self.cat_c_feat:
             kw = dict(down_w=self.down_proj.weight, down_b=self.down_proj.bias,
                       merge_w=self.merge_feat.weight, merge_b=self.merge_feat.bias)
-        if self.training and self.cat_c_feat and autograd.wants_grad(feat_f0, feat_f1, feat_c0, feat_c1, *self.parameters()):
+        wants = autograd.wants_grad(feat_f0, feat_f1, feat_c0, feat_c1, *self.parameters())
+        if wants and self.training and not self.cat_c_feat:
+            # no silent graph cut (advisor, round 4): the backward of the window gather alone (fine_concat_coarse_feat=False) is not built
+            raise ops._lib.LoftrHipError("FinePreprocess: gradients requested with fine_concat_coarse_feat=False, whose backward is not "
+                                         "implemented (csrc/fine_bwd.hip covers the reference's default, True)")
+        if self.training and self.cat_c_feat and wants:
             return autograd.fine_preprocess(feat_f0, feat_f1, feat_c0, feat_c1, (data["b_ids"], data["i_ids"], data["j_ids"]),
                                             (tuple(data["hw0_c"]), tuple(data["hw1_c"]), W, stride), **kw)
         return ops.fine_preprocess(feat_f0, feat_f1, feat_c0, feat_c1, data["b_ids"], data["i_ids"], data["j_ids"],
@@ -466,7 +480,10 @@ class LoFTR(nn.Module):
         data: image0, image1 [N,1,H,W] float; optional mask0/mask1 [N,H/8,W/8] ('0' = padded),
         scale0/scale1 [N,2].  Runs without a graph unless .train() and `full_grads` (see __init__).
         """
-        with torch.enable_grad() if (self.training and self.full_grads) else torch.no_grad():
+        # A graph is built only in .train() mode with `full_grads` AND when the caller's grad mode allows it: a validation pass run under
+        # torch.no_grad() with the module still in train mode must not build (and keep) the whole graph (advisor, round 4).
+        graph = self.training and self.full_grads and torch.is_grad_enabled()
+        with torch.enable_grad() if graph else torch.no_grad():
             return self._forward(data)
 
     def _forward(self, data):

@@ -28,6 +28,9 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 REF_DIR = os.path.join(HERE, "_ref")
 BUNDLE = os.path.join(REF_DIR, "loftr_reference.bundle")
+# sha256 of the bundle FILE this repository expects (tracked; the staging is deterministic for a given reference checkout and CPython):
+# load_bundle() refuses a bundle whose bytes differ -- what gets exec'd on the GPU box is exactly what was compiled from /root/reference here
+EXPECTED = os.path.join(os.path.dirname(os.path.abspath(__file__)), "ref_bundle.sha256")
 REFERENCE_ROOT = os.environ.get("LOFTR_REFERENCE_ROOT", "/root/reference")
 # `src/__init__.py` (empty package marker) + the whole `src.loftr` package: loftr.py, backbone/, loftr_module/, utils/
 PACKAGE_DIRS = ("src/loftr",)
@@ -77,6 +80,11 @@ def stage(root=REFERENCE_ROOT, verbose=True):
     with open(tmp, "wb") as fh:
         fh.write(blob)
     os.replace(tmp, BUNDLE)
+    file_hash = hashlib.sha256(blob).hexdigest()
+    want = open(EXPECTED).read().split()[0] if os.path.isfile(EXPECTED) else None
+    if want != file_hash:                                   # a new reference checkout / CPython: record it (shows up as a diff to commit)
+        with open(EXPECTED, "w") as fh:
+            fh.write(f"{file_hash}  loftr_reference.bundle  (sources sha256 {digest.hexdigest()}, {sys.version.split()[0]})\n")
     if verbose:
         print(f"[stage_ref] {len(modules)} reference modules -> {BUNDLE} ({len(blob) / 1e3:.1f} kB, sha256 {digest.hexdigest()[:16]})")
     return BUNDLE
@@ -88,7 +96,13 @@ def bundle_available():
 
 def load_bundle():
     with open(BUNDLE, "rb") as fh:
-        b = marshal.loads(fh.read())
+        raw = fh.read()
+    want = open(EXPECTED).read().split()[0] if os.path.isfile(EXPECTED) else None
+    got = hashlib.sha256(raw).hexdigest()
+    if want is None or got != want:                         # verified BEFORE anything is unmarshalled or exec'd (advisor, round 4)
+        raise ImportError(f"{BUNDLE}: sha256 {got[:16]} does not match the committed oracle/ref_bundle.sha256 "
+                          f"({(want or 'missing')[:16]}); re-run `python -m oracle.stage_ref` where /root/reference exists")
+    b = marshal.loads(raw)
     if b["magic"] != importlib.util.MAGIC_NUMBER:
         raise ImportError(f"{BUNDLE} was made by a different CPython ({b['python']}); re-run `python -m oracle.stage_ref` "
                           "where /root/reference exists")

@@ -55,7 +55,9 @@ KEEP = ("b_ids", "i_ids", "j_ids", "mkpts0_c", "mkpts1_c", "mconf", "expec_f", "
 
 def e2e_cfg(thr, rc=None):
     cfg = get_cfg(thr=thr)
-    cfg["coarse"]["temp_bug_fix"] = True
+    cfg["coarse"]["temp_bug_fix"] = bool((rc or {}).get("temp_bug_fix", True))     # outdoor_ds.ckpt: False (configs/loftr/outdoor/buggy_pos_enc/loftr_ds.py:3-4)
+    if rc and "border_rm" in rc:
+        cfg["match_coarse"]["border_rm"] = int(rc["border_rm"])
     if rc and rc.get("match_type") == "sinkhorn":        # configs/loftr/indoor/loftr_ot.py + default.py:29-36 (BASELINE configs[4])
         cfg["match_coarse"].update(match_type="sinkhorn", skh_prefilter=False, sparse_spvs=True)
     if rc and rc.get("resolution"):                      # ResNetFPN_16_4: coarse map at 1/16, fine at 1/4 (resnet_fpn.py:121-199)
@@ -81,7 +83,15 @@ CASES = {"e2e_scannet": dict(images="scannet", bn_strength=0.3),
          # round 3, "trained-like" statistics from IMAGES: the coarse head of the backbone (layer3_outconv) is scaled so that the
          # residual stream of the random-weight transformer dominates its updates; image1 is image0 shifted by whole coarse cells, so
          # corresponding cells keep near-identical descriptors: conf close to 1 and hundreds of matches at the STOCK threshold 0.2
-         "e2e_peaked": dict(images="synth", bn_strength=0.3, crop0=(384, 512), crop1=(384, 512), coarse_gain=6.0)}
+         "e2e_peaked": dict(images="synth", bn_strength=0.3, crop0=(384, 512), crop1=(384, 512), coarse_gain=6.0),
+         # round 5 (round-4 verdict, missing #2).  A BATCH from images: pairs 0..2 of the bench's batch in one forward -- catches
+         # batch-position mistakes in the backbone and the image-level plumbing that the feature-level invariance tests cannot see.
+         "e2e_batch": dict(images="synth", bn_strength=0.3, n=3),
+         # BASELINE configs[3] from images, exactly bench.py:other_configs' workload: 2 pairs of 840 x 840, valid region 560 rows x 840
+         # columns zero-padded at the bottom, mask0 / mask1 [2, 105, 105], scale 1.9, temp_bug_fix=False (outdoor_ds.ckpt), border_rm 2
+         # (configs/loftr/outdoor/loftr_ds.py:1-5, coarse_matching.py:28-43,115-118, fine_matching.py:68); L = S = 11 025
+         "e2e_outdoor_840": dict(images="synth", bn_strength=0.3, n=2, size=(840, 840), valid0=(560, 840), valid1=(560, 840),
+                                 scale0=(1.9, 1.9), scale1=(1.9, 1.9), temp_bug_fix=False, border_rm=2)}
 
 
 def e2e_state_dict(module_with_backbone, cfg, bn_strength, coarse_gain=1.0, fine_gain=1.0):
@@ -104,9 +114,19 @@ def load_images(name):
               for p in SCANNET]
         imgs = [(a.astype(np.float32) / np.float32(255.0))[None, None] for a in u8]
         return imgs[0], imgs[1], dict(image0_u8=u8[0], image1_u8=u8[1])
-    i0, i1 = make_images(1234, 8, H_IMG, W_IMG)          # the bench's rank-0 batch; pair 0
-    i0, i1 = _crop(i0[:1], CASES[name].get("crop0")), _crop(i1[:1], CASES[name].get("crop1"))
+    i0, i1 = synth_images(CASES[name])
     return i0, i1, dict(image_checksums=np.array([checksum(i0), checksum(i1)]))
+
+
+def synth_images(rc):
+    """The first rc['n'] (default 1) pairs of the bench's rank-0 batch (480 x 640), cropped; or of make_images(1234, n, *rc['size'])
+    (the bench's outdoor workload)."""
+    n = int(rc.get("n", 1))
+    if rc.get("size"):                                   # (the recipes' "hw" is the constant 480 x 640 of the older cases)
+        i0, i1 = make_images(1234, n, int(rc["size"][0]), int(rc["size"][1]))
+    else:
+        i0, i1 = make_images(1234, 8, H_IMG, W_IMG)
+    return _crop(i0[:n], rc.get("crop0")), _crop(i1[:n], rc.get("crop1"))
 
 
 def _crop(img, hw):
@@ -123,10 +143,10 @@ def extras(rc, img0, img1):
         vh, vw = rc["valid" + tag]
         img[:, :, vh:, :] = 0
         img[:, :, :, vw:] = 0
-        m = np.zeros((1, img.shape[2] // 8, img.shape[3] // 8), bool)
+        m = np.zeros((img.shape[0], img.shape[2] // 8, img.shape[3] // 8), bool)
         m[:, :vh // 8, :vw // 8] = True
         out["mask" + tag] = m
-        out["scale" + tag] = np.asarray([rc["scale" + tag]], np.float32)
+        out["scale" + tag] = np.asarray([rc["scale" + tag]] * img.shape[0], np.float32)
     return out
 
 
@@ -134,9 +154,8 @@ def images_from_golden(g):
     """Inverse of the storage above (used by the tests on boxes without the reference / the JPEGs)."""
     if "image0_u8" in g:
         return tuple((np.asarray(g[k]).astype(np.float32) / np.float32(255.0))[None, None] for k in ("image0_u8", "image1_u8"))
-    i0, i1 = make_images(1234, 8, H_IMG, W_IMG)
     rc = json.loads(str(g["recipe"]))
-    i0, i1 = _crop(i0[:1], rc.get("crop0")), _crop(i1[:1], rc.get("crop1"))
+    i0, i1 = synth_images(rc)
     want = np.asarray(g["image_checksums"])
     assert np.allclose([checksum(i0), checksum(i1)], want, rtol=1e-12), "synthetic images drifted"
     return i0, i1
@@ -185,16 +204,15 @@ def make(name):
     out64 = run_reference(img0, img1, 0.0, CASES[name]["bn_strength"], dtype=torch.float64, extra=ex, rc=CASES[name])
     for k in KEEP:
         store[f"ref64/{k}"] = out64[k]
-    k32 = list(zip(store["thr0/i_ids"].tolist(), store["thr0/j_ids"].tolist()))
-    k64 = {k: n for n, k in enumerate(zip(out64["i_ids"].tolist(), out64["j_ids"].tolist()))}
+    k32 = list(zip(store["thr0/b_ids"].tolist(), store["thr0/i_ids"].tolist(), store["thr0/j_ids"].tolist()))
+    k64 = {k: n for n, k in enumerate(zip(out64["b_ids"].tolist(), out64["i_ids"].tolist(), out64["j_ids"].tolist()))}
     com = [(n, k64[k]) for n, k in enumerate(k32) if k in k64]
     ia, ib = [c[0] for c in com], [c[1] for c in com]
     print(f"{name} ref fp32 vs ref fp64: common {len(com)}/{len(k32)}/{len(k64)} "
           f"d_mconf={np.abs(store['thr0/mconf'][ia] - out64['mconf'][ib]).max():.2e} "
           f"d_mkpts1_f={np.abs(store['thr0/mkpts1_f'][ia] - out64['mkpts1_f'][ib]).max():.2e}px")
-    store["recipe"] = np.array(json.dumps(dict(name=name, hw=[H_IMG, W_IMG], backbone_seed=BACKBONE_SEED, **CASES[name],
-                                               matcher_seed=MATCHER_SEED, temp_bug_fix=True, thr=[0.0, 0.2],
-                                               ref_cpu_count=os.cpu_count())))
+    store["recipe"] = np.array(json.dumps({**dict(name=name, hw=[H_IMG, W_IMG], backbone_seed=BACKBONE_SEED, matcher_seed=MATCHER_SEED,
+                                                  temp_bug_fix=True, thr=[0.0, 0.2], ref_cpu_count=os.cpu_count()), **CASES[name]}))
     path = os.path.join(HERE, f"{name}.npz")
     np.savez_compressed(path, **store)
     print(f"-> {path} {os.path.getsize(path) / 1e3:.1f} kB")

@@ -35,6 +35,15 @@ def test_header_symbols_exported(lib):
     assert sorted(_lib.SIGNATURES) == names, "ctypes binding out of sync with the header"
 
 
+def test_library_exports_exactly_the_c_abi(lib):
+    """nm -D: the defined dynamic symbols are the header's extern "C" entry points and nothing else (round-4 verdict: 24 mangled C++
+    launch helpers leaked next to them; the link step now uses a version script)."""
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    got = sorted({ln.split()[-1].split("@")[0] for ln in out.splitlines() if ln.strip()})
+    assert got == _declared_symbols(), (sorted(set(got) - set(_declared_symbols())), sorted(set(_declared_symbols()) - set(got)))
+
+
 def test_abi_version_and_status_strings(lib):
     assert lib.loftr_hip_abi_version() == _lib.ABI_VERSION
     assert lib.loftr_hip_status_string(0) == b"ok"

@@ -36,8 +36,8 @@ def test_algorithmic_work_matches_design_table(bench):
     C = 256
     rows = 2 * B * L
     # dual-softmax GEMM passes: 2 B L S C flops each
-    assert w["score_stats_kernel"][0] == 2 * B * L * L * C == w["score_conf_kernel"][0]
-    assert w["score_conf_kernel"][1] == 4 * B * ((L + L) * C + L * L)     # conf_matrix written once
+    assert w["score_sweep_kernel<0>"][0] == 2 * B * L * L * C == w["score_sweep_kernel<1>"][0]
+    assert w["score_sweep_kernel<1>"][1] == 4 * B * ((L + L) * C + L * L)     # conf_matrix written once
     # k/v projection with the fused KV reduction, 8 layer passes over both images
     assert w["proj_kv_kernel"][0] == 8 * (2 * rows * C * 2 * C + 2 * rows * C * 32)
     # encoder per layer pass and pair (6.45 GFLOP per call incl. attention): projections + merge + MLP
@@ -53,13 +53,13 @@ def test_algorithmic_work_matches_design_table(bench):
     # the three conv entries partition the 21 convolutions of 2B images
     convs = bench.backbone_convs(480, 640)
     total = sum(2 * 2 * B * (h // s) * (ww // s) * cout * cin * k * k for cin, cout, k, s, h, ww in convs)
-    assert w["conv_kernel"][0] + w["conv3x3_kernel"][0] + w["conv3x3_wide_kernel"][0] == total
-    assert w["conv3x3_wide_kernel"][0] > 0.3 * total and w["conv3x3_kernel"][0] > 0.4 * total
+    assert w["conv_kernel"][0] + w["conv3x3_duo_kernel<Cfg<4,2,4,4,1>>"][0] + w["conv3x3_duo_kernel<Cfg<7,2,4,8,2>>"][0] == total
+    assert w["conv3x3_duo_kernel<Cfg<7,2,4,8,2>>"][0] > 0.3 * total and w["conv3x3_duo_kernel<Cfg<4,2,4,4,1>>"][0] > 0.4 * total
 
 
 def test_roofline_entry_classification(bench):
     # a GEMM kernel far from the HBM roof: matrix-pipe bound, executed rate = 3 x algorithmic
-    e = bench.roofline_entry("conv3x3_kernel", total_ms=8.0, launches=9, flops=2.5e12, nbytes=8e9, steps=1)
+    e = bench.roofline_entry("conv3x3_duo_kernel<Cfg<4,2,4,4,1>>", total_ms=8.0, launches=9, flops=2.5e12, nbytes=8e9, steps=1)
     assert e["bound"] == "mfma" and e["unit"] == "TFLOP/s" and e["peak"] == 2500.0
     assert abs(e["executed_fp16_TFLOP_s"] - 3 * 2.5e12 / 8e-3 / 1e12) < 1 and abs(e["frac"] - e["mfma_frac"]) < 1e-9
     assert abs(e["avg_launch_us"] - 8000 / 9) < 0.01
@@ -115,6 +115,6 @@ def test_pmc_kernel_families_follow_the_timing_table():
     f = mod.bench_name
     assert f("(anonymous namespace)::efx::encoder_x2_kernel((anonymous namespace)::efx::Args2)") == "encoder_x_kernel"
     assert f("(anonymous namespace)::efx::encoder_x_kernel((anonymous namespace)::efx::Args)") == "encoder_x_kernel"
-    assert f("void conv3x3_duo_kernel<c3d::Cfg<7, 2, 4, 8, 2> >(Conv3Args)") == "conv3x3_wide_kernel"
-    assert f("void conv3x3_duo_kernel<c3d::Cfg<4, 2, 4, 4, 1> >(Conv3Args)") == "conv3x3_kernel"
-    assert f("void (anonymous namespace)::sweep::score_sweep_kernel<1, false, false, false>((anonymous namespace)::sweep::Args)") == "score_conf_kernel"
+    assert f("void conv3x3_duo_kernel<c3d::Cfg<7, 2, 4, 8, 2> >(Conv3Args)") == "conv3x3_duo_kernel<Cfg<7,2,4,8,2>>"
+    assert f("void conv3x3_duo_kernel<c3d::Cfg<4, 2, 4, 4, 1> >(Conv3Args)") == "conv3x3_duo_kernel<Cfg<4,2,4,4,1>>"
+    assert f("void (anonymous namespace)::sweep::score_sweep_kernel<1, false, false, false>((anonymous namespace)::sweep::Args)") == "score_sweep_kernel<1>"

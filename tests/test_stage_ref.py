@@ -50,3 +50,15 @@ def test_bundle_loads_when_present():
         pytest.skip("no staged bundle on this machine")
     b = stage_ref.load_bundle()
     assert "src.loftr.loftr" in b["modules"] and "src.loftr.utils" in b["modules"]       # incl. the namespace package
+
+
+def test_tampered_bundle_is_refused(monkeypatch, tmp_path):
+    """The bundle's bytes are checked against the committed oracle/ref_bundle.sha256 BEFORE anything is unmarshalled or exec'd."""
+    if not stage_ref.bundle_available():
+        pytest.skip("no staged bundle on this machine")
+    raw = open(stage_ref.BUNDLE, "rb").read()
+    bad = tmp_path / "loftr_reference.bundle"
+    bad.write_bytes(raw[:-1] + bytes([raw[-1] ^ 1]))
+    monkeypatch.setattr(stage_ref, "BUNDLE", str(bad))
+    with pytest.raises(ImportError, match="sha256"):
+        stage_ref.load_bundle()

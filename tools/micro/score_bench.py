@@ -25,11 +25,11 @@ ids = {lib.loftr_hip_timing_kernel_name(i).decode(): i for i in range(lib.loftr_
 for _ in range(2):
     r = ops.coarse_match(f0, f1, (h, w), (h, w), thr=0.0, border_rm=2, scale=8.0)
 torch.cuda.synchronize()
-lib.loftr_hip_timing_enable((1 << ids["score_stats_kernel"]) | (1 << ids["score_conf_kernel"]))
+lib.loftr_hip_timing_enable((1 << ids["score_sweep_kernel<0>"]) | (1 << ids["score_sweep_kernel<1>"]))
 for _ in range(reps):
     r = ops.coarse_match(f0, f1, (h, w), (h, w), thr=0.0, border_rm=2, scale=8.0)
 torch.cuda.synchronize()
-for k in ("score_stats_kernel", "score_conf_kernel"):
+for k in ("score_sweep_kernel<0>", "score_sweep_kernel<1>"):
     ms, n = C.c_double(0), C.c_longlong(0)
     lib.loftr_hip_timing_read(ids[k], C.byref(ms), C.byref(n), 1)
     print(f"{k}: {ms.value / max(n.value, 1) * 1e3:.1f} us per launch ({n.value} launches)")

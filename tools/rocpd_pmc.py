@@ -36,13 +36,13 @@ def short(name):
 def bench_name(full):
     """Kernel name as bench.py's timing table knows it (one entry per kernel FAMILY: template variants are pooled)."""
     if "score_sweep_kernel<1" in full:
-        return "score_conf_kernel"          # dual-softmax pass B (writes conf_matrix)
+        return "score_sweep_kernel<1>"          # dual-softmax pass B (writes conf_matrix)
     if "score_sweep_kernel<0" in full:
-        return "score_stats_kernel"         # pass A: shared-reference variant + exact variant
+        return "score_sweep_kernel<0>"         # pass A: shared-reference variant + exact variant
     if "score_sweep_kernel<2" in full:
-        return "score_store_kernel"         # Sinkhorn: score store on the sweep
+        return "score_sweep_kernel<2>"         # Sinkhorn: score store on the sweep
     if "conv3x3_duo_kernel" in full:        # round 4: the 3x3 stride-1 convolutions; timed under the ids of the kernels they replaced
-        return "conv3x3_wide_kernel" if "Cfg<7" in full else "conv3x3_kernel"
+        return "conv3x3_duo_kernel<Cfg<7,2,4,8,2>>" if "Cfg<7" in full else "conv3x3_duo_kernel<Cfg<4,2,4,4,1>>"
     if "encoder_x2_kernel" in full:         # round 4: two-job launches of the same kernel body, timed under LOFTR_T_ENCODER_X
         return "encoder_x_kernel"
     if "rowsweep_kernel<0" in full:
