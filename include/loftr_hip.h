@@ -323,7 +323,8 @@ int loftr_fine_loss_sums(const float* expec_f, int ld, const float* expec_f_gt, 
  * src/losses/loftr_loss.py:165-192) and the INPUTS OF THE TWO HEADS: feat_c0 / feat_c1 entering CoarseMatching
  * (src/loftr/utils/coarse_matching.py:105-119, dual-softmax) and feat_f0 / feat_f1 entering FineMatching
  * (src/loftr/utils/fine_matching.py:43-57).  One kernel per node; each recomputes the forward quantities it needs from the
- * node's inputs.  The chain stops there: the transformers, FinePreprocess and the backbone have no backward.
+ * node's inputs.  Upstream of the heads the chain continues with loftr_encoder_layer_bwd, loftr_fine_preprocess_bwd and
+ * loftr_conv_wgrad (+ the forward convolutions on the transposed filter for the input gradient) declared further down.
  *
  * loftr_coarse_loss_grad: grad_conf = d(pos_scale * sum_pos + neg_scale * sum_neg) / d conf for the sums of
  *   loftr_coarse_loss_sums with the same kind, ids and masks ([N,L,S]; kind 1: [N,L+1,S+1] = conf_matrix_with_bin, workspace
@@ -334,7 +335,7 @@ int loftr_fine_loss_sums(const float* expec_f, int ld, const float* expec_f_gt, 
  *   (loftr_fine_loss_sums) filled; the std column gets 0 (weight.detach(), :131); training = the module's .training (:113-117).
  * loftr_dual_softmax_bwd: dsim [N,L,S] = dL/d sim_matrix from grad_conf = dL/d conf_matrix (:110-119; 0 on the mask-filled
  *   entries).  sim = <feat_c0, feat_c1> / (C * temperature), so dL/dfeat_c0 = dsim . feat_c1 / (C T) and dL/dfeat_c1 =
- *   dsim^T . feat_c0 / (C T): two plain batched GEMMs left to the caller (rocBLAS via torch.bmm in loftr_amd/autograd.py).
+ *   dsim^T . feat_c0 / (C T): loftr_head_feat_grads below (split-fp16 MFMA, csrc/head_grads.hip).
  *   Workspace: loftr_coarse_match_workspace_bytes(N, L, S, C).
  * loftr_fine_match_bwd: grad_f0 / grad_f1 [M,WW,C] from grad_expec [M,3] = dL/d expec_f (x, y, std) (:43-57; grad_f0 is
  *   non-zero at the centre row only, :43).

@@ -20,7 +20,7 @@ __global__ __launch_bounds__(256, MINWG) void probe(unsigned* bad, float* sink, 
   for (int i = 0; i < 8; ++i) { a[i] = (_Float16)(1.0f + 0.001f * threadIdx.x + i); b[i] = (_Float16)(0.5f - 0.002f * threadIdx.x + i); }
   f16v acc;
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  unsigned nbad = 0;
+  unsigned nbad = 0, selmask = 0;
   const int lane = threadIdx.x & 63;
   for (int it = 0; it < rounds; ++it) {
     // skew the phases of the waves of a SIMD against each other: waves of odd workgroups start with the conversion phase
@@ -52,6 +52,14 @@ __global__ __launch_bounds__(256, MINWG) void probe(unsigned* bad, float* sink, 
             const f2 one = {1.f, 1.f};
             asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0]" : "=v"(r) : "v"(x), "v"(s), "v"(one));
             e0 = fmaf(x0, s1, 1.f); e1 = fmaf(x1, s1, 1.f);
+          } else if (form == 9 || form == 10) {   // v_pk_mov_b32 (kv_finalize_kernel carries op_sel:[1,0]): its result must be one of the four
+            if (form == 9) asm volatile("v_pk_mov_b32 %0, %1, %2 op_sel:[1,0]" : "=v"(r) : "v"(x), "v"(s));      // (x0|x1, s0|s1) selections --
+            else asm volatile("v_pk_mov_b32 %0, %1, %2 op_sel:[0,1]" : "=v"(r) : "v"(x), "v"(s));               // whichever the ISA defines, ALWAYS the same one
+            const int sel = (r[0] == x1 ? 1 : 0) | (r[1] == s1 ? 2 : 0);
+            const bool valid = (r[0] == x0 || r[0] == x1) && (r[1] == s0 || r[1] == s1);
+            e0 = r[0]; e1 = r[1];
+            if (!valid) nbad += 1;
+            selmask |= 1u << sel;
           } else if (form == 8) {      // add, src1 low <- high: r = (x0 + s1, x1 + s1)
             asm volatile("v_pk_add_f32 %0, %1, %2 op_sel:[0,1]" : "=v"(r) : "v"(x), "v"(s));
             e0 = x0 + s1; e1 = x1 + s1;
@@ -72,25 +80,27 @@ __global__ __launch_bounds__(256, MINWG) void probe(unsigned* bad, float* sink, 
   for (int r = 0; r < 16; ++r) t += acc[r];
   if (t == 1234.5f) sink[threadIdx.x] = t + lds[(threadIdx.x * 7) & 255];
   if (nbad) atomicAdd(bad, nbad);
+  if (selmask) atomicOr(bad + 1, selmask);          // pk_mov forms: which (lo, hi) selections were observed; more than one bit = inconsistent
 }
 
 template <int MINWG, int LDS_BYTES> void run(const char* tag, unsigned* d_bad, float* d_sink, int mfmas) {
-  for (int form = 0; form < 9; ++form) {
-    unsigned total = 0;
+  for (int form = 0; form < 11; ++form) {
+    unsigned total = 0, selseen = 0;
     for (int rep = 0; rep < 5; ++rep) {
-      hipMemset(d_bad, 0, 4);
+      hipMemset(d_bad, 0, 8);
       hipLaunchKernelGGL((probe<MINWG, LDS_BYTES>), dim3(1024), dim3(256), 0, 0, d_bad, d_sink, 200, form, mfmas);
-      unsigned h; hipMemcpy(&h, d_bad, 4, hipMemcpyDeviceToHost);
-      total += h;
+      unsigned h[2]; hipMemcpy(h, d_bad, 8, hipMemcpyDeviceToHost);
+      total += h[0]; selseen |= h[1];
     }
-    printf("%s, %2d MFMAs per round, form %d (%s): wrong packed products in 5 launches of 1024 workgroups: %u\n", tag, mfmas, form,
+    printf("%s, %2d MFMAs per round, form %d (%s): wrong packed products in 5 launches of 1024 workgroups: %u%s\n", tag, mfmas, form,
            form == 0 ? "mul op_sel:[0,1]" : form == 1 ? "mul op_sel_hi control" : form == 2 ? "v_mov-fed mul op_sel:[0,1]" : form == 3 ? "fma op_sel:[1,0,0]" :
-           form == 4 ? "add op_sel:[1,0]" : form == 5 ? "fma op_sel:[0,1,0]" : form == 8 ? "add op_sel:[0,1]" : form == 6 ? "fma op_sel:[0,0,1]" : "mul op_sel:[0,1] op_sel_hi:[1,0]", total);
+           form == 4 ? "add op_sel:[1,0]" : form == 5 ? "fma op_sel:[0,1,0]" : form == 8 ? "add op_sel:[0,1]" : form == 9 ? "pk_mov op_sel:[1,0] (invalid results; see selections)" : form == 10 ? "pk_mov op_sel:[0,1] (invalid results; see selections)" : form == 6 ? "fma op_sel:[0,0,1]" : "mul op_sel:[0,1] op_sel_hi:[1,0]", total,
+           form >= 9 ? (selseen == 1 || selseen == 2 || selseen == 4 || selseen == 8 ? "  [one selection observed: consistent]" : "  [SEVERAL selections observed: inconsistent]") : "");
   }
 }
 int main() {
   unsigned* d_bad; float* d_sink;
-  hipMalloc(&d_bad, 4); hipMalloc(&d_sink, 4096);
+  hipMalloc(&d_bad, 8); hipMalloc(&d_sink, 4096);
   run<2, 49152>("two workgroups per CU", d_bad, d_sink, 48);
   run<1, 98304>("one workgroup per CU ", d_bad, d_sink, 48);
   run<2, 49152>("two workgroups per CU", d_bad, d_sink, 0);
