@@ -498,7 +498,8 @@ def other_configs(lib, ids, dev, sd, backbone, steps=5, warmup=2):
              "scale0": torch.full((N, 2), 1.9).to(dev), "scale1": torch.full((N, 2), 1.9).to(dev)}
     run("outdoor_840_masked", cfg, lambda: dict(fixed), N, 105 * 105,
         {"workload": "BASELINE configs[3]: 2 pairs 840x840 (valid 840x560, zero-padded), mask0/1 [2,105,105], scale 1.9, dual-softmax, thr 0.0",
-         "parity": "this exact batch is pinned against the reference's forward from images: tests/golden/e2e_outdoor_840.npz (tests/test_e2e_golden.py)"})
+         "parity": "the same images, masks, scales and configuration are pinned against the reference's forward from images (with the goldens' seeded backbone weights, "
+                   "not this run's): tests/golden/e2e_outdoor_840.npz, tests/test_e2e_golden.py"})
     del fixed
     # ---- configs[4]: indoor_ot
     B = 8
