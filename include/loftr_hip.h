@@ -43,8 +43,9 @@ typedef enum {
  * 17: loftr_head_feat_grads (the feature-gradient GEMMs of both coarse heads);
  * 18: loftr_encoder_layer_bwd;
  * 19: loftr_fine_preprocess_bwd;
- * 20: loftr_conv_wgrad (backbone training: weight gradient of a convolution) */
-#define LOFTR_HIP_ABI_VERSION 20
+ * 20: loftr_conv_wgrad (backbone training: weight gradient of a convolution);
+ * 21: training-mode glue of the backbone (loftr_bn_train_fwd / _bwd, loftr_act_fwd / _bwd, loftr_upsample2x_bilinear_fwd / _bwd) */
+#define LOFTR_HIP_ABI_VERSION 21
 
 int loftr_hip_abi_version(void);
 const char* loftr_hip_status_string(int status);
@@ -392,6 +393,33 @@ int loftr_five_point(const double* q0, const double* q1, int n, double* E_out, i
  *   src [N, *, *] uint8 with byte pitches per image / per row; hw [N,2] int32 device: valid (h, w) <= (PH, PW);
  *   image [N,1,PH,PW] f32; mask [N,PH,PW] u8 or NULL; mask_c [N,PH/coarse_div,PW/coarse_div] u8 or NULL.
  * Decoding and cv2.resize stay with the caller (OpenCV; not reproducible without the library). */
+/* ---- training-mode glue of the backbone (round 5; csrc/train_glue.hip) -------------------------------------------------------------
+ * What sits between the convolutions of a TRAINING step of the ResNet-FPN (src/loftr/backbone/resnet_fpn.py:22-40,66-77,110-116) and was
+ * PyTorch autograd until ABI 20.  fp32 tensors of logical shape [N, C, H, W] stored NCHW (channels_last = 0) or NHWC (channels_last = 1:
+ * what the convolution nodes of the training path produce and consume -- no layout copy between a convolution and its BatchNorm; C % 4 == 0,
+ * C <= 1024); HW = H * W; every reduction is a two-stage sum with float64 partials merged in a fixed order (deterministic).  Not used by the inference path (eval-mode BatchNorm is folded into the convolutions there).
+ *
+ * loftr_bn_train_fwd: nn.BatchNorm2d in .train() mode: mean / biased variance over (N, H, W) per channel, y = (x - mean) * invstd * gamma
+ *   + beta (gamma / beta may be null: affine=False); mean [C], invstd [C] = 1 / sqrt(var + eps) are returned for the backward,
+ *   var_unbiased [C] (may be null) is what the caller's running_var update takes (torch: momentum update with the UNBIASED variance).
+ *   The reference trains with SyncBatchNorm (train.py:108): the same arithmetic over the union of the ranks' batches; one process here.
+ * loftr_bn_train_bwd: dx, dgamma = sum dy * xhat, dbeta = sum dy (batch statistics: mean and variance depend on x).
+ *   Workspace of both: loftr_bn_train_workspace_bytes(N, C, HW).
+ * loftr_act_fwd: y = act(a + b) (b may be null; y may alias a): act 0 none, 1 ReLU, 2 LeakyReLU(slope) -- BasicBlock's relu(x + y)
+ *   (resnet_fpn.py:40) and the heads' LeakyReLU (:70,:76).  loftr_act_bwd: dx = dy * act'(.) from the forward's OUTPUT y (the sign of the
+ *   output is the sign of the input for a positive slope; dx is the gradient of a AND of b).
+ * loftr_upsample2x_bilinear_fwd / _bwd: F.interpolate(x, scale_factor=2., mode='bilinear', align_corners=True) on N * C maps
+ *   of H x W -> 2H x 2W (resnet_fpn.py:110,115) and its adjoint, evaluated as a gather (no atomics: deterministic, unlike torch's). */
+size_t loftr_bn_train_workspace_bytes(int N, int C, long HW);
+int loftr_bn_train_fwd(const float* x, int N, int C, long HW, int channels_last, const float* gamma, const float* beta, float eps, float* y,
+                       float* mean, float* invstd, float* var_unbiased, void* ws, size_t ws_bytes, void* stream);
+int loftr_bn_train_bwd(const float* dy, const float* x, int N, int C, long HW, int channels_last, const float* mean, const float* invstd,
+                       const float* gamma, float* dx, float* dgamma, float* dbeta, void* ws, size_t ws_bytes, void* stream);
+int loftr_act_fwd(const float* a, const float* b, long n, int act, float slope, float* y, void* stream);
+int loftr_act_bwd(const float* dy, const float* y, long n, int act, float slope, float* dx, void* stream);
+int loftr_upsample2x_bilinear_fwd(const float* x, int N, int C, int H, int W, int channels_last, float* y, void* stream);
+int loftr_upsample2x_bilinear_bwd(const float* dy, int N, int C, int H, int W, int channels_last, float* dx, void* stream);
+
 /* cv2.resize(image_u8, (dw, dh)) with the default INTER_LINEAR (dataset.py:108,146) on the device, one grayscale image.
  * PARITY UNPINNED: restates OpenCV 4.x's fixed-point bilinear (11-bit coefficients, half-pixel centres); OpenCV is not
  * in this image, so it is verified against the numpy restatement only (oracle/input_oracle.py). */

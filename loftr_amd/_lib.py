@@ -70,6 +70,13 @@ SIGNATURES = {
     "loftr_conv_bn_act": (_i, [_p, _i, _i, _i, _i, _p, C.POINTER(_l), _i, _i, _i, _i, _i, _p, _p, _p, _p, _f, _i, _p, _p, _p, _p, _sz, _p, _p]),
     "loftr_stem_conv_bn_relu": (_i, [_p, C.POINTER(_l), _i, _i, _i, _p, C.POINTER(_l), _i, _p, _p, _p, _p, _f, _p, _p]),
     "loftr_upsample2x_add": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
+    "loftr_bn_train_workspace_bytes": (_sz, [_i, _i, _l]),
+    "loftr_bn_train_fwd": (_i, [_p, _i, _i, _l, _i, _p, _p, _f, _p, _p, _p, _p, _p, _sz, _p]),
+    "loftr_bn_train_bwd": (_i, [_p, _p, _i, _i, _l, _i, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
+    "loftr_act_fwd": (_i, [_p, _p, _l, _i, _f, _p, _p]),
+    "loftr_act_bwd": (_i, [_p, _p, _l, _i, _f, _p, _p]),
+    "loftr_upsample2x_bilinear_fwd": (_i, [_p, _i, _i, _i, _i, _i, _p, _p]),
+    "loftr_upsample2x_bilinear_bwd": (_i, [_p, _i, _i, _i, _i, _i, _p, _p]),
     "loftr_resize_linear_u8": (_i, [_p, _i, _i, _l, _p, _i, _i, _l, _p]),
     "loftr_pack_gray_u8": (_i, [_p, _l, _l, _p, _i, _i, _i, _p, _p, _p, _i, _p]),
     "loftr_epipolar_errors": (_i, [_p, _p, _p, _p, _p, _p, _l, _i, _p, _p]),
@@ -110,7 +117,7 @@ SIGNATURES = {
     "loftr_linear_fwd": (_i, [_p, _p, _p, _i, _i, _i, _p, _sz, _p]),
 }
 
-ABI_VERSION = 20
+ABI_VERSION = 21
 _lib = None
 
 

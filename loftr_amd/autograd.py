@@ -291,3 +291,68 @@ class _Conv2d(torch.autograd.Function):
 def conv2d(x, weight, stride=1, padding=0):
     """Differentiable bias-free convolution on the HIP kernels (see _Conv2d)."""
     return _Conv2d.apply(x, weight, int(stride), int(padding))
+
+
+# ---- training-mode glue of the backbone: BatchNorm with batch statistics, activations (+ residual add), bilinear x2 upsampling ---------
+class _BatchNormTrain(torch.autograd.Function):
+    """nn.BatchNorm2d.forward in .train() mode (resnet_fpn.py:25-26,36,68 ...) on csrc/train_glue.hip; the running statistics are updated by
+    the module (backbone.BatchNorm2d) from the returned batch mean / unbiased variance."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        xc = x.detach()
+        xc = xc if (xc.is_contiguous() or xc.is_contiguous(memory_format=torch.channels_last)) else xc.contiguous()
+        y, mean, invstd, varu = ops.bn_train_fwd(xc, None if gamma is None else gamma.detach(), None if beta is None else beta.detach(), eps)
+        ctx.save_for_backward(xc, mean, invstd, gamma)
+        ctx.mark_non_differentiable(mean, varu)
+        return y, mean, varu
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy, _dm, _dv):
+        x, mean, invstd, gamma = ctx.saved_tensors
+        dx, dgamma, dbeta = ops.bn_train_bwd(dy, x, mean, invstd, None if gamma is None else gamma.detach())
+        return dx, (dgamma if gamma is not None else None), (dbeta if ctx.needs_input_grad[2] else None), None
+
+
+def batch_norm_train(x, gamma, beta, eps):
+    return _BatchNormTrain.apply(x, gamma, beta, eps)
+
+
+class _Act(torch.autograd.Function):
+    """act(a [+ b]): nn.ReLU / nn.LeakyReLU, and BasicBlock's relu(x + y) (resnet_fpn.py:40) in one pass; the backward needs the output only."""
+
+    @staticmethod
+    def forward(ctx, a, b, act, slope):
+        y = ops.act_fwd(a.detach(), None if b is None else b.detach(), act, slope)
+        ctx.save_for_backward(y)
+        ctx.act, ctx.slope, ctx.has_b = act, slope, b is not None
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        dx = ops.act_bwd(dy, y, ctx.act, ctx.slope)
+        return dx, (dx if ctx.has_b else None), None, None
+
+
+def act(a, b=None, kind="relu", slope=0.01):
+    return _Act.apply(a, b, kind, slope)
+
+
+class _Upsample2x(torch.autograd.Function):
+    """F.interpolate(x, scale_factor=2., mode='bilinear', align_corners=True) (resnet_fpn.py:110,115) and its adjoint."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return ops.upsample2x_bilinear(x.detach())
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        return ops.upsample2x_bilinear_bwd(dy)
+
+
+def upsample2x(x):
+    return _Upsample2x.apply(x)

@@ -47,6 +47,44 @@ class Conv2d(nn.Conv2d):
         return super().forward(x)
 
 
+# LOFTR_TRAIN_GLUE=0: BatchNorm (batch statistics), activations, residual adds and the bilinear upsampling of a training step stay PyTorch (A/B)
+TRAIN_GLUE_HIP = os.environ.get("LOFTR_TRAIN_GLUE", "1") != "0"
+GLUE_PARTS = set(os.environ.get("LOFTR_TRAIN_GLUE_PARTS", "bn,act,add,up").split(","))      # (bisecting aid)
+
+
+def _glue(module, x):
+    """The training-mode glue runs on csrc/train_glue.hip: .train() mode, fp32 on the GPU, a graph wanted."""
+    return (TRAIN_GLUE_HIP and module.training and x.is_cuda and x.dtype == torch.float32 and torch.is_grad_enabled()
+            and (x.requires_grad or any(p.requires_grad for p in module.parameters(recurse=False))))
+
+
+class BatchNorm2d(nn.BatchNorm2d):
+    """nn.BatchNorm2d of the backbone.  In .train() mode on the GPU with a graph wanted: batch statistics, normalisation and their backward
+    on the library (autograd.batch_norm_train), running statistics updated here exactly like torch (momentum update, unbiased variance,
+    num_batches_tracked); everywhere else the stock module (inference folds the eval-mode statistics into the convolutions)."""
+
+    def forward(self, x):
+        if not (_glue(self, x) and "bn" in GLUE_PARTS and x.dim() == 4 and self.track_running_stats and self.running_mean is not None):
+            return super().forward(x)
+        y, mean, varu = autograd.batch_norm_train(x, self.weight, self.bias, self.eps)
+        with torch.no_grad():
+            self.num_batches_tracked += 1
+            m = self.momentum if self.momentum is not None else 1.0 / float(self.num_batches_tracked)
+            self.running_mean.mul_(1.0 - m).add_(mean, alpha=m)
+            self.running_var.mul_(1.0 - m).add_(varu, alpha=m)
+        return y
+
+
+class ReLU(nn.ReLU):
+    def forward(self, x):
+        return autograd.act(x, None, "relu") if _glue(self, x) and "act" in GLUE_PARTS else super().forward(x)
+
+
+class LeakyReLU(nn.LeakyReLU):
+    def forward(self, x):
+        return autograd.act(x, None, "leaky_relu", self.negative_slope) if _glue(self, x) and "act" in GLUE_PARTS else super().forward(x)
+
+
 def _c1(cin, cout, stride=1):
     return Conv2d(cin, cout, kernel_size=1, stride=stride, padding=0, bias=False)
 
@@ -60,23 +98,25 @@ class BasicBlock(nn.Module):
         super().__init__()
         self.conv1 = _c3(in_planes, planes, stride)
         self.conv2 = _c3(planes, planes)
-        self.bn1 = nn.BatchNorm2d(planes)
-        self.bn2 = nn.BatchNorm2d(planes)
-        self.relu = nn.ReLU(inplace=True)
+        self.bn1 = BatchNorm2d(planes)
+        self.bn2 = BatchNorm2d(planes)
+        self.relu = ReLU(inplace=True)
         self.downsample = None
         if stride != 1:
-            self.downsample = nn.Sequential(_c1(in_planes, planes, stride=stride), nn.BatchNorm2d(planes))
+            self.downsample = nn.Sequential(_c1(in_planes, planes, stride=stride), BatchNorm2d(planes))
 
     def forward(self, x):
         y = self.relu(self.bn1(self.conv1(x)))
         y = self.bn2(self.conv2(y))
         if self.downsample is not None:
             x = self.downsample(x)
+        if _glue(self.relu, y) and "add" in GLUE_PARTS:
+            return autograd.act(x, y, "relu")                 # relu(x + y) in one pass (resnet_fpn.py:40)
         return self.relu(x + y)
 
 
 def _fuse_head(cin, cout):
-    return nn.Sequential(_c3(cin, cin), nn.BatchNorm2d(cin), nn.LeakyReLU(), _c3(cin, cout))
+    return nn.Sequential(_c3(cin, cin), BatchNorm2d(cin), LeakyReLU(), _c3(cin, cout))
 
 
 class _ResNetFPN(nn.Module):
@@ -95,6 +135,8 @@ class _ResNetFPN(nn.Module):
 
     @staticmethod
     def _up(x):
+        if TRAIN_GLUE_HIP and "up" in GLUE_PARTS and x.is_cuda and x.dtype == torch.float32 and torch.is_grad_enabled() and x.requires_grad:
+            return autograd.upsample2x(x)                     # training: forward and adjoint on csrc/train_glue.hip
         return F.interpolate(x, scale_factor=2., mode="bilinear", align_corners=True)
 
     # ---- HIP path helpers: an activation is (SP int32 tensor [B,H,W,ceil32(C)], C) -----------------
@@ -154,8 +196,8 @@ class ResNetFPN_8_2(_ResNetFPN):
         d1, d2, d3 = config["block_dims"]
         self.in_planes = d0
         self.conv1 = Conv2d(1, d0, kernel_size=7, stride=2, padding=3, bias=False)
-        self.bn1 = nn.BatchNorm2d(d0)
-        self.relu = nn.ReLU(inplace=True)
+        self.bn1 = BatchNorm2d(d0)
+        self.relu = ReLU(inplace=True)
         self.layer1 = self._stage(d1, 1)     # 1/2
         self.layer2 = self._stage(d2, 2)     # 1/4
         self.layer3 = self._stage(d3, 2)     # 1/8
@@ -214,8 +256,8 @@ class ResNetFPN_16_4(_ResNetFPN):
         d1, d2, d3, d4 = config["block_dims"]
         self.in_planes = d0
         self.conv1 = Conv2d(1, d0, kernel_size=7, stride=2, padding=3, bias=False)
-        self.bn1 = nn.BatchNorm2d(d0)
-        self.relu = nn.ReLU(inplace=True)
+        self.bn1 = BatchNorm2d(d0)
+        self.relu = ReLU(inplace=True)
         self.layer1 = self._stage(d1, 1)     # 1/2
         self.layer2 = self._stage(d2, 2)     # 1/4
         self.layer3 = self._stage(d3, 2)     # 1/8

@@ -20,7 +20,11 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // src0 / src2 op_sel and every op_sel_hi form are fine).  hipcc emits that form for "pair x scalar" when the scalar sits in the odd
 // register of a pair.  Kernels in which it shows up are compiled without packed fp32 arithmetic; tests/test_isa_audit.py scans the
 // ISA of every translation unit for the form.
+#ifdef __HIP_DEVICE_COMPILE__
 #define LOFTR_NO_PACKED_FP32 __attribute__((target("no-packed-fp32-ops")))
+#else
+#define LOFTR_NO_PACKED_FP32          /* (the host pass does not know the feature) */
+#endif
 
 __host__ __device__ static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }

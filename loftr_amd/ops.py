@@ -611,3 +611,96 @@ def epipolar_errors(mkpts0_f, mkpts1_f, m_bids, T_0to1, K0, K1):
     args = [t.contiguous() for t in (mkpts0_f, mkpts1_f, m_bids, T_0to1, K0, K1)]
     check(_lib.load().loftr_epipolar_errors(*[_ptr(t) for t in args], M, N, _ptr(out), _stream()), "loftr_epipolar_errors")
     return out
+
+
+# ---- training-mode glue of the backbone (csrc/train_glue.hip; resnet_fpn.py:22-40,66-77,110-116) ------------------------------------------
+def _dense4(t, name):
+    """A 4-D fp32 GPU tensor [N,C,H,W] stored densely either NCHW or NHWC (channels_last: what the convolution nodes produce); returns
+    (tensor as given or made contiguous, channels_last flag)."""
+    if not isinstance(t, torch.Tensor) or not t.is_cuda or t.dtype != torch.float32 or t.dim() != 4:
+        raise _lib.LoftrHipError(f"{name}: expected a 4-D float32 GPU tensor")
+    if t.is_contiguous():
+        return t, 0
+    if t.is_contiguous(memory_format=torch.channels_last) and t.shape[1] % 4 == 0 and t.shape[1] <= 1024:
+        return t, 1
+    return t.contiguous(), 0
+
+
+def _like_layout(t, cl):
+    """t in the layout `cl` names (a copy only when it is not already there)."""
+    if cl:
+        return t if t.is_contiguous(memory_format=torch.channels_last) else t.contiguous(memory_format=torch.channels_last)
+    return t.contiguous()
+
+
+@_on_device
+def bn_train_fwd(x, gamma, beta, eps):
+    """nn.BatchNorm2d in .train() mode on an [N,C,H,W] fp32 tensor (NCHW or channels-last storage, kept): (y, mean [C], invstd [C], unbiased
+    variance [C])."""
+    x, cl = _dense4(x, "x")
+    N, Cc, H, W = x.shape
+    lib = _lib.load()
+    y = torch.empty_like(x)                                      # preserves the memory format
+    mean, invstd, varu = (torch.empty(Cc, dtype=torch.float32, device=x.device) for _ in range(3))
+    ws = workspace(lib.loftr_bn_train_workspace_bytes(N, Cc, H * W), x.device)
+    check(lib.loftr_bn_train_fwd(_ptr(x), N, Cc, H * W, cl, _ptr(gamma), _ptr(beta), float(eps), _ptr(y), _ptr(mean), _ptr(invstd), _ptr(varu),
+                                 _ptr(ws), ws.numel(), _stream()), "loftr_bn_train_fwd")
+    return y, mean, invstd, varu
+
+
+@_on_device
+def bn_train_bwd(dy, x, mean, invstd, gamma):
+    """(dx, dgamma, dbeta) of bn_train_fwd; dx in x's layout."""
+    x, cl = _dense4(x, "x")
+    dy = _like_layout(dy, cl)
+    N, Cc, H, W = x.shape
+    lib = _lib.load()
+    dx = torch.empty_like(x)
+    dgamma, dbeta = (torch.empty(Cc, dtype=torch.float32, device=x.device) for _ in range(2))
+    ws = workspace(lib.loftr_bn_train_workspace_bytes(N, Cc, H * W), x.device)
+    check(lib.loftr_bn_train_bwd(_ptr(dy), _ptr(x), N, Cc, H * W, cl, _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(dx), _ptr(dgamma), _ptr(dbeta),
+                                 _ptr(ws), ws.numel(), _stream()), "loftr_bn_train_bwd")
+    return dx, dgamma, dbeta
+
+
+ACT_CODES = {"none": 0, "relu": 1, "leaky_relu": 2}
+
+
+@_on_device
+def act_fwd(a, b, act, slope=0.01):
+    """act(a + b) (b may be None), act in ACT_CODES; elementwise: any dense layout, the result takes a's."""
+    a, cl = _dense4(a, "a") if a.dim() == 4 else (_need(a, "a"), 0)
+    if b is not None:
+        assert b.shape == a.shape
+        b = _like_layout(b, cl) if a.dim() == 4 else _need(b, "b")
+    y = torch.empty_like(a)
+    check(_lib.load().loftr_act_fwd(_ptr(a), _ptr(b), a.numel(), ACT_CODES[act], float(slope), _ptr(y), _stream()), "loftr_act_fwd")
+    return y
+
+
+@_on_device
+def act_bwd(dy, y, act, slope=0.01):
+    y, cl = _dense4(y, "y") if y.dim() == 4 else (_need(y, "y"), 0)
+    dy = _like_layout(dy, cl) if y.dim() == 4 else _need(dy, "dy")
+    dx = torch.empty_like(y)
+    check(_lib.load().loftr_act_bwd(_ptr(dy), _ptr(y), dy.numel(), ACT_CODES[act], float(slope), _ptr(dx), _stream()), "loftr_act_bwd")
+    return dx
+
+
+@_on_device
+def upsample2x_bilinear(x):
+    """F.interpolate(x, scale_factor=2., mode='bilinear', align_corners=True) of an [N,C,H,W] fp32 tensor, in x's memory format."""
+    x, cl = _dense4(x, "x")
+    N, Cc, H, W = x.shape
+    y = torch.empty(N, Cc, 2 * H, 2 * W, dtype=torch.float32, device=x.device, memory_format=torch.channels_last if cl else torch.contiguous_format)
+    check(_lib.load().loftr_upsample2x_bilinear_fwd(_ptr(x), N, Cc, H, W, cl, _ptr(y), _stream()), "loftr_upsample2x_bilinear_fwd")
+    return y
+
+
+@_on_device
+def upsample2x_bilinear_bwd(dy):
+    dy, cl = _dense4(dy, "dy")
+    N, Cc, Ho, Wo = dy.shape
+    dx = torch.empty(N, Cc, Ho // 2, Wo // 2, dtype=torch.float32, device=dy.device, memory_format=torch.channels_last if cl else torch.contiguous_format)
+    check(_lib.load().loftr_upsample2x_bilinear_bwd(_ptr(dy), N, Cc, Ho // 2, Wo // 2, cl, _ptr(dx), _stream()), "loftr_upsample2x_bilinear_bwd")
+    return dx

@@ -351,6 +351,10 @@ def make_step_grads(name):
         a = (prm.grad if prm.grad is not None else torch.zeros_like(prm)).double()
         b_ = p64.grad if p64.grad is not None else torch.zeros_like(p64)
         noise[pname] = float((a - b_).abs().max() / max(float(b_.abs().max()), 1e-300))
+        g64 = b_.numpy()
+        # (round 5) the float64 gradients themselves, same digest: what an arithmetic that is INDEPENDENT of the reference's float32
+        # kernels is to be measured against -- its distance to this, next to the reference's own (noise), not its distance to one float32 sample
+        full.update(digest("grad64/" + pname, g64.reshape(g64.shape[0], -1) if g64.ndim > 2 else g64))
     full["ref_noise"] = np.array(json.dumps(noise))
     full["ref64_same_matches"] = np.array(same)
     print("reference fp32 vs fp64 (same match set: %s): worst relative gradient deviations" % same,

@@ -289,7 +289,8 @@ def test_training_step_head_gradients_against_reference(name, monkeypatch):
         assert abs(got - float(g["grad_bin_score"])) <= 2e-3 * abs(float(g["grad_bin_score"])), (got, g["grad_bin_score"])
 
 
-@pytest.mark.parametrize("name,backbone_on", [("tfull_ds", "cpu"), ("tfull_ot", "cpu"), ("tfull_ds", "hip"), ("tfull_ot", "hip")])
+@pytest.mark.parametrize("name,backbone_on", [("tfull_ds", "cpu"), ("tfull_ot", "cpu"), ("tfull_ds", "hip"), ("tfull_ot", "hip"),
+                                              ("tfull_ds", "hipglue"), ("tfull_ot", "hipglue")])
 def test_training_step_full_backward_against_reference(name, backbone_on, monkeypatch):
     """The WHOLE training step's backward (round 4, LoFTR.full_grads): supervision -> matcher in .train() mode -> losses ->
     data['loss'].backward(), every node after the backbone an autograd node whose forward and backward are HIP kernels (position
@@ -297,7 +298,15 @@ def test_training_step_full_backward_against_reference(name, backbone_on, monkey
     the CPU in train mode (its autograd, the reference's own arithmetic).  Compared: the gradient of EVERY parameter (160 / 161
     tensors) with the reference's own training step under torch.autograd (tests/golden/tfull_*.npz, digests).
     backbone_on = "hip": the backbone runs on the GPU in train mode as well, every convolution the HIP autograd node (autograd.conv2d:
-    forward, input gradient, weight gradient), BatchNorm / activations / adds / upsampling PyTorch autograd on the GPU."""
+    forward, input gradient, weight gradient), BatchNorm / activations / adds / upsampling PyTorch autograd on the GPU -- the SAME float32
+    arithmetic as the reference's for those nodes, so the convolution nodes are held to the tight bar against the reference's float32 step.
+    backbone_on = "hipglue" (round 5, the default of a training step): BatchNorm with batch statistics, activations, residual adds and the
+    bilinear upsampling run on csrc/train_glue.hip as well.  That arithmetic is independent of the reference's float32 kernels (float64 sums
+    for the statistics instead of float32 Welford ...), and the backbone's gradients at this size are ill-conditioned (the reference's own
+    float32 step is up to 3.4e-2 from its float64 step; profiles/r05_glue_vs_fp64.txt: PyTorch's float32 graph, HIP convolutions + PyTorch
+    glue and HIP convolutions + HIP glue sit at medians 3.3e-3 / 3.7e-3 / 3.3e-3 and maxima 4.2e-2 / 2.9e-2 / 1.9e-2 from a float64 run):
+    two independent float32 evaluations differ by more than either differs from the truth, so the backbone tensors of this variant are
+    measured against the reference's FLOAT64 gradients (grad64/* digests of the golden), next to the reference's own float32 distance."""
     import copy
     import importlib.util
     import os
@@ -336,7 +345,9 @@ def test_training_step_full_backward_against_reference(name, backbone_on, monkey
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
     data = {"dataset_name": ["scannet"] * N, **{k: t(v) for k, v in batch.items()}}
     monkeypatch.setattr(torch, "randint", MG.det_randint)
-    if backbone_on == "hip":
+    from loftr_amd import backbone as BBmod
+    monkeypatch.setattr(BBmod, "TRAIN_GLUE_HIP", backbone_on == "hipglue")
+    if backbone_on in ("hip", "hipglue"):
         # the user's training step (training.trainval_inference = lightning_loftr.py:76-91): supervision, LoFTR.forward(data) itself --
         # backbone in train mode on the stacked image batch, every convolution the HIP node, its two halves straight into the matcher --
         # fine supervision, loss
@@ -357,11 +368,19 @@ def test_training_step_full_backward_against_reference(name, backbone_on, monkey
         assert abs(float(data["loss_scalars"][k]) - want[k]) <= 2e-4 * max(1.0, abs(want[k])), (k, data["loss_scalars"], want)
     data["loss"].backward()
     torch.cuda.synchronize()
-    params = {"backbone." + n: p for n, p in (model if backbone_on == "hip" else cpu).backbone.named_parameters()}
+    params = {"backbone." + n: p for n, p in (model if backbone_on != "cpu" else cpu).backbone.named_parameters()}
     params.update({n: p for n, p in model.named_parameters() if not n.startswith("backbone.")})
     names = sorted({k.split("/")[1] for k in g if k.startswith("grad/")})
     assert set(names) == set(params), set(names) ^ set(params)
-    worst = {}
+    def dist(key, got):
+        if key in g:                                             # vectors (and scalars): stored whole
+            ref = g[key]
+            return np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-12)
+        d = LG.digest(key, got)
+        scale = max(float(g[key + "/absmax"]), 1e-12)
+        return max(np.abs(d[key + "/sub"] - g[key + "/sub"]).max() / scale,
+                   max(np.abs(d[key + "/" + s_] - g[key + "/" + s_]).max() / max(np.abs(g[key + "/" + s_]).max(), scale) for s_ in ("rowsum", "colsum")))
+    worst, worst64 = {}, {}
     for n in names:
         key = "grad/" + n
         got = params[n].grad
@@ -376,6 +395,7 @@ def test_training_step_full_backward_against_reference(name, backbone_on, monkey
             err = max(np.abs(d[key + "/sub"] - g[key + "/sub"]).max() / scale,
                       max(np.abs(d[key + "/" + s_] - g[key + "/" + s_]).max() / max(np.abs(g[key + "/" + s_]).max(), scale) for s_ in ("rowsum", "colsum")))
         worst[n] = float(err)
+        worst64[n] = float(dist("grad64/" + n, got.astype(np.float64)))
     # Bar per tensor, relative to its largest entry: 3e-3 (round-4 verdict; was 6e-3), or 3 x the reference's OWN float32 rounding noise on
     # that tensor -- |its fp32 gradient - its fp64 gradient| of the same step, stored in the golden -- where that is larger (BatchNorm
     # shifts and the stride-2 block of layer2 are sums with heavy cancellation: the reference itself is off by up to 3.4e-2 there, and two
@@ -391,7 +411,7 @@ def test_training_step_full_backward_against_reference(name, backbone_on, monkey
     noise = json.loads(str(g["ref_noise"]))
     assert bool(g["ref64_same_matches"])
     loose = {"loftr_fine.layers.0.q_proj.weight": 8e-3, "loftr_fine.layers.1.q_proj.weight": 8e-3}
-    if backbone_on == "hip":
+    if backbone_on != "cpu":
         loose["loftr_coarse.layers.7.mlp.0.weight"] = 8e-3
     # BatchNorm shifts of the backbone: the plain sum of the feature gradient over every pixel of the batch (cancellation): 4e-3
     # (measured 3.06e-3 on backbone.layer1.1.bn2.bias with the CPU mirror, where the reference's own noise is 7.4e-4)
@@ -412,7 +432,25 @@ def test_training_step_full_backward_against_reference(name, backbone_on, monkey
         fh.write(f"== {name} (backbone on {backbone_on}); training matches M = {len(ids)}, sha1 of (b, i, j) {hashlib.sha1(ids.tobytes()).hexdigest()[:12]}, "
                  f"loss_c {float(data['loss_scalars']['loss_c']):.7f} loss_f {float(data['loss_scalars']['loss_f']):.7f}\n" + "".join(f"{n:52s} {e:.2e}  ref noise {noise[n]:.2e}  x{e / max(noise[n], 1e-12):7.1f}\n"
                                                                          for n, e in sorted(worst.items(), key=lambda kv: -kv[1])))
-    bad = {n: (e, tol[n]) for n, e in worst.items() if e > tol[n]}
+    if backbone_on == "hipglue":
+        # Backbone tensors against the reference's FLOAT64 gradients, as ratios to the reference's own float32 distance.  The tight statement
+        # is the aggregate: median ratio <= 2 (measured 1.29 / 1.30).  Individual tensors cannot be held to a few x their noise: the
+        # derivative of ReLU is discontinuous, and with the sparse gradients of a matching loss ONE unit whose pre-activation lies within
+        # rounding noise of zero can carry percent of a layer's gradient.  Measured (tools/micro/relu_flip_probe.py,
+        # profiles/r05_relu_flip_probe.txt): between the PyTorch-BatchNorm and the HIP-BatchNorm evaluation of tfull_ot (outputs equal to
+        # 1e-6) exactly one of the 1 572 864 units behind layer1.1.bn1 changes sign (|pre-activation| 5e-7), and that layer's bias gradient
+        # moves by 2.9e-2 while every layer upstream of it agrees to <= 7e-4; the tensors downstream of it (layer1.0, the stem) inherit 4e-3.
+        # So: at most a quarter of the backbone tensors beyond 6 x their noise, none beyond 5e-2 of its scale.
+        ratios = sorted(worst64[n] / max(noise[n], 1e-12) for n in bb)
+        with open(os.path.join(rep, "full_backward_margins.txt"), "a") as fh:
+            fh.write(f"   {name} (hipglue) backbone tensors vs the reference's float64 gradients: ratio to the reference's own float32 distance: median {ratios[len(ratios) // 2]:.2f}, "
+                     f"max {ratios[-1]:.2f}, beyond 6x: {sum(r > 6 for r in ratios)} of {len(ratios)}; worst {max(bb, key=lambda n: worst64[n])} {max(worst64[n] for n in bb):.2e}\n")
+        assert ratios[len(ratios) // 2] <= 2.0, ratios[len(ratios) // 2]
+        assert sum(worst64[n] > max(3e-3, 6.0 * noise[n]) for n in bb) <= len(bb) // 4, sorted(((worst64[n], noise[n], n) for n in bb), reverse=True)[:16]
+        bad = {n: (worst64[n], noise[n]) for n in bb if worst64[n] > 5e-2}
+        bad.update({n: (e, tol[n]) for n, e in hip.items() if e > tol[n]})
+    else:
+        bad = {n: (e, tol[n]) for n, e in worst.items() if e > tol[n]}
     assert not bad, (sorted(bad.items(), key=lambda kv: -kv[1][0])[:8], len(bad), len(worst))
 
 
