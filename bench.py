@@ -190,20 +190,38 @@ def source_hash():
     return h.hexdigest()[:16]
 
 
+def pmc_kernel_code_hash(table_keys, lib_path=None):
+    """Identity of the MACHINE CODE of the kernels a PMC table describes: sha256 over the gfx950 function bodies (tools/kernel_code_hash.py, pure
+    Python over the library's offload bundles) of every device function whose name contains the base name of a table entry
+    ("conv3x3_duo_kernel<Cfg<4,2,4,4,1>>" -> "conv3x3_duo", "encoder_x_kernel" -> "encoder_x": the pooled variants are included)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("kernel_code_hash", os.path.join(ROOT, "tools", "kernel_code_hash.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    subs = sorted({k.split("<")[0][:-len("_kernel")] if k.split("<")[0].endswith("_kernel") else k.split("<")[0] for k in table_keys if not k.startswith("_")})
+    return m.kernel_code_hash(lib_path or _lib.LIB_PATH, subs)[0]
+
+
 _PMC = None
+PMC_IDENTITY = None          # "source" | "kernel_code" | None: which identity tied profiles/pmc_traffic.json to this build
 
 
 def pmc_table():
-    """profiles/pmc_traffic.json (rocprofv3 --pmc passes: FETCH_SIZE x2 + WRITE_SIZE, SQ_VALU_MFMA_BUSY_CYCLES) if it
-    was collected on THIS build of the kernels (source hash match), else {}."""
-    global _PMC
+    """profiles/pmc_traffic.json (rocprofv3 --pmc passes: FETCH_SIZE x2 + WRITE_SIZE, SQ_VALU_MFMA_BUSY_CYCLES) if it was collected on THIS
+    build of the kernels it describes, else {}.  "This build": the hash of every kernel source matches, or -- round 5: a training-only
+    translation unit must not invalidate the forward kernels' counters -- the machine code of the kernels in the table is byte-identical
+    (pmc_kernel_code_hash)."""
+    global _PMC, PMC_IDENTITY
     if _PMC is None:
         _PMC = {}
         p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         try:
             t = json.load(open(p))
-            if t.get("_meta", {}).get("source_hash") == source_hash():
-                _PMC = t
+            meta = t.get("_meta", {})
+            if meta.get("source_hash") == source_hash():
+                _PMC, PMC_IDENTITY = t, "source"
+            elif meta.get("kernel_code_hash") and meta["kernel_code_hash"] == pmc_kernel_code_hash(t.keys()):
+                _PMC, PMC_IDENTITY = t, "kernel_code"
         except Exception:
             pass
     return _PMC
@@ -800,6 +818,7 @@ def main():
                        "parity": "image-level goldens of the reference forward, both backbones (incl. a 3-pair batch and the 840 x 840 masked outdoor batch): profiles/r05_parity_margins.txt"},
             "per_rank_ms_per_step": per_rank_ms,
             "collective": {"transport": transport, "ranks_in_communicator": (rccl.ranks_seen if rccl is not None else world) if multi else 1},
+            "pmc_identity": PMC_IDENTITY if pmc_table() else None,      # what ties profiles/pmc_traffic.json to this build: "source" (every kernel source unchanged) / "kernel_code" (machine code of the profiled kernels byte-identical) / None (no traffic figures)
             "stage_ms": {"backbone": round(backbone_ms, 3), "backbone_impl": args.backbone, "hot_path_hip": round(hot_ms, 3),
                          "note": "median of 3 instrumented steps (after one unmeasured instrumented step) run WITHOUT the two-stream overlap (serial sum > ms_per_step when "
                                  "the timed region overlaps the FPN fine branch with the coarse stage); `kernels` likewise"},

@@ -138,3 +138,31 @@ def test_timing_slot_names_are_the_kernels_that_run(bench):
     assert set(bench.POOLED_FROM) <= set(slots)
     w = bench.algorithmic_work(B=8, L=4800, S=4800, M=7600)
     assert set(w) <= set(slots) | {"attn_small_kernel"}, set(w) - set(slots)
+
+
+def test_pmc_table_describes_the_kernels_of_this_build(bench):
+    """profiles/pmc_traffic.json is quoted by bench.py only for the build it was collected on.  Its identity stamp is the hash of the kernel
+    sources OR (round 5) of the machine code of the kernels it lists, dug out of the library's gfx950 code objects by tools/kernel_code_hash.py:
+    a change to any profiled kernel's code -- and only that -- must fail here until the PMC passes are re-collected."""
+    import json
+    import os
+    from loftr_amd import build as build_mod
+    build_mod.build(verbose=False)
+    t = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+    meta = t["_meta"]
+    ok_source = meta.get("source_hash") == bench.source_hash()
+    ok_code = meta.get("kernel_code_hash") == bench.pmc_kernel_code_hash(t.keys())
+    assert ok_source or ok_code, ("profiles/pmc_traffic.json belongs to another build of the profiled kernels: re-run tools/gpu/r5_profile.sh", meta)
+    assert bench.pmc_table() and bench.pmc_traffic("encoder_x_kernel") > 1e8 and bench.PMC_IDENTITY in ("source", "kernel_code")
+    # the extractor sees the library's kernels: every family of the table has device functions behind it
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("kernel_code_hash", os.path.join(ROOT, "tools", "kernel_code_hash.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    from loftr_amd import _lib
+    funcs = m.kernel_functions(_lib.LIB_PATH)
+    assert len(funcs) >= 150
+    for key in t:
+        if not key.startswith("_"):
+            base = key.split("<")[0]
+            assert any(base in n for n in funcs), key

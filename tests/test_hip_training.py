@@ -335,7 +335,7 @@ def test_training_step_full_backward_against_reference(name, backbone_on, monkey
     model = model.to(dev).train()
     model.full_grads = True
     images = torch.from_numpy(np.concatenate([batch["image0"], batch["image1"]], 0))
-    if backbone_on != "hip":
+    if backbone_on == "cpu":
         fc, ff = cpu.backbone(images)                                                                        # WITH its graph
         eps = float(os.environ.get("LOFTR_TEST_PERTURB_FEATURES", "0"))      # sensitivity experiment (tools/gpu/r5_bwd_sensitivity.sh): how far do the
         if eps > 0:                                                          # gradients move when the features move by eps (relative, Gaussian)?

@@ -92,8 +92,9 @@ def main():
     try:
         b = importlib.util.module_from_spec(spec)
         spec.loader.exec_module(b)
-        out["_meta"] = dict(source_hash=b.source_hash(), fetch_correction="FETCH_SIZE x2 (gfx950)", write_correction="none")
-        print("# source hash", out["_meta"]["source_hash"])
+        out["_meta"] = dict(source_hash=b.source_hash(), kernel_code_hash=b.pmc_kernel_code_hash(out.keys()),
+                            fetch_correction="FETCH_SIZE x2 (gfx950)", write_correction="none")
+        print("# source hash", out["_meta"]["source_hash"], "kernel code hash", out["_meta"]["kernel_code_hash"])
     except Exception as e:      # noqa: BLE001
         print("# could not stamp the source hash:", e)
     if "--json" in sys.argv:
