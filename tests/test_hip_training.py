@@ -408,6 +408,8 @@ def test_training_step_full_backward_against_reference(name, backbone_on, monkey
     #     layer next to the loss sees gradients on few tokens, and a ReLU unit whose pre-activation changes sign under the 1e-5 forward
     #     difference switches its whole contribution on or off -- the same experiment moves mlp.0 gradients of other layers by 24 x their
     #     noise (5.6e-4); the match set, the sampled ids and both losses are identical to 7 digits in the two variants (full_backward_all.txt).
+    #     Shown directly (tools/micro/mlp_flip_probe.py, profiles/r05_mlp_flip_probe.txt): exactly one of the layer's 196 608 ReLU units changes
+    #     sign between the two variants (|pre-activation| 1.7e-6); mlp.0's gradient moves by 5.3e-3, mlp.2 / norm2 behind the ReLU by 3-6e-5.
     noise = json.loads(str(g["ref_noise"]))
     assert bool(g["ref64_same_matches"])
     loose = {"loftr_fine.layers.0.q_proj.weight": 8e-3, "loftr_fine.layers.1.q_proj.weight": 8e-3}
