@@ -59,3 +59,35 @@ def test_head_grad_kernel_is_built_for_two_workgroups_per_cu(isa):
         assert lds < 80 * 1024 and scratch == 0 and vgpr <= 256, (m.group(1), lds, scratch, vgpr)
         found += 1
     assert found == 2
+
+
+def _kernel_resources(text):
+    out = {}
+    for m in re.finditer(r"\.amdhsa_kernel (\S+)\n(.*?)\.end_amdhsa_kernel", text, re.S):
+        body = m.group(2)
+        g = lambda key: int(re.search(rf"\.amdhsa_{key} (\d+)", body).group(1))
+        out[m.group(1)] = dict(lds=g("group_segment_fixed_size"), scratch=g("private_segment_fixed_size"), vgpr=g("next_free_vgpr"))
+    return out
+
+
+def test_hot_kernels_keep_their_register_and_lds_budgets(isa):
+    """The occupancy each hot kernel is designed for, read off the compiled code objects: a change that spills a k-loop to scratch or
+    pushes a two-workgroups-per-CU kernel over its LDS / register budget fails here, on the CPU, before it costs GPU time."""
+    conv = _kernel_resources(isa["conv.hip"])
+    duo = {k: v for k, v in conv.items() if "conv3x3_duo_kernel" in k}
+    assert len(duo) >= 5
+    for k, v in duo.items():
+        assert v["scratch"] == 0, (k, v)
+        four_wave = "ELi4ELi1EEE" in k                       # Cfg<.., WAVES = 4, WN = 1>: two workgroups per CU
+        assert v["lds"] <= (80 if four_wave else 160) * 1024 and v["vgpr"] <= 256, (k, v)
+    enc = _kernel_resources(isa["encoder_fused.hip"])
+    for k, v in enc.items():
+        if "encoder_x_kernel" in k or "encoder_x2_kernel" in k:
+            assert v["vgpr"] <= 512 and v["lds"] <= 160 * 1024 and v["scratch"] <= 160, (k, v)      # 148 B: spills around LayerNorm1, outside the panel loops
+    fine = _kernel_resources(isa["fine_fused.hip"])
+    fp = [v for k, v in fine.items() if "fine_pair_kernel" in k]
+    assert fp and all(v["scratch"] == 0 and v["vgpr"] <= 512 and v["lds"] <= 160 * 1024 for v in fp), fp
+    sweep = {k: v for k, v in _kernel_resources(isa["coarse_match.hip"]).items() if "score_sweep_kernel" in k}
+    assert sweep and all(v["vgpr"] <= 256 for v in sweep.values()), sweep                             # 512-thread workgroups: two waves per SIMD
+    lin = {k: v for k, v in _kernel_resources(isa["linear.hip"]).items() if "proj_kv_kernel" in k or "linear_kernel" in k}
+    assert lin and all(v["scratch"] == 0 and v["lds"] <= 80 * 1024 and v["vgpr"] <= 256 for v in lin.values()), lin
