@@ -619,6 +619,8 @@ def _dense4(t, name):
     (tensor as given or made contiguous, channels_last flag)."""
     if not isinstance(t, torch.Tensor) or not t.is_cuda or t.dtype != torch.float32 or t.dim() != 4:
         raise _lib.LoftrHipError(f"{name}: expected a 4-D float32 GPU tensor")
+    if t.data_ptr() % 16:                                        # (a view into the middle of a buffer: the kernels use 16-byte accesses)
+        t = t.clone(memory_format=torch.preserve_format)
     if t.is_contiguous():
         return t, 0
     if t.is_contiguous(memory_format=torch.channels_last) and t.shape[1] % 4 == 0 and t.shape[1] <= 1024:
@@ -627,7 +629,9 @@ def _dense4(t, name):
 
 
 def _like_layout(t, cl):
-    """t in the layout `cl` names (a copy only when it is not already there)."""
+    """t in the layout `cl` names (a copy only when it is not already there, or not 16-byte aligned)."""
+    if t.data_ptr() % 16:
+        t = t.clone(memory_format=torch.preserve_format)
     if cl:
         return t if t.is_contiguous(memory_format=torch.channels_last) else t.contiguous(memory_format=torch.channels_last)
     return t.contiguous()
