@@ -388,10 +388,10 @@ POOLED_FROM = {
     "score_sweep_kernel<2>": ["sweep::score_sweep_kernel<2, false>", "sweep::score_sweep_kernel<2, true>", "(C != 256: score_store_kernel)"],
     "conv3x3_duo_kernel<Cfg<4,2,4,4,1>>": ["conv3x3_duo_kernel<c3d::Cfg<4, 2, 4, 4, 1> >", "(Cout not a multiple of 128: conv3x3_kernel)"],
     "conv3x3_duo_kernel<Cfg<7,2,4,8,2>>": ["conv3x3_duo_kernel<c3d::Cfg<7, 2, 4, 8, 2> >"],
-    "encoder_x_kernel": ["efx::encoder_x_kernel", "efx::encoder_x2_kernel"],
+    "encoder_x_kernel": ["efx::coarse_persistent_kernel", "efx::encoder_x_kernel", "efx::encoder_x2_kernel"],
     "fine_pair_kernel": ["ffx::fine_pair_kernel"],
     "conv_kernel": ["conv_kernel<GemmCfg<...>, false> (strided 3x3, 1x1)", "conv_kernel<GemmCfg<...>, true> (FPN top-down: 1x1 + bilinear x2 + add)"],
-    "proj_kernel": ["proj_kernel", "rowsweep_kernel<0>"], "linear_ln_kernel": ["linear_ln_kernel", "rowsweep_kernel<1>"],
+    "proj_kernel": ["proj_kernel"], "linear_ln_kernel": ["linear_ln_kernel"],
 }
 
 

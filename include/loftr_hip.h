@@ -13,7 +13,9 @@
  *   - all floating point data is fp32 (GEMMs evaluate fp32 products as 3 fp16 MFMAs with fp32
  *     accumulation, csrc/gemm.h), ids are int64, masks are uint8 (0 = padded), as in the
  *     reference;
- *   - return value: 0 = ok, negative = loftr_status below (no exceptions, no global state).
+ *   - return value: 0 = ok, negative = loftr_status below (no exceptions);
+ *   - no environment variable is read; the only process-global state are the debug switches, the timing mask and the
+ *     range guard at the end of this header, all off / at their defaults unless set through their entry points.
  */
 #ifndef LOFTR_HIP_H_
 #define LOFTR_HIP_H_
@@ -44,8 +46,10 @@ typedef enum {
  * 18: loftr_encoder_layer_bwd;
  * 19: loftr_fine_preprocess_bwd;
  * 20: loftr_conv_wgrad (backbone training: weight gradient of a convolution);
- * 21: training-mode glue of the backbone (loftr_bn_train_fwd / _bwd, loftr_act_fwd / _bwd, loftr_upsample2x_bilinear_fwd / _bwd) */
-#define LOFTR_HIP_ABI_VERSION 21
+ * 21: training-mode glue of the backbone (loftr_bn_train_fwd / _bwd, loftr_act_fwd / _bwd, loftr_upsample2x_bilinear_fwd / _bwd);
+ * 22: the persistent coarse transformer (loftr_coarse_plan_bytes / _build / _signature, loftr_transformer_fwd_planned) and the
+ *     debug switches (loftr_hip_debug_set / _get) that replace the library's environment variables */
+#define LOFTR_HIP_ABI_VERSION 22
 
 int loftr_hip_abi_version(void);
 const char* loftr_hip_status_string(int status);
@@ -120,6 +124,29 @@ int loftr_transformer_fwd(float* feat0, float* feat1, const uint8_t* mask0, cons
                           const loftr_layer_weights* layers, const int* layer_is_cross,
                           int n_layers, int N, int L, int S, int C, int H, const void* prepared,
                           size_t prepared_bytes, void* ws, size_t ws_bytes, void* stream);
+/* The same forward as ONE persistent launch (csrc/encoder_fused.hip: coarse_persistent_kernel).  The reference's schedule
+ * (transformer.py:91-99) synchronises whole calls; its data dependency -- feat1 attends to the UPDATED feat0 -- is per pair, and
+ * below that per 128-token tile.  A PLAN is the dependency graph of one forward's work items for a shape (n_layers of the pattern
+ * [self, cross] * P, N pairs, L and S tokens), ordered by a list schedule on the host; 256 resident workgroups pull it in order and
+ * wait on counters in the workspace.  Build it once per shape into a caller-owned DEVICE buffer of loftr_coarse_plan_bytes() bytes
+ * (0 = shape not supported; loftr_coarse_plan_build is a set-up call: it synchronises the stream), then pass it here.
+ *   order 0 = dependency-driven (critical path first), 1 = the reference's call order (same arithmetic item by item: results are
+ *   bit-identical, tests/test_hip_parity.py); the same value must be given to _build and to _fwd_planned.
+ *   diag: NULL, or a device buffer of diag_bytes >= 16: word 0 = error (0 ok; 2 = the plan was built for another shape / order and
+ *   nothing was computed; odd = a workgroup gave up waiting for a dependency after ~1 s, value = 1 + 2 * item), words 1-3 reserved;
+ *   with diag_bytes >= 16 + 32 * items (items = loftr_coarse_plan_bytes / 32 - 1) additionally per work item four 8-byte words
+ *   {popped, dependencies met, done} in 10 ns ticks and the workgroup id (profiling).  The caller zeroes word 0.
+ * C = 256, H = 8, n_layers <= 8 even; anything else: LOFTR_ERR_UNSUPPORTED (use loftr_transformer_fwd). */
+size_t loftr_coarse_plan_bytes(const int* layer_is_cross, int n_layers, int N, int L, int S);
+int loftr_coarse_plan_build(const int* layer_is_cross, int n_layers, int N, int L, int S, int order, void* plan,
+                            size_t plan_bytes, void* stream);
+unsigned loftr_coarse_plan_signature(int n_layers, int N, int L, int S, int order);
+int loftr_transformer_fwd_planned(float* feat0, float* feat1, const uint8_t* mask0, const uint8_t* mask1,
+                                  const loftr_layer_weights* layers, const int* layer_is_cross,
+                                  int n_layers, int N, int L, int S, int C, int H, const void* prepared,
+                                  size_t prepared_bytes, void* ws, size_t ws_bytes, const void* plan,
+                                  size_t plan_bytes, int plan_order, void* diag, size_t diag_bytes, void* stream);
+
 /* Inference with constant weights: every layer matrix is re-encoded once (row-scaled split-fp16 operand format,
  * csrc/gemm.h) into a caller-owned buffer of loftr_transformer_prepared_bytes(n_layers, C) bytes; hand it to
  * loftr_transformer_fwd as `prepared` (NULL there = convert on every call into the workspace).  The LayerNorm vectors
@@ -443,7 +470,17 @@ int loftr_rccl_comm_info(void* comm, int* rank_out, int* world_out);
 int loftr_rccl_comm_destroy(void* comm);
 int loftr_rccl_allgather_counts(void* comm, const int32_t* counts_in, int32_t* counts_out, int n, void* stream);
 
-/* ---- per-kernel timing (profiling aid; the only process-global state of the library) ---------
+/* ---- debug / A-B switches (process-global; the library reads NO environment variable) -------------
+ * Named integer switches that select an alternative schedule of the same arithmetic for A/B measurements and tests:
+ *   "encoder_schedule"  1: loftr_transformer_fwd runs the coarse level as scheduled launches; 0: call by call in the reference's order
+ *   "conv_persist_cap"  0: persistent convolution grids span the device's CUs; n >= 8: at most n workgroups (tests: many tiles each)
+ *   "wgrad_chunk"       0: split-K chunk of the weight-gradient GEMMs chosen by shape; n > 0: forced
+ *   "reduce_tall"       1: tall partial-sum reductions use the tall kernel; 0: the generic one
+ * Unknown key: LOFTR_ERR_BAD_ARG.  Results never depend on a switch beyond the last bits of a floating-point sum order. */
+int loftr_hip_debug_set(const char* key, int value);
+int loftr_hip_debug_get(const char* key, int* value, int* default_value);
+
+/* ---- per-kernel timing (profiling aid; process-global like the debug switches) ---------------
  * When bit `id` of the mask is set, every launch of that kernel is bracketed by hipEvents
  * recorded on the launch stream (up to 4096 launches between reads).  Replaces the reference's
  * InferenceProfiler (src/utils/profiler.py:7-28: cuda.synchronize()-bracketed wall clocks).

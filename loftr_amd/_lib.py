@@ -53,6 +53,13 @@ SIGNATURES = {
     "loftr_encoder_layer_bwd": (_i, [_p, _p, _p, _p, C.POINTER(LayerWeights), _p, _p, _p, C.POINTER(LayerWeights), _i, _i, _i, _i, _i, _p, _sz, _p]),
     "loftr_transformer_fwd": (_i, [_p, _p, _p, _p, C.POINTER(LayerWeights), C.POINTER(_i), _i, _i, _i, _i, _i, _i,
                                    _p, _sz, _p, _sz, _p]),
+    "loftr_coarse_plan_bytes": (_sz, [C.POINTER(_i), _i, _i, _i, _i]),
+    "loftr_coarse_plan_build": (_i, [C.POINTER(_i), _i, _i, _i, _i, _i, _p, _sz, _p]),
+    "loftr_coarse_plan_signature": (C.c_uint, [_i, _i, _i, _i, _i]),
+    "loftr_transformer_fwd_planned": (_i, [_p, _p, _p, _p, C.POINTER(LayerWeights), C.POINTER(_i), _i, _i, _i, _i, _i, _i,
+                                           _p, _sz, _p, _sz, _p, _sz, _i, _p, _sz, _p]),
+    "loftr_hip_debug_set": (_i, [C.c_char_p, _i]),
+    "loftr_hip_debug_get": (_i, [C.c_char_p, C.POINTER(_i), C.POINTER(_i)]),
     "loftr_transformer_prepared_bytes": (_sz, [_i, _i]),
     "loftr_transformer_prepare": (_i, [C.POINTER(LayerWeights), _i, _i, _p, _sz, _p]),
     "loftr_coarse_match_workspace_bytes": (_sz, [_i, _i, _i, _i]),
@@ -117,7 +124,7 @@ SIGNATURES = {
     "loftr_linear_fwd": (_i, [_p, _p, _p, _i, _i, _i, _p, _sz, _p]),
 }
 
-ABI_VERSION = 21
+ABI_VERSION = 22
 _lib = None
 
 

@@ -14,8 +14,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ_DIR = os.path.join(CSRC, "build")
 LIB_PATH = os.path.join(HERE, "libloftr_hip.so")
-SOURCES = ["linear.hip", "attention.hip", "transformer.hip", "coarse_match.hip", "fine.hip", "misc.hip",
-           "sp_convert.hip", "conv.hip", "eval.hip", "input.hip", "comm.hip", "pose.hip", "train.hip", "train_bwd.hip", "rowsweep.hip", "encoder_fused.hip", "fine_fused.hip", "head_grads.hip", "encoder_bwd.hip", "fine_bwd.hip", "train_glue.hip"]
+SOURCES = ["linear.hip", "coarse_plan.hip", "attention.hip", "transformer.hip", "coarse_match.hip", "fine.hip", "misc.hip",
+           "sp_convert.hip", "conv.hip", "eval.hip", "input.hip", "comm.hip", "pose.hip", "train.hip", "train_bwd.hip", "encoder_fused.hip", "fine_fused.hip", "head_grads.hip", "encoder_bwd.hip", "fine_bwd.hip", "train_glue.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-parameter"]
 
 

@@ -48,6 +48,19 @@ enum LoftrTimedKernel {
   LOFTR_T_FINE_PAIR = 14,   // fine_fused.hip: fine_pair_kernel     (the whole fine-level transformer of a match, one launch)
   LOFTR_T_COUNT = 15
 };
+// ---- debug / A-B switches (loftr_hip_debug_set in the header): the library reads no environment variable
+enum LoftrDebugKey {
+  LOFTR_DBG_ENCODER_SCHEDULE = 0,   // 1 (default): coarse transformer without a plan runs the scheduled launches; 0: the reference's call order
+  LOFTR_DBG_CONV_PERSIST_CAP,       // 0 (default): persistent convolution grids ask the device for its CU count; n >= 8: cap them at n workgroups
+  LOFTR_DBG_WGRAD_CHUNK,            // 0 (default): split-K chunk of the weight-gradient GEMM chosen by shape; n > 0: forced
+  LOFTR_DBG_REDUCE_TALL,            // 1 (default): tall partial-sum reductions of the weight gradients use the tall kernel; 0: the generic one
+  LOFTR_DBG_PCT_GRID,               // 0 (default): the persistent coarse transformer runs one workgroup per CU (256); n > 0: n workgroups
+  LOFTR_DBG_PCT_SKIP,               // 0 (default); bit t set: work items of type t (0 X, 1 K, 2 F) are popped and signalled but not executed (queue tests: WRONG results)
+  LOFTR_DBG_CONV_DUO,               // 1 (default): 3x3 / stride-1 convolutions with 128 k / 192 / 224 output columns run conv3x3_duo_kernel; 0: the generic conv3x3_kernel (any Cout)
+  LOFTR_DBG_CONV_PATCH,             // 1 (default): 3x3 / stride-1 convolutions run the patch kernels; 0: the implicit-GEMM conv_kernel (the strided / 1x1 path)
+  LOFTR_DBG_COUNT
+};
+int loftr_debug_value(int key);
 extern unsigned g_loftr_timing_mask;
 extern int g_loftr_range_check;      // loftr_hip_range_check_enable: fp16-range guard on unscaled operands (sp_convert.hip)
 void loftr_timing_mark(int id, hipStream_t st, bool end);

@@ -13,7 +13,6 @@
 
 namespace {
 
-using CfgR = GemmCfg<128, 128, 2, 2>;        // register-staged, 2 workgroups per CU
 using CfgD = GemmCfg<256, 128, 4, 2, 3>;     // 8 waves, 3-stage global_load_lds ring, 1 workgroup per CU
 
 struct ConvArgs {
@@ -494,227 +493,6 @@ __global__ __launch_bounds__(512, 2) void conv3x3_kernel(Conv3Args p) {
 
 #include "conv3x3_duo.h"
 
-#ifdef LOFTR_LEGACY_CONV   // round-3 kernel for the 224-column layers, superseded by conv3x3_duo_kernel<Cfg<7, 2, 4, 8, 2>> (round 4); kept for A/B builds only:
-                           // python -m loftr_amd.build --variant legacy -DLOFTR_LEGACY_CONV, then LOFTR_CONV_DUO=0
-// 3x3 convolutions whose padded output width is 7 MFMA column tiles (Cout = 196 -> 224, the FPN's middle
-// dimension: 5 of the 14 3x3 layers, among them the most expensive one).  The 128-column kernel above runs them
-// as a full tile plus a 96-column tile whose waves idle at the k-tile barrier for half of their MFMA slots and
-// which loads the input patch a second time (76 % of the matrix work useful).  Here one workgroup owns all 224
-// columns: wave w computes output row w of the 8 x 32 pixel tile x 7 column tiles (1 x 7 MFMA tiles, 21 MFMAs per
-// 16-wide k-step), the patch is loaded once, and there are 42 MFMAs per wave between two barriers instead of 24.
-//   LDS: patch ring 2 x 43 KB (as above), weight ring 2 x 256 rows x 128 B (rows >= Cout are clamped copies),
-//   weight tile t+1 is issued right after the barrier of k-tile t (2-stage ring, one tile of lookahead).
-namespace c3w {
-constexpr int NT = 7, BROWS = 256, BQ = BROWS / 64;                    // column tiles; weight-tile rows (4 DMA instr. / wave)
-constexpr int BTILE_BYTES = BROWS * 128;
-constexpr int LDS_BYTES = 2 * c3::PATCH_BYTES + 2 * BTILE_BYTES + 1024;
-}  // namespace c3w
-
-__global__ __launch_bounds__(512, 2) void conv3x3_wide_kernel(Conv3Args p) {
-  using namespace c3;
-  constexpr int NT = c3w::NT;
-  typedef __attribute__((address_space(3))) void* lds_ptr_t;
-  typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
-  __shared__ __attribute__((aligned(16))) char lds[c3w::LDS_BYTES];
-  char* const patch_base = lds;
-  char* const bring_base = lds + 2 * PATCH_BYTES;
-  char* const scratch = lds + 2 * PATCH_BYTES + 2 * c3w::BTILE_BYTES;
-
-  int tm, tn;
-  const int tiles_m = p.B * p.tiles_y * p.tiles_x;
-  if (!xcd_tile(tiles_m, 1, tm, tn)) return;
-  const int b = tm / (p.tiles_y * p.tiles_x), trem = tm - b * (p.tiles_y * p.tiles_x);
-  const int y0 = (trem / p.tiles_x) * TY, x0 = (trem % p.tiles_x) * TX;
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int rsub = lane >> 3, slot = lane & 7;
-  const int g = lane >> 5, tx = lane & 31;
-
-  int poff[PQ];                       // patch rows: -1 = outside the image / unused slot -> zero page
-#pragma unroll
-  for (int q = 0; q < PQ; ++q) {
-    const int s_ = q * 8 + wave, r = s_ * 8 + rsub;
-    const int py = r / PW, px = r - py * PW;
-    const int gy = y0 - 1 + py, gx = x0 - 1 + px;
-    const bool in = s_ < PSLOTS && r < PROWS && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
-    poff[q] = in ? ((b * p.H + gy) * p.W + gx) * p.Cp + ((slot ^ ((r >> 1) & 7)) << 2) : -1;
-  }
-  int boff[c3w::BQ];
-#pragma unroll
-  for (int q = 0; q < c3w::BQ; ++q) {
-    const int r = (q * 8 + wave) * 8 + rsub;
-    boff[q] = min(r, p.Cout - 1) * p.K + ((slot ^ ((r >> 1) & 7)) << 2);
-  }
-  const int gpt = p.Cp >> 5, nk = 9 * gpt;
-
-  // (the base pointers are laundered through an empty asm in every iteration: otherwise the ten 64-bit DMA
-  //  addresses are hoisted out of the k-loop and, next to 112 accumulator registers, spilled)
-#define C3W_ISSUE_PATCH(cg_, stage_)                                                                        \
-  {                                                                                                         \
-    const sp_t* xb__ = p.x;                                                                                 \
-    asm volatile("" : "+s"(xb__));                                                                          \
-    _Pragma("unroll") for (int q = 0; q < PQ; ++q) {                                                        \
-      const sp_t* g__ = poff[q] >= 0 ? xb__ + (poff[q] + (cg_) * 32) : p.zeros;                             \
-      char* d__ = (q * 8 + wave < PSLOTS) ? patch_base + (stage_) * PATCH_BYTES + (q * 8 + wave) * 1024 : scratch; \
-      __builtin_amdgcn_global_load_lds((gbl_ptr_t)g__, (lds_ptr_t)d__, 16, 0, 0);                           \
-    }                                                                                                       \
-  }
-#define C3W_ISSUE_B(cg_, tap_, stage_)                                                                      \
-  {                                                                                                         \
-    const int k0__ = (tap_) * p.Cp + (cg_) * 32;                                                            \
-    const sp_t* wb__ = p.w;                                                                                 \
-    asm volatile("" : "+s"(wb__));                                                                          \
-    _Pragma("unroll") for (int q = 0; q < c3w::BQ; ++q)                                                     \
-      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(wb__ + (boff[q] + k0__)),                                \
-                                       (lds_ptr_t)(bring_base + (stage_) * c3w::BTILE_BYTES + (q * 8 + wave) * 1024), 16, 0, 0); \
-  }
-
-  f32x16 acc[NT];
-#pragma unroll
-  for (int j = 0; j < NT; ++j)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-
-  int bbase[NT];
-#pragma unroll
-  for (int j = 0; j < NT; ++j) {
-    const int br = j * 32 + tx;
-    bbase[j] = br * 128 + ((g ^ ((br >> 1) & 7)) << 4);
-  }
-
-  // (dead second k-step of the last channel group: see conv3x3_kernel; a single loop with a uniform branch here --
-  //  three loop instantiations next to 112 accumulator registers make the register allocator spill)
-  const bool dead_last = p.Cin <= (gpt - 1) * 32 + 16;
-  C3W_ISSUE_PATCH(0, 0);
-  C3W_ISSUE_B(0, 0, 0);
-  int cg = 0, tap = 0;                                   // of k-tile t
-  int cg1 = 0, tap1 = 1;                                 // of k-tile t + 1 (issued in iteration t)
-  bool patch_m1 = false;                                 // a patch was issued in iteration t-1 (after weight tile t)
-
-  // one 16-wide k-step: the column tiles go through the matrix pipe in two chunks (3 + 2 + 2) so that at most ten B
-  // fragments are live next to the 112 accumulator registers
-#define C3W_CHUNK(ks_, J0_, NJ_)                                                                            \
-  {                                                                                                         \
-    h16x8 bh[NJ_], bl[NJ_];                                                                                 \
-    _Pragma("unroll") for (int j = 0; j < (NJ_); ++j) {                                                     \
-      bh[j] = *reinterpret_cast<const h16x8*>(sB + (bbase[(J0_) + j] ^ ((ks_) << 5)));                      \
-      bl[j] = *reinterpret_cast<const h16x8*>(sB + (bbase[(J0_) + j] ^ (((ks_) << 5) | 64)));               \
-    }                                                                                                       \
-    _Pragma("unroll") for (int j = 0; j < (NJ_); ++j)                                                       \
-      acc[(J0_) + j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[j], acc[(J0_) + j], 0, 0, 0);          \
-    _Pragma("unroll") for (int j = 0; j < (NJ_); ++j)                                                       \
-      acc[(J0_) + j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[j], acc[(J0_) + j], 0, 0, 0);          \
-    _Pragma("unroll") for (int j = 0; j < (NJ_); ++j)                                                       \
-      acc[(J0_) + j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[j], acc[(J0_) + j], 0, 0, 0);          \
-  }
-#define C3W_PIN_PAIRS(n_)                                                                                   \
-    _Pragma("unroll") for (int u__ = 0; u__ < (n_); ++u__) {                                                \
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                    \
-      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                    \
-    }
-  // pinned issue order: the reads of chunk c+1 are slotted one per MFMA behind the first MFMAs of chunk c
-#define C3W_KSTEP(ks_)                                                                                      \
-  {                                                                                                         \
-    const h16x8 ah = *reinterpret_cast<const h16x8*>(sP + (abase ^ ((ks_) << 5)));                          \
-    const h16x8 al = *reinterpret_cast<const h16x8*>(sP + (abase ^ (((ks_) << 5) | 64)));                   \
-    C3W_CHUNK(ks_, 0, 3)                                                                                    \
-    C3W_CHUNK(ks_, 3, 2)                                                                                    \
-    C3W_CHUNK(ks_, 5, 2)                                                                                    \
-    __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);                    /* A 2 + chunk 0..2: 6 */         \
-    C3W_PIN_PAIRS(4) __builtin_amdgcn_sched_group_barrier(0x008, 5, 0);   /* 9 MFMAs | 4 reads of chunk 3..4 */ \
-    C3W_PIN_PAIRS(4) __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);   /* 6 MFMAs | 4 reads of chunk 5..6 */ \
-    __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);                                                      \
-  }
-#define C3W_ITER()                                                                                     \
-  {                                                                                                         \
-    /* weight tile t (and, in order before it, patch cg) landed; a patch issued after it may stay in flight */ \
-    if (patch_m1) LOFTR_WAITCNT_VM(PQ);                                                                     \
-    else LOFTR_WAITCNT_VM(0);                                                                               \
-    __builtin_amdgcn_s_barrier();                                                                           \
-    if (t + 1 < nk) C3W_ISSUE_B(cg1, tap1, (t + 1) & 1);                                                    \
-    if (++tap1 == 9) { tap1 = 0; ++cg1; }                                                                   \
-    patch_m1 = false;                                                                                       \
-    if (tap == 0 && cg + 1 < gpt) { C3W_ISSUE_PATCH(cg + 1, (cg + 1) & 1); patch_m1 = true; }               \
-    const int ky = tap / 3, kx = tap - ky * 3;                                                              \
-    const char* sP = patch_base + (cg & 1) * PATCH_BYTES;                                                   \
-    const char* sB = bring_base + (t & 1) * c3w::BTILE_BYTES;                                               \
-    const int pr = (wave + ky) * PW + kx + tx;                     /* patch pixel of this lane's output pixel */ \
-    const int abase = pr * 128 + ((g ^ ((pr >> 1) & 7)) << 4);                                              \
-    C3W_KSTEP(0);                                                                                           \
-    if (!(dead_last && cg == gpt - 1)) C3W_KSTEP(1);                                                        \
-    if (++tap == 9) { tap = 0; ++cg; }                                                                      \
-  }
-  for (int t = 0; t < nk; ++t) C3W_ITER()
-#undef C3W_ITER
-#undef C3W_KSTEP
-#undef C3W_PIN_PAIRS
-#undef C3W_CHUNK
-#undef C3W_ISSUE_PATCH
-#undef C3W_ISSUE_B
-
-  // ---- epilogue: bias (folded BN shift), residual, activation, SP / fp32 stores ---------------------
-  const bool odd = lane & 1;
-  const int Ho = p.H, Wo = p.W;
-  const int y = y0 + wave;
-  // residual words of column tile j_ -> buf_ (raw SP words; rows outside the image / pad columns read as 0)
-#define C3W_RES_LOAD(j_, buf_)                                                                              \
-  {                                                                                                         \
-    const int col__ = (j_) * 32 + tx;                                                                       \
-    const int spc__ = (col__ & ~31) + (odd ? 16 : 0) + ((col__ & 31) >> 1);                                 \
-    _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                        \
-      const int x = x0 + (r & 3) + 8 * (r >> 2) + 4 * g;                                                    \
-      const bool ok = y < Ho && x < Wo && col__ < p.Coutp;                                                  \
-      buf_[r] = ok ? p.residual[(unsigned)(((b * Ho + y) * Wo + x) * p.Coutp + spc__)] : 0u;                \
-    }                                                                                                       \
-  }
-#define C3W_FINISH(j_, buf_, RES_)                                                                          \
-  {                                                                                                         \
-    const int col = (j_) * 32 + tx;                                                                         \
-    const bool creal = col < p.Cout, cpad = col < p.Coutp;                                                  \
-    const float bia = (p.bias && creal) ? p.bias[col] : 0.f;                                                \
-    const float wsc = (creal ? p.wscale[col] : 1.f) * (p.x_inv ? *p.x_inv : 1.f);                           \
-    const int spc = (col & ~31) + (odd ? 16 : 0) + ((col & 31) >> 1);   /* dword of this lane inside the SP row */ \
-    f32x16 v = acc[j_] * wsc;                                                                               \
-    if (RES_) { _Pragma("unroll") for (int r = 0; r < 16; ++r) v[r] += sp_value(buf_[r], odd); }            \
-    _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                        \
-      float xv = v[r] + bia;                                                                                \
-      if (p.act == 1) xv = fmaxf(xv, 0.f);                                                                  \
-      if (p.act == 2) xv = xv > 0.f ? xv : 0.01f * xv;                                                      \
-      v[r] = creal ? xv : 0.f;                                                                              \
-    }                                                                                                       \
-    if (p.y_f32) {                                                                                          \
-      _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                      \
-        const int x = x0 + (r & 3) + 8 * (r >> 2) + 4 * g;                                                  \
-        if (y < Ho && x < Wo && creal) p.y_f32[(unsigned)(((b * Ho + y) * Wo + x) * p.Cout + col)] = v[r];  \
-      }                                                                                                     \
-    }                                                                                                       \
-    if (p.y_sp) {                                                                                           \
-      uint32_t w16[16];                                                                                     \
-      sp_words16(v, odd, w16);                                                                              \
-      _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                      \
-        const int x = x0 + (r & 3) + 8 * (r >> 2) + 4 * g;                                                  \
-        if (y < Ho && x < Wo && cpad) p.y_sp[(unsigned)(((b * Ho + y) * Wo + x) * p.Coutp + spc)] = w16[r]; \
-      }                                                                                                     \
-    }                                                                                                       \
-  }
-  if (p.residual) {
-    // the residual reads run four column tiles ahead of their use (the 112 accumulator registers leave no room for
-    // the compiler to hoist them by itself: seven dependent load -> use rounds cost +30 % on these layers)
-    uint32_t r0[16], r1[16], r2[16], r3[16];
-    C3W_RES_LOAD(0, r0) C3W_RES_LOAD(1, r1) C3W_RES_LOAD(2, r2) C3W_RES_LOAD(3, r3)
-    C3W_FINISH(0, r0, 1) C3W_RES_LOAD(4, r0)
-    C3W_FINISH(1, r1, 1) C3W_RES_LOAD(5, r1)
-    C3W_FINISH(2, r2, 1) C3W_RES_LOAD(6, r2)
-    C3W_FINISH(3, r3, 1) C3W_FINISH(4, r0, 1) C3W_FINISH(5, r1, 1) C3W_FINISH(6, r2, 1)
-  } else {
-    uint32_t none[1] = {0u};
-#pragma unroll
-    for (int j = 0; j < NT; ++j) C3W_FINISH(j, none, 0)
-  }
-#undef C3W_FINISH
-#undef C3W_RES_LOAD
-}
-#endif  // LOFTR_LEGACY_CONV
 
 // Weight preparation: fold eval-mode BN, transpose to tap-major, pad channels, encode as SP.
 //   w [Cout, Cin, KH, KW] -> wsp [Cout, KH*KW*Cp];  bias[co] = beta - mean * scale,  scale = gamma / sqrt(var + eps)
@@ -892,15 +670,11 @@ extern "C" size_t loftr_conv_workspace_bytes(int Cin, int Cout, int KH, int KW) 
 }
 
 // Grid of a persistent kernel that holds one workgroup per CU: min(virtual workgroups, CUs), CUs rounded down to a
-// multiple of the XCD count so that the grid stride keeps every workgroup on its XCD (LOFTR_CONV_PERSIST=0: one
-// workgroup per tile, the non-persistent schedule, for A/B runs; LOFTR_CONV_PERSIST=n >= 8: cap the grid at n).
+// multiple of the XCD count so that the grid stride keeps every workgroup on its XCD (debug switch "conv_persist_cap" = n >= 8:
+// cap the grid at n workgroups -- tests: many tiles per workgroup).
 static unsigned persistent_grid(unsigned nvirt) {
-  static const int forced = []() {                      // -1: ask the device
-    const char* e = getenv("LOFTR_CONV_PERSIST");
-    if (e && atoi(e) == 0) return 0;
-    if (e && atoi(e) >= NUM_XCD) return atoi(e) / NUM_XCD * NUM_XCD;      // explicit workgroup cap (tests: many tiles per workgroup)
-    return -1;
-  }();
+  const int cap = loftr_debug_value(LOFTR_DBG_CONV_PERSIST_CAP);
+  const int forced = cap >= NUM_XCD ? cap / NUM_XCD * NUM_XCD : -1;      // -1: ask the device
   int cus = forced;
   if (cus < 0) {                                        // per CURRENT device (a process may drive several GPUs)
     static int per_dev[64];                             // 0 = not asked yet; benign race: every thread computes the same value
@@ -978,46 +752,29 @@ static int conv_run(const uint32_t* x_sp, int B, int H, int W, int Cin, const vo
   p.up = up_sp; p.Hl = g.Ho / 2; p.Wl = g.Wo / 2;
   p.sy = g.Ho > 1 ? (float)(p.Hl - 1) / (float)(g.Ho - 1) : 0.f;
   p.sx = g.Wo > 1 ? (float)(p.Wl - 1) / (float)(g.Wo - 1) : 0.f;
-  static const int use_patch = []() { const char* e = getenv("LOFTR_CONV_PATCH"); return e ? atoi(e) : 1; }();
-  if (use_patch && KH == 3 && KW == 3 && stride == 1 && pad == 1 && !up_sp) {
+  if (loftr_debug_value(LOFTR_DBG_CONV_PATCH) && KH == 3 && KW == 3 && stride == 1 && pad == 1 && !up_sp) {
     Conv3Args c;
     c.x = x_sp; c.B = B; c.H = H; c.W = W; c.Cp = g.Cp; c.Cin = Cin; c.w = wsp; c.K = K; c.bias = bias; c.wscale = pr.wscale; c.x_inv = x_inv; c.residual = residual_sp;
     c.y_sp = y_sp; c.y_f32 = y_f32; c.Cout = Cout; c.Coutp = ceil32(Cout); c.act = act; c.zeros = zeros;
     c.tiles_x = ceil_div(W, c3::TX); c.tiles_y = ceil_div(H, c3::TY);
-    // LOFTR_CONV_WIDE=0: run 7-column-tile outputs as 128 + 96 columns on the generic kernel (A/B experiments)
-    static const int use_wide = []() { const char* e = getenv("LOFTR_CONV_WIDE"); return e ? atoi(e) : 1; }();
-    const bool wide = use_wide && c.Coutp == 32 * 7;
+    const bool duo = loftr_debug_value(LOFTR_DBG_CONV_DUO) != 0;
+    const bool wide = duo && c.Coutp == 32 * 7;
     TimedLaunch tl(wide ? LOFTR_T_CONV3W : LOFTR_T_CONV3, st);
-    // round 4: conv3x3_duo.h
-    static const int use_duo = []() { const char* e = getenv("LOFTR_CONV_DUO"); return e ? atoi(e) : 9; }();   // default: 128-column tiles on two workgroups per CU, 224-column tiles on one 8-wave workgroup (tools/gpu/r4_octo.sh)
-    // LOFTR_CONV_DUO bits: 1 = 128-column tiles on two 4-wave workgroups per CU, 4 = on one 8-wave workgroup (512 px tiles);
-    //                      2 = 224-column tiles on two 4-wave workgroups, 8 = on one 8-wave workgroup (256 px tiles); 0 = round-3 kernels
-    if ((use_duo & 4) && c.Coutp % 128 == 0) {
-      using CF = c3d::Cfg<4, 2, 4, 8, 1>;
-      c.tiles_y = ceil_div(H, CF::TY);
-      hipLaunchKernelGGL((conv3x3_duo_kernel<CF>), dim3(xcd_grid(B * c.tiles_x * c.tiles_y, c.Coutp / 128)), dim3(512), 0, st, c);
-    } else if ((use_duo & 1) && c.Coutp % 128 == 0) {
+    // round 4 (conv3x3_duo.h): 128-column tiles on two 4-wave workgroups per CU; 192 / 224 columns on one 8-wave workgroup whose wave
+    // pairs split the column tiles (tools/gpu/r4_octo.sh)
+    if (duo && c.Coutp % 128 == 0) {
       using CF = c3d::Cfg<4, 2, 4>;
       c.tiles_y = ceil_div(H, CF::TY);
       hipLaunchKernelGGL((conv3x3_duo_kernel<CF>), dim3(xcd_grid(B * c.tiles_x * c.tiles_y, c.Coutp / 128)), dim3(256), 0, st, c);
-    } else if ((use_duo & 8) && c.Coutp == 192) {        // six column tiles (3 + 3 per wave pair)
+    } else if (duo && c.Coutp == 192) {        // six column tiles (3 + 3 per wave pair)
       using CF = c3d::Cfg<6, 2, 4, 8, 2>;
       c.tiles_y = ceil_div(H, CF::TY);
       hipLaunchKernelGGL((conv3x3_duo_kernel<CF>), dim3(xcd_grid(B * c.tiles_x * c.tiles_y, 1)), dim3(512), 0, st, c);
-    } else if ((use_duo & 8) && wide) {
+    } else if (wide) {
       using CF = c3d::Cfg<7, 2, 4, 8, 2>;
       c.tiles_y = ceil_div(H, CF::TY);
       hipLaunchKernelGGL((conv3x3_duo_kernel<CF>), dim3(xcd_grid(B * c.tiles_x * c.tiles_y, 1)), dim3(512), 0, st, c);
-    } else if ((use_duo & 2) && wide) {
-      using CF = c3d::Cfg<7, 1, 3>;
-      c.tiles_y = ceil_div(H, CF::TY);
-      hipLaunchKernelGGL((conv3x3_duo_kernel<CF>), dim3(xcd_grid(B * c.tiles_x * c.tiles_y, 1)), dim3(256), 0, st, c);
-    }
-#ifdef LOFTR_LEGACY_CONV
-    else if (wide)
-      hipLaunchKernelGGL(conv3x3_wide_kernel, dim3(xcd_grid(B * c.tiles_x * c.tiles_y, 1)), dim3(512), 0, st, c);
-#endif
-    else                          // any other Cout (not a multiple of 128, not 192 / 224): the generic patch kernel, column tiles of 128
+    } else                        // any other Cout (not a multiple of 128, not 192 / 224): the generic patch kernel, column tiles of 128
       hipLaunchKernelGGL(conv3x3_kernel, dim3(shared_gpu ? xcd_grid(B * c.tiles_x * c.tiles_y, ceil_div(c.Coutp, 128))
                                                          : persistent_grid(xcd_grid(B * c.tiles_x * c.tiles_y, ceil_div(c.Coutp, 128)))),
                          dim3(512), 0, st, c);
@@ -1025,18 +782,13 @@ static int conv_run(const uint32_t* x_sp, int B, int H, int W, int Cin, const vo
     return LOFTR_OK;
   }
   {
-    // LOFTR_CONV_DMA=0 selects the register-staged 128x128 configuration (A/B experiments; DMA ring is ~7 % faster)
-    static const int use_dma = []() { const char* e = getenv("LOFTR_CONV_DMA"); return e ? atoi(e) : 1; }();
     TimedLaunch tl(LOFTR_T_CONV, st);
     if (up_sp)
       hipLaunchKernelGGL((conv_kernel<CfgD, true>), dim3(xcd_grid(ceil_div(p.M, CfgD::BM), ceil_div(p.Coutp, CfgD::BN))),
                          dim3(CfgD::THREADS), 0, st, p);
-    else if (use_dma)
+    else
       hipLaunchKernelGGL((conv_kernel<CfgD, false>), dim3(xcd_grid(ceil_div(p.M, CfgD::BM), ceil_div(p.Coutp, CfgD::BN))),
                          dim3(CfgD::THREADS), 0, st, p);
-    else
-      hipLaunchKernelGGL((conv_kernel<CfgR, false>), dim3(xcd_grid(ceil_div(p.M, CfgR::BM), ceil_div(p.Coutp, CfgR::BN))),
-                         dim3(CfgR::THREADS), 0, st, p);
   }
   LOFTR_CHECK_LAUNCH();
   return LOFTR_OK;

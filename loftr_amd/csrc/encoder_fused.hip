@@ -27,6 +27,8 @@
 // HBM traffic per call: x (SP) and x (fp32, residual) in, out (fp32 + SP) in place: 4 tensor streams instead of 13.
 // Weights: 2 MB per workgroup (128 tokens) from the XCD's L2 -- one sequence's workgroups run on one XCD.
 #include "linear.h"
+#include "attention.h"
+#include "coarse_plan.h"
 
 namespace {
 namespace efx {
@@ -42,9 +44,6 @@ namespace efx {
 #endif
 #ifndef EFX_PROBE_EPI
 #define EFX_PROBE_EPI 1
-#endif
-#ifndef EFX_PIPE
-#define EFX_PIPE 0                // 1, 2: inline-asm fragment reads with counted lgkmcnt waits, that many units ahead (measured: 2.88 / 2.97 / 3.27 ms per transformer call for 0 / 1 / 2 -- the third buffer spills inside the loops)
 #endif
 constexpr int W = 4, PT = 32, STAGE = 32 * 1024, NST = EFX_NST, BLK = 4096;     // ring stages: panels are fetched NST - 1 ahead
 constexpr int NPANEL = 16 + 48;                         // 8 x (Wq_h, P_h) + 16 x (W0a, W0b, W2_k)
@@ -102,15 +101,18 @@ __device__ __forceinline__ void pack_panel(const float (&v)[16], h16x8 (&fh)[2],
   }
 }
 
-// One workgroup of the layer: `id` is its index inside the job `a` (= blockIdx.x when the launch holds one job)
-__device__ __forceinline__ void encoder_x_body(const Args& a, const int id, char* const lds) {
-  // ---- workgroup -> (sequence, group of token blocks): a sequence's groups run back to back on one XCD (weights, P in its L2)
-  // (with fewer sequences than XCDs -- 1 / 2 / 4 at the outdoor configuration's batch sizes -- a sequence is cut into xsplit chunks
-  //  of groups that take one XCD each: pinned one sequence per XCD, 2 sequences used 64 of the 256 CUs)
+// workgroup index inside a job -> (sequence, group of token blocks): a sequence's groups run back to back on one XCD (weights, P in
+// its L2); with fewer sequences than XCDs -- 1 / 2 / 4 at the outdoor configuration's batch sizes -- a sequence is cut into xsplit
+// chunks of groups that take one XCD each (pinned one sequence per XCD, 2 sequences used 64 of the 256 CUs)
+__device__ __forceinline__ bool job_tile(const Args& a, const int id, int& seq, int& grp) {
   const int xcd = id % NUM_XCD, slot = id / NUM_XCD;
   const int vs = (slot / a.gpc) * NUM_XCD + xcd;        // virtual sequence = (sequence, chunk)
-  const int seq = vs / a.xsplit, grp = (vs % a.xsplit) * a.gpc + slot % a.gpc;
-  if (seq >= a.nseq || grp >= a.groups) return;
+  seq = vs / a.xsplit; grp = (vs % a.xsplit) * a.gpc + slot % a.gpc;
+  return seq < a.nseq && grp < a.groups;
+}
+
+// One workgroup of the layer: 128 tokens (group `grp` of sequence `seq`) through the whole x side
+__device__ __forceinline__ void encoder_x_body(const Args& a, const int seq, const int grp, char* const lds) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 5, li = lane & 31;
   const int T = a.T;
   const int tok = (grp * W + wave) * PT + li;
@@ -151,6 +153,17 @@ __device__ __forceinline__ void encoder_x_body(const Args& a, const int id, char
     dro[oct] = oct * 8 + (lane >> 3);
     dch[oct] = ((lane & 7) ^ ((oct * 4 + (lane >> 4)) & 7)) << 2;
   }
+#define EFX_ISSUE_SRC(p_, base_, pitch_, kt_)                                                              \
+  {                                                                                                        \
+    char* st__ = lds + ((p_) % NST) * STAGE;                                                               \
+    _Pragma("unroll") for (int bi__ = 0; bi__ < 2; ++bi__) {                                               \
+      const int b__ = wave + 4 * bi__;                                                                     \
+      const sp_t* bb__ = (kt_) ? (base_) + (long)b__ * 32 * (pitch_) : (base_) + b__ * 32;                 \
+      _Pragma("unroll") for (int oct__ = 0; oct__ < 4; ++oct__)                                            \
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(bb__ + dro[oct__] * (pitch_) + dch[oct__]),           \
+                                         (lds_ptr_t)(st__ + b__ * BLK + oct__ * 1024), 16, 0, 0);          \
+    }                                                                                                      \
+  }
 #define EFX_ISSUE(p_)                                                                                      \
   {                                                                                                        \
     const int p__ = (p_);                                                                                  \
@@ -164,26 +177,20 @@ __device__ __forceinline__ void encoder_x_body(const Args& a, const int id, char
       if (i__ == 2) { base__ = a.w2 + hp__ * 32; pitch__ = 512; kt__ = true; }                             \
       else { base__ = a.w0 + (long)hp__ * 32 * 512 + i__ * 256; pitch__ = 512; kt__ = false; }             \
     }                                                                                                      \
-    char* st__ = lds + (p__ % NST) * STAGE;                                                                \
-    _Pragma("unroll") for (int bi__ = 0; bi__ < 2; ++bi__) {                                               \
-      const int b__ = wave + 4 * bi__;                                                                     \
-      const sp_t* bb__ = kt__ ? base__ + (long)b__ * 32 * pitch__ : base__ + b__ * 32;                     \
-      _Pragma("unroll") for (int oct__ = 0; oct__ < 4; ++oct__)                                            \
-        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(bb__ + dro[oct__] * pitch__ + dch[oct__]),            \
-                                         (lds_ptr_t)(st__ + b__ * BLK + oct__ * 1024), 16, 0, 0);          \
-    }                                                                                                      \
+    EFX_ISSUE_SRC(p__, base__, pitch__, kt__)                                                              \
   }
   // panel p has landed once at most the DMAs of the NST - 2 newer panels are outstanding (VMEM operations retire in order); the
   // barrier makes every wave's share visible and proves every wave is past panel p - 1, whose stage panel p + NST - 1 then overwrites
-#define EFX_BEGIN(p_)                                                                                      \
+#define EFX_BEGIN_G(p_, NP_, ISSUE_)                                                                       \
   {                                                                                                        \
     if (!EFX_PROBE_DMA) LOFTR_WAITCNT_VM(0);                                                               \
-    else if (NST >= 4 && (p_) + 2 < NPANEL) LOFTR_WAITCNT_VM(2 * DMA_PER_WAVE);                            \
-    else if ((p_) + 1 < NPANEL) LOFTR_WAITCNT_VM(DMA_PER_WAVE);                                            \
+    else if (NST >= 4 && (p_) + 2 < (NP_)) LOFTR_WAITCNT_VM(2 * DMA_PER_WAVE);                             \
+    else if ((p_) + 1 < (NP_)) LOFTR_WAITCNT_VM(DMA_PER_WAVE);                                             \
     else LOFTR_WAITCNT_VM(0);                                                                              \
     if (EFX_PROBE_BARRIER) __builtin_amdgcn_s_barrier();                                                   \
-    if (EFX_PROBE_DMA && (p_) + NST - 1 < NPANEL) EFX_ISSUE((p_) + NST - 1);                               \
+    if (EFX_PROBE_DMA && (p_) + NST - 1 < (NP_)) ISSUE_((p_) + NST - 1);                                   \
   }
+#define EFX_BEGIN(p_) EFX_BEGIN_G(p_, NPANEL, EFX_ISSUE)
   const int a_off = lds_chunk_off(li, g);               // hi chunk of the even k-step; odd k-step: ^ 32, lo: ^ 64
   // LDS fragment reads run one UNIT (four 16-B fragments, six MFMAs = 192 matrix-pipe cycles) ahead of the MFMAs that
   // consume them -- one wave per SIMD: nobody else hides the ds_read latency.  With LDS-DMA in flight hipcc turns every
@@ -191,102 +198,37 @@ __device__ __forceinline__ void encoder_x_body(const Args& a, const int id, char
   // unit's reads are issued, so it only ever waits for reads issued a whole unit earlier.
 #define EFX_RD(st_, blk_, odd_, lo_) (*reinterpret_cast<const h16x8*>((st_) + (blk_) * BLK + (a_off ^ (((odd_) ? 32 : 0) | ((lo_) ? 64 : 0)))))
 #define EFX_USE(a_, b_, c_, d_) asm volatile("" :: "v"(a_), "v"(b_), "v"(c_), "v"(d_))
-#if EFX_PIPE
-  // ---- fragment reads as inline asm with COUNTED lgkmcnt waits, EFX_PIPE units ahead (the idiom of score_sweep.h, SWEEP_PIPE).
-  // With compiler-visible reads every wait is lgkmcnt(0) (previous note), i.e. a unit can only be ONE unit ahead, and a read
-  // issued behind the first MFMAs of unit u has ~5 MFMAs (160 cycles) to land: the measured LDS latency under four waves' fragment
-  // traffic plus the DMA fills is longer, and with one wave per SIMD every late fragment is a matrix-pipe bubble (bare loop: 42
-  // cycles per MFMA against the 32.7 of tools/micro/mfma_chain.hip).  LDS reads return in order: "unit u has landed" is
-  // lgkmcnt(4 x younger units in flight); the wait statement names the fragments it releases ("+v"), which keeps their MFMAs below it.
-  h16x8 fr[EFX_PIPE + 1][4];
-  const unsigned lds_base = (unsigned)(size_t)(lds_ptr_t)lds;
-#define EFX_LOADU(buf_, A0_, A1_, A2_, A3_, O01_, O23_)                                                    \
-    asm volatile("ds_read_b128 %0, %4 offset:%8\n\tds_read_b128 %1, %5 offset:%8\n\t"                      \
-                 "ds_read_b128 %2, %6 offset:%9\n\tds_read_b128 %3, %7 offset:%9"                           \
-                 : "=&v"(fr[buf_][0]), "=&v"(fr[buf_][1]), "=&v"(fr[buf_][2]), "=&v"(fr[buf_][3])          \
-                 : "v"(A0_), "v"(A1_), "v"(A2_), "v"(A3_), "i"(O01_), "i"(O23_));
-#define EFX_WAITU(buf_, n_)                                                                                \
-    asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(fr[buf_][0]), "+v"(fr[buf_][1]), "+v"(fr[buf_][2]), "+v"(fr[buf_][3]) : "i"(n_));
-#define EFX_YOUNGER(u_) (4 * ((u_) + EFX_PIPE < 8 ? EFX_PIPE : 7 - (u_)))
-  // R panel (32 rows x 256 k): unit u = k-group u (block u): even k-step hi / lo, odd k-step hi / lo
-#define EFX_RLOAD(u_) EFX_LOADU((u_) % (EFX_PIPE + 1), ad0__, ad1__, ad2__, ad3__, (u_) * BLK, (u_) * BLK)
-#define EFX_RUNIT(u_, bh_, bl_)                                                                            \
-    if ((u_) + EFX_PIPE < 8) EFX_RLOAD((u_) + EFX_PIPE)                                                    \
-    EFX_WAITU((u_) % (EFX_PIPE + 1), EFX_YOUNGER(u_))                                                      \
-    {                                                                                                      \
-      const h16x8 eh__ = fr[(u_) % (EFX_PIPE + 1)][0], el__ = fr[(u_) % (EFX_PIPE + 1)][1];                \
-      const h16x8 oh__ = fr[(u_) % (EFX_PIPE + 1)][2], ol__ = fr[(u_) % (EFX_PIPE + 1)][3];                \
-      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(eh__, bl_[2 * (u_)], acc0, 0, 0, 0);                   \
-      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(el__, bh_[2 * (u_)], acc0, 0, 0, 0);                   \
-      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(eh__, bh_[2 * (u_)], acc0, 0, 0, 0);                   \
-      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(oh__, bl_[2 * (u_) + 1], acc0, 0, 0, 0);               \
-      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ol__, bh_[2 * (u_) + 1], acc0, 0, 0, 0);               \
-      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(oh__, bh_[2 * (u_) + 1], acc0, 0, 0, 0);               \
-    }                                                                                                      \
-    __builtin_amdgcn_sched_barrier(0);
-#define EFX_RPANEL(st_, bh_, bl_)                                                                          \
-  {                                                                                                        \
-    const unsigned stb__ = (unsigned)(size_t)(lds_ptr_t)(st_);                                             \
-    const unsigned ad0__ = stb__ + a_off, ad1__ = stb__ + (a_off ^ 64), ad2__ = stb__ + (a_off ^ 32), ad3__ = stb__ + (a_off ^ 96); \
-    EFX_RLOAD(0) if (EFX_PIPE > 1) EFX_RLOAD(1)                                                            \
-    EFX_RUNIT(0, bh_, bl_) EFX_RUNIT(1, bh_, bl_) EFX_RUNIT(2, bh_, bl_) EFX_RUNIT(3, bh_, bl_)            \
-    EFX_RUNIT(4, bh_, bl_) EFX_RUNIT(5, bh_, bl_) EFX_RUNIT(6, bh_, bl_) EFX_RUNIT(7, bh_, bl_)            \
-  }
-  // K panel (256 rows x 32 k): unit u = (output panels 2 (u >> 1), 2 (u >> 1) + 1; k-step u & 1): blocks 2 (u >> 1) and + 1
-#define EFX_KLOAD(u_)                                                                                      \
-    if ((u_) & 1) EFX_LOADU((u_) % (EFX_PIPE + 1), ad2__, ad3__, ad2__, ad3__, 2 * ((u_) >> 1) * BLK, (2 * ((u_) >> 1) + 1) * BLK) \
-    else EFX_LOADU((u_) % (EFX_PIPE + 1), ad0__, ad1__, ad0__, ad1__, 2 * ((u_) >> 1) * BLK, (2 * ((u_) >> 1) + 1) * BLK)
-#define EFX_KUNIT(u_, fh_, fl_, out_)                                                                      \
-    if ((u_) + EFX_PIPE < 8) { EFX_KLOAD((u_) + EFX_PIPE) }                                                \
-    EFX_WAITU((u_) % (EFX_PIPE + 1), EFX_YOUNGER(u_))                                                      \
-    {                                                                                                      \
-      const h16x8 ah__ = fr[(u_) % (EFX_PIPE + 1)][0], al__ = fr[(u_) % (EFX_PIPE + 1)][1];                \
-      const h16x8 bh__ = fr[(u_) % (EFX_PIPE + 1)][2], bl__ = fr[(u_) % (EFX_PIPE + 1)][3];                \
-      constexpr int ja__ = 2 * ((u_) >> 1), jb__ = 2 * ((u_) >> 1) + 1, s__ = (u_) & 1;                    \
-      out_[ja__] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah__, fl_[s__], out_[ja__], 0, 0, 0);            \
-      out_[jb__] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh__, fl_[s__], out_[jb__], 0, 0, 0);            \
-      out_[ja__] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al__, fh_[s__], out_[ja__], 0, 0, 0);            \
-      out_[jb__] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl__, fh_[s__], out_[jb__], 0, 0, 0);            \
-      out_[ja__] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah__, fh_[s__], out_[ja__], 0, 0, 0);            \
-      out_[jb__] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh__, fh_[s__], out_[jb__], 0, 0, 0);            \
-    }                                                                                                      \
-    __builtin_amdgcn_sched_barrier(0);
-#define EFX_KPANEL(st_, fh_, fl_, out_)                                                                    \
-  {                                                                                                        \
-    const unsigned stb__ = (unsigned)(size_t)(lds_ptr_t)(st_);                                             \
-    const unsigned ad0__ = stb__ + a_off, ad1__ = stb__ + (a_off ^ 64), ad2__ = stb__ + (a_off ^ 32), ad3__ = stb__ + (a_off ^ 96); \
-    { EFX_KLOAD(0) } if (EFX_PIPE > 1) { EFX_KLOAD(1) }                                                    \
-    EFX_KUNIT(0, fh_, fl_, out_) EFX_KUNIT(1, fh_, fl_, out_) EFX_KUNIT(2, fh_, fl_, out_) EFX_KUNIT(3, fh_, fl_, out_) \
-    EFX_KUNIT(4, fh_, fl_, out_) EFX_KUNIT(5, fh_, fl_, out_) EFX_KUNIT(6, fh_, fl_, out_) EFX_KUNIT(7, fh_, fl_, out_) \
-  }
-#else
   // R panel: acc0 += W[32 rows][256 k] . B fragments bh / bl; unit u = k-group u = k-steps 2u, 2u + 1.  ONE accumulator chain:
   // a dependent v_mfma_f32_32x32x16_f16 issues at the full rate (tools/micro/mfma_chain.hip: 32.7 cycles per MFMA with 1, 2, 3
   // or 4 chains).  The next unit's four fragment reads are issued in pairs BEHIND the first two MFMAs of this unit -- each pair
   // in the shadow of a 32-cycle MFMA instead of as a burst in front of the unit -- and still >= 4 MFMAs ahead of their wait.
-#define EFX_RPANEL(st_, bh_, bl_)                                                                          \
+#define EFX_RPANEL_G(st_, bh_, bl_, MF_)                                                                   \
   {                                                                                                        \
-    h16x8 eh__ = EFX_RD(st_, 0, 0, 0), el__ = EFX_RD(st_, 0, 0, 1), oh__ = EFX_RD(st_, 0, 1, 0), ol__ = EFX_RD(st_, 0, 1, 1); \
+    h16x8 eh__ = EFX_RD(st_, 0, 0, 0), el__ = EFX_RD(st_, 0, 0, 1), oh__ = EFX_RD(st_, 0, 1, 0), ol__ = EFX_RD(st_, 0, 1, 1);\
     _Pragma("unroll") for (int u = 0; u < 8; ++u) {                                                        \
       EFX_USE(eh__, el__, oh__, ol__);                                                                     \
       __builtin_amdgcn_sched_barrier(0);                                                                   \
       h16x8 neh__ = eh__, nel__ = el__, noh__ = oh__, nol__ = ol__;                                        \
-      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(eh__, bl_[2 * u], acc0, 0, 0, 0);                      \
+      acc0 = MF_(eh__, bl_[2 * u], acc0);                                                                  \
       __builtin_amdgcn_sched_barrier(0);                                                                   \
       if (u + 1 < 8) { neh__ = EFX_RD(st_, u + 1, 0, 0); nel__ = EFX_RD(st_, u + 1, 0, 1); }               \
       __builtin_amdgcn_sched_barrier(0);                                                                   \
-      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(el__, bh_[2 * u], acc0, 0, 0, 0);                      \
+      acc0 = MF_(el__, bh_[2 * u], acc0);                                                                  \
       __builtin_amdgcn_sched_barrier(0);                                                                   \
       if (u + 1 < 8) { noh__ = EFX_RD(st_, u + 1, 1, 0); nol__ = EFX_RD(st_, u + 1, 1, 1); }               \
       __builtin_amdgcn_sched_barrier(0);                                                                   \
-      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(eh__, bh_[2 * u], acc0, 0, 0, 0);                      \
-      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(oh__, bl_[2 * u + 1], acc0, 0, 0, 0);                  \
-      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ol__, bh_[2 * u + 1], acc0, 0, 0, 0);                  \
-      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(oh__, bh_[2 * u + 1], acc0, 0, 0, 0);                  \
+      acc0 = MF_(eh__, bh_[2 * u], acc0);                                                                  \
+      acc0 = MF_(oh__, bl_[2 * u + 1], acc0);                                                              \
+      acc0 = MF_(ol__, bh_[2 * u + 1], acc0);                                                              \
+      acc0 = MF_(oh__, bh_[2 * u + 1], acc0);                                                              \
       __builtin_amdgcn_sched_barrier(0);                                                                   \
       eh__ = neh__; el__ = nel__; oh__ = noh__; ol__ = nol__;                                              \
     }                                                                                                      \
   }
+  // operand order: N = weights (LDS) as A, activations (registers) as B -> D[feature][token];  T = activations as A -> D[token][feature]
+#define EFX_MF_N(w_, x_, c_) __builtin_amdgcn_mfma_f32_32x32x16_f16(w_, x_, c_, 0, 0, 0)
+#define EFX_MF_T(w_, x_, c_) __builtin_amdgcn_mfma_f32_32x32x16_f16(x_, w_, c_, 0, 0, 0)
+#define EFX_RPANEL(st_, bh_, bl_) EFX_RPANEL_G(st_, bh_, bl_, EFX_MF_N)
   // K panel: out_[jp] += W[32 jp .. + 31][32 k] . the two k-step fragments fh / fl; unit u = (output panels 2 j2, 2 j2 + 1,
   // k-step s): six MFMAs, the next unit's reads behind the first two
 #define EFX_KPANEL(st_, fh_, fl_, out_)                                                                    \
@@ -315,7 +257,6 @@ __device__ __forceinline__ void encoder_x_body(const Args& a, const int id, char
     }                                                                                                      \
   }
 
-#endif
   LOFTR_WAITCNT_VM(0);                                  // x fragments, tables: complete before the first DMA
   __syncthreads();
   EFX_ISSUE(0);
@@ -436,19 +377,6 @@ __device__ __forceinline__ void encoder_x_body(const Args& a, const int id, char
     if (live) EFX_KPANEL(lds + ((p + 2) % NST) * STAGE, hh, hl, big);
   }
 #undef EFX_PASS2_HEAD
-#undef EFX_RPANEL
-#undef EFX_KPANEL
-#undef EFX_RD
-#undef EFX_USE
-#if EFX_PIPE
-#undef EFX_LOADU
-#undef EFX_WAITU
-#undef EFX_YOUNGER
-#undef EFX_RLOAD
-#undef EFX_RUNIT
-#undef EFX_KLOAD
-#undef EFX_KUNIT
-#endif
 
   // ================= out = x + LayerNorm2(mlp.2 output), fp32 and SP                                          transformer.py:55-58
   if (!live) return;
@@ -525,7 +453,8 @@ __device__ __forceinline__ void encoder_x_body(const Args& a, const int id, char
 
 __global__ __launch_bounds__(W * 64, 1) void encoder_x_kernel(Args a) {
   __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
-  encoder_x_body(a, blockIdx.x, lds);
+  int seq, grp;
+  if (job_tile(a, blockIdx.x, seq, grp)) encoder_x_body(a, seq, grp, lds);
 }
 
 // TWO jobs in one launch.  A call's time is set by whole rounds of 256 workgroups (one per CU: tools/gpu/r4_enc_sweep.sh -- 256
@@ -538,57 +467,80 @@ __global__ __launch_bounds__(W * 64, 1) void encoder_x2_kernel(Args2 m) {
   __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
   const bool second = (int)blockIdx.x >= m.n0;          // workgroup-uniform
   const Args* a = second ? &m.j[1] : &m.j[0];           // (one copy of the body: its arguments come from a uniform kernarg offset)
-  encoder_x_body(*a, second ? (int)blockIdx.x - m.n0 + m.off1 : (int)blockIdx.x + m.off0, lds);
+  int seq, grp;
+  if (job_tile(*a, second ? (int)blockIdx.x - m.n0 + m.off1 : (int)blockIdx.x + m.off0, seq, grp)) encoder_x_body(*a, seq, grp, lds);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// The TAIL of a launch.  encoder_x_kernel's unit of work is one wave x 32 tokens for the whole layer (~110 us): a call with
-// 1200 blocks on the 1024 SIMDs costs two rounds although it holds 1.17 rounds of work.  The blocks beyond the last full
-// round of workgroups go through this kernel instead: ONE 32-token block per workgroup, its four waves sharing every panel:
-//   * an R panel (32 output features x 256 k) is split along K -- wave w owns k-steps 4 w .. 4 w + 3, i.e. features 64 w .. + 63 of
-//     the input, and holds only that slice of x and of the message (32 registers each); the four partial 32 x 32 tiles are
-//     all-reduced through a 16 KB LDS buffer (fixed order: every wave gets bitwise the same sum) and every wave runs the
-//     (cheap) epilogue redundantly, so all of them hold the resulting Q' / hidden fragments;
-//   * a K panel (256 output features x 32 k) is split along N -- wave w owns output panels 2 w, 2 w + 1: no exchange, and what it
-//     accumulates (features 64 w .. + 63 of the message, then of the output) is exactly the K slice it needs next: the N split
-//     of one stage IS the K split of the following one.  LayerNorm combines four per-wave (mean, M2) pairs (exact parallel form).
-// Per block: 864 MFMAs per wave instead of 3072, 24 exchanges; the weights are streamed per 32 tokens here (4x the main kernel's
-// L2 traffic per token), which is why this is the tail path and not the kernel.
-constexpr int OFF_XB = OFF_TAB + T_N * 4, OFF_ST = OFF_XB + 4 * 4096, LDS_BYTES_C = OFF_ST + 4 * 32 * 8;
-static_assert(LDS_BYTES_C <= 160 * 1024, "one workgroup per CU");
+// The PERSISTENT coarse transformer (round 6): one launch per LocalFeatureTransformer.forward (transformer.py:80-101).
+//
+// Until round 5 a transformer call was 12 encoder_x launches + 15 proj_kv + 15 kv_finalize launches, every one a grid-wide barrier: a
+// launch's time is whole rounds of 256 workgroups (one per CU, ~110 us each), and at the BASELINE size (8 pairs x 4800 tokens = 300 /
+// 600 workgroups per call) the x side ran 25 rounds for 19 rounds of work (profiles/r05_encoder_rounds.txt).  But the dependency
+// `feat1 attends to the UPDATED feat0` (transformer.py:96-97) is PER PAIR and, below that, per 128-token tile:
+//     K(c, p, t)   k / v projection of tile t of pair p's source + its partial K^T V      needs the X item that last wrote that tile
+//     F(c, p, h)   fixed-order sum of the partials of head h, KV folded into the merge weight (P)      needs all K(c, p, .)
+//     X(c, p, g)   the whole x side of the layer for 128 tokens (encoder_x_body)          needs all F(c, p, .), the X item that last
+//                  wrote its tile, and (write-after-read) the F items of every other call that reads the tile's OLD content
+// so here 256 resident workgroups pull these items from ONE queue whose order the host planned (coarse_plan in transformer.hip: a
+// list schedule of the dependency graph, critical path first) and wait on per-item / per-(call, pair) counters in HBM.  The queue
+// order is a topological order and items are popped in order, so an item's dependencies are always held by running workgroups: no
+// deadlock whatever the residency.  Visibility between workgroups: agent-scope release (buffer_wbl2 sc1) by one lane after the
+// workgroup's stores have drained, relaxed counter add; consumer: relaxed poll by one lane, agent-scope acquire (buffer_inv sc1),
+// barrier, plain loads -- placement independent (guide: "inter-workgroup communication").
+// Results do not depend on the queue order: every item computes from the same inputs in the same internal order
+// (tests: dependency order vs call order bit-identical).
+struct PctCall { int layer, x_img, s_img, pad; };
+struct PctArgs {
+  float* f32[2]; sp_t* sp[2]; const uint8_t* mask[2]; int T[2];
+  int N, n_calls, n_items, splits;                      // splits: row tiles per sequence the partial buffers are strided by (max over the images)
+  const PctItem* items; unsigned* cnt;                  // cnt[0] = queue head, cnt[1] = error word, cnt[2] = plan signature check, cnt[PCT_CNT0 ..] dependency counters
+  float* part; float* kv; sp_t* pm;                     // per (call, pair): [8][splits][33][32], [8][33][32], [256][256] SP
+  unsigned long long* trace;                            // null, or per item {popped, ready, done, workgroup} (wall_clock64: 100 MHz)
+  unsigned* status;                                     // null, or where the error word is copied to
+  unsigned signature; int skip;
+  PctLayerPtrs layer[PCT_MAX_LAYERS]; PctCall call[PCT_MAX_CALLS];
+};
+constexpr int OFF_RED = OFF_TAB + T_N * 4, RED_FLOATS = 33 * 32, OFF_CTRL = OFF_RED + W * RED_FLOATS * 4, LDS_BYTES_P = OFF_CTRL + 64;
+static_assert(LDS_BYTES_P <= 160 * 1024, "one workgroup per CU");
 
-__global__ __launch_bounds__(W * 64, 1) void encoder_xc_kernel(Args a, int id0) {
-  __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES_C];
-  const int id = id0 + (int)(blockIdx.x >> 2), xcd = id % NUM_XCD, slot = id / NUM_XCD;
-  const int seq = (slot / a.groups) * NUM_XCD + xcd, grp = slot % a.groups;
-  const int blk = grp * W + (int)(blockIdx.x & 3);
-  const int T = a.T;
-  if (seq >= a.nseq || blk * PT >= T) return;
+// ---- K item: k / v projection of 128 source tokens + their partial K^T V and K sum (replaces proj_kv_kernel, linear.hip) ------------
+//   linear_attention.py:31-32 (elu + 1), :37-42 (masks, values / v_length), :43-44 (einsum nshd,nshv->nhdv; K.sum)
+// Same frame as encoder_x_body: a wave owns 32 tokens, their SP fragments stay in registers, the interleaved [K_h | V_h] weight rows
+// (transformer.hip: stage_layer) stream through the LDS ring as 16 R panels.  Here the activations are the MFMA's A operand, so
+// D[token][feature]: lane = feature d (resp. v) of the head, registers = 16 of the wave's tokens -- exactly the operands of the fp32
+// MFMA that contracts over the tokens (KV_h[d][v] += K[t][d] V[t][v], 16 v_mfma_f32_32x32x2_f32 per head as in proj_kv_kernel).
+// The four waves' results are summed through LDS in a fixed order: one partial per (tile, head), [33][32] (row 32 = K sum).
+struct KvTile {
+  const sp_t* x_sp; const uint8_t* mask; int T;         // the source sequence (already offset to it), its mask or null
+  const sp_t* wkv; const float* wkv_s;
+  float inv_s;
+  float* part; long head_stride;                        // partial of head h at part + h * head_stride
+};
+__device__ __forceinline__ void kv_tile_body(const KvTile& a, const int tile, char* const lds) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 5, li = lane & 31;
-  const int tok = blk * PT + li;
-  const long row = (long)seq * T + min(tok, T - 1);
+  const int T = a.T;
+  const int tok0 = (tile * W + wave) * PT;
+  const bool live = tok0 < T;                           // wave-uniform
+  const int nlive = min(W, (T - tile * W * PT + PT - 1) / PT);
   float* tab = reinterpret_cast<float*>(lds + OFF_TAB);
-  for (int f = threadIdx.x; f < 256; f += W * 64) {
-    tab[T_WQS + f] = a.wq_s[f];
-    tab[T_KSUM + f] = a.kv[((long)seq * 8 + (f >> 5)) * (33 * 32) + 32 * 32 + (f & 31)];
-    tab[T_G1 + f] = a.g1[f]; tab[T_B1 + f] = a.b1[f];
-    tab[T_W0S + f] = a.w0_s[f]; tab[T_W0S + 256 + f] = a.w0_s[256 + f];
-    tab[T_W2S + f] = a.w2_s[f];
-    tab[T_G2 + f] = a.g2[f]; tab[T_B2 + f] = a.b2[f];
-  }
-  const float mk = (a.mask && !a.mask[row]) ? 0.f : 1.f;
-  // this wave's K slice of x: k-steps 4 wave + i (features 64 wave + 16 i + 8 g + e)
-  h16x8 xh[4], xl[4];
+  for (int f = threadIdx.x; f < 512; f += W * 64) tab[T_W0S + f] = a.wkv_s[f];
+  h16x8 xh[16], xl[16];
   {
-    const u32x4* src = reinterpret_cast<const u32x4*>(a.x_sp + row * 256);
+    const u32x4* src = reinterpret_cast<const u32x4*>(a.x_sp + (long)min(tok0 + li, T - 1) * 256);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int ks = 4 * wave + i, c = (ks >> 1) * 8 + 2 * (ks & 1) + g;
-      xh[i] = __builtin_bit_cast(h16x8, src[c]);
-      xl[i] = __builtin_bit_cast(h16x8, src[c + 4]);
+    for (int ks = 0; ks < 16; ++ks) {
+      const int c = (ks >> 1) * 8 + 2 * (ks & 1) + g;
+      xh[ks] = __builtin_bit_cast(h16x8, src[c]);
+      xl[ks] = __builtin_bit_cast(h16x8, src[c + 4]);
     }
   }
-  const sp_t* pm = a.pm + (long)seq * a.pm_seq_stride;
+  float mk[16];                                         // register r <-> token tok0 + (r & 3) + 8 (r >> 2) + 4 g
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int t = tok0 + (r & 3) + 8 * (r >> 2) + 4 * g;
+    mk[r] = (t < T && (!a.mask || a.mask[min(t, T - 1)])) ? 1.f : 0.f;
+  }
   int dro[4], dch[4];
 #pragma unroll
   for (int oct = 0; oct < 4; ++oct) {
@@ -596,247 +548,260 @@ __global__ __launch_bounds__(W * 64, 1) void encoder_xc_kernel(Args a, int id0) 
     dch[oct] = ((lane & 7) ^ ((oct * 4 + (lane >> 4)) & 7)) << 2;
   }
   const int a_off = lds_chunk_off(li, g);
-  const bool live = true; (void)live;
-  // exchange buffer: partial tile of wave w, register quad q, lane l at ((w * 4 + q) * 64 + l) * 16
-  const unsigned xb_w = (unsigned)(size_t)(lds_ptr_t)(lds + OFF_XB) + (unsigned)((wave * 4 * 64 + lane) * 16);
-  const char* xb_r = lds + OFF_XB + lane * 16;
-  const unsigned st_w = (unsigned)(size_t)(lds_ptr_t)(lds + OFF_ST) + (unsigned)((wave * 32 + li) * 8);
-  const float2* st_r = reinterpret_cast<const float2*>(lds + OFF_ST) + li;
-#define EFX_CRD(st_, blk_, odd_, lo_) (*reinterpret_cast<const h16x8*>((st_) + (blk_) * BLK + (a_off ^ (((odd_) ? 32 : 0) | ((lo_) ? 64 : 0)))))
-  // this wave's share of an R panel: k-groups 2 wave, 2 wave + 1 against its K slice bh / bl (four k-steps)
-#define EFX_CR(st_, bh_, bl_, acc_)                                                                        \
-  {                                                                                                        \
-    const char* s0__ = (st_) + (2 * wave) * BLK;                                                           \
-    const h16x8 e0h = EFX_CRD(s0__, 0, 0, 0), e0l = EFX_CRD(s0__, 0, 0, 1), o0h = EFX_CRD(s0__, 0, 1, 0), o0l = EFX_CRD(s0__, 0, 1, 1); \
-    const h16x8 e1h = EFX_CRD(s0__, 1, 0, 0), e1l = EFX_CRD(s0__, 1, 0, 1), o1h = EFX_CRD(s0__, 1, 1, 0), o1l = EFX_CRD(s0__, 1, 1, 1); \
-    acc_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(e0h, bl_[0], acc_, 0, 0, 0);                             \
-    acc_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(e0l, bh_[0], acc_, 0, 0, 0);                             \
-    acc_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(e0h, bh_[0], acc_, 0, 0, 0);                             \
-    acc_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(o0h, bl_[1], acc_, 0, 0, 0);                             \
-    acc_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(o0l, bh_[1], acc_, 0, 0, 0);                             \
-    acc_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(o0h, bh_[1], acc_, 0, 0, 0);                             \
-    acc_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(e1h, bl_[2], acc_, 0, 0, 0);                             \
-    acc_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(e1l, bh_[2], acc_, 0, 0, 0);                             \
-    acc_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(e1h, bh_[2], acc_, 0, 0, 0);                             \
-    acc_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(o1h, bl_[3], acc_, 0, 0, 0);                             \
-    acc_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(o1l, bh_[3], acc_, 0, 0, 0);                             \
-    acc_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(o1h, bh_[3], acc_, 0, 0, 0);                             \
-  }
-  // this wave's share of a K panel: output panels 2 wave, 2 wave + 1 against the two k-step fragments fh / fl
-#define EFX_CK(st_, fh_, fl_, o0_, o1_)                                                                    \
-  {                                                                                                        \
-    const char* s0__ = (st_) + (2 * wave) * BLK;                                                           \
-    const h16x8 a0h = EFX_CRD(s0__, 0, 0, 0), a0l = EFX_CRD(s0__, 0, 0, 1), a1h = EFX_CRD(s0__, 0, 1, 0), a1l = EFX_CRD(s0__, 0, 1, 1); \
-    const h16x8 b0h = EFX_CRD(s0__, 1, 0, 0), b0l = EFX_CRD(s0__, 1, 0, 1), b1h = EFX_CRD(s0__, 1, 1, 0), b1l = EFX_CRD(s0__, 1, 1, 1); \
-    o0_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h, fl_[0], o0_, 0, 0, 0);                               \
-    o1_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(b0h, fl_[0], o1_, 0, 0, 0);                               \
-    o0_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0l, fh_[0], o0_, 0, 0, 0);                               \
-    o1_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(b0l, fh_[0], o1_, 0, 0, 0);                               \
-    o0_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h, fh_[0], o0_, 0, 0, 0);                               \
-    o1_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(b0h, fh_[0], o1_, 0, 0, 0);                               \
-    o0_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, fl_[1], o0_, 0, 0, 0);                               \
-    o1_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(b1h, fl_[1], o1_, 0, 0, 0);                               \
-    o0_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1l, fh_[1], o0_, 0, 0, 0);                               \
-    o1_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(b1l, fh_[1], o1_, 0, 0, 0);                               \
-    o0_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, fh_[1], o0_, 0, 0, 0);                               \
-    o1_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(b1h, fh_[1], o1_, 0, 0, 0);                               \
-  }
-  // all-reduce of the four waves' partial tiles (asm LDS stores: a compiler-visible one would drain the weight DMA); the
-  // buffer is reused by the next exchange only after at least one panel barrier, which every wave reaches after its reads
-#define EFX_XCHG(acc_, full_)                                                                              \
-  {                                                                                                        \
-    _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                        \
-      const f32x4 v4__ = {acc_[4 * q], acc_[4 * q + 1], acc_[4 * q + 2], acc_[4 * q + 3]};                 \
-      asm volatile("ds_write_b128 %0, %1 offset:%2" :: "v"(xb_w), "v"(v4__), "i"(q * 1024) : "memory");    \
-    }                                                                                                      \
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                     \
-    __builtin_amdgcn_s_barrier();                                                                          \
-    _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                        \
-      f32x4 s4__ = *reinterpret_cast<const f32x4*>(xb_r + (0 * 4 + q) * 1024);                             \
-      s4__ += *reinterpret_cast<const f32x4*>(xb_r + (1 * 4 + q) * 1024);                                  \
-      s4__ += *reinterpret_cast<const f32x4*>(xb_r + (2 * 4 + q) * 1024);                                  \
-      s4__ += *reinterpret_cast<const f32x4*>(xb_r + (3 * 4 + q) * 1024);                                  \
-      full_[4 * q] = s4__[0]; full_[4 * q + 1] = s4__[1]; full_[4 * q + 2] = s4__[2]; full_[4 * q + 3] = s4__[3]; \
+  const sp_t* const wkv = a.wkv;
+#define KVX_ISSUE(p_) EFX_ISSUE_SRC((p_), wkv + (long)(p_) * 32 * 256, 256, false)
+  // reduction buffer: wave w's [33][32] block; element (d, v) of the fp32 MFMA's D: row d = (r & 3) + 8 (r >> 2) + 4 g, column v = li
+  const unsigned red_w = (unsigned)(size_t)(lds_ptr_t)(lds + OFF_RED) + (unsigned)((wave * RED_FLOATS + 4 * g * 32 + li) * 4);
+  const char* red_r = lds + OFF_RED;
+  // the sum of head h's four blocks (live waves only, fixed order) -> the tile's partial; done by wave h & 3 one barrier after the blocks were written
+#define KVX_REDUCE(h_)                                                                                     \
+  if (wave == ((h_) & 3)) {                                                                                \
+    float* out__ = a.part + (long)(h_) * a.head_stride;                                                    \
+    _Pragma("unroll") for (int u = 0; u < 5; ++u) {                                                        \
+      const int v__ = lane + u * 64;                                                                       \
+      if (v__ < RED_FLOATS / 4) {                                                                          \
+        f32x4 s__ = *reinterpret_cast<const f32x4*>(red_r + v__ * 16);                                     \
+        if (nlive > 1) s__ += *reinterpret_cast<const f32x4*>(red_r + 1 * RED_FLOATS * 4 + v__ * 16);     \
+        if (nlive > 2) s__ += *reinterpret_cast<const f32x4*>(red_r + 2 * RED_FLOATS * 4 + v__ * 16);     \
+        if (nlive > 3) s__ += *reinterpret_cast<const f32x4*>(red_r + 3 * RED_FLOATS * 4 + v__ * 16);     \
+        reinterpret_cast<f32x4*>(out__)[v__] = s__;                                                        \
+      }                                                                                                    \
     }                                                                                                      \
   }
-  // LayerNorm statistics over the 256 features of a token: this wave holds 64 of them (v_[2][16] + the partner lane's)
-#define EFX_CSTATS(v_, mean_, rstd_, eps_)                                                                 \
-  {                                                                                                        \
-    float s__ = 0.f;                                                                                       \
-    _Pragma("unroll") for (int j = 0; j < 2; ++j) _Pragma("unroll") for (int r = 0; r < 16; ++r) s__ += v_[j][r]; \
-    s__ += swap32(s__);                                                                                    \
-    const float mw__ = s__ * (1.f / 64.f);                                                                 \
-    float m2__ = 0.f;                                                                                      \
-    _Pragma("unroll") for (int j = 0; j < 2; ++j) _Pragma("unroll") for (int r = 0; r < 16; ++r) { const float d = v_[j][r] - mw__; m2__ = fmaf(d, d, m2__); } \
-    m2__ += swap32(m2__);                                                                                  \
-    if (g == 0) { const f32x2 pr__ = {mw__, m2__}; asm volatile("ds_write_b64 %0, %1" :: "v"(st_w), "v"(pr__) : "memory"); } \
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                     \
-    __builtin_amdgcn_s_barrier();                                                                          \
-    const float2 e0 = st_r[0], e1 = st_r[32], e2 = st_r[64], e3 = st_r[96];                                \
-    mean_ = (e0.x + e1.x + e2.x + e3.x) * 0.25f;                                                           \
-    const float d0 = e0.x - mean_, d1 = e1.x - mean_, d2 = e2.x - mean_, d3 = e3.x - mean_;                \
-    const float M2__ = (e0.y + e1.y + e2.y + e3.y) + 64.f * (d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3);       \
-    rstd_ = rsqrtf(M2__ * (1.f / 256.f) + (eps_));                                                         \
-  }
-
-  LOFTR_WAITCNT_VM(0);
+  LOFTR_WAITCNT_VM(0);                                  // x fragments, tables: complete before the first DMA
   __syncthreads();
-  EFX_ISSUE(0);
-  EFX_ISSUE(1);
-  if (NST >= 4) EFX_ISSUE(2);
-  const int fq = 4 * g;
-  f32x16 acc, big0, big1;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) { big0[r] = 0.f; big1[r] = 0.f; }
-  // ================= pass 1
+  KVX_ISSUE(0);
+  KVX_ISSUE(1);
+  if (NST >= 4) KVX_ISSUE(2);
+  f32x16 acc0, acck;
 #pragma unroll 1
   for (int h = 0; h < 8; ++h) {
     const int p = 2 * h;
-    EFX_BEGIN(p);
+    EFX_BEGIN_G(p, 16, KVX_ISSUE);
+    if (h > 0) KVX_REDUCE(h - 1)
+    if (live) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    EFX_CR(lds + (p % NST) * STAGE, xh, xl, acc);
-    float full[16];
-    EFX_XCHG(acc, full);
-    float v[16], den = 0.f;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const f32x4 ws = *reinterpret_cast<const f32x4*>(tab + T_WQS + 32 * h + fq + 8 * q);
-      const f32x4 ks4 = *reinterpret_cast<const f32x4*>(tab + T_KSUM + 32 * h + fq + 8 * q);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        float x = full[4 * q + e] * ws[e];
-        x = x > 0.f ? x + 1.f : __expf(x);
-        x *= mk;
-        v[4 * q + e] = x;
-        den = fmaf(x, ks4[e], den);
-      }
+      for (int r = 0; r < 16; ++r) acc0[r] = 0.f;
+      EFX_RPANEL_G(lds + (p % NST) * STAGE, xh, xl, EFX_MF_T);
+      acck = acc0;
     }
-    den += swap32(den);
-    const float z = a.v_length * __builtin_amdgcn_rcpf(den + a.attn_eps);
+    EFX_BEGIN_G(p + 1, 16, KVX_ISSUE);
+    if (live) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) v[r] *= z;
-    h16x8 qh[2], ql[2];
-    pack_panel(v, qh, ql);
-    EFX_BEGIN(p + 1);
-    EFX_CK(lds + ((p + 1) % NST) * STAGE, qh, ql, big0, big1);
-  }
-  // ---- message slice = LayerNorm1 over all 256 features, this wave's 64 -> its K slice of the mlp.0 input
-  h16x8 mh[4], ml[4];
-  {
-    float vv[2][16];
+      for (int r = 0; r < 16; ++r) acc0[r] = 0.f;
+      EFX_RPANEL_G(lds + ((p + 1) % NST) * STAGE, xh, xl, EFX_MF_T);
+      const float wk = tab[T_W0S + 64 * h + li], wv = tab[T_W0S + 64 * h + 32 + li];
+      float ksum = 0.f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { vv[0][r] = big0[r] * a.p_out_scale; vv[1][r] = big1[r] * a.p_out_scale; }
-    float mean, rstd;
-    EFX_CSTATS(vv, mean, rstd, a.ln_eps);
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      float y[16];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int f = 32 * (2 * wave + j) + fq + 8 * q;
-        const f32x4 ga = *reinterpret_cast<const f32x4*>(tab + T_G1 + f);
-        const f32x4 be = *reinterpret_cast<const f32x4*>(tab + T_B1 + f);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) y[4 * q + e] = (vv[j][4 * q + e] - mean) * rstd * ga[e] + be[e];
+      for (int r = 0; r < 16; ++r) {
+        const float k = acck[r] * wk;
+        acck[r] = (k > 0.f ? k + 1.f : __expf(k)) * mk[r];            // elu(k) + 1, masked
+        acc0[r] = acc0[r] * (wv * (mk[r] * a.inv_s));                  // values * mask / v_length
+        ksum += acck[r];
       }
-      h16x8 fh[2], fl[2];
-      pack_panel(y, fh, fl);
-      mh[2 * j] = fh[0]; mh[2 * j + 1] = fh[1]; ml[2 * j] = fl[0]; ml[2 * j + 1] = fl[1];
+      f32x16 kv;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) kv[r] = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) kv = __builtin_amdgcn_mfma_f32_32x32x2f32(acck[r], acc0[r], kv, 0, 0, 0);
+      ksum += swap32(ksum);
+      // (asm LDS stores: a compiler-visible one would drain the weight DMA in flight)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        asm volatile("ds_write_b32 %0, %1 offset:%2" :: "v"(red_w), "v"(kv[r]), "i"(((r & 3) + 8 * (r >> 2)) * 128) : "memory");
+      if (g == 0) asm volatile("ds_write_b32 %0, %1 offset:%2" :: "v"(red_w), "v"(ksum), "i"(32 * 128) : "memory");
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
   }
-#pragma unroll
-  for (int r = 0; r < 16; ++r) { big0[r] = 0.f; big1[r] = 0.f; }
-  // ================= pass 2
-#pragma unroll 1
-  for (int hp = 0; hp < 16; ++hp) {
-    const int p = 16 + 3 * hp;
-    EFX_BEGIN(p);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    EFX_CR(lds + (p % NST) * STAGE, xh, xl, acc);
-    EFX_BEGIN(p + 1);
-    EFX_CR(lds + ((p + 1) % NST) * STAGE, mh, ml, acc);
-    float full[16];
-    EFX_XCHG(acc, full);
-    float v[16];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const f32x4 ws = *reinterpret_cast<const f32x4*>(tab + T_W0S + 32 * hp + fq + 8 * q);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) v[4 * q + e] = fmaxf(full[4 * q + e] * ws[e], 0.f);
-    }
-    h16x8 hh[2], hl[2];
-    pack_panel(v, hh, hl);
-    EFX_BEGIN(p + 2);
-    EFX_CK(lds + ((p + 2) % NST) * STAGE, hh, hl, big0, big1);
-  }
-  // ================= out slice = x + LayerNorm2(mlp.2 output), features 64 wave .. + 63
-  {
-    float vv[2][16];
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const f32x4 ws = *reinterpret_cast<const f32x4*>(tab + T_W2S + 32 * (2 * wave + j) + fq + 8 * q);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) vv[j][4 * q + e] = (j ? big1[4 * q + e] : big0[4 * q + e]) * ws[e];
-      }
-    float mean, rstd;
-    EFX_CSTATS(vv, mean, rstd, a.ln_eps);
-    if (tok < T) {
-      const float* xr = a.x_f32 + row * 256;
-      float* of = a.out_f32 + row * 256;
-      sp_t* os = a.out_sp + row * 256;
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int jp = 2 * wave + j;
-        float y[16];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int f = 32 * jp + fq + 8 * q;
-          const f32x4 ga = *reinterpret_cast<const f32x4*>(tab + T_G2 + f);
-          const f32x4 be = *reinterpret_cast<const f32x4*>(tab + T_B2 + f);
-          const f32x4 xr4 = *reinterpret_cast<const f32x4*>(xr + f);
-          f32x4 o;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            o[e] = xr4[e] + ((vv[j][4 * q + e] - mean) * rstd * ga[e] + be[e]);
-            y[4 * q + e] = o[e];
-          }
-          *reinterpret_cast<f32x4*>(of + f) = o;
-        }
-        if (!a.out_sp) continue;
-        h16x8 fh[2], fl[2];
-        pack_panel(y, fh, fl);
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-          *reinterpret_cast<u32x4*>(os + jp * 32 + (2 * s2 + g) * 4) = __builtin_bit_cast(u32x4, fh[s2]);
-          *reinterpret_cast<u32x4*>(os + jp * 32 + 16 + (2 * s2 + g) * 4) = __builtin_bit_cast(u32x4, fl[s2]);
-        }
-      }
-    }
-  }
-#undef EFX_CRD
-#undef EFX_CR
-#undef EFX_CK
-#undef EFX_XCHG
-#undef EFX_CSTATS
+  __builtin_amdgcn_s_barrier();
+  KVX_REDUCE(7)
+#undef KVX_ISSUE
+#undef KVX_REDUCE
 }
+
+// ---- F item: head h of a (call, pair): sum of the row-tile partials in a fixed order, KV folded into the merge projection ----------
+// The arithmetic of kv_finalize_kernel (attention.hip), thread for thread: P[j][h * 32 + d] = sum_v KV[d][v] Wm[j][h * 32 + v], SP.
+__device__ __forceinline__ void kv_final_body(const float* part, const int splits, float* kvout, const float* wm, const int h,
+                                              sp_t* pm, char* const lds) {
+  float* skv = reinterpret_cast<float*>(lds);
+  float* sgrp = reinterpret_cast<float*>(lds + 8192);   // [4][33 * 32]
+  {
+    constexpr int NV = 33 * 32 / 4;
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    f32x4 a[5];
+#pragma unroll
+    for (int u = 0; u < 5; ++u) a[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+    for (int k = w; k < splits; k += 4) {
+      const f32x4* pk = reinterpret_cast<const f32x4*>(part + (long)k * (33 * 32));
+#pragma unroll
+      for (int u = 0; u < 5; ++u) {
+        const int v = lane + u * 64;
+        if (v < NV) a[u] += pk[v];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 5; ++u) {
+      const int v = lane + u * 64;
+      if (v < NV) reinterpret_cast<f32x4*>(sgrp + w * (33 * 32))[v] = a[u];
+    }
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < 33 * 32; e += 256) {
+    const float s = ((sgrp[e] + sgrp[33 * 32 + e]) + sgrp[2 * 33 * 32 + e]) + sgrp[3 * 33 * 32 + e];
+    kvout[e] = s;
+    skv[e] = s;
+  }
+  __syncthreads();
+  const int q = threadIdx.x & 3;
+#pragma unroll 1
+  for (int z = 0; z < 4; ++z) {
+    const int j = z * 64 + (threadIdx.x >> 2);
+    f32x4 w4[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) w4[i] = reinterpret_cast<const f32x4*>(wm + (long)j * 256 + h * 32)[i];
+    float r[8];
+#pragma unroll
+    for (int dd = 0; dd < 8; ++dd) {
+      const float* kvrow = &skv[(q * 8 + dd) * 32];
+      float s = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const f32x4 k4 = *reinterpret_cast<const f32x4*>(kvrow + i * 4);
+        s += k4.x * w4[i].x + k4.y * w4[i].y + k4.z * w4[i].z + k4.w * w4[i].w;
+      }
+      r[dd] = s * ATTN_P_SCALE;
+    }
+    u32x4 hi, lo;
+    sp_pack8(r, hi, lo);
+    sp_t* dst = pm + (long)j * 256 + h * 32 + q * 4;
+    *reinterpret_cast<u32x4*>(dst) = hi;
+    *reinterpret_cast<u32x4*>(dst + 16) = lo;
+  }
+}
+
+typedef __attribute__((address_space(1))) unsigned gu32;
+__device__ __forceinline__ unsigned pct_load(unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+__global__ __launch_bounds__(W * 64, 1) void coarse_persistent_kernel(PctArgs P) {
+  __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES_P];
+  int* const ctrl = reinterpret_cast<int*>(lds + OFF_CTRL);
+  if (P.items[-1].what != P.signature || P.items[-1].signal != (unsigned)P.n_items) {     // a plan built for another shape: refuse (error word 2)
+    if (threadIdx.x == 0) {
+      __hip_atomic_fetch_or(P.cnt + 1, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (P.status) __hip_atomic_fetch_or(P.status, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    return;
+  }
+  // Everything between the barriers that only one lane needs to do runs WAVE-UNIFORMLY in wave 0 (scalar branches, values broadcast
+  // with readfirstlane; single-lane regions hold one atomic each and no barrier).  A plain `if (threadIdx.x == 0)` around the
+  // pop / poll and the publish makes hipcc rotate those two blocks into an outer loop run by lane 0 alone while lanes 1..63 of its
+  // wave go round the barriers without it: the workgroup then re-reads the same queue entry for ever (round 6, first build).
+  const int lane0 = (threadIdx.x & 63) == 0;
+  const bool wave0 = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) == 0;
+  for (;;) {
+    unsigned long long t_pop = 0, t_rdy = 0;
+    if (wave0) {
+      unsigned itv = 0;
+      if (lane0) itv = __hip_atomic_fetch_add(P.cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned it = __builtin_amdgcn_readfirstlane(itv);
+      int go = it < (unsigned)P.n_items ? 1 : 0;
+      if (P.trace) t_pop = wall_clock64();
+      if (go) {
+        // wait for the item's dependencies: relaxed polls of monotonic counters (one address per poll), then ONE agent-scope acquire
+        const PctItem* pi = P.items + it;
+        bool any = false;
+#pragma unroll 1
+        for (int d = 0; d < 4 && go; ++d) {
+          const uint32_t dep = __builtin_amdgcn_readfirstlane(pi->dep[d]);
+          if (dep == PCT_NODEP) continue;
+          any = true;
+          unsigned* c = P.cnt + (dep & 0xfffffu);
+          const unsigned target = dep >> 20;
+          unsigned spins = 0;
+          while (__builtin_amdgcn_readfirstlane(pct_load(c)) < target) {
+            __builtin_amdgcn_s_sleep(8);
+            if ((++spins & 1023u) == 0 && (__builtin_amdgcn_readfirstlane(pct_load(P.cnt + 1)) != 0 || spins > (1u << 20))) {   // someone gave up, or ~1 s without progress: give up too
+              if (lane0) {
+                __hip_atomic_fetch_or(P.cnt + 1, 1u + (it << 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (P.status) __hip_atomic_fetch_or(P.status, 1u + (it << 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              }
+              go = 0;
+              break;
+            }
+          }
+        }
+        if (any) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        if (P.trace) t_rdy = wall_clock64();
+      }
+      if (lane0) ctrl[0] = go ? (int)it : -1;
+    }
+    __syncthreads();
+    const int it = __builtin_amdgcn_readfirstlane(ctrl[0]);
+    if (it < 0) break;
+    const PctItem* pi = P.items + it;
+    const unsigned what = __builtin_amdgcn_readfirstlane(pi->what), signal = __builtin_amdgcn_readfirstlane(pi->signal);
+    const int type = what & 15, c = (what >> 4) & 255, pair = (what >> 12) & 255, idx = what >> 20;
+    const PctCall call = P.call[c];
+    const PctLayerPtrs& lw = P.layer[call.layer];
+    const int Tx = P.T[call.x_img], Ts = P.T[call.s_img];
+    const long cp = (long)c * P.N + pair;
+    if ((P.skip >> type) & 1) {
+    } else if (type == PCT_X) {
+      Args a;
+      a.x_sp = P.sp[call.x_img]; a.x_f32 = P.f32[call.x_img]; a.out_f32 = P.f32[call.x_img]; a.out_sp = P.sp[call.x_img];
+      a.wq = lw.wq; a.pm = P.pm + (long)c * P.N * 65536; a.pm_seq_stride = 65536; a.w0 = lw.w0; a.w2 = lw.w2;
+      a.wq_s = lw.wq_s; a.w0_s = lw.w0_s; a.w2_s = lw.w2_s;
+      a.kv = P.kv + (long)c * P.N * (8 * 33 * 32);
+      a.mask = P.mask[call.x_img];
+      a.g1 = lw.g1; a.b1 = lw.b1; a.g2 = lw.g2; a.b2 = lw.b2;
+      a.v_length = (float)Ts; a.attn_eps = 1e-6f; a.p_out_scale = 1.f / ATTN_P_SCALE; a.ln_eps = 1e-5f;
+      a.nseq = P.N; a.T = Tx; a.groups = 0; a.xsplit = 1; a.gpc = 0;
+      encoder_x_body(a, pair, idx, lds);
+    } else if (type == PCT_K) {
+      KvTile k;
+      k.x_sp = P.sp[call.s_img] + (long)pair * Ts * 256;
+      k.mask = P.mask[call.s_img] ? P.mask[call.s_img] + (long)pair * Ts : nullptr;
+      k.T = Ts; k.wkv = lw.wkv; k.wkv_s = lw.wkv_s; k.inv_s = 1.f / (float)Ts;
+      k.part = P.part + (cp * 8 * P.splits + idx) * (33 * 32); k.head_stride = (long)P.splits * (33 * 32);
+      kv_tile_body(k, idx, lds);
+    } else {
+      kv_final_body(P.part + (cp * 8 + idx) * P.splits * (33 * 32), ceil_div(Ts, W * PT), P.kv + (cp * 8 + idx) * (33 * 32), lw.merge_f32, idx,
+                    P.pm + cp * 65536, lds);
+    }
+    // publish: every wave's stores drained, then ONE lane releases at agent scope (L2 write-back) and bumps the item's counter
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (wave0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // (the compiler may drop the wait behind buffer_wbl2: guide, pitfall 12)
+      if (lane0) {
+        __hip_atomic_fetch_add(P.cnt + signal, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (P.trace) {
+          unsigned long long* tr = P.trace + (long)it * 4;
+          tr[0] = t_pop; tr[1] = t_rdy; tr[2] = wall_clock64(); tr[3] = blockIdx.x;
+        }
+      }
+    }
+  }
+}
+#undef EFX_RPANEL
+#undef EFX_RPANEL_G
+#undef EFX_MF_N
+#undef EFX_MF_T
+#undef EFX_KPANEL
+#undef EFX_RD
+#undef EFX_USE
 #undef EFX_ISSUE
+#undef EFX_ISSUE_SRC
 #undef EFX_BEGIN
+#undef EFX_BEGIN_G
 }  // namespace efx
 }  // namespace
 
-// LOFTR_FUSED_ENCODER=0 keeps the four-kernel form (A/B)
-static bool fused_enabled() {
-  static const bool on = []() { const char* e = getenv("LOFTR_FUSED_ENCODER"); return !(e && atoi(e) == 0); }();
-  return on;
-}
-
 // the job's kernel arguments and its number of workgroups (0: not a shape the fused kernel takes)
 static int make_job(const EncoderXArgs& p, efx::Args& a) {
-  if (!fused_enabled() || p.C != 256 || p.nseq <= 0 || p.T <= 0 || !p.wq_s || !p.w0_s || !p.w2_s || !p.kv) return 0;
+  if (p.C != 256 || p.nseq <= 0 || p.T <= 0 || !p.wq_s || !p.w0_s || !p.w2_s || !p.kv) return 0;
   a = efx::Args{};
   a.x_sp = p.x_sp; a.x_f32 = p.x_f32; a.out_f32 = p.out_f32; a.out_sp = p.out_sp;
   a.wq = p.wq; a.pm = p.pm; a.pm_seq_stride = p.pm_seq_stride; a.w0 = p.w0; a.w2 = p.w2;
@@ -875,27 +840,37 @@ int launch_encoder_x(const EncoderXArgs& p, hipStream_t st) {
   efx::Args a;
   const int grid = make_job(p, a);
   if (grid == 0) return LOFTR_ERR_UNSUPPORTED;
-  // Split the launch: the largest whole number of 256-workgroup rounds goes to the main kernel (a wave x 32 tokens for the whole
-  // layer), the remainder to the cooperative tail kernel (a workgroup x 32 tokens) when that is the cheaper way to finish:
-  // OFF by default (LOFTR_ENCODER_TAIL=1 enables it).  Measured at the bench size (tools/gpu/r3_tail.sh): a cooperative round costs
-  // 65 us, not a third of the main kernel's 110 -- 64 barriers, 24 exchanges and a 2 MB weight stream per 32 tokens -- so only a
-  // single tail round pays (cross calls: 221 -> 175 us; 2.91 -> 2.79 ms per transformer call, -4 %), while a pair's result would
-  // then depend, in the last bits, on the batch it was part of (test_batch_consistency_full_size) and the two-stream bench fills
-  // the idle SIMDs of a partial round with convolution workgroups anyway.
-  static const bool tail_on = []() { const char* e = getenv("LOFTR_ENCODER_TAIL"); return e && atoi(e) == 1; }();
-  auto live = [&](int id) { const int xcd = id % NUM_XCD, slot = id / NUM_XCD; return (slot / a.groups) * NUM_XCD + xcd < a.nseq; };
-  int total = 0;
-  for (int id = 0; id < grid; ++id) total += live(id);
-  const int full = total / 256 * 256;
-  int g_main = 0;
-  for (int cnt = 0; g_main < grid && cnt < full; ++g_main) cnt += live(g_main);
-  int tail = 0;
-  for (int id = g_main; id < grid; ++id) tail += live(id);
-  const bool use_tail = tail_on && a.xsplit == 1 && tail > 0 && ceil_div(tail * efx::W, 256) <= 1;      // (the tail kernel keeps the one-sequence-per-XCD mapping)
-  if (!use_tail) g_main = grid;
   TimedLaunch tl(LOFTR_T_ENCODER_X, st);
-  if (g_main > 0) hipLaunchKernelGGL(efx::encoder_x_kernel, dim3(g_main), dim3(efx::W * 64), 0, st, a);
-  if (g_main < grid) hipLaunchKernelGGL(efx::encoder_xc_kernel, dim3((grid - g_main) * efx::W), dim3(efx::W * 64), 0, st, a, g_main);
+  hipLaunchKernelGGL(efx::encoder_x_kernel, dim3(grid), dim3(efx::W * 64), 0, st, a);
+  LOFTR_CHECK_LAUNCH();
+  return LOFTR_OK;
+}
+
+// ---- the persistent coarse transformer: ONE launch per LocalFeatureTransformer.forward (see coarse_persistent_kernel) ----------
+int launch_coarse_persistent(const PctLaunch& p, hipStream_t st) {
+  const PctShape& s = p.shape;
+  if (!s.ok() || !p.plan) return LOFTR_ERR_UNSUPPORTED;
+  if (p.plan_bytes < pct_plan_bytes(s) || p.ws_bytes < pct_ws_bytes(s)) return LOFTR_ERR_WORKSPACE;
+  const size_t cp = (size_t)s.n_calls() * s.N;
+  WsAlloc wa(p.ws, p.ws_bytes);
+  efx::PctArgs a{};
+  a.cnt = wa.take<unsigned>(s.n_counters());
+  a.part = wa.take<float>(cp * 8 * s.gmax() * 33 * 32);
+  a.kv = wa.take<float>(cp * 8 * 33 * 32);
+  a.pm = wa.take<sp_t>(cp * 65536);
+  if (!wa.ok()) return LOFTR_ERR_WORKSPACE;
+  for (int i = 0; i < 2; ++i) { a.f32[i] = p.f32[i]; a.sp[i] = p.sp[i]; a.mask[i] = p.mask[i]; a.T[i] = s.T[i]; }
+  a.N = s.N; a.n_calls = s.n_calls(); a.n_items = (int)s.n_items(); a.splits = s.gmax();
+  a.items = reinterpret_cast<const PctItem*>(p.plan) + 1;
+  a.trace = p.trace; a.status = p.status; a.signature = p.plan_signature;
+  for (int l = 0; l < s.n_layers; ++l) a.layer[l] = p.layer[l];
+  for (int c = 0; c < s.n_calls(); ++c) s.call(c, a.call[c].layer, a.call[c].x_img, a.call[c].s_img);
+  if (hipMemsetAsync(a.cnt, 0, s.n_counters() * 4, st) != hipSuccess) return LOFTR_ERR_LAUNCH;
+  TimedLaunch tl(LOFTR_T_ENCODER_X, st);
+  a.skip = loftr_debug_value(LOFTR_DBG_PCT_SKIP);
+  const int cap = loftr_debug_value(LOFTR_DBG_PCT_GRID) > 0 ? loftr_debug_value(LOFTR_DBG_PCT_GRID) : 256;
+  const int grid = a.n_items < cap ? a.n_items : cap;      // one workgroup per CU; fewer resident ones only slow the queue down (in-order pops: no deadlock)
+  hipLaunchKernelGGL(efx::coarse_persistent_kernel, dim3(grid), dim3(efx::W * 64), 0, st, a);
   LOFTR_CHECK_LAUNCH();
   return LOFTR_OK;
 }

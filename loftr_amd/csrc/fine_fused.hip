@@ -576,14 +576,8 @@ __global__ __launch_bounds__(W * 64, 1) void fine_pair_kernel(Args a) {
 }  // namespace ffx
 }  // namespace
 
-// LOFTR_FUSED_FINE=0 keeps the per-layer kernels (A/B)
-static bool fine_fused_enabled() {
-  static const bool on = []() { const char* e = getenv("LOFTR_FUSED_FINE"); return !(e && atoi(e) == 0); }();
-  return on;
-}
-
 int launch_fine_pair(const FinePairArgs& p, hipStream_t st) {
-  if (!fine_fused_enabled() || p.C != 128 || p.T < 1 || p.T > 32 || p.M <= 0) return LOFTR_ERR_UNSUPPORTED;
+  if (p.C != 128 || p.T < 1 || p.T > 32 || p.M <= 0) return LOFTR_ERR_UNSUPPORTED;
   ffx::Args a{};
   a.f0 = p.f0; a.f1 = p.f1; a.M = p.M; a.T = p.T; a.attn_eps = p.attn_eps; a.ln_eps = p.ln_eps;
   for (int l = 0; l < 2; ++l) {

@@ -333,7 +333,7 @@ __global__ void colsum_part_kernel(const float* __restrict__ x, long rows, int C
 // Tokens per split-K partial: enough partials to put ~256 workgroups on the chip (one 128-row tile of dW per workgroup and partial),
 // between 128 and 512 tokens, a multiple of the k-tile.  (A fixed 512 left a 256 x 256 gradient over 9600 tokens on 38 workgroups.)
 static int wgrad_chunk(long T, int O) {
-  static const int forced = []() { const char* e = getenv("LOFTR_WGRAD_CHUNK"); return e ? atoi(e) : 0; }();      // (debug / A-B)
+  const int forced = loftr_debug_value(LOFTR_DBG_WGRAD_CHUNK);      // (debug / A-B)
   if (forced > 0) return forced;
   const int tiles = ceil_div(O, 128);
   const int target = tiles >= 256 ? 1 : 256 / tiles;
@@ -368,7 +368,7 @@ int launch_wgrad(const float* dy, int O, const float* act, int I, long T, float*
   return launch_reduce_partials(part, dW, ns, (long)O * I, (long)O * I, st);
 }
 int launch_reduce_partials(const float* part, float* out, int P, long stride, long n, hipStream_t st) {
-  static const int no_tall = []() { const char* e = getenv("LOFTR_REDUCE_TALL"); return e && atoi(e) == 0; }();    // (debug / A-B)
+  const bool no_tall = loftr_debug_value(LOFTR_DBG_REDUCE_TALL) == 0;    // (debug / A-B)
   if (P >= 16 && !no_tall)       // many partials (split-K weight gradients, LayerNorm weight gradients: one partial per 64 rows): 8 lanes share the walk over P
     hipLaunchKernelGGL(reduce_partials_tall_kernel, dim3((unsigned)((n + 31) / 32)), dim3(256), 0, st, part, out, P, stride, n);
   else
@@ -406,7 +406,7 @@ extern "C" int loftr_head_feat_grads(const float* dsim, long dsim_ld, long dsim_
 // Tokens per partial for the convolution: all KH KW taps go in one launch, so the reduction is cut only as far as it takes to put
 // ~512 workgroups (two rounds of one per CU) on the chip -- at least 128 pixels per partial, a multiple of the k-tile.
 static int conv_wgrad_chunk(long T, int Cout, int taps) {
-  static const int forced = []() { const char* e = getenv("LOFTR_WGRAD_CHUNK"); return e ? atoi(e) : 0; }();      // (debug: tools/micro/conv_wgrad_debug.py)
+  const int forced = loftr_debug_value(LOFTR_DBG_WGRAD_CHUNK);      // (debug: tools/micro/conv_wgrad_debug.py)
   if (forced > 0) return forced;
   const int per = ceil_div(Cout, hg::BM) * taps;
   const int target = per >= 512 ? 1 : 512 / per;

@@ -78,14 +78,9 @@ struct LinearLNArgs {
 };
 int launch_linear_ln(const LinearLNArgs& p, hipStream_t st);
 
-// Stationary-weight sweep variants of the two K = 256 layers of the coarse level (rowsweep.hip).  They return
-// LOFTR_ERR_UNSUPPORTED for any other shape / option; the caller then uses launch_proj / launch_linear_ln.
-int launch_rowsweep_q(const ProjArgs& p, hipStream_t st);
-int launch_rowsweep_ln(const LinearLNArgs& p, hipStream_t st);
-
 // The whole x side of a coarse encoder layer (q projection + feature map + normaliser, merge with the per-sequence P +
 // norm1, mlp.0 + ReLU, mlp.2 + norm2 + residual) in one launch with the tokens stationary in registers (encoder_fused.hip).
-// C = 256 only; LOFTR_ERR_UNSUPPORTED otherwise (the caller then runs the four separate kernels).
+// C = 256 only; LOFTR_ERR_UNSUPPORTED otherwise (C = 128: the per-GEMM kernels of transformer.hip: encoder_layer).
 struct EncoderXArgs {
   const sp_t* x_sp; const float* x_f32; float* out_f32; sp_t* out_sp;   // [nseq * T, C]; out may alias x
   int nseq, T, C;

@@ -52,6 +52,26 @@ extern "C" int loftr_pos_encode_flatten(const loftr_fmap* feat, const float* pe,
   return LOFTR_OK;
 }
 
+// ---- debug / A-B switches -----------------------------------------------------------------
+namespace {
+struct DebugSwitch { const char* name; int def; int value; };
+DebugSwitch g_debug[LOFTR_DBG_COUNT] = {{"encoder_schedule", 1, 1}, {"conv_persist_cap", 0, 0}, {"wgrad_chunk", 0, 0}, {"reduce_tall", 1, 1},
+                                        {"pct_grid", 0, 0}, {"pct_skip", 0, 0}, {"conv_duo", 1, 1}, {"conv_patch", 1, 1}};
+}  // namespace
+int loftr_debug_value(int key) { return (key >= 0 && key < LOFTR_DBG_COUNT) ? g_debug[key].value : 0; }
+extern "C" int loftr_hip_debug_set(const char* key, int value) {
+  LOFTR_CHECK_ARG(key != nullptr);
+  for (auto& d : g_debug)
+    if (strcmp(d.name, key) == 0) { d.value = value; return LOFTR_OK; }
+  return LOFTR_ERR_BAD_ARG;
+}
+extern "C" int loftr_hip_debug_get(const char* key, int* value, int* default_value) {
+  LOFTR_CHECK_ARG(key != nullptr && value != nullptr);
+  for (auto& d : g_debug)
+    if (strcmp(d.name, key) == 0) { *value = d.value; if (default_value) *default_value = d.def; return LOFTR_OK; }
+  return LOFTR_ERR_BAD_ARG;
+}
+
 // ---- per-kernel timing ---------------------------------------------------------------------
 unsigned g_loftr_timing_mask = 0;
 int g_loftr_range_check = 0;

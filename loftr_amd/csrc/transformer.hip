@@ -8,6 +8,7 @@
 // The residual stream is kept in fp32 (in place in the caller's buffers); its SP mirror only feeds GEMMs.
 #include "linear.h"
 #include "attention.h"
+#include "coarse_plan.h"
 
 namespace {
 
@@ -197,18 +198,8 @@ int encoder_layer(const float* x_f32, const sp_t* x_sp, const sp_t* src_sp, bool
     {
       EncoderXArgs fx{x_sp, x_f32, out_f32, out_sp, nb, L, C, w.q, pm, (long)C * C, w.mlp0, w.mlp2, w.q_s, w.mlp0_s, w.mlp2_s,
                       kv, x_mask, w.n1w, w.n1b, w.n2w, w.n2b, (float)S, attn_eps, 1.f / ATTN_P_SCALE, 1e-5f};
-      if ((rc = launch_encoder_x(fx, st)) != LOFTR_ERR_UNSUPPORTED) return rc;
+      return launch_encoder_x(fx, st);
     }
-    // q projection with the normaliser applied in its epilogue (per pair: grid.z = nb)
-    ProjArgs pq{x_sp, L, C, nb, 1, {w.q, nullptr, nullptr}, {e.q, nullptr, nullptr}, {0, 0, 0}, x_mask, inv_s,
-                kv, (float)S, attn_eps, {w.q_s, nullptr, nullptr}};
-    if ((rc = launch_rowsweep_q(pq, st)) == LOFTR_ERR_UNSUPPORTED) rc = launch_proj(pq, st);
-    if (rc) return rc;
-    // message = norm1(merge(attention))  as ONE GEMM against P                    transformer.py:50-52
-    LinearLNArgs m{asrc_plain(e.q, C), pm, C, w.n1w, w.n1b, nullptr, nullptr, e.msgn, L, C, C, 1e-5f,
-                   nb, (long)C * C, nullptr, 1.f / ATTN_P_SCALE};
-    if ((rc = launch_rowsweep_ln(m, st)) == LOFTR_ERR_UNSUPPORTED) rc = launch_linear_ln(m, st);
-    if (rc) return rc;
   } else {
     float* qf = reinterpret_cast<float*>(e.q);
     if (self) {
@@ -244,8 +235,12 @@ int encoder_layer(const float* x_f32, const sp_t* x_sp, const sp_t* src_sp, bool
 extern "C" size_t loftr_encoder_workspace_bytes(int nb, int L, int S, int C) {
   if (nb <= 0 || L <= 0 || S <= 0 || C <= 0) return 0;
   const int m = L > S ? L : S;
-  return encoder_ws_bytes(nb, m, m, C) + 2 * align_up((size_t)nb * m * C * 4, 256) +
-         align_up(weights_sp_dwords(C) * 4 * MAX_LAYERS, 256) + 4096;
+  size_t b = encoder_ws_bytes(nb, m, m, C) + 2 * align_up((size_t)nb * m * C * 4, 256) +
+             align_up(weights_sp_dwords(C) * 4 * MAX_LAYERS, 256) + 4096;
+  // the persistent coarse transformer (loftr_transformer_fwd_planned): counters, per-(call, pair) partials / KV / P of nb / 2 pairs
+  const PctShape ps{PCT_MAX_LAYERS, nb / 2, {L, S}};
+  if (C == 256 && ps.ok()) b += align_up(pct_ws_bytes(ps), 256);
+  return b;
 }
 
 extern "C" int loftr_encoder_layer_fwd(const float* x, const float* source, const uint8_t* x_mask,
@@ -315,11 +310,11 @@ extern "C" int loftr_transformer_prepare(const loftr_layer_weights* layers, int 
   return convert_layers(layers, n_layers, C, reinterpret_cast<sp_t*>(prepared), jobs, lw, (hipStream_t)stream);
 }
 
-extern "C" int loftr_transformer_fwd(float* feat0, float* feat1, const uint8_t* mask0,
-                                     const uint8_t* mask1, const loftr_layer_weights* layers,
-                                     const int* layer_is_cross, int n_layers, int N, int L, int S,
-                                     int C, int H, const void* prepared, size_t prepared_bytes, void* ws, size_t ws_bytes,
-                                     void* stream) {
+static int transformer_fwd(float* feat0, float* feat1, const uint8_t* mask0,
+                           const uint8_t* mask1, const loftr_layer_weights* layers,
+                           const int* layer_is_cross, int n_layers, int N, int L, int S,
+                           int C, int H, const void* prepared, size_t prepared_bytes, void* ws, size_t ws_bytes,
+                           const void* plan, size_t plan_bytes, int plan_order, void* diag, size_t diag_bytes, void* stream) {
   LOFTR_CHECK_ARG(feat0 && feat1 && layers && layer_is_cross && n_layers >= 0 && N >= 0 && L > 0 && S > 0);
   LOFTR_CHECK_ARG((mask0 == nullptr) == (mask1 == nullptr));
   if (!((C == 256 || C == 128) && H == 8) || n_layers > MAX_LAYERS) return LOFTR_ERR_UNSUPPORTED;
@@ -378,10 +373,29 @@ extern "C" int loftr_transformer_fwd(float* feat0, float* feat1, const uint8_t* 
     } else if ((rc = convert_layers(layers, n_layers, C, w_sp, jobs, lw, st))) return rc;
   }
   {
-    // coarse level with the stock layer pattern: the scheduled form (bit-identical results, fewer rounds of workgroups)
-    static const bool sched_on = []() { const char* v = getenv("LOFTR_ENCODER_SCHEDULE"); return !(v && atoi(v) == 0); }();
     bool pattern = C == 256 && n_layers >= 2 && n_layers % 2 == 0;
     for (int i = 0; pattern && i < n_layers; ++i) pattern = (layer_is_cross[i] != 0) == ((i & 1) != 0);
+    // coarse level with the stock layer pattern and a plan: ONE persistent launch, dependencies per pair and tile (encoder_fused.hip)
+    if (plan && pattern && n_layers <= PCT_MAX_LAYERS) {
+      PctLaunch pl{};
+      pl.shape = PctShape{n_layers, N, {L, S}};
+      if (!pl.shape.ok()) return LOFTR_ERR_UNSUPPORTED;
+      pl.f32[0] = feat0; pl.f32[1] = feat1; pl.sp[0] = sp0; pl.sp[1] = sp1; pl.mask[0] = mask0; pl.mask[1] = mask1;
+      for (int i = 0; i < n_layers; ++i) {
+        const LayerSp& w = lw[i];
+        pl.layer[i] = PctLayerPtrs{w.q, w.mlp0, w.mlp2, w.kv, w.q_s, w.mlp0_s, w.mlp2_s, w.kv_s, w.merge_f32, w.n1w, w.n1b, w.n2w, w.n2b};
+      }
+      pl.plan = plan; pl.plan_bytes = plan_bytes; pl.plan_signature = pl.shape.signature(plan_order);
+      pl.ws = wa.take<char>(pct_ws_bytes(pl.shape)); pl.ws_bytes = pct_ws_bytes(pl.shape);
+      if (!wa.ok()) return LOFTR_ERR_WORKSPACE;
+      if (diag && diag_bytes >= 16) {
+        pl.status = reinterpret_cast<unsigned*>(diag);
+        if (diag_bytes >= 16 + 32 * pl.shape.n_items()) pl.trace = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(diag) + 16);
+      }
+      return launch_coarse_persistent(pl, st);
+    }
+    // ... without a plan: the scheduled launches (bit-identical to the call order, fewer rounds of workgroups)
+    const bool sched_on = loftr_debug_value(LOFTR_DBG_ENCODER_SCHEDULE) != 0;
     if (sched_on && pattern) {
       rc = coarse_transformer_scheduled(feat0, feat1, sp0, sp1, mask0, mask1, lw, n_layers / 2, stacked, N, L, S, C, H, e, st);
       if (rc != LOFTR_ERR_UNSUPPORTED) return rc;
@@ -402,6 +416,26 @@ extern "C" int loftr_transformer_fwd(float* feat0, float* feat1, const uint8_t* 
     }
   }
   return LOFTR_OK;
+}
+
+extern "C" int loftr_transformer_fwd(float* feat0, float* feat1, const uint8_t* mask0,
+                                     const uint8_t* mask1, const loftr_layer_weights* layers,
+                                     const int* layer_is_cross, int n_layers, int N, int L, int S,
+                                     int C, int H, const void* prepared, size_t prepared_bytes, void* ws, size_t ws_bytes,
+                                     void* stream) {
+  return transformer_fwd(feat0, feat1, mask0, mask1, layers, layer_is_cross, n_layers, N, L, S, C, H, prepared, prepared_bytes, ws, ws_bytes,
+                         nullptr, 0, 0, nullptr, 0, stream);
+}
+
+extern "C" int loftr_transformer_fwd_planned(float* feat0, float* feat1, const uint8_t* mask0,
+                                             const uint8_t* mask1, const loftr_layer_weights* layers,
+                                             const int* layer_is_cross, int n_layers, int N, int L, int S,
+                                             int C, int H, const void* prepared, size_t prepared_bytes, void* ws, size_t ws_bytes,
+                                             const void* plan, size_t plan_bytes, int plan_order, void* diag, size_t diag_bytes,
+                                             void* stream) {
+  LOFTR_CHECK_ARG(plan != nullptr && (plan_order == 0 || plan_order == 1));
+  return transformer_fwd(feat0, feat1, mask0, mask1, layers, layer_is_cross, n_layers, N, L, S, C, H, prepared, prepared_bytes, ws, ws_bytes,
+                         plan, plan_bytes, plan_order, diag, diag_bytes, stream);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -5,6 +5,7 @@ path happens in the HIP kernels.  Every wrapper requires CUDA(ROCm) float32 cont
 and raises otherwise -- there is no CPU fallback.
 """
 import ctypes as C
+import os
 import weakref
 import functools
 
@@ -74,6 +75,36 @@ def _need(t, name, dtype=torch.float32):
 
 def _ptr(t):
     return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def debug_set(key, value):
+    """loftr_hip_debug_set: a named A/B switch of the library (include/loftr_hip.h; process-global, the library reads no environment variable)."""
+    check(_lib.load().loftr_hip_debug_set(key.encode(), int(value)), f"loftr_hip_debug_set({key})")
+
+
+def debug_get(key):
+    """(value, default) of a debug switch."""
+    v, d = C.c_int(0), C.c_int(0)
+    check(_lib.load().loftr_hip_debug_get(key.encode(), C.byref(v), C.byref(d)), f"loftr_hip_debug_get({key})")
+    return v.value, d.value
+
+
+class debug_switch:
+    """``with ops.debug_switch(conv_duo=0, conv_persist_cap=8): ...`` -- switches set for the block, restored afterwards."""
+
+    def __init__(self, **kv):
+        self.kv, self.old = kv, {}
+
+    def __enter__(self):
+        for k, v in self.kv.items():
+            self.old[k] = debug_get(k)[0]
+            debug_set(k, v)
+        return self
+
+    def __exit__(self, *exc):
+        for k, v in self.old.items():
+            debug_set(k, v)
+        return False
 
 
 def _stream():
@@ -202,11 +233,40 @@ def transformer_prepare(layer_structs, Cc, device):
     return buf
 
 
+# The coarse transformer's work queue for a shape (loftr_coarse_plan_build), per device: (device, kinds, N, L, S, order) -> uint8 tensor
+_COARSE_PLANS = {}
+# "persistent": one dependency-driven launch per coarse transformer call;  "persistent_call_order": the same kernel on the
+# reference's call order (bit-identical results; A/B and tests);  "launches": the per-call launches of loftr_transformer_fwd;
+# "auto" (default): persistent when a call has enough tiles to keep 256 workgroups busy between its dependencies -- a single
+# 640 x 480 pair is a chain of 12 calls of 38 tiles each and finishes sooner as launches (2.06 vs 1.51 ms; 8 pairs: 3.19 vs 3.56 ms,
+# 2 pairs of 840 x 840: 2.36 vs 2.42 ms; tools/micro/pct_check.py, profiles/r06_pct_check.txt)
+COARSE_MODE = os.environ.get("LOFTR_COARSE_MODE", "auto")
+COARSE_AUTO_MIN_TILES = 150
+
+
+def coarse_plan(kinds, N, L, S, device, order=0):
+    """The persistent coarse transformer's plan for this shape, built once (None: the shape has no persistent form)."""
+    key = (str(device), tuple(kinds), N, L, S, order)
+    if key not in _COARSE_PLANS:
+        lib = _lib.load()
+        arr = (C.c_int * len(kinds))(*kinds)
+        nbytes = lib.loftr_coarse_plan_bytes(arr, len(kinds), N, L, S)
+        plan = None
+        if nbytes:
+            plan = torch.empty(nbytes, dtype=torch.uint8, device=device)
+            with torch.cuda.device(device):
+                check(lib.loftr_coarse_plan_build(arr, len(kinds), N, L, S, order, _ptr(plan), plan.numel(), _stream()), "loftr_coarse_plan_build")
+        _COARSE_PLANS[key] = plan
+    return _COARSE_PLANS[key]
+
+
 @_on_device
-def transformer(feat0, feat1, layer_structs, layer_names, nhead, mask0=None, mask1=None, inplace=False, prepared=None):
+def transformer(feat0, feat1, layer_structs, layer_names, nhead, mask0=None, mask1=None, inplace=False, prepared=None, mode=None,
+                diag=None):
     """LocalFeatureTransformer.forward.  Returns new (feat0, feat1); inputs are not modified unless
     ``inplace`` (then, when feat0 / feat1 are the contiguous halves of one buffer, the layers run on
-    that buffer directly instead of on a torch.cat copy of it)."""
+    that buffer directly instead of on a torch.cat copy of it).  ``mode``: see COARSE_MODE; ``diag``: uint8 tensor for
+    loftr_transformer_fwd_planned's status word / per-item trace."""
     _need(feat0, "feat0"); _need(feat1, "feat1")
     N, L, Cc = feat0.shape
     S = feat1.shape[1]
@@ -223,13 +283,28 @@ def transformer(feat0, feat1, layer_structs, layer_names, nhead, mask0=None, mas
         f0, f1 = feat0.clone(), feat1.clone()
     n_layers = len(layer_names)
     arr = (LayerWeights * n_layers)(*layer_structs)
-    kinds = (C.c_int * n_layers)(*[{"self": 0, "cross": 1}[n] for n in layer_names])   # KeyError like the reference
+    kind_list = [{"self": 0, "cross": 1}[n] for n in layer_names]    # KeyError like the reference
+    kinds = (C.c_int * n_layers)(*kind_list)
     lib = _lib.load()
     nbytes = lib.loftr_encoder_workspace_bytes(2 * N, L, S, Cc)
     ws = workspace(nbytes, feat0.device)
-    check(lib.loftr_transformer_fwd(_ptr(f0), _ptr(f1), _ptr(m0), _ptr(m1), arr, kinds, n_layers, N, L, S, Cc, nhead,
-                                    _ptr(prepared), prepared.numel() if prepared is not None else 0,
-                                    _ptr(ws), ws.numel(), _stream()), "loftr_transformer_fwd")
+    mode = mode or COARSE_MODE
+    if mode == "auto":
+        mode = "persistent" if N * ((max(L, S) + 127) // 128) >= COARSE_AUTO_MIN_TILES else "launches"
+    plan = None
+    if mode != "launches" and Cc == 256 and nhead == 8 and N > 0:
+        order = 1 if mode == "persistent_call_order" else 0
+        plan = coarse_plan(kind_list, N, L, S, feat0.device, order)
+    if plan is not None:
+        check(lib.loftr_transformer_fwd_planned(_ptr(f0), _ptr(f1), _ptr(m0), _ptr(m1), arr, kinds, n_layers, N, L, S, Cc, nhead,
+                                                _ptr(prepared), prepared.numel() if prepared is not None else 0,
+                                                _ptr(ws), ws.numel(), _ptr(plan), plan.numel(), order,
+                                                _ptr(diag), diag.numel() if diag is not None else 0, _stream()),
+              "loftr_transformer_fwd_planned")
+    else:
+        check(lib.loftr_transformer_fwd(_ptr(f0), _ptr(f1), _ptr(m0), _ptr(m1), arr, kinds, n_layers, N, L, S, Cc, nhead,
+                                        _ptr(prepared), prepared.numel() if prepared is not None else 0,
+                                        _ptr(ws), ws.numel(), _stream()), "loftr_transformer_fwd")
     return f0, f1
 
 

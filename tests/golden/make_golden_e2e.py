@@ -91,7 +91,15 @@ CASES = {"e2e_scannet": dict(images="scannet", bn_strength=0.3),
          # columns zero-padded at the bottom, mask0 / mask1 [2, 105, 105], scale 1.9, temp_bug_fix=False (outdoor_ds.ckpt), border_rm 2
          # (configs/loftr/outdoor/loftr_ds.py:1-5, coarse_matching.py:28-43,115-118, fine_matching.py:68); L = S = 11 025
          "e2e_outdoor_840": dict(images="synth", bn_strength=0.3, n=2, size=(840, 840), valid0=(560, 840), valid1=(560, 840),
-                                 scale0=(1.9, 1.9), scale1=(1.9, 1.9), temp_bug_fix=False, border_rm=2)}
+                                 scale0=(1.9, 1.9), scale1=(1.9, 1.9), temp_bug_fix=False, border_rm=2),
+         # round 6 (round-5 verdict, next #2): the "trained-like" peaked regime (the e2e_peaked recipe: coarse_gain 6) on the OTHER
+         # heads and shapes -- the masked 840 x 840 outdoor batch, indoor Sinkhorn, and a 3-pair batch: real checkpoints produce
+         # exactly this regime (conf close to 1, hundreds of matches at the stock threshold) and one 640 x 480 dual-softmax pair was
+         # the only image-level case that covered it
+         "e2e_peaked_outdoor": dict(images="synth", bn_strength=0.3, n=2, size=(840, 840), valid0=(560, 840), valid1=(560, 840),
+                                    scale0=(1.9, 1.9), scale1=(1.9, 1.9), temp_bug_fix=False, border_rm=2, coarse_gain=6.0),
+         "e2e_peaked_ot": dict(images="synth", bn_strength=0.3, crop0=(384, 512), crop1=(384, 512), match_type="sinkhorn", coarse_gain=6.0),
+         "e2e_peaked_batch": dict(images="synth", bn_strength=0.3, n=3, coarse_gain=6.0)}
 
 
 def e2e_state_dict(module_with_backbone, cfg, bn_strength, coarse_gain=1.0, fine_gain=1.0):

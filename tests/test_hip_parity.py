@@ -328,20 +328,111 @@ def test_dual_softmax_paths_vs_oracle(hw0, hw1, C, masked):
     assert len(got ^ want) <= 1 and len(want) > 10, sorted(got ^ want)
 
 
-@pytest.mark.parametrize("shape", [("8", "4800", "4800"), ("3", "300", "300"), ("2", "700", "500", "mask")])
-def test_scheduled_transformer_is_bit_identical_to_call_order(shape, tmp_path):
-    """The coarse transformer runs as a schedule of two-job launches (csrc/transformer.hip: coarse_transformer_scheduled -- the next
-    self-attention call on image 0 rides in the idle slots of the cross call on image 1); LOFTR_ENCODER_SCHEDULE=0 keeps the
-    reference's call order (transformer.py:92-97).  Both must give the same bits: full batch-8 size (a split self call), fewer
-    sequences than XCDs, unequal masked grids.  (The switch is read once per process: two subprocesses.)"""
-    import os
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    script = os.path.join(root, "tools", "micro", "encoder_ab.py")
-    env = dict(os.environ, LOFTR_AB_DIR=str(tmp_path))
-    r0 = subprocess.run([sys.executable, script, "callwise", *shape], env=dict(env, LOFTR_ENCODER_SCHEDULE="0"), capture_output=True, text=True, timeout=300)
-    assert r0.returncode == 0, r0.stderr[-2000:]
-    r1 = subprocess.run([sys.executable, script, "scheduled", *shape], env=dict(env, LOFTR_ENCODER_SCHEDULE="1"), capture_output=True, text=True, timeout=300)
-    assert r1.returncode == 0, r1.stderr[-2000:]
-    assert "bit-identical" in r1.stdout and "finite=True" in r1.stdout and "DIFFERENT" not in r1.stdout, r1.stdout[-2000:]
+def _coarse_transformer_case(N, L0, L1, masked):
+    import torch
+    from loftr_amd import LoFTR, get_cfg
+    from loftr_amd.synth import make_weights
+    cfg = get_cfg(thr=0.0)
+    model = LoFTR(cfg).eval()
+    model.load_state_dict({k: torch.from_numpy(np.ascontiguousarray(np.asarray(v))) for k, v in make_weights(0, cfg).items()}, strict=False)
+    tr = model.cuda().loftr_coarse
+    g = torch.Generator(device="cpu").manual_seed(N * 7 + L0 + L1)
+    f0 = torch.randn(N, L0, 256, generator=g).cuda()
+    f1 = torch.randn(N, L1, 256, generator=g).cuda()
+    m0 = m1 = None
+    if masked:
+        m0 = torch.ones(N, L0, dtype=torch.bool); m0[:, L0 - L0 // 5:] = False
+        m1 = torch.ones(N, L1, dtype=torch.bool); m1[0, L1 - L1 // 3:] = False
+        m0, m1 = m0.cuda(), m1.cuda()
+    structs = [layer.weight_struct() for layer in tr.layers]
+    prepared = tr._prepared(structs, f0.device)
+
+    def run(mode, diag=None):
+        from loftr_amd import ops
+        with torch.no_grad():
+            o = ops.transformer(f0, f1, structs, tr.layer_names, tr.nhead, m0, m1, inplace=False, prepared=prepared, mode=mode, diag=diag)
+        torch.cuda.synchronize()
+        return o[0].clone(), o[1].clone()
+    return run, tr
+
+
+COARSE_SHAPES = [(8, 4800, 4800, False), (3, 300, 300, False), (2, 700, 500, True)]
+
+
+@pytest.mark.parametrize("shape", COARSE_SHAPES)
+def test_scheduled_transformer_is_bit_identical_to_call_order(shape):
+    """The coarse transformer as launches runs a schedule of two-job launches (csrc/transformer.hip: coarse_transformer_scheduled -- the
+    next self-attention call on image 0 rides in the idle slots of the cross call on image 1); debug switch encoder_schedule = 0 keeps
+    the reference's call order (transformer.py:92-97).  Both must give the same bits: full batch-8 size (a split self call), fewer
+    sequences than XCDs, unequal masked grids."""
+    import torch
+    from loftr_amd import ops
+    run, _ = _coarse_transformer_case(*shape)
+    with ops.debug_switch(encoder_schedule=0):
+        a = run("launches")
+    assert ops.debug_get("encoder_schedule") == (1, 1)
+    b = run("launches")
+    assert torch.isfinite(a[0]).all() and torch.isfinite(a[1]).all()
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+
+
+@pytest.mark.parametrize("shape", COARSE_SHAPES + [(1, 4800, 4800, False), (2, 11025, 11025, True)])
+def test_persistent_transformer_order_independent_and_matches_launches(shape):
+    """Round 6: the coarse transformer as ONE persistent launch (csrc/encoder_fused.hip: coarse_persistent_kernel) whose 256 resident
+    workgroups pull K / F / X work items from a host-planned queue and wait on per-pair / per-tile counters (transformer.py:96-97: the
+    dependency `feat1 attends to the updated feat0` is per pair).  The queue order must not change a bit: the dependency-driven plan
+    (critical path first) against the plan in the reference's call order, repeated runs against the first (a difference is a race);
+    against the per-call launches the results agree to float32 noise (the K items sum the four waves' K^T V blocks in another order than
+    proj_kv_kernel).  The status word stays 0."""
+    import torch
+    run, _ = _coarse_transformer_case(*shape)
+    ref = run("launches")
+    scale = max(ref[0].abs().max().item(), ref[1].abs().max().item())
+    outs = {}
+    for mode in ("persistent_call_order", "persistent"):
+        diag = torch.zeros(16, dtype=torch.uint8, device="cuda")
+        outs[mode] = run(mode, diag)
+        assert int(diag.view(torch.int32)[0].item()) == 0, mode
+        for _ in range(2):
+            diag.zero_()
+            again = run(mode, diag)
+            assert int(diag.view(torch.int32)[0].item()) == 0
+            assert torch.equal(again[0], outs[mode][0]) and torch.equal(again[1], outs[mode][1]), mode
+    a, b = outs["persistent_call_order"], outs["persistent"]
+    assert torch.isfinite(b[0]).all() and torch.isfinite(b[1]).all()
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    for k in range(2):
+        assert (b[k] - ref[k]).abs().max().item() <= 2e-6 * scale, (k, (b[k] - ref[k]).abs().max().item(), scale)
+
+
+def test_persistent_transformer_refuses_a_plan_of_another_shape():
+    """loftr_transformer_fwd_planned with a plan built for other sizes: nothing is computed, the status word reports 2, and the C-ABI
+    call returns an error for a plan buffer that is too small (include/loftr_hip.h)."""
+    import ctypes as C
+    import torch
+    from loftr_amd import ops, _lib
+    lib = _lib.load()
+    run, tr = _coarse_transformer_case(2, 300, 300, False)
+    kinds = [{"self": 0, "cross": 1}[n] for n in tr.layer_names]
+    arr = (C.c_int * len(kinds))(*kinds)
+    assert lib.loftr_coarse_plan_bytes(arr, len(kinds), 2, 300, 300) > 0
+    assert lib.loftr_coarse_plan_bytes(arr, 3, 2, 300, 300) == 0                  # an odd number of layers has no persistent form
+    assert lib.loftr_coarse_plan_signature(len(kinds), 2, 300, 300, 0) != lib.loftr_coarse_plan_signature(len(kinds), 2, 300, 300, 1)
+    # a plan for (2, 300, 260) has the same number of items as (2, 300, 300) (3 + 3 tiles): hand it to the (2, 300, 300) call
+    other = ops.coarse_plan(kinds, 2, 300, 260, torch.device("cuda:0"))
+    key = ("cuda:0", tuple(kinds), 2, 300, 300, 0)
+    saved = ops._COARSE_PLANS.get(key)
+    ops._COARSE_PLANS[key] = other
+    try:
+        diag = torch.zeros(16, dtype=torch.uint8, device="cuda")
+        run("persistent", diag)
+        assert int(diag.view(torch.int32)[0].item()) == 2
+    finally:
+        if saved is None:
+            ops._COARSE_PLANS.pop(key, None)
+        else:
+            ops._COARSE_PLANS[key] = saved
+    diag = torch.zeros(16, dtype=torch.uint8, device="cuda")
+    a = run("persistent", diag)
+    b = run("launches")
+    assert int(diag.view(torch.int32)[0].item()) == 0 and (a[0] - b[0]).abs().max().item() <= 2e-6 * b[0].abs().max().item()

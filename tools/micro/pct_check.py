@@ -1,0 +1,135 @@
+#!/usr/bin/env python
+"""The persistent coarse transformer (csrc/encoder_fused.hip: coarse_persistent_kernel) against the per-call launches.
+
+    python tools/micro/pct_check.py [N] [L0] [L1] [mask] [--reps R] [--trace]
+
+For one shape: outputs of mode "launches" (loftr_transformer_fwd), "persistent_call_order" and "persistent" (dependency-driven plan);
+the two persistent orders must be bit-identical (same arithmetic, another schedule: a difference is a race), R repeated runs of
+each must be bit-identical to their first run, persistent vs launches within float32 noise; the status word must stay 0.
+Then hipEvent timings of the three modes and, with --trace, the per-item trace of the dependency-driven plan: item durations by
+type, time waiting for dependencies, makespan."""
+import faulthandler
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from loftr_amd import LoFTR, get_cfg, ops, _lib   # noqa: E402
+from loftr_amd.synth import make_weights            # noqa: E402
+
+faulthandler.dump_traceback_later(int(os.environ.get("PCT_WATCHDOG", "100")), exit=True)     # a hung kernel: say where, then leave
+args = [a for a in sys.argv[1:] if not a.startswith("--")]
+N = int(args[0]) if len(args) > 0 else 8
+L0 = int(args[1]) if len(args) > 1 else 4800
+L1 = int(args[2]) if len(args) > 2 else L0
+masked = len(args) > 3 and args[3] == "mask"
+reps = int(sys.argv[sys.argv.index("--reps") + 1]) if "--reps" in sys.argv else 3
+want_trace = "--trace" in sys.argv
+
+cfg = get_cfg(thr=0.0)
+model = LoFTR(cfg).eval()
+model.load_state_dict({k: torch.from_numpy(np.ascontiguousarray(np.asarray(v))) for k, v in make_weights(0, cfg).items()}, strict=False)
+model = model.cuda()
+tr = model.loftr_coarse
+g = torch.Generator(device="cpu").manual_seed(N * 7 + L0 + L1)
+f0 = torch.randn(N, L0, 256, generator=g).cuda()
+f1 = torch.randn(N, L1, 256, generator=g).cuda()
+m0 = m1 = None
+if masked:
+    m0 = torch.ones(N, L0, dtype=torch.bool); m0[:, L0 - L0 // 5:] = False
+    m1 = torch.ones(N, L1, dtype=torch.bool); m1[0, L1 - L1 // 3:] = False
+    m0, m1 = m0.cuda(), m1.cuda()
+structs = [layer.weight_struct() for layer in tr.layers]
+prepared = tr._prepared(structs, f0.device)
+lib = _lib.load()
+for kv in os.environ.get("PCT_DEBUG", "").split(","):        # e.g. PCT_DEBUG=pct_grid=1,pct_skip=7
+    if "=" in kv:
+        _lib.check(lib.loftr_hip_debug_set(kv.split("=")[0].encode(), int(kv.split("=")[1])), "debug_set " + kv)
+only = os.environ.get("PCT_ONLY")                           # run just this mode once and report the status word
+kinds = [{"self": 0, "cross": 1}[n] for n in tr.layer_names]
+n_items = lib.loftr_coarse_plan_bytes((ops.C.c_int * len(kinds))(*kinds), len(kinds), N, L0, L1) // 32 - 1
+
+
+def run(mode, diag=None):
+    if os.environ.get("PCT_VERBOSE"):
+        print("run", mode, flush=True)
+    with torch.no_grad():
+        return ops.transformer(f0, f1, structs, tr.layer_names, tr.nhead, m0, m1, inplace=False, prepared=prepared, mode=mode, diag=diag)
+
+
+if only:
+    diag = torch.zeros(16, dtype=torch.uint8, device="cuda")
+    o = run(only, diag)
+    torch.cuda.synchronize()
+    print(f"{only}: completed, status={int(diag.view(torch.int32)[0].item())} finite={bool(torch.isfinite(o[0]).all() and torch.isfinite(o[1]).all())}", flush=True)
+    sys.exit(0)
+ok = True
+outs = {}
+for mode in ("launches", "persistent_call_order", "persistent"):
+    diag = torch.zeros(16, dtype=torch.uint8, device="cuda") if mode != "launches" else None
+    o = run(mode, diag)
+    torch.cuda.synchronize()
+    outs[mode] = (o[0].clone(), o[1].clone())
+    finite = bool(torch.isfinite(o[0]).all() and torch.isfinite(o[1]).all())
+    status = int(diag.view(torch.int32)[0].item()) if diag is not None else 0
+    same_runs = True
+    for _ in range(reps - 1):
+        if diag is not None:
+            diag.zero_()
+        o2 = run(mode, diag)
+        torch.cuda.synchronize()
+        same_runs &= torch.equal(o2[0], outs[mode][0]) and torch.equal(o2[1], outs[mode][1])
+        if diag is not None:
+            status |= int(diag.view(torch.int32)[0].item())
+    print(f"{mode:24s} finite={finite} status={status} repeat-runs-identical={same_runs}")
+    ok &= finite and status == 0 and same_runs
+a, b, c = outs["launches"], outs["persistent_call_order"], outs["persistent"]
+ident = torch.equal(b[0], c[0]) and torch.equal(b[1], c[1])
+d = max(float((a[0] - c[0]).abs().max()), float((a[1] - c[1]).abs().max()))
+scale = float(a[0].abs().max())
+print(f"N={N} L=({L0},{L1}) mask={masked} items={n_items}: dependency order vs call order: {'bit-identical' if ident else 'DIFFERENT'};  "
+      f"persistent vs launches: max |d| = {d:.3e} (outputs up to {scale:.2f})")
+ok &= ident and d <= 2e-4 * max(scale, 1.0)
+
+
+def timed(mode, n=6):
+    for _ in range(2):
+        run(mode)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    ts = []
+    for _ in range(n):
+        torch.cuda.synchronize()
+        ev[0].record()
+        run(mode)
+        ev[1].record()
+        torch.cuda.synchronize()
+        ts.append(ev[0].elapsed_time(ev[1]))
+    return float(np.median(ts)), float(np.min(ts))
+
+
+for mode in ("launches", "persistent_call_order", "persistent"):
+    med, mn = timed(mode)
+    print(f"time {mode:24s} median {med:.3f} ms  min {mn:.3f} ms   (incl. the torch.cat copy of the inputs and the SP conversion)")
+
+if want_trace:
+    diag = torch.zeros(16 + 32 * n_items, dtype=torch.uint8, device="cuda")
+    run("persistent", diag)
+    torch.cuda.synchronize()
+    raw = diag[16:].view(torch.int64).cpu().numpy().reshape(n_items, 4)
+    plan = ops.coarse_plan(kinds, N, L0, L1, f0.device, 0).cpu().numpy().view(np.uint32).reshape(-1, 8)[1:]
+    typ = plan[:, 0] & 15
+    t0 = raw[:, 0].min()
+    pop, rdy, done, wg = (raw[:, 0] - t0) * 0.01, (raw[:, 1] - t0) * 0.01, (raw[:, 2] - t0) * 0.01, raw[:, 3]
+    print(f"trace: makespan {done.max():.1f} us over {len(np.unique(wg))} workgroups")
+    for t, name in ((0, "X"), (1, "K"), (2, "F")):
+        m = typ == t
+        dur, wait = (done - rdy)[m], (rdy - pop)[m]
+        print(f"  {name}: {m.sum():5d} items  run median {np.median(dur):7.2f} us  p90 {np.percentile(dur, 90):7.2f}  max {dur.max():7.2f}   "
+              f"wait median {np.median(wait):6.2f}  mean {wait.mean():6.2f}  max {wait.max():7.2f} us   sum(run) / 256 = {dur.sum() / 256:.1f} us  sum(wait) / 256 = {wait.sum() / 256:.1f} us")
+    idle = done.max() * 256 - (done - pop).sum()
+    print(f"  per workgroup: busy+wait {(done - pop).sum() / 256:.1f} us, pop gaps / tail idle {idle / 256:.1f} us")
+print("PCT_CHECK", "OK" if ok else "FAILED")
+sys.exit(0 if ok else 1)

@@ -45,10 +45,8 @@ def bench_name(full):
         return "conv3x3_duo_kernel<Cfg<7,2,4,8,2>>" if "Cfg<7" in full else "conv3x3_duo_kernel<Cfg<4,2,4,4,1>>"
     if "encoder_x2_kernel" in full:         # round 4: two-job launches of the same kernel body, timed under LOFTR_T_ENCODER_X
         return "encoder_x_kernel"
-    if "rowsweep_kernel<0" in full:
-        return "proj_kernel"                # coarse q projection (timed under LOFTR_T_PROJ)
-    if "rowsweep_kernel<1" in full:
-        return "linear_ln_kernel"           # coarse merge + LayerNorm (LOFTR_T_LINEAR_LN)
+    if "coarse_persistent_kernel" in full:  # round 6: the whole coarse transformer as one persistent launch (X, K and F work items), timed under LOFTR_T_ENCODER_X
+        return "encoder_x_kernel"
     return short(full).split("::")[-1]    # efx::encoder_x_kernel, ffx::fine_pair_kernel -> the timing table's names
 
 
