@@ -54,7 +54,7 @@ sys.path.insert(0, ROOT)
 
 from loftr_amd import LoFTR, get_cfg, _lib          # noqa: E402
 from loftr_amd.distributed import all_gather_match_counts, RcclCounts   # noqa: E402
-from loftr_amd.synth import make_images, make_weights   # noqa: E402
+from loftr_amd.synth import make_images, make_weights, make_backbone_weights   # noqa: E402
 
 H_IMG, W_IMG = 480, 640
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
@@ -80,7 +80,7 @@ def read_timing(lib, kid, reset=True):
     return ms.value, n.value
 
 
-def algorithmic_work(B, L, S, M, C_=256, Cf=128, WW=25, fused=True, fused_fine=True):
+def algorithmic_work(B, L, S, M, C_=256, Cf=128, WW=25, fused=True, fused_fine=True, persistent=False):
     """Algorithmic (flops, bytes) per STEP of every instrumented kernel for a batch of B pairs with
     M matches in total.  fp32 everywhere: 4 bytes per element.  fused: the x side of a coarse
     layer runs as encoder_x_kernel (csrc/encoder_fused.hip) instead of proj / linear_ln / linear / linear_ln; fused_fine: the whole
@@ -122,6 +122,11 @@ def algorithmic_work(B, L, S, M, C_=256, Cf=128, WW=25, fused=True, fused_fine=T
     w["linear_kernel"] = (w["linear_kernel"][0] + fp_f, w["linear_kernel"][1] + fp_b)
     nl = n_self + n_cross
     w["proj_kv_kernel"] = (nl * (2 * rows_c * C_ * 2 * C_ + 2 * rows_c * C_ * 32), nl * 4 * (rows_c * C_ + 2 * C_ * C_))
+    if persistent and fused:
+        # round 6: the coarse transformer as ONE persistent launch (csrc/encoder_fused.hip: coarse_persistent_kernel) -- its K items are
+        # proj_kv_kernel's work (k / v projection + the K^T V reduction), timed in the encoder_x slot together with the X items
+        w["encoder_x_kernel"] = (w["encoder_x_kernel"][0] + w["proj_kv_kernel"][0], w["encoder_x_kernel"][1] + w["proj_kv_kernel"][1])
+        w["proj_kv_kernel"] = (0, 0)
     w["score_sweep_kernel<0>"] = (2 * B * L * S * C_, 4 * B * (L + S) * C_)
     w["score_sweep_kernel<1>"] = (2 * B * L * S * C_, 4 * B * ((L + S) * C_ + L * S))
     w["gather_windows_kernel"] = (0, 2 * 4 * 2 * M * WW * Cf)
@@ -375,8 +380,9 @@ def cpu_baseline(model, img0, img1, gpu_data=None):
 
 BACKBONE_KERNELS = ("conv3x3_duo_kernel<Cfg<4,2,4,4,1>>", "conv3x3_duo_kernel<Cfg<7,2,4,8,2>>", "conv_kernel", "conv3x3s2_kernel")
 ENCODER_KERNELS = ("proj_kv_kernel", "proj_kernel", "linear_kernel", "linear_ln_kernel", "encoder_x_kernel", "fine_pair_kernel")
-# Only the bench line's `roofline` kernel carries hipEvents inside the timed region (one launch per step); everything else
-# is measured in the serial instrumented steps just before it (round-2 verdict: 83 event pairs per step in the timed region).
+# The north_star kernels carry hipEvents inside the timed region: the score-volume kernel (one launch per step) and, since round 6, the
+# encoder group (8 launches per step with the persistent coarse transformer; 34 as launches); everything else is measured in the
+# serial instrumented steps just before it (round-2 verdict: 83 event pairs per step in the timed region).
 NORTH_STAR_TIMED = ("score_sweep_kernel<1>",)
 # The library times kernel FAMILIES (one hipEvent slot per family, csrc/common.h: LoftrTimedKernel); a slot is named after the kernel the
 # default path launches, and these are the names `rocprofv3 --kernel-trace --stats` prints for everything pooled in it.
@@ -428,7 +434,9 @@ def self_spawn(argv, n):
 
 
 def group_roofline(names, timing, work, steps):
-    """One MFMA-roof entry over a set of GEMM kernels (the encoder): summed executed fp16 MFMA flops / summed time."""
+    """One MFMA-roof entry over a set of GEMM kernels (the encoder group, the backbone): `achieved` / `frac` = summed ALGORITHMIC fp32
+    flops / summed launch time against the dense fp16 MFMA peak (the task's definition; round-5 verdict, weak #3), `executed_*` = the
+    fp16 MFMAs the matrix pipe actually runs (3 per fp32 product, csrc/gemm.h) -- its ceiling for algorithmic work is 1 / 3."""
     ms = sum(timing[n][0] for n in names if n in timing)
     launches = sum(timing[n][1] for n in names if n in timing)
     if ms <= 0 or not launches:
@@ -436,15 +444,19 @@ def group_roofline(names, timing, work, steps):
     fl = sum(work[n][0] for n in names if n in timing and n in work)
     by = sum(work[n][1] for n in names if n in timing and n in work)
     t = ms / steps * 1e-3
-    exec_tf = fl * SPLIT_FACTOR / t / 1e12
+    alg_tf = fl / t / 1e12
+    exec_tf = alg_tf * SPLIT_FACTOR
     traffic = [pmc_traffic(n) for n in names if n in timing]
     busy = [(pmc_mfma_busy(n), timing[n][0]) for n in names if n in timing]
-    e = {"kernels": [n for n in names if n in timing], "bound": "mfma", "achieved": round(exec_tf, 1), "peak": MFMA_F16_PEAK_TF,
-         "unit": "TFLOP/s", "frac": round(exec_tf / MFMA_F16_PEAK_TF, 4), "ms_per_step": round(ms / steps, 4),
-         "launches_per_step": round(launches / steps, 2), "alg_TFLOP_s": round(fl / t / 1e12, 2),
+    e = {"kernels": [n for n in names if n in timing], "bound": "mfma", "achieved": round(alg_tf, 2), "peak": MFMA_F16_PEAK_TF,
+         "unit": "TFLOP/s", "frac": round(alg_tf / MFMA_F16_PEAK_TF, 4),
+         "executed_TFLOP_s": round(exec_tf, 1), "executed_frac": round(exec_tf / MFMA_F16_PEAK_TF, 4),
+         "ms_per_step": round(ms / steps, 4),
+         "launches_per_step": round(launches / steps, 2), "alg_TFLOP_s": round(alg_tf, 2),
          "alg_GB_s": round(by / t / 1e9, 1), "hbm_frac": round(by / t / 1e9 / HBM_PEAK_GBS, 4),
          "traffic": None, "mfma_busy": None,
-         "note": "executed rate = 3 fp16 MFMAs per fp32 product (csrc/gemm.h) against the 2.5 PF dense fp16 peak; "
+         "note": "achieved / frac = ALGORITHMIC fp32 flops of these kernels / their launch time against the 2.5 PF dense fp16 peak; executed_* = "
+                 "3 fp16 MFMAs per fp32 product (csrc/gemm.h: fp32-accurate products on the fp16 matrix cores; ceiling for algorithmic work = 1/3); "
                  "mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs * 1024 SIMDs), time-weighted over the kernels"}
     if all(x is not None for x in traffic) and traffic:
         # bytes per STEP: per-launch PMC bytes x launches per step of each kernel
@@ -455,29 +467,31 @@ def group_roofline(names, timing, work, steps):
     return e
 
 
-def other_configs(lib, ids, dev, sd, backbone, steps=5, warmup=2):
+def other_configs(lib, ids, dev, sd, backbone, overlap=True, steps=5, warmup=2):
     """BASELINE configs[3] (MegaDepth outdoor_ds: 840 x 840 pairs zero-padded from 840 x 560, coarse padding masks, scale0 / scale1,
     L = S = 11 025, /root/reference configs/loftr/outdoor/loftr_ds.py:1-5) and configs[4] (indoor_ot: Sinkhorn matching,
     configs/loftr/indoor/loftr_ot.py:1-3) through the SAME library, after the headline's timed region and outside it:
     a few full forwards each (same seeded weights, thr 0.0), plus two instrumented ones for the score-volume kernels."""
     out = {}
 
-    def run(tag, cfg, batch_fn, n_pairs, L, extra):
+    def run(tag, cfg, batch_fn, n_pairs, L, extra, impl=None, strict=True, n_steps=None):
         model = LoFTR(cfg).eval()
-        model.load_state_dict(sd, strict=False)
+        model.load_state_dict(dict(sd), strict=strict)
         model = model.to(dev)
-        model.backbone_impl = backbone
+        model.backbone_impl = impl or backbone
+        model.overlap_fine_branch = overlap
+        n_steps = n_steps or steps
         for _ in range(warmup):
             d = batch_fn(); model(d)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        for _ in range(steps):
+        for _ in range(n_steps):
             d = batch_fn(); model(d)
         e1.record(); torch.cuda.synchronize()
-        ms = e0.elapsed_time(e1) / steps
+        ms = e0.elapsed_time(e1) / n_steps
         M = int(d["mconf"].shape[0])
-        names = [n for n in ("score_sweep_kernel<1>", "score_sweep_kernel<0>", "score_sweep_kernel<2>", "encoder_x_kernel", "fine_pair_kernel") if n in ids]
+        names = [n for n in ("score_sweep_kernel<1>", "score_sweep_kernel<0>", "score_sweep_kernel<2>", "encoder_x_kernel", "proj_kv_kernel", "fine_pair_kernel") if n in ids]
         mask = 0
         for n in names:
             mask |= 1 << ids[n]; read_timing(lib, ids[n])
@@ -487,14 +501,16 @@ def other_configs(lib, ids, dev, sd, backbone, steps=5, warmup=2):
         torch.cuda.synchronize()
         lib.loftr_hip_timing_enable(0)
         ent = {"pairs_per_s": round(n_pairs / ms * 1e3, 2), "ms_per_step": round(ms, 3), "pairs_per_step": n_pairs, "matches_per_pair": round(M / n_pairs, 1),
-               "L": L, "steps": steps}
+               "L": L, "steps": n_steps, "backbone_impl": model.backbone_impl}
         ent.update(extra)
-        kt = {}
+        kt, kl = {}, {}
         for n in names:
             t, c = read_timing(lib, ids[n])
             if c:
                 kt[n] = round(t / c * 1e3, 1)
+                kl[n] = c // 2
         ent["kernel_avg_us"] = kt
+        ent["kernel_launches_per_step"] = kl
         if "score_sweep_kernel<1>" in kt:                       # dual-softmax pass B against the HBM roof at THIS L
             by = 4 * n_pairs * (2 * L * 256 + L * L)
             gbs = by / (kt["score_sweep_kernel<1>"] * 1e-6) / 1e9
@@ -504,6 +520,29 @@ def other_configs(lib, ids, dev, sd, backbone, steps=5, warmup=2):
         del model
         torch.cuda.empty_cache()
 
+    # ---- configs[0] on the GPU: ONE 640 x 480 pair per forward (notebooks/demo_single_pair.ipynb cells 3-4; demo/demo_loftr.py:150-158
+    # is a batch-1 stream) -- the latency every interactive caller of the reference sees.  The coarse transformer has 38 token tiles per
+    # sequence here (76 workgroups in a self call, 38 in a cross call) for 256 CUs: ops.COARSE_MODE "auto" runs it as launches
+    # (a chain of 12 dependent calls; the persistent form wins from ~150 tiles per call on).
+    cfg = get_cfg(thr=0.0)
+    cfg["coarse"]["temp_bug_fix"] = True
+    s0, s1 = make_images(1234, 1, H_IMG, W_IMG)
+    s0, s1 = torch.from_numpy(s0).to(dev), torch.from_numpy(s1).to(dev)
+    Lc = (H_IMG // 8) * (W_IMG // 8)
+    tiles = (Lc + 127) // 128
+    run("single_pair_640", cfg, lambda: {"image0": s0, "image1": s1}, 1, Lc,
+        {"workload": "BASELINE configs[0] on the GPU: one 640x480 pair per forward (batch 1), dual-softmax, thr 0.0; ms_per_step = latency of a pair",
+         "encoder_occupancy": {"token_tiles_per_sequence": tiles, "workgroups_per_self_call": 2 * tiles, "workgroups_per_cross_call": tiles,
+                               "cus": 256, "cu_occupancy_self": round(2 * tiles / 256, 3), "cu_occupancy_cross": round(tiles / 256, 3)}},
+        n_steps=4 * steps)
+    # ---- the north_star's literal split: ResNet-FPN in PyTorch-ROCm (MIOpen fp32, channels-last) + the HIP matching path
+    if backbone == "hip":
+        a0, a1 = make_images(1234, 8, H_IMG, W_IMG)
+        a0, a1 = torch.from_numpy(a0).to(dev), torch.from_numpy(a1).to(dev)
+        run("torch_backbone", cfg, lambda: {"image0": a0, "image1": a1}, 8, Lc,
+            {"workload": "the headline step (8 pairs 640x480, dual-softmax) with backbone_impl='torch': the backbone stays in PyTorch-ROCm as north_star "
+                         "words it; the headline runs this library's HIP convolutions instead"}, impl="torch")
+        del a0, a1
     # ---- configs[3]: outdoor
     N = 2
     cfg = get_cfg(thr=0.0, border_rm=2)
@@ -527,7 +566,8 @@ def other_configs(lib, ids, dev, sd, backbone, steps=5, warmup=2):
     a0, a1 = make_images(1234, B, H_IMG, W_IMG)
     a0, a1 = torch.from_numpy(a0).to(dev), torch.from_numpy(a1).to(dev)
     run("indoor_ot", cfg, lambda: {"image0": a0, "image1": a1}, B, (H_IMG // 8) * (W_IMG // 8),
-        {"workload": "BASELINE configs[4]: 8 pairs 640x480, match_type sinkhorn (3 iterations, conf_matrix_with_bin), thr 0.0"})
+        {"workload": "BASELINE configs[4]: 8 pairs 640x480, match_type sinkhorn (3 iterations, conf_matrix_with_bin), thr 0.0"},
+        strict=False)                                          # (bin_score keeps its constructor value 1.0: not in the seeded state dict)
     return out
 
 
@@ -633,8 +673,13 @@ def main():
     if args.match_type == "sinkhorn":                      # configs/loftr/indoor/loftr_ot.py + default.py:29-36
         cfg["match_coarse"].update(match_type="sinkhorn", skh_prefilter=False, sparse_spvs=True)
     model = LoFTR(cfg).eval()
+    # the WHOLE state dict, loaded strict=True like a reference checkpoint (README.md:57-60): matcher weights seed 0 and the seeded backbone
+    # (filters + non-trivial BatchNorm statistics) of the image-level goldens e2e_synth / e2e_batch (tests/golden/make_golden_e2e.py:
+    # BACKBONE_SEED 7, bn_strength 0.3) -- pair 0 of this batch with these weights is pinned against the reference there
     sd = {k: torch.from_numpy(np.ascontiguousarray(np.asarray(v))) for k, v in make_weights(0, cfg).items()}
-    model.load_state_dict(sd, strict=False)
+    for k, v in make_backbone_weights(7, model.backbone, 0.3).items():
+        sd["backbone." + k] = v
+    model.load_state_dict(dict(sd), strict=True)
     model = model.to(dev)
     model.coarse_matching.materialize_conf = not args.no_conf
     model.backbone_impl = args.backbone
@@ -696,8 +741,9 @@ def main():
     M = int(data["mconf"].shape[0])
     L = (H_IMG // 8) * (W_IMG // 8)
     raw = {name: read_timing(lib, kid) for name, kid in ids.items()}
+    persistent = raw.get("encoder_x_kernel", (0, 0))[1] > 0 and raw.get("proj_kv_kernel", (0, 0))[1] == 0
     work = algorithmic_work(B, L, L, M, fused=raw.get("encoder_x_kernel", (0, 0))[1] > 0,
-                            fused_fine=raw.get("fine_pair_kernel", (0, 0))[1] > 0)
+                            fused_fine=raw.get("fine_pair_kernel", (0, 0))[1] > 0, persistent=persistent)
     kernels = []
     for name, (ms, n) in raw.items():
         if name in work and n:
@@ -711,8 +757,8 @@ def main():
     model.overlap_fine_branch = not args.no_overlap
     kernels.sort(key=lambda k: -k["ms_per_step"])
 
-    # ---- timed region: the north_star kernels (score volume + encoder) carry events
-    timed_ids = [n for n in NORTH_STAR_TIMED if n in ids]
+    # ---- timed region: the north_star kernels (score volume AND the encoder group) carry events -- `roofline` is measured HERE
+    timed_ids = [n for n in NORTH_STAR_TIMED + ENCODER_KERNELS if n in ids]
     if args.match_type != "dual_softmax":
         timed_ids = [n for n in timed_ids if not n.startswith("score_")]
     mask = 0
@@ -732,24 +778,7 @@ def main():
         ms, cnt = read_timing(lib, ids[n])
         if cnt:
             timing[n] = (ms, cnt)
-    # ---- the encoder group INSIDE the two-stream step (after the timed region, same step function): its launches share the CUs with the
-    # FPN fine branch's convolution workgroups there, so an event-bracketed launch is longer than alone -- reported as in_region_*
-    in_region = {}
-    if model.overlap_fine_branch:
-        enc_ids = [n for n in ENCODER_KERNELS if n in ids]
-        m2 = 0
-        for n in enc_ids:
-            m2 |= 1 << ids[n]
-            read_timing(lib, ids[n])
-        lib.loftr_hip_timing_enable(m2)
-        for _ in range(NB):
-            step()
-        torch.cuda.synchronize()
-        lib.loftr_hip_timing_enable(0)
-        for n in enc_ids:
-            ms, cnt = read_timing(lib, ids[n])
-            if cnt:
-                in_region[n] = (ms, cnt)
+    # the timed region's match count can differ from the instrumented steps' only if the inputs did (they do not); same work table
     roof = None
     if "score_sweep_kernel<1>" in timing:
         ms, cnt = timing["score_sweep_kernel<1>"]
@@ -758,31 +787,31 @@ def main():
         roof["traffic"] = pmc_traffic("score_sweep_kernel<1>")
         roof["note"] = ("north_star score-volume kernel (dual-softmax pass B: recompute the score tile on MFMA, write conf_matrix "
                         "once): algorithmic bytes = descriptors + conf_matrix (DESIGN.md §4) / in-region hipEvent launch time")
-    # Encoder group: from the serial instrumented steps (same process, just before the timed region).  In the timed region
-    # the FPN fine branch runs on the side stream concurrently with the encoder, so event-bracketed encoder launches
-    # there include time-slicing with convolution workgroups (about 2x longer); that figure is kept as `in_region_*`.
+    # Encoder group (the headline `roofline`): hipEvents around every launch of these kernels INSIDE the timed region (round-5 verdict,
+    # weak #3: until round 5 the headline figure came from serialised instrumented steps while the timed step ran two streams).  The
+    # serial instrumented steps before the timed region give `alone` (the kernels with the GPU to themselves).
     serial = {k["kernel"]: (k["ms_per_step"] * NB, int(round(k["launches_per_step"] * NB))) for k in kernels}
-    roof_enc = group_roofline([n for n in ENCODER_KERNELS if n in serial], serial, work, NB)
+    roof_alone = group_roofline([n for n in ENCODER_KERNELS if n in serial], serial, work, NB)
     roof_bb = group_roofline([n for n in BACKBONE_KERNELS if n in serial], serial, work, NB)
+    roof_enc = group_roofline([n for n in ENCODER_KERNELS if n in timing], timing, work, args.steps)
     serial_step_ms = backbone_ms + hot_ms
-    for r_ in (roof_enc, roof_bb):
-        if r_:
-            r_["measured"] = ("hipEvents around every launch of these kernels in 3 instrumented steps of this run with the two HIP "
-                              "streams serialised (kernels alone on the GPU)")
-            r_["share_of_serial_step"] = round(r_["ms_per_step"] / serial_step_ms, 4)
-    if roof_enc and in_region:
-        r2 = group_roofline([n for n in ENCODER_KERNELS if n in in_region], in_region, work, NB)
-        if r2:
-            roof_enc["in_region_frac"] = r2["frac"]
-            roof_enc["in_region_ms_per_step"] = r2["ms_per_step"]
-            roof_enc["in_region_note"] = ("the same kernels event-bracketed inside the two-stream step (3 steps after the timed region): launches time-slice "
-                                          "the CUs with the fine branch's convolutions; `frac` / `achieved` above are the kernels alone on the GPU")
+    if roof_bb:
+        roof_bb["measured"] = "hipEvents around every launch of these kernels in 3 instrumented steps of this run on one stream (kernels alone on the GPU)"
+        roof_bb["share_of_serial_step"] = round(roof_bb["ms_per_step"] / serial_step_ms, 4)
     if roof_enc:
-        roof_enc["kernel"] = "encoder_x_kernel (+ proj_kv / fine_pair / linear: the linear-attention encoder group)"
+        roof_enc["measured"] = (f"hipEvents (recorded by the library on the launch stream) around every launch of these kernels in the {args.steps} steps of the "
+                                "TIMED region" + (", in which the FPN fine branch runs on a second HIP stream next to the coarse transformer" if model.overlap_fine_branch else ""))
+        roof_enc["kernel"] = ("coarse_persistent_kernel (the whole coarse LocalFeatureTransformer: q / k / v projections, K^T V, merge, MLP, LayerNorms; one launch) "
+                              "+ fine_pair_kernel + the fine-level linear kernels: the linear-attention encoder group" if persistent else
+                              "encoder_x_kernel (+ proj_kv / fine_pair / linear: the linear-attention encoder group)")
+        roof_enc["coarse_transformer"] = "one persistent launch (work queue, per-pair / per-tile dependencies)" if persistent else "per-call launches"
         roof_enc["pooled_from"] = sorted({x for n in ENCODER_KERNELS for x in POOLED_FROM.get(n, [n])})
-        roof_enc["dominant_share_of_step"] = round(roof_enc["ms_per_step"] / hot_ms, 4)
-        roof_enc["dominant_share_note"] = ("share of the hand-written matching path (stage_ms.hot_path_hip) these kernels account for; "
-                                           "share_of_serial_step = of backbone + matching path run serially")
+        roof_enc["share_of_step"] = round(roof_enc["ms_per_step"] / (elapsed_local / args.steps * 1e3), 4)
+        if roof_alone:
+            roof_enc["alone"] = {k: roof_alone[k] for k in ("achieved", "frac", "executed_TFLOP_s", "executed_frac", "ms_per_step", "launches_per_step")}
+            roof_enc["alone"]["measured"] = "the same kernels in 3 instrumented steps on one stream before the timed region"
+            roof_enc["alone_frac"] = roof_alone["frac"]
+            roof_enc["dominant_share_of_matching_path"] = round(roof_alone["ms_per_step"] / hot_ms, 4)
     if roof is not None:
         roof["share_of_serial_step"] = round(roof["ms_per_step"] / serial_step_ms, 4)
     elapsed, per_rank_ms = elapsed_local, [round(elapsed_local / args.steps * 1e3, 3)]
@@ -815,14 +844,14 @@ def main():
                        "thr_note": "stock thr 0.2 gives 0 matches with random weights; thr 0.0 keeps the fine stage loaded",
                        "conf_matrix_materialised": not args.no_conf, "match_type": args.match_type, "matches_per_pair": round(m_total / (world * B), 1),
                        "global_batch": world * B, "parallelism": f"dp{world} (pairs sharded; RCCL all-gather of match counts)",
-                       "parity": "image-level goldens of the reference forward, both backbones (incl. a 3-pair batch and the 840 x 840 masked outdoor batch): profiles/r05_parity_margins.txt"},
+                       "parity": "image-level goldens of the reference forward, both backbones (incl. a 3-pair batch and the 840 x 840 masked outdoor batch): profiles/r06_parity_margins.txt"},
             "per_rank_ms_per_step": per_rank_ms,
             "collective": {"transport": transport, "ranks_in_communicator": (rccl.ranks_seen if rccl is not None else world) if multi else 1},
             "pmc_identity": PMC_IDENTITY if pmc_table() else None,      # what ties profiles/pmc_traffic.json to this build: "source" (every kernel source unchanged) / "kernel_code" (machine code of the profiled kernels byte-identical) / None (no traffic figures)
             "stage_ms": {"backbone": round(backbone_ms, 3), "backbone_impl": args.backbone, "hot_path_hip": round(hot_ms, 3),
                          "note": "median of 3 instrumented steps (after one unmeasured instrumented step) run WITHOUT the two-stream overlap (serial sum > ms_per_step when "
                                  "the timed region overlaps the FPN fine branch with the coarse stage); `kernels` likewise"},
-            "fine_branch_overlapped_in_timed_region": not args.no_overlap,
+            "fine_branch_overlapped_in_timed_region": bool(model.overlap_fine_branch), "coarse_mode": "persistent" if persistent else "launches",
             **({"attempt": int(os.environ["LOFTR_BENCH_ATTEMPT"]), "attempt_note": "the first attempt was killed by a signal (run_with_retry)"}
                if os.environ.get("LOFTR_BENCH_ATTEMPT", "1") != "1" else {}),
             "hot_path_pairs_per_s": round(B / (hot_ms * 1e-3), 2),
@@ -835,7 +864,7 @@ def main():
         }
         if world == 1 and not args.no_other_configs and args.match_type == "dual_softmax":
             try:
-                out["other_configs"] = other_configs(lib, ids, dev, sd, args.backbone)
+                out["other_configs"] = other_configs(lib, ids, dev, sd, args.backbone, overlap=not args.no_overlap)
             except Exception as e:                          # noqa: BLE001  (the headline line must not depend on the extras)
                 out["other_configs"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:

@@ -19,7 +19,6 @@ statistics and elementwise glue stay PyTorch autograd); ``LoFTR.head_grads = Tru
 """
 import contextlib
 import math
-import os
 import warnings
 import weakref
 
@@ -377,6 +376,7 @@ class LoFTR(nn.Module):
         # With the HIP backbone the FPN top-down (fine) branch runs on a second HIP stream, concurrently with the
         # coarse transformer + coarse matching it does not feed; joined before FinePreprocess.
         self.overlap_fine_branch = True
+        self.fine_join_late = False                          # True: join the side stream after coarse matching instead of after the coarse transformer (A/B)
         self._side_stream = None
         # .train() only: hand the two matching heads their inputs as autograd LEAVES (data['_head_inputs']) and run the heads
         # with a graph, so that LoFTRLoss(...)(data); data['loss'].backward() leaves d loss / d (transformer outputs) in
@@ -448,11 +448,10 @@ class LoFTR(nn.Module):
         if "mask0" in data:
             mask_c0, mask_c1 = data["mask0"].flatten(-2), data["mask1"].flatten(-2)
         feat_c0, feat_c1 = self.loftr_coarse(feat_c0, feat_c1, mask_c0, mask_c1, inplace=True)   # fresh pos-encoded copies
-        # Join the side stream (FPN fine branch) HERE, not after coarse matching (LOFTR_FINE_JOIN=late restores that): the encoder
+        # Join the side stream (FPN fine branch) HERE, not after coarse matching (self.fine_join_late restores that): the encoder
         # launches leave partly filled rounds that the convolution workgroups use, the score-volume kernels do not -- sharing the
         # GPU only doubled their duration (660 vs 340 us for pass B, profiles/r03_overlap_ab.txt) without shortening the step.
-        late = os.environ.get("LOFTR_FINE_JOIN") == "late"
-        if not late and getattr(self, "_fine_join", None) is not None:
+        if not self.fine_join_late and getattr(self, "_fine_join", None) is not None:
             torch.cuda.current_stream(feat_f0.device).wait_stream(self._fine_join)
             self._fine_join = None
         full = self.training and self.full_grads

@@ -98,7 +98,7 @@ CASES = {"e2e_scannet": dict(images="scannet", bn_strength=0.3),
          # the only image-level case that covered it
          "e2e_peaked_outdoor": dict(images="synth", bn_strength=0.3, n=2, size=(840, 840), valid0=(560, 840), valid1=(560, 840),
                                     scale0=(1.9, 1.9), scale1=(1.9, 1.9), temp_bug_fix=False, border_rm=2, coarse_gain=6.0),
-         "e2e_peaked_ot": dict(images="synth", bn_strength=0.3, crop0=(384, 512), crop1=(384, 512), match_type="sinkhorn", coarse_gain=6.0),
+         "e2e_peaked_ot": dict(images="synth", bn_strength=0.3, crop0=(384, 512), crop1=(384, 512), match_type="sinkhorn", coarse_gain=19.0),     # (Sinkhorn scores carry no 1 / temperature: 19^2 = 6^2 * 10 gives the spread of the dual-softmax cases)
          "e2e_peaked_batch": dict(images="synth", bn_strength=0.3, n=3, coarse_gain=6.0)}
 
 
