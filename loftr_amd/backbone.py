@@ -82,7 +82,8 @@ class ReLU(nn.ReLU):
 
 class LeakyReLU(nn.LeakyReLU):
     def forward(self, x):
-        return autograd.act(x, None, "leaky_relu", self.negative_slope) if _glue(self, x) and "act" in GLUE_PARTS else super().forward(x)
+        # (a negative slope has no HIP node: the backward reads the derivative off the sign of the output)
+        return autograd.act(x, None, "leaky_relu", self.negative_slope) if _glue(self, x) and "act" in GLUE_PARTS and self.negative_slope >= 0 else super().forward(x)
 
 
 def _c1(cin, cout, stride=1):

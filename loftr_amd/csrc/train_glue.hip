@@ -444,6 +444,7 @@ extern "C" int loftr_bn_train_bwd(const float* dy, const float* x, int N, int C,
 }
 extern "C" int loftr_act_fwd(const float* a, const float* b, long n, int act, float slope, float* y, void* stream) {
   LOFTR_CHECK_ARG(a && y && n >= 0 && act >= 0 && act <= 2);
+  if (act == 2 && !(slope >= 0.f)) return LOFTR_ERR_UNSUPPORTED;      // the backward reads the derivative off the sign of the OUTPUT: valid for slope >= 0 only
   if (n == 0) return LOFTR_OK;
   hipLaunchKernelGGL(tg::act_fwd_kernel, tg::grid1d(n, 4), dim3(256), 0, (hipStream_t)stream, a, b, n, act, slope, y);
   LOFTR_CHECK_LAUNCH();
@@ -451,6 +452,7 @@ extern "C" int loftr_act_fwd(const float* a, const float* b, long n, int act, fl
 }
 extern "C" int loftr_act_bwd(const float* dy, const float* y, long n, int act, float slope, float* dx, void* stream) {
   LOFTR_CHECK_ARG(dy && dx && n >= 0 && act >= 0 && act <= 2 && (act == 0 || y));
+  if (act == 2 && !(slope >= 0.f)) return LOFTR_ERR_UNSUPPORTED;
   if (n == 0) return LOFTR_OK;
   hipLaunchKernelGGL(tg::act_bwd_kernel, tg::grid1d(n), dim3(256), 0, (hipStream_t)stream, dy, y, n, act, slope, dx);
   LOFTR_CHECK_LAUNCH();

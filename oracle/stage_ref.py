@@ -55,7 +55,7 @@ def _sources(root):
     return rels
 
 
-def stage(root=REFERENCE_ROOT, verbose=True):
+def stage(root=REFERENCE_ROOT, verbose=True, update_hash=False):
     """Compile the reference's `src.loftr` package into oracle/_ref/loftr_reference.bundle.  Returns the path,
     or None when the reference is not on this machine (the GPU box: it then uses the bundle that travelled)."""
     if not os.path.isfile(os.path.join(root, "src", "loftr", "loftr.py")):
@@ -75,14 +75,22 @@ def stage(root=REFERENCE_ROOT, verbose=True):
             modules.setdefault(".".join(parts[:n]), (True, None))
     blob = marshal.dumps({"magic": importlib.util.MAGIC_NUMBER, "python": sys.version, "sha256": digest.hexdigest(),
                           "modules": modules})
+    # The tracked oracle/ref_bundle.sha256 names the bundle's bytes AND the digest of the reference sources they were compiled from.
+    # A re-stage of the SAME sources may produce other bytes (marshal is not byte-stable across processes): then the record follows
+    # the new file.  Sources that differ from the recorded ones are a different reference: refuse unless told to (--update-hash) --
+    # until round 5 any re-stage silently blessed whatever it had built (advisor, round 5).
+    rec = open(EXPECTED).read().split() if os.path.isfile(EXPECTED) else []
+    rec_sources = rec[rec.index("sha256") + 1].rstrip(",") if "sha256" in rec else None
+    if rec and rec_sources is not None and rec_sources != digest.hexdigest() and not update_hash:
+        raise RuntimeError(f"the reference under {root} (sources sha256 {digest.hexdigest()[:16]}) is not the one oracle/ref_bundle.sha256 records "
+                           f"({rec_sources[:16]}): run `python -m oracle.stage_ref --update-hash` if that is intended")
     os.makedirs(REF_DIR, exist_ok=True)
     tmp = BUNDLE + ".tmp"
     with open(tmp, "wb") as fh:
         fh.write(blob)
     os.replace(tmp, BUNDLE)
     file_hash = hashlib.sha256(blob).hexdigest()
-    want = open(EXPECTED).read().split()[0] if os.path.isfile(EXPECTED) else None
-    if want != file_hash:                                   # a new reference checkout / CPython: record it (shows up as a diff to commit)
+    if not rec or rec[0] != file_hash:
         with open(EXPECTED, "w") as fh:
             fh.write(f"{file_hash}  loftr_reference.bundle  (sources sha256 {digest.hexdigest()}, {sys.version.split()[0]})\n")
     if verbose:
@@ -143,6 +151,6 @@ def install_finder():
 
 
 if __name__ == "__main__":
-    if stage() is None:
+    if stage(update_hash="--update-hash" in sys.argv) is None:
         print(f"[stage_ref] no reference at {REFERENCE_ROOT}; nothing staged"
               + (f" (existing bundle kept: {BUNDLE})" if bundle_available() else ""))

@@ -114,6 +114,31 @@ for mode in ("launches", "persistent_call_order", "persistent"):
     med, mn = timed(mode)
     print(f"time {mode:24s} median {med:.3f} ms  min {mn:.3f} ms   (incl. the torch.cat copy of the inputs and the SP conversion)")
 
+if "--burn" in sys.argv:
+    # back-to-back runs without a host synchronisation in between (inplace on a scratch copy: no clone inside the loop): does the
+    # per-run time rise when the GPU gets no idle time between transformer calls (power limit)?
+    K = int(sys.argv[sys.argv.index("--burn") + 1])
+    both = torch.cat([f0, f1]) if L0 == L1 else None
+    for mode in ("launches", "persistent"):
+        if both is None:
+            break
+        h0, h1 = both[:N], both[N:]
+        run_ip = lambda: ops.transformer(h0, h1, structs, tr.layer_names, tr.nhead, m0, m1, inplace=True, prepared=prepared, mode=mode)
+        with torch.no_grad():
+            for reps in (1, K):
+                for _ in range(2):
+                    run_ip()
+                torch.cuda.synchronize()
+                import time
+                time.sleep(0.5 if reps == 1 else 0.0)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(reps):
+                    run_ip()
+                e1.record()
+                torch.cuda.synchronize()
+                print(f"burn {mode:12s} {reps:4d} back-to-back runs (in place, no copies): {e0.elapsed_time(e1) / reps:.3f} ms per run")
+
 if want_trace:
     diag = torch.zeros(16 + 32 * n_items, dtype=torch.uint8, device="cuda")
     run("persistent", diag)
