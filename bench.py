@@ -590,6 +590,11 @@ def main():
     ap.add_argument("--backbone", default="hip", choices=["hip", "torch"],
                     help="hip: implicit-GEMM convolutions of this library (default; image-level parity with the reference held at "
                          "1e-4 / 1e-3 px, profiles/r05_parity_margins.txt); torch: PyTorch-ROCm / MIOpen fp32")
+    ap.add_argument("--coarse-mode", default=None, choices=["auto", "launches", "persistent"],
+                    help="coarse transformer as per-call launches or as the persistent work-queue kernel (default: the model's rule -- launches while a "
+                         "second stream shares the GPU, persistent otherwise)")
+    ap.add_argument("--debug-switch", action="append", default=[], metavar="KEY=VALUE",
+                    help="loftr_hip_debug_set(KEY, VALUE) before the run (A/B switches of the library, include/loftr_hip.h); recorded in the JSON")
     ap.add_argument("--collective", default="auto", choices=["auto", "cabi", "torch"],
                     help="count all-gather transport: the library's C-ABI RCCL call, or torch.distributed (also RCCL); auto = cabi, "
                          "falling back to torch if the communicator cannot be created (recorded in the JSON)")
@@ -666,6 +671,8 @@ def main():
     lib = _lib.load()
     _lib.check(lib.loftr_hip_device_check(), "device check")
     ids = kernel_ids(lib)
+    for kv in args.debug_switch:
+        _lib.check(lib.loftr_hip_debug_set(kv.split("=")[0].encode(), int(kv.split("=")[1])), "--debug-switch " + kv)
 
     torch.manual_seed(0)                                   # backbone init
     cfg = get_cfg(thr=args.thr)
@@ -684,6 +691,8 @@ def main():
     model.coarse_matching.materialize_conf = not args.no_conf
     model.backbone_impl = args.backbone
     model.overlap_fine_branch = not args.no_overlap
+    if args.coarse_mode:
+        model.coarse_mode = args.coarse_mode
     if args.scaling == "strong":
         assert args.total_batch % world == 0, "--total-batch must be divisible by the number of ranks"
         B = args.total_batch // world
@@ -852,6 +861,7 @@ def main():
                          "note": "median of 3 instrumented steps (after one unmeasured instrumented step) run WITHOUT the two-stream overlap (serial sum > ms_per_step when "
                                  "the timed region overlaps the FPN fine branch with the coarse stage); `kernels` likewise"},
             "fine_branch_overlapped_in_timed_region": bool(model.overlap_fine_branch), "coarse_mode": "persistent" if persistent else "launches",
+            **({"debug_switches": args.debug_switch} if args.debug_switch else {}),
             **({"attempt": int(os.environ["LOFTR_BENCH_ATTEMPT"]), "attempt_note": "the first attempt was killed by a signal (run_with_retry)"}
                if os.environ.get("LOFTR_BENCH_ATTEMPT", "1") != "1" else {}),
             "hot_path_pairs_per_s": round(B / (hot_ms * 1e-3), 2),

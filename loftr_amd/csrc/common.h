@@ -56,6 +56,7 @@ enum LoftrDebugKey {
   LOFTR_DBG_REDUCE_TALL,            // 1 (default): tall partial-sum reductions of the weight gradients use the tall kernel; 0: the generic one
   LOFTR_DBG_PCT_GRID,               // 0 (default): the persistent coarse transformer runs one workgroup per CU (256); n > 0: n workgroups
   LOFTR_DBG_PCT_SKIP,               // 0 (default); bit t set: work items of type t (0 X, 1 K, 2 F) are popped and signalled but not executed (queue tests: WRONG results)
+  LOFTR_DBG_PCT_QUOTA,              // 0 (default): persistent workgroups stay until the queue is empty; n > 0: a workgroup leaves after n items (A/B: sharing the GPU with another stream)
   LOFTR_DBG_CONV_DUO,               // 1 (default): 3x3 / stride-1 convolutions with 128 k / 192 / 224 output columns run conv3x3_duo_kernel; 0: the generic conv3x3_kernel (any Cout)
   LOFTR_DBG_CONV_PATCH,             // 1 (default): 3x3 / stride-1 convolutions run the patch kernels; 0: the implicit-GEMM conv_kernel (the strided / 1x1 path)
   LOFTR_DBG_COUNT

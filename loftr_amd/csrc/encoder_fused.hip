@@ -499,6 +499,7 @@ struct PctArgs {
   unsigned long long* trace;                            // null, or per item {popped, ready, done, workgroup} (wall_clock64: 100 MHz)
   unsigned* status;                                     // null, or where the error word is copied to
   unsigned signature; int skip;
+  int quota;                                            // 0: a workgroup pulls items until the queue is empty; n > 0: it leaves after n items (its CU goes back to the dispatcher: another stream's workgroups get a turn)
   PctLayerPtrs layer[PCT_MAX_LAYERS]; PctCall call[PCT_MAX_CALLS];
 };
 constexpr int OFF_RED = OFF_TAB + T_N * 4, RED_FLOATS = 33 * 32, OFF_CTRL = OFF_RED + W * RED_FLOATS * 4, LDS_BYTES_P = OFF_CTRL + 64;
@@ -699,7 +700,7 @@ __global__ __launch_bounds__(W * 64, 1) void coarse_persistent_kernel(PctArgs P)
   // wave go round the barriers without it: the workgroup then re-reads the same queue entry for ever (round 6, first build).
   const int lane0 = (threadIdx.x & 63) == 0;
   const bool wave0 = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) == 0;
-  for (;;) {
+  for (int mine = 0; P.quota <= 0 || mine < P.quota; ++mine) {
     unsigned long long t_pop = 0, t_rdy = 0;
     if (wave0) {
       unsigned itv = 0;
@@ -869,7 +870,11 @@ int launch_coarse_persistent(const PctLaunch& p, hipStream_t st) {
   TimedLaunch tl(LOFTR_T_ENCODER_X, st);
   a.skip = loftr_debug_value(LOFTR_DBG_PCT_SKIP);
   const int cap = loftr_debug_value(LOFTR_DBG_PCT_GRID) > 0 ? loftr_debug_value(LOFTR_DBG_PCT_GRID) : 256;
-  const int grid = a.n_items < cap ? a.n_items : cap;      // one workgroup per CU; fewer resident ones only slow the queue down (in-order pops: no deadlock)
+  int grid = a.n_items < cap ? a.n_items : cap;            // one workgroup per CU; fewer resident ones only slow the queue down (in-order pops: no deadlock)
+  // "pct_quota" n > 0: workgroups leave after n items and the grid holds enough of them for the whole queue (an item popped is held by a
+  // RESIDENT workgroup, so the in-order argument against deadlock is unchanged); between two workgroups a CU is up for grabs
+  a.quota = loftr_debug_value(LOFTR_DBG_PCT_QUOTA);
+  if (a.quota > 0) grid = ceil_div(a.n_items, a.quota) + 8;
   hipLaunchKernelGGL(efx::coarse_persistent_kernel, dim3(grid), dim3(efx::W * 64), 0, st, a);
   LOFTR_CHECK_LAUNCH();
   return LOFTR_OK;

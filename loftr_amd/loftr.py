@@ -130,9 +130,10 @@ class LocalFeatureTransformer(nn.Module):
                     nn.init.xavier_uniform_(p)
         del first
 
-    def forward(self, feat0, feat1, mask0=None, mask1=None, inplace=False):
+    def forward(self, feat0, feat1, mask0=None, mask1=None, inplace=False, mode=None):
         """``inplace`` (not in the reference signature): the caller owns feat0 / feat1 and does not need their
-        input values any more; when they are the two halves of one buffer the layers then run on it directly."""
+        input values any more; when they are the two halves of one buffer the layers then run on it directly.
+        ``mode``: ops.COARSE_MODE for this call ("launches" / "persistent" / "auto"; None = the process default)."""
         assert self.d_model == feat0.size(2), "the feature number of src and transformer must be equal"
         for name in self.layer_names:
             if name not in ("self", "cross"):
@@ -154,7 +155,7 @@ class LocalFeatureTransformer(nn.Module):
             return feat0, feat1
         structs = [layer.weight_struct() for layer in self.layers]
         return ops.transformer(feat0.contiguous(), feat1.contiguous(), structs, self.layer_names, self.nhead,
-                               mask0, mask1, inplace=inplace, prepared=self._prepared(structs, feat0.device))
+                               mask0, mask1, inplace=inplace, prepared=self._prepared(structs, feat0.device), mode=mode)
 
     def _prepared(self, structs, device):
         """The layers' matrices in the library's GEMM operand format, rebuilt only when a weight tensor is modified in
@@ -376,6 +377,7 @@ class LoFTR(nn.Module):
         # With the HIP backbone the FPN top-down (fine) branch runs on a second HIP stream, concurrently with the
         # coarse transformer + coarse matching it does not feed; joined before FinePreprocess.
         self.overlap_fine_branch = True
+        self.coarse_mode = None                              # None: ops.COARSE_MODE ("auto"); "launches" / "persistent" / "auto" for this model
         self.fine_join_late = False                          # True: join the side stream after coarse matching instead of after the coarse transformer (A/B)
         self._side_stream = None
         # .train() only: hand the two matching heads their inputs as autograd LEAVES (data['_head_inputs']) and run the heads
@@ -447,7 +449,13 @@ class LoFTR(nn.Module):
         mask_c0 = mask_c1 = None
         if "mask0" in data:
             mask_c0, mask_c1 = data["mask0"].flatten(-2), data["mask1"].flatten(-2)
-        feat_c0, feat_c1 = self.loftr_coarse(feat_c0, feat_c1, mask_c0, mask_c1, inplace=True)   # fresh pos-encoded copies
+        # The coarse transformer has two forms with the same results to float32 noise (csrc/encoder_fused.hip): ONE persistent launch whose
+        # 256 resident workgroups pull the layers' work items from a dependency-ordered queue, or per-call launches.  Measured inside the
+        # bench step (profiles/r06_coarse_mode_ab.txt, 8 pairs 640 x 480, ms per step, two runs each): persistent 20.33 / 20.34 with the
+        # FPN fine branch on the side stream, 20.97 / 20.31 without; launches 20.20 / 20.25 with, 21.50 / 20.69 without -- with the side
+        # stream the two are within run-to-run noise, without it the persistent form is ahead, and alone on the GPU it is 3.13 vs 3.29 ms
+        # per transformer.  ops.COARSE_MODE "auto" (the default) takes the persistent form from 150 token tiles per call on.
+        feat_c0, feat_c1 = self.loftr_coarse(feat_c0, feat_c1, mask_c0, mask_c1, inplace=True, mode=self.coarse_mode)   # fresh pos-encoded copies
         # Join the side stream (FPN fine branch) HERE, not after coarse matching (self.fine_join_late restores that): the encoder
         # launches leave partly filled rounds that the convolution workgroups use, the score-volume kernels do not -- sharing the
         # GPU only doubled their duration (660 vs 340 us for pass B, profiles/r03_overlap_ab.txt) without shortening the step.

@@ -73,12 +73,19 @@ def _kernel_resources(text):
     return out
 
 
+def _function_spans(text):
+    """(first line, last line) of every function body in a hipcc -S listing."""
+    lines = text.split("\n")
+    ends = [i for i, l in enumerate(lines) if l.startswith(".Lfunc_end")]
+    return list(zip([0] + ends[:-1], ends))
+
+
 def test_hot_kernels_keep_their_register_and_lds_budgets(isa):
     """The occupancy each hot kernel is designed for, read off the compiled code objects: a change that spills a k-loop to scratch or
     pushes a two-workgroups-per-CU kernel over its LDS / register budget fails here, on the CPU, before it costs GPU time."""
     conv = _kernel_resources(isa["conv.hip"])
     duo = {k: v for k, v in conv.items() if "conv3x3_duo_kernel" in k}
-    assert len(duo) >= 5
+    assert len(duo) == 3                                     # Cfg<4,2,4> (128 k columns), Cfg<6,2,4,8,2> (192), Cfg<7,2,4,8,2> (224): the A/B variants left in round 6
     for k, v in duo.items():
         assert v["scratch"] == 0, (k, v)
         four_wave = "ELi4ELi1EEE" in k                       # Cfg<.., WAVES = 4, WN = 1>: two workgroups per CU
@@ -87,6 +94,24 @@ def test_hot_kernels_keep_their_register_and_lds_budgets(isa):
     for k, v in enc.items():
         if "encoder_x_kernel" in k or "encoder_x2_kernel" in k:
             assert v["vgpr"] <= 512 and v["lds"] <= 160 * 1024 and v["scratch"] <= 160, (k, v)      # 148 B: spills around LayerNorm1, outside the panel loops
+        if "coarse_persistent_kernel" in k:
+            # three item bodies (X, K, F) in one kernel: 500 B of spills at the item prologues and around LayerNorm1 -- none may sit inside a
+            # panel loop (checked below on the instruction stream)
+            assert v["vgpr"] <= 512 and v["lds"] <= 160 * 1024 and v["scratch"] <= 512, (k, v)
+    # no scratch access between the MFMAs of a panel loop: bursts = runs of v_mfma lines less than 40 lines apart
+    for start, end in _function_spans(isa["encoder_fused.hip"]):
+        lines = isa["encoder_fused.hip"].split("\n")[start:end]
+        mf = [i for i, l in enumerate(lines) if "v_mfma" in l]
+        if len(mf) < 100:
+            continue
+        bursts, b0 = [], mf[0]
+        for a, b in zip(mf, mf[1:]):
+            if b - a >= 40:
+                bursts.append((b0, a)); b0 = b
+        bursts.append((b0, mf[-1]))
+        inside = [i for i, l in enumerate(lines) if "scratch_" in l and any(lo < i < hi for lo, hi in bursts)]
+        assert not inside, (start, [lines[i].strip() for i in inside[:4]])
+    assert any("coarse_persistent_kernel" in k for k in enc)
     fine = _kernel_resources(isa["fine_fused.hip"])
     fp = [v for k, v in fine.items() if "fine_pair_kernel" in k]
     assert fp and all(v["scratch"] == 0 and v["vgpr"] <= 512 and v["lds"] <= 160 * 1024 for v in fp), fp
