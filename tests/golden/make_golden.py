@@ -91,12 +91,12 @@ CASES = {
     # (small_ot_prefilter has M = 0: with flat scores every row's arg-max is the dustbin)
     "peaked_ot_prefilter": dict(n=2, hw0_c=(12, 16), hw1_c=(12, 16), wseed=3, fseed=23, corr=0.9, scale_c=3.0,
                                 mc=dict(thr=0.2, border_rm=2, match_type="sinkhorn", skh_prefilter=True,
-                                        sparse_spvs=True), temp_bug_fix=True, full=True),
+                                        sparse_spvs=True), temp_bug_fix=True, full=True, ref64=True),
     "peaked_ot_mask_prefilter": dict(n=2, hw0_c=(12, 12), hw1_c=(12, 12), wseed=5, fseed=24, corr=0.9, scale_c=3.0,
                                      mc=dict(thr=0.2, border_rm=1, match_type="sinkhorn", skh_prefilter=True,
                                              sparse_spvs=False), temp_bug_fix=False, full=True,
                                      valid0=[(9, 12), (12, 10)], valid1=[(12, 8), (10, 12)],
-                                     scale0=[[1.9, 1.9], [1.25, 1.5]], scale1=[[1.0, 2.0], [1.6, 1.6]]),
+                                     scale0=[[1.9, 1.9], [1.25, 1.5]], scale1=[[1.0, 2.0], [1.6, 1.6]], ref64=True),
 }
 
 
