@@ -590,6 +590,7 @@ def main():
     ap.add_argument("--backbone", default="hip", choices=["hip", "torch"],
                     help="hip: implicit-GEMM convolutions of this library (default; image-level parity with the reference held at "
                          "1e-4 / 1e-3 px, profiles/r05_parity_margins.txt); torch: PyTorch-ROCm / MIOpen fp32")
+    ap.add_argument("--backbone-halves", type=int, default=None, help="1 / 0: image0 / image1 batches through the backbone on two side streams (default: the model's)")
     ap.add_argument("--coarse-mode", default=None, choices=["auto", "launches", "persistent"],
                     help="coarse transformer as per-call launches or as the persistent work-queue kernel (default: the model's rule -- launches while a "
                          "second stream shares the GPU, persistent otherwise)")
@@ -693,6 +694,8 @@ def main():
     model.overlap_fine_branch = not args.no_overlap
     if args.coarse_mode:
         model.coarse_mode = args.coarse_mode
+    if args.backbone_halves is not None:
+        model.backbone_halves = bool(args.backbone_halves)
     if args.scaling == "strong":
         assert args.total_batch % world == 0, "--total-batch must be divisible by the number of ranks"
         B = args.total_batch // world
@@ -860,7 +863,7 @@ def main():
             "stage_ms": {"backbone": round(backbone_ms, 3), "backbone_impl": args.backbone, "hot_path_hip": round(hot_ms, 3),
                          "note": "median of 3 instrumented steps (after one unmeasured instrumented step) run WITHOUT the two-stream overlap (serial sum > ms_per_step when "
                                  "the timed region overlaps the FPN fine branch with the coarse stage); `kernels` likewise"},
-            "fine_branch_overlapped_in_timed_region": bool(model.overlap_fine_branch), "coarse_mode": "persistent" if persistent else "launches",
+            "fine_branch_overlapped_in_timed_region": bool(model.overlap_fine_branch), "coarse_mode": "persistent" if persistent else "launches", "backbone_halves_on_two_streams": bool((B >= 8 if model.backbone_halves is None else model.backbone_halves) and model.overlap_fine_branch and args.backbone == "hip"),
             **({"debug_switches": args.debug_switch} if args.debug_switch else {}),
             **({"attempt": int(os.environ["LOFTR_BENCH_ATTEMPT"]), "attempt_note": "the first attempt was killed by a signal (run_with_retry)"}
                if os.environ.get("LOFTR_BENCH_ATTEMPT", "1") != "1" else {}),

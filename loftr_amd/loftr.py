@@ -380,6 +380,11 @@ class LoFTR(nn.Module):
         self.coarse_mode = None                              # None: ops.COARSE_MODE ("auto"); "launches" / "persistent" / "auto" for this model
         self.fine_join_late = False                          # True: join the side stream after coarse matching instead of after the coarse transformer (A/B)
         self._side_stream = None
+        # None: from 8 pairs on, image0 / image1 batches go through the backbone on two side streams (see run_backbone; measured in the bench
+        # step, profiles/r06_coarse_mode_ab.txt: 8 pairs 20.52 -> 20.10 ms, a single pair 4.29 -> 5.34 ms: below 8 pairs the extra launches cost
+        # more than the filled tails give); True / False: always / never
+        self.backbone_halves = None
+        self._half_streams = None
         # .train() only: hand the two matching heads their inputs as autograd LEAVES (data['_head_inputs']) and run the heads
         # with a graph, so that LoFTRLoss(...)(data); data['loss'].backward() leaves d loss / d (transformer outputs) in
         # their .grad -- the part of the reference's backward pass this library provides (loftr_amd/autograd.py).
@@ -414,6 +419,29 @@ class LoFTR(nn.Module):
             if use_hip and x.shape[0] > cap:
                 outs = [run(x[i:i + cap]) for i in range(0, x.shape[0], cap)]
                 feats_c, feats_f = torch.cat([o[0] for o in outs]), torch.cat([o[1] for o in outs])
+            elif use_hip and self.overlap_fine_branch and (data["bs"] >= 8 if self.backbone_halves is None else self.backbone_halves):
+                # The two image sets on TWO side streams (image0 batch, image1 batch -- the halves the outputs are split into anyway): the
+                # launches of one half fill the last partly filled round of workgroups of the other's (tools/micro/backbone_halves.py:
+                # 14.30 -> 14.00 ms for the 16-image backbone; bit-identical maps), each half's FPN fine branch follows its trunk on the same
+                # stream and is joined before FinePreprocess like the single side stream below.
+                main = torch.cuda.current_stream(x.device)
+                if self._half_streams is None:
+                    self._half_streams = [torch.cuda.Stream(device=x.device) for _ in range(2)]
+                outs, fines, evs = [], [], []
+                for k, st in enumerate(self._half_streams):
+                    st.wait_stream(main)
+                    xk = data["image0"] if k == 0 else data["image1"]
+                    xk.record_stream(st)
+                    with torch.cuda.stream(st):
+                        fc, fine_fn = run(cl(xk), defer_fine=True)
+                        ev = torch.cuda.Event(); ev.record(st)
+                        ff = fine_fn()
+                    outs.append(fc); fines.append(ff); evs.append(ev)
+                for k in range(2):
+                    main.wait_event(evs[k])                  # the coarse maps; the fine maps are joined later (self._fine_join)
+                    outs[k].record_stream(main); fines[k].record_stream(main)
+                self._fine_join = list(self._half_streams)
+                return outs[0], outs[1], fines[0], fines[1]
             elif use_hip and self.overlap_fine_branch:
                 feats_c, fine_fn = run(x, defer_fine=True)
                 main = torch.cuda.current_stream(x.device)
@@ -434,6 +462,13 @@ class LoFTR(nn.Module):
             (feat_c0, feat_f0), (feat_c1, feat_f1) = run(cl(data["image0"])), run(cl(data["image1"]))
         return feat_c0, feat_c1, feat_f0, feat_f1
 
+    def _join_fine(self, device):
+        j = getattr(self, "_fine_join", None)
+        if j is not None:
+            for st in (j if isinstance(j, list) else [j]):
+                torch.cuda.current_stream(device).wait_stream(st)
+            self._fine_join = None
+
     def match_from_features(self, feat_c0, feat_c1, feat_f0, feat_f1, data):
         """Steps 2-5 of forward (loftr.py:51-75): THE hot path.  `data` needs bs, hw0_i, hw1_i."""
         data.update({"hw0_c": feat_c0.shape[2:], "hw1_c": feat_c1.shape[2:],
@@ -450,18 +485,17 @@ class LoFTR(nn.Module):
         if "mask0" in data:
             mask_c0, mask_c1 = data["mask0"].flatten(-2), data["mask1"].flatten(-2)
         # The coarse transformer has two forms with the same results to float32 noise (csrc/encoder_fused.hip): ONE persistent launch whose
-        # 256 resident workgroups pull the layers' work items from a dependency-ordered queue, or per-call launches.  Measured inside the
-        # bench step (profiles/r06_coarse_mode_ab.txt, 8 pairs 640 x 480, ms per step, two runs each): persistent 20.33 / 20.34 with the
-        # FPN fine branch on the side stream, 20.97 / 20.31 without; launches 20.20 / 20.25 with, 21.50 / 20.69 without -- with the side
-        # stream the two are within run-to-run noise, without it the persistent form is ahead, and alone on the GPU it is 3.13 vs 3.29 ms
-        # per transformer.  ops.COARSE_MODE "auto" (the default) takes the persistent form from 150 token tiles per call on.
+        # 256 resident workgroups pull the layers' work items from a dependency-ordered queue, or per-call launches.  Alone on the GPU the
+        # persistent form takes 3.13 ms against 3.29 (8 pairs, back to back); inside the bench step the variants of the schedule
+        # (persistent / launches, fine branch on a side stream, half batches on two streams) all end within 2 % of each other -- the
+        # MFMA-dense kernels run at the part's power limit (profiles/r06_coarse_mode_ab.txt, r06_power.txt).  ops.COARSE_MODE "auto" (the
+        # default) takes the persistent form from 150 token tiles per call on.
         feat_c0, feat_c1 = self.loftr_coarse(feat_c0, feat_c1, mask_c0, mask_c1, inplace=True, mode=self.coarse_mode)   # fresh pos-encoded copies
         # Join the side stream (FPN fine branch) HERE, not after coarse matching (self.fine_join_late restores that): the encoder
         # launches leave partly filled rounds that the convolution workgroups use, the score-volume kernels do not -- sharing the
         # GPU only doubled their duration (660 vs 340 us for pass B, profiles/r03_overlap_ab.txt) without shortening the step.
-        if not self.fine_join_late and getattr(self, "_fine_join", None) is not None:
-            torch.cuda.current_stream(feat_f0.device).wait_stream(self._fine_join)
-            self._fine_join = None
+        if not self.fine_join_late:
+            self._join_fine(feat_f0.device)
         full = self.training and self.full_grads
         grads = self.training and self.head_grads and not full
         if grads:
@@ -469,9 +503,7 @@ class LoFTR(nn.Module):
             data["_head_inputs"] = {"feat_c0": feat_c0, "feat_c1": feat_c1}
         with torch.enable_grad() if grads else contextlib.nullcontext():
             self.coarse_matching(feat_c0, feat_c1, data, mask_c0=mask_c0, mask_c1=mask_c1)
-        if getattr(self, "_fine_join", None) is not None:    # fine maps come from the side stream
-            torch.cuda.current_stream(feat_f0.device).wait_stream(self._fine_join)
-            self._fine_join = None
+        self._join_fine(feat_f0.device)                      # fine maps come from the side stream(s)
         feat_f0_unfold, feat_f1_unfold = self.fine_preprocess(feat_f0, feat_f1, feat_c0, feat_c1, data)
         if feat_f0_unfold.size(0) != 0:
             feat_f0_unfold, feat_f1_unfold = self.loftr_fine(feat_f0_unfold, feat_f1_unfold, inplace=True)
