@@ -476,6 +476,11 @@ int loftr_rccl_allgather_counts(void* comm, const int32_t* counts_in, int32_t* c
  *   "conv_persist_cap"  0: persistent convolution grids span the device's CUs; n >= 8: at most n workgroups (tests: many tiles each)
  *   "wgrad_chunk"       0: split-K chunk of the weight-gradient GEMMs chosen by shape; n > 0: forced
  *   "reduce_tall"       1: tall partial-sum reductions use the tall kernel; 0: the generic one
+ *   "conv_duo"          1: 3x3 / stride-1 convolutions of 128 k / 192 / 224 output columns run conv3x3_duo_kernel; 0: the generic conv3x3_kernel
+ *   "conv_patch"        1: 3x3 / stride-1 convolutions run the patch kernels; 0: the implicit-GEMM kernel of the strided / 1x1 layers
+ *   "pct_grid"          0: the persistent coarse transformer runs 256 workgroups (one per CU); n > 0: n workgroups
+ *   "pct_quota"         0: its workgroups stay until the queue is empty; n > 0: a workgroup leaves after n work items (yielding variant)
+ *   "pct_skip"          0; bit t: work items of type t (0 X, 1 K, 2 F) are popped and signalled but NOT executed (queue tests: wrong results)
  * Unknown key: LOFTR_ERR_BAD_ARG.  Results never depend on a switch beyond the last bits of a floating-point sum order. */
 int loftr_hip_debug_set(const char* key, int value);
 int loftr_hip_debug_get(const char* key, int* value, int* default_value);
