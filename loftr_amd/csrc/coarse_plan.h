@@ -3,7 +3,7 @@
 #pragma once
 #include "gemm.h"
 
-struct PctItem { uint32_t what; uint32_t signal; uint32_t dep[4]; uint32_t pad[2]; };   // what: type | call << 4 | pair << 12 | index << 20
+struct PctItem { uint32_t what; uint32_t signal; uint32_t dep[4]; uint32_t sig2[2]; };  // what: type | call << 4 | pair << 12 | index << 20; sig2: further counters an X item bumps (PCT_NODEP: none)
 constexpr uint32_t PCT_NODEP = 0xffffffffu;            // dep: counter index (20 bits) | target << 20
 constexpr int PCT_X = 0, PCT_K = 1, PCT_F = 2;
 constexpr int PCT_MAX_LAYERS = 8, PCT_MAX_CALLS = 2 * PCT_MAX_LAYERS, PCT_TILE = 128, PCT_CNT0 = 4;
@@ -25,13 +25,26 @@ struct PctShape {
     const int i = c / 4, k = c % 4;
     layer = 2 * i + (k >= 2); x_img = k & 1; s_img = k < 2 ? (k & 1) : 1 - (k & 1);
   }
+  // K / V of a call's source: calls 0 and 1 (the first self layer) read the transformer's input and run K items; every later call's
+  // source tile is the OUTPUT tile of an earlier X item, which computes that call's K / V partial in its tail while the tile is still in
+  // registers ("fold"): X items of call B_i fold C_i; of C_i fold D_i and A_(i+1); of D_i fold B_(i+1)          transformer.py:91-99
+  bool standalone_k(int c) const { return c < 2; }
+  int folds(int c, int (&out)[2]) const {
+    const int k = c % 4;
+    int n = 0;
+    if (k == 1) out[n++] = c + 1;
+    if (k == 2) { out[n++] = c + 1; if (c + 2 < n_calls()) out[n++] = c + 2; }
+    if (k == 3 && c + 2 < n_calls()) out[n++] = c + 2;
+    for (int i = n; i < 2; ++i) out[i] = -1;
+    return n;
+  }
   size_t n_items() const {
     size_t n = 0;
-    for (int c = 0; c < n_calls(); ++c) { int l, x, s; call(c, l, x, s); n += (size_t)N * (tiles(s) + 8 + tiles(x)); }
+    for (int c = 0; c < n_calls(); ++c) { int l, x, s; call(c, l, x, s); n += (size_t)N * ((standalone_k(c) ? tiles(s) : 0) + 8 + tiles(x)); }
     return n;
   }
   uint32_t signature(int order) const {
-    uint32_t h = 0x9e3779b9u ^ 6u;                     // (6: plan format)
+    uint32_t h = 0x9e3779b9u ^ 7u;                     // (7: plan format)
     for (uint32_t v : {(uint32_t)n_layers, (uint32_t)N, (uint32_t)T[0], (uint32_t)T[1], (uint32_t)order}) h = (h ^ v) * 0x01000193u + 0x7ed55d16u;
     return h | 1u;
   }

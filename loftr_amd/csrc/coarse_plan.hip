@@ -10,48 +10,61 @@
 #include "coarse_plan.h"
 
 namespace {
-struct Node { uint32_t what, signal, dep[4]; float dur; std::vector<int> pred; };
+struct Node { uint32_t what, signal, dep[4], sig2[2]; float dur; std::vector<int> pred; };
 
-void build_graph(const PctShape& s, std::vector<Node>& nodes, float tX, float tK, float tF) {
+void build_graph(const PctShape& s, std::vector<Node>& nodes, float tX, float tK, float tF, float tKf) {
   const int N = s.N, nc = s.n_calls();
   // writer[img][p][t]: node that last wrote tile t (-1: the input);  readers[img][p]: calls that took K / V of the CURRENT content
   std::vector<int> writer[2];
   std::vector<std::vector<int>> readers[2];
   for (int i = 0; i < 2; ++i) { writer[i].assign((size_t)N * s.tiles(i), -1); readers[i].assign(N, {}); }
   std::vector<int> f_first((size_t)nc * N, -1);         // first F node of (call, pair); the 8 heads are consecutive
+  std::vector<int> x_first((size_t)nc * N, -1);         // first X node of (call, pair)
   nodes.reserve(s.n_items());
   for (int c = 0; c < nc; ++c) {
     int layer, xi, si;
     s.call(c, layer, xi, si);
     const int gs = s.tiles(si), gx = s.tiles(xi);
+    // the call whose X items computed this call's K / V partials in their tails (none: K items)
+    int producer = -1;
+    for (int q = 0; q < c && producer < 0; ++q) { int f[2]; s.folds(q, f); if (f[0] == c || f[1] == c) producer = q; }
+    int fold[2];
+    const int nfold = s.folds(c, fold);
     for (int p = 0; p < N; ++p) {
       const int k0 = (int)nodes.size();
-      for (int t = 0; t < gs; ++t) {
-        Node n{};
-        n.what = PCT_K | (uint32_t)c << 4 | (uint32_t)p << 12 | (uint32_t)t << 20; n.signal = s.kcnt(c, p); n.dur = tK;
-        for (auto& d : n.dep) d = PCT_NODEP;
-        const int w = writer[si][(size_t)p * gs + t];
-        if (w >= 0) { n.dep[0] = nodes[w].signal | 1u << 20; n.pred.push_back(w); }
-        nodes.push_back(n);
+      if (s.standalone_k(c)) {
+        for (int t = 0; t < gs; ++t) {
+          Node n{};
+          n.what = PCT_K | (uint32_t)c << 4 | (uint32_t)p << 12 | (uint32_t)t << 20; n.signal = s.kcnt(c, p); n.dur = tK;
+          for (auto& d : n.dep) d = PCT_NODEP;
+          n.sig2[0] = n.sig2[1] = PCT_NODEP;
+          const int w = writer[si][(size_t)p * gs + t];
+          if (w >= 0) { n.dep[0] = nodes[w].signal | 1u << 20; n.pred.push_back(w); }
+          nodes.push_back(n);
+        }
+        readers[si][p].push_back(c);
       }
-      readers[si][p].push_back(c);
       f_first[(size_t)c * N + p] = (int)nodes.size();
       for (int h = 0; h < 8; ++h) {
         Node n{};
         n.what = PCT_F | (uint32_t)c << 4 | (uint32_t)p << 12 | (uint32_t)h << 20; n.signal = s.fcnt(c, p); n.dur = tF;
         for (auto& d : n.dep) d = PCT_NODEP;
-        n.dep[0] = s.kcnt(c, p) | (uint32_t)gs << 20;
-        for (int t = 0; t < gs; ++t) n.pred.push_back(k0 + t);
+        n.sig2[0] = n.sig2[1] = PCT_NODEP;
+        n.dep[0] = s.kcnt(c, p) | (uint32_t)gs << 20;     // gs partials: from the K items, or from the producer call's X items
+        if (producer < 0) for (int t = 0; t < gs; ++t) n.pred.push_back(k0 + t);
+        else for (int t = 0; t < gs; ++t) n.pred.push_back(x_first[(size_t)producer * N + p] + t);
         nodes.push_back(n);
       }
-      // X items: their own F items, the previous writer of the tile, and (write-after-read) the F items of every OTHER call that
-      // reads the content they overwrite
+      // X items: their own F items, the previous writer of the tile, and (write-after-read) the F items of every OTHER call whose K
+      // items read the content they overwrite
       std::vector<int> war;
       for (int rc : readers[xi][p]) if (rc != c) war.push_back(rc);
+      x_first[(size_t)c * N + p] = (int)nodes.size();
       for (int g = 0; g < gx; ++g) {
         Node n{};
-        n.what = PCT_X | (uint32_t)c << 4 | (uint32_t)p << 12 | (uint32_t)g << 20; n.signal = s.xflag(c, p, g); n.dur = tX;
+        n.what = PCT_X | (uint32_t)c << 4 | (uint32_t)p << 12 | (uint32_t)g << 20; n.signal = s.xflag(c, p, g); n.dur = tX + nfold * tKf;
         for (auto& d : n.dep) d = PCT_NODEP;
+        for (int i = 0; i < 2; ++i) n.sig2[i] = fold[i] >= 0 ? s.kcnt(fold[i], p) : PCT_NODEP;
         int nd = 0;
         n.dep[nd++] = s.fcnt(c, p) | 8u << 20;
         for (int h = 0; h < 8; ++h) n.pred.push_back(f_first[(size_t)c * N + p] + h);
@@ -123,7 +136,7 @@ extern "C" int loftr_coarse_plan_build(const int* layer_is_cross, int n_layers, 
   if (plan_bytes < pct_plan_bytes(s)) return LOFTR_ERR_WORKSPACE;
   std::vector<Node> nodes;
   // estimated durations [us] of an X / K / F item with every CU busy (profiles/r06_pct_trace.txt)
-  build_graph(s, nodes, 112.f, 40.f, 8.f);
+  build_graph(s, nodes, 112.f, 40.f, 8.f, 30.f);
   if (nodes.size() != s.n_items()) return LOFTR_ERR_BAD_ARG;
   std::vector<int> ord;
   if (order == 0) ord = list_schedule(nodes, 256);
@@ -143,7 +156,7 @@ extern "C" int loftr_coarse_plan_build(const int* layer_is_cross, int n_layers, 
   items[0] = PctItem{s.signature(order), (uint32_t)nodes.size(), {PCT_NODEP, PCT_NODEP, PCT_NODEP, PCT_NODEP}, {0, 0}};
   for (size_t k = 0; k < ord.size(); ++k) {
     const Node& n = nodes[ord[k]];
-    items[1 + k] = PctItem{n.what, n.signal, {n.dep[0], n.dep[1], n.dep[2], n.dep[3]}, {0, 0}};
+    items[1 + k] = PctItem{n.what, n.signal, {n.dep[0], n.dep[1], n.dep[2], n.dep[3]}, {n.sig2[0], n.sig2[1]}};
   }
   // a set-up call like loftr_transformer_prepare: synchronous with respect to the host vector
   if (hipMemcpyAsync(plan, items.data(), items.size() * sizeof(PctItem), hipMemcpyHostToDevice, (hipStream_t)stream) != hipSuccess)

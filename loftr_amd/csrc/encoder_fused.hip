@@ -111,8 +111,21 @@ __device__ __forceinline__ bool job_tile(const Args& a, const int id, int& seq, 
   return seq < a.nseq && grp < a.groups;
 }
 
+// K / V partial of a 128-token tile (kv_tile_main, below): what an X item of the persistent kernel appends for the calls that take its
+// OUTPUT tile as their source ("fold": the tile is still in registers as MFMA fragments)
+struct KvTile {
+  const sp_t* x_sp; const uint8_t* mask; int T;         // the source sequence (already offset to it), its mask or null
+  const sp_t* wkv; const float* wkv_s;
+  float inv_s;
+  float* part; long head_stride;                        // partial of head h at part + h * head_stride
+};
+struct FoldArgs { int n; KvTile k[2]; };
+__device__ __forceinline__ void kv_tile_main(const KvTile& a, char* const lds, const h16x8 (&xh)[16], const h16x8 (&xl)[16],
+                                             const float (&mk)[16], const bool live, const int nlive);
+
 // One workgroup of the layer: 128 tokens (group `grp` of sequence `seq`) through the whole x side
-__device__ __forceinline__ void encoder_x_body(const Args& a, const int seq, const int grp, char* const lds) {
+template <bool FOLD>
+__device__ __forceinline__ void encoder_x_body(const Args& a, const int seq, const int grp, char* const lds, const FoldArgs* fa = nullptr) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 5, li = lane & 31;
   const int T = a.T;
   const int tok = (grp * W + wave) * PT + li;
@@ -379,8 +392,8 @@ __device__ __forceinline__ void encoder_x_body(const Args& a, const int seq, con
 #undef EFX_PASS2_HEAD
 
   // ================= out = x + LayerNorm2(mlp.2 output), fp32 and SP                                          transformer.py:55-58
-  if (!live) return;
-  {
+  if (!FOLD && !live) return;
+  if (live) {
     // o = acc * w2 row scale, evaluated on the fly in each of the three passes (the accumulators are only read)
     float s = 0.f;
 #pragma unroll
@@ -407,7 +420,9 @@ __device__ __forceinline__ void encoder_x_body(const Args& a, const int seq, con
     const float rstd = rsqrtf(m2 * (1.f / 256.f) + a.ln_eps);
     asm volatile("" ::: "memory");
     // (both lanes of a token -- lane, lane ^ 32 -- take the same branch, so the exchanges inside stay paired)
-    if (tok < T) {
+    // FOLD: every lane computes (lanes beyond the sequence on the clamped row: finite values the K / V tail masks out), stores stay guarded
+    const bool in_seq = tok < T;
+    if (FOLD || in_seq) {
       const float* xr = a.x_f32 + row * 256;
       float* of = a.out_f32 + row * 256;
       sp_t* os = a.out_sp + row * 256;
@@ -436,17 +451,35 @@ __device__ __forceinline__ void encoder_x_body(const Args& a, const int seq, con
             o[e] = xc[q][e] + ((big[j][4 * q + e] * ws[e] - mean) * rstd * ga[e] + be[e]);
             y[4 * q + e] = o[e];
           }
-          *reinterpret_cast<f32x4*>(of + f) = o;
+          if (!FOLD || in_seq) *reinterpret_cast<f32x4*>(of + f) = o;
         }
-        if (!a.out_sp) continue;                          // (loftr_encoder_layer_fwd: fp32 result only)
+        if (!FOLD && !a.out_sp) continue;                 // (loftr_encoder_layer_fwd: fp32 result only)
         h16x8 fh[2], fl[2];
         pack_panel(y, fh, fl);
+        if (FOLD) { xh[2 * j] = fh[0]; xh[2 * j + 1] = fh[1]; xl[2 * j] = fl[0]; xl[2 * j + 1] = fl[1]; }   // the output tile as the next calls' source fragments
+        if (!FOLD || in_seq) {
 #pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-          *reinterpret_cast<u32x4*>(os + j * 32 + (2 * s2 + g) * 4) = __builtin_bit_cast(u32x4, fh[s2]);
-          *reinterpret_cast<u32x4*>(os + j * 32 + 16 + (2 * s2 + g) * 4) = __builtin_bit_cast(u32x4, fl[s2]);
+          for (int s2 = 0; s2 < 2; ++s2) {
+            *reinterpret_cast<u32x4*>(os + j * 32 + (2 * s2 + g) * 4) = __builtin_bit_cast(u32x4, fh[s2]);
+            *reinterpret_cast<u32x4*>(os + j * 32 + 16 + (2 * s2 + g) * 4) = __builtin_bit_cast(u32x4, fl[s2]);
+          }
         }
       }
+    }
+  }
+  // ================= fold: K / V partials of the calls whose source is this output tile (persistent kernel only) =================
+  if constexpr (FOLD) {
+    if (fa->n > 0) {
+      const int tok0 = (grp * W + wave) * PT;
+      const int nlive = min(W, (T - grp * W * PT + PT - 1) / PT);
+      float mk[16];                                       // register r <-> token tok0 + (r & 3) + 8 (r >> 2) + 4 g   (D[token][feature])
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int t = tok0 + (r & 3) + 8 * (r >> 2) + 4 * g;
+        mk[r] = (t < T && (!a.mask || a.mask[(long)seq * T + min(t, T - 1)])) ? 1.f : 0.f;
+      }
+#pragma unroll 1
+      for (int s = 0; s < fa->n; ++s) kv_tile_main(fa->k[s], lds, xh, xl, mk, live, nlive);
     }
   }
 }
@@ -454,7 +487,7 @@ __device__ __forceinline__ void encoder_x_body(const Args& a, const int seq, con
 __global__ __launch_bounds__(W * 64, 1) void encoder_x_kernel(Args a) {
   __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
   int seq, grp;
-  if (job_tile(a, blockIdx.x, seq, grp)) encoder_x_body(a, seq, grp, lds);
+  if (job_tile(a, blockIdx.x, seq, grp)) encoder_x_body<false>(a, seq, grp, lds);
 }
 
 // TWO jobs in one launch.  A call's time is set by whole rounds of 256 workgroups (one per CU: tools/gpu/r4_enc_sweep.sh -- 256
@@ -468,7 +501,7 @@ __global__ __launch_bounds__(W * 64, 1) void encoder_x2_kernel(Args2 m) {
   const bool second = (int)blockIdx.x >= m.n0;          // workgroup-uniform
   const Args* a = second ? &m.j[1] : &m.j[0];           // (one copy of the body: its arguments come from a uniform kernarg offset)
   int seq, grp;
-  if (job_tile(*a, second ? (int)blockIdx.x - m.n0 + m.off1 : (int)blockIdx.x + m.off0, seq, grp)) encoder_x_body(*a, seq, grp, lds);
+  if (job_tile(*a, second ? (int)blockIdx.x - m.n0 + m.off1 : (int)blockIdx.x + m.off0, seq, grp)) encoder_x_body<false>(*a, seq, grp, lds);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -490,7 +523,7 @@ __global__ __launch_bounds__(W * 64, 1) void encoder_x2_kernel(Args2 m) {
 // barrier, plain loads -- placement independent (guide: "inter-workgroup communication").
 // Results do not depend on the queue order: every item computes from the same inputs in the same internal order
 // (tests: dependency order vs call order bit-identical).
-struct PctCall { int layer, x_img, s_img, pad; };
+struct PctCall { int layer, x_img, s_img, pad, fold[2], pad2[2]; };   // fold: calls whose K / V partials this call's X items compute in their tails (-1: none)
 struct PctArgs {
   float* f32[2]; sp_t* sp[2]; const uint8_t* mask[2]; int T[2];
   int N, n_calls, n_items, splits;                      // splits: row tiles per sequence the partial buffers are strided by (max over the images)
@@ -512,20 +545,14 @@ static_assert(LDS_BYTES_P <= 160 * 1024, "one workgroup per CU");
 // D[token][feature]: lane = feature d (resp. v) of the head, registers = 16 of the wave's tokens -- exactly the operands of the fp32
 // MFMA that contracts over the tokens (KV_h[d][v] += K[t][d] V[t][v], 16 v_mfma_f32_32x32x2_f32 per head as in proj_kv_kernel).
 // The four waves' results are summed through LDS in a fixed order: one partial per (tile, head), [33][32] (row 32 = K sum).
-struct KvTile {
-  const sp_t* x_sp; const uint8_t* mask; int T;         // the source sequence (already offset to it), its mask or null
-  const sp_t* wkv; const float* wkv_s;
-  float inv_s;
-  float* part; long head_stride;                        // partial of head h at part + h * head_stride
-};
+// kv_tile_body: a K item (loads the tile's fragments and token mask, then kv_tile_main); kv_tile_main: the 16 weight panels, feature map,
+// K^T V on the fp32 matrix cores and the cross-wave reduction -- also the tail of an X item whose output tile is the source ("fold").
 __device__ __forceinline__ void kv_tile_body(const KvTile& a, const int tile, char* const lds) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 5, li = lane & 31;
   const int T = a.T;
   const int tok0 = (tile * W + wave) * PT;
   const bool live = tok0 < T;                           // wave-uniform
   const int nlive = min(W, (T - tile * W * PT + PT - 1) / PT);
-  float* tab = reinterpret_cast<float*>(lds + OFF_TAB);
-  for (int f = threadIdx.x; f < 512; f += W * 64) tab[T_W0S + f] = a.wkv_s[f];
   h16x8 xh[16], xl[16];
   {
     const u32x4* src = reinterpret_cast<const u32x4*>(a.x_sp + (long)min(tok0 + li, T - 1) * 256);
@@ -542,6 +569,17 @@ __device__ __forceinline__ void kv_tile_body(const KvTile& a, const int tile, ch
     const int t = tok0 + (r & 3) + 8 * (r >> 2) + 4 * g;
     mk[r] = (t < T && (!a.mask || a.mask[min(t, T - 1)])) ? 1.f : 0.f;
   }
+  kv_tile_main(a, lds, xh, xl, mk, live, nlive);
+}
+
+__device__ __forceinline__ void kv_tile_main(const KvTile& a, char* const lds, const h16x8 (&xh)[16], const h16x8 (&xl)[16],
+                                             const float (&mk)[16], const bool live, const int nlive) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 5, li = lane & 31;
+  float* tab = reinterpret_cast<float*>(lds + OFF_TAB);
+  // (entered with no DMA in flight and every wave past its last use of the ring and of the scale tables: the barrier below)
+  LOFTR_WAITCNT_VM(0);
+  __syncthreads();
+  for (int f = threadIdx.x; f < 512; f += W * 64) tab[T_W0S + f] = a.wkv_s[f];
   int dro[4], dch[4];
 #pragma unroll
   for (int oct = 0; oct < 4; ++oct) {
@@ -742,6 +780,7 @@ __global__ __launch_bounds__(W * 64, 1) void coarse_persistent_kernel(PctArgs P)
     if (it < 0) break;
     const PctItem* pi = P.items + it;
     const unsigned what = __builtin_amdgcn_readfirstlane(pi->what), signal = __builtin_amdgcn_readfirstlane(pi->signal);
+    const unsigned sig2a = __builtin_amdgcn_readfirstlane(pi->sig2[0]), sig2b = __builtin_amdgcn_readfirstlane(pi->sig2[1]);
     const int type = what & 15, c = (what >> 4) & 255, pair = (what >> 12) & 255, idx = what >> 20;
     const PctCall call = P.call[c];
     const PctLayerPtrs& lw = P.layer[call.layer];
@@ -758,7 +797,19 @@ __global__ __launch_bounds__(W * 64, 1) void coarse_persistent_kernel(PctArgs P)
       a.g1 = lw.g1; a.b1 = lw.b1; a.g2 = lw.g2; a.b2 = lw.b2;
       a.v_length = (float)Ts; a.attn_eps = 1e-6f; a.p_out_scale = 1.f / ATTN_P_SCALE; a.ln_eps = 1e-5f;
       a.nseq = P.N; a.T = Tx; a.groups = 0; a.xsplit = 1; a.gpc = 0;
-      encoder_x_body(a, pair, idx, lds);
+      FoldArgs fa;
+      fa.n = 0;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int cf = call.fold[i];
+        if (cf < 0) continue;
+        const PctLayerPtrs& lf = P.layer[P.call[cf].layer];
+        KvTile& k = fa.k[fa.n++];
+        k.x_sp = nullptr; k.mask = nullptr; k.T = Tx;                   // (fragments and token mask come from the X item)
+        k.wkv = lf.wkv; k.wkv_s = lf.wkv_s; k.inv_s = 1.f / (float)Tx;
+        k.part = P.part + (((long)cf * P.N + pair) * 8 * P.splits + idx) * (33 * 32); k.head_stride = (long)P.splits * (33 * 32);
+      }
+      encoder_x_body<true>(a, pair, idx, lds, &fa);
     } else if (type == PCT_K) {
       KvTile k;
       k.x_sp = P.sp[call.s_img] + (long)pair * Ts * 256;
@@ -778,6 +829,8 @@ __global__ __launch_bounds__(W * 64, 1) void coarse_persistent_kernel(PctArgs P)
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // (the compiler may drop the wait behind buffer_wbl2: guide, pitfall 12)
       if (lane0) {
         __hip_atomic_fetch_add(P.cnt + signal, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (sig2a != PCT_NODEP) __hip_atomic_fetch_add(P.cnt + sig2a, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (sig2b != PCT_NODEP) __hip_atomic_fetch_add(P.cnt + sig2b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (P.trace) {
           unsigned long long* tr = P.trace + (long)it * 4;
           tr[0] = t_pop; tr[1] = t_rdy; tr[2] = wall_clock64(); tr[3] = blockIdx.x;
@@ -865,7 +918,7 @@ int launch_coarse_persistent(const PctLaunch& p, hipStream_t st) {
   a.items = reinterpret_cast<const PctItem*>(p.plan) + 1;
   a.trace = p.trace; a.status = p.status; a.signature = p.plan_signature;
   for (int l = 0; l < s.n_layers; ++l) a.layer[l] = p.layer[l];
-  for (int c = 0; c < s.n_calls(); ++c) s.call(c, a.call[c].layer, a.call[c].x_img, a.call[c].s_img);
+  for (int c = 0; c < s.n_calls(); ++c) { s.call(c, a.call[c].layer, a.call[c].x_img, a.call[c].s_img); s.folds(c, a.call[c].fold); }
   if (hipMemsetAsync(a.cnt, 0, s.n_counters() * 4, st) != hipSuccess) return LOFTR_ERR_LAUNCH;
   TimedLaunch tl(LOFTR_T_ENCODER_X, st);
   a.skip = loftr_debug_value(LOFTR_DBG_PCT_SKIP);

@@ -95,10 +95,11 @@ def test_debug_switches_replace_the_environment_variables(lib):
 
 def test_coarse_plan_queries(lib):
     """loftr_coarse_plan_bytes / _signature are host-only: sizes of the persistent coarse transformer's work queue (32 bytes per item + a
-    header item) for the BASELINE shape -- per call and pair: source tiles (K) + 8 heads (F) + token tiles (X)."""
+    header item) for the BASELINE shape -- per call and pair: 8 heads (F) + token tiles (X), + source tiles (K) for the two calls of the first
+    self layer only (every later call's K / V partials are computed in the tails of the X items that produce its source tiles)."""
     kinds = (ctypes.c_int * 8)(0, 1, 0, 1, 0, 1, 0, 1)
     n = lib.loftr_coarse_plan_bytes(kinds, 8, 8, 4800, 4800)
-    assert n == 32 * (1 + 16 * 8 * (38 + 8 + 38))
+    assert n == 32 * (1 + 16 * 8 * (8 + 38) + 2 * 8 * 38)
     assert lib.loftr_coarse_plan_bytes(kinds, 8, 8, 4800, 0) == 0 and lib.loftr_coarse_plan_bytes(kinds, 7, 8, 4800, 4800) == 0
     bad = (ctypes.c_int * 8)(0, 0, 1, 1, 0, 1, 0, 1)
     assert lib.loftr_coarse_plan_bytes(bad, 8, 8, 4800, 4800) == 0             # only the [self, cross] * P pattern has a persistent form

@@ -159,6 +159,13 @@ if want_trace:
         dur, wait = (done - rdy)[m], (rdy - pop)[m]
         print(f"  {name}: {m.sum():5d} items  run median {np.median(dur):7.2f} us  p90 {np.percentile(dur, 90):7.2f}  max {dur.max():7.2f}   "
               f"wait median {np.median(wait):6.2f}  mean {wait.mean():6.2f}  max {wait.max():7.2f} us   sum(run) / 256 = {dur.sum() / 256:.1f} us  sum(wait) / 256 = {wait.sum() / 256:.1f} us")
+    call = (plan[:, 0] >> 4) & 255                          # X items by the number of K / V partials they compute in their tail
+    ncall = int(call.max()) + 1
+    nfold = np.where(call % 4 == 1, 1, np.where(call % 4 == 2, 1 + (call + 2 < ncall), np.where(call % 4 == 3, 1 * (call + 2 < ncall), 0)))
+    for k in (0, 1, 2):
+        m = (typ == 0) & (nfold == k)
+        if m.any():
+            print(f"  X with {k} folded K / V tail(s): {m.sum():5d} items  run median {np.median((done - rdy)[m]):7.2f} us")
     idle = done.max() * 256 - (done - pop).sum()
     print(f"  per workgroup: busy+wait {(done - pop).sum() / 256:.1f} us, pop gaps / tail idle {idle / 256:.1f} us")
 print("PCT_CHECK", "OK" if ok else "FAILED")
