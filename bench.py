@@ -311,7 +311,7 @@ def reference_cpu_forward(model, img0, img1, gpu_data):
     par = {"pairs": pars,
            "note": "GPU forward (HIP backbone + HIP matching path) vs the reference's fp32 CPU forward on the same pair and weights in this run, for the "
                    "first and the last pair of the batch; match sets can differ by near-tie flips at thr 0 with random weights (the goldens pin this "
-                   "against the reference's fp64 run: profiles/r05_parity_margins.txt)"}
+                   "against the reference's fp64 run: profiles/r06_parity_margins.txt)"}
     out = {"value": round(1.0 / total, 4), "unit": "image-pairs/s", "cores": threads, "kind": "reference", "reference_import": mode,
            "reference_forward_s": round(total, 3), "reference_backbone_s": round(bbt, 3), "reference_hot_path_s": round(total - bbt, 3),
            "sample": f"pair 0 of the GPU batch (640x480), zju3dv/LoFTR LoFTR.forward (eval, no_grad, fp32, torch CPU), the GPU model's weights: "

@@ -48,8 +48,9 @@ typedef enum {
  * 20: loftr_conv_wgrad (backbone training: weight gradient of a convolution);
  * 21: training-mode glue of the backbone (loftr_bn_train_fwd / _bwd, loftr_act_fwd / _bwd, loftr_upsample2x_bilinear_fwd / _bwd);
  * 22: the persistent coarse transformer (loftr_coarse_plan_bytes / _build / _signature, loftr_transformer_fwd_planned) and the
- *     debug switches (loftr_hip_debug_set / _get) that replace the library's environment variables */
-#define LOFTR_HIP_ABI_VERSION 22
+ *     debug switches (loftr_hip_debug_set / _get) that replace the library's environment variables;
+ * 23: loftr_conv_scratch_bytes / loftr_conv_bn_act_prepared_scratch (the 196-channel layers' remainder channels as a tap-decomposed product) */
+#define LOFTR_HIP_ABI_VERSION 23
 
 int loftr_hip_abi_version(void);
 const char* loftr_hip_status_string(int status);
@@ -277,6 +278,18 @@ int loftr_conv_bn_act_prepared(const uint32_t* x_sp, int B, int H, int W, int Ci
                                size_t prepared_bytes, int Cout, int KH, int KW, int stride, int pad, int act,
                                const uint32_t* residual_sp, const uint32_t* low_sp, uint32_t* y_sp, float* y_f32,
                                const float* x_inv_scale, void* stream);
+/* The same with a SCRATCH buffer (round 6, ABI 23).  3x3 / stride-1 layers whose output width is 193 .. 199 channels (LoFTR's 196) pad to 224
+ * columns: the 7th 32-column tile spends a whole tile's matrix work on <= 7 real channels.  With loftr_conv_scratch_bytes(..) bytes of scratch
+ * (0 = this shape has no such form) those channels are computed as a TAP-DECOMPOSED product instead -- conv = sum over the nine taps of shifted
+ * 1x1 convolutions, so all (tap, channel) pairs are the columns of ONE K = Cin product on the unshifted pixels, evaluated at the centre-tap
+ * steps of the main kernel into the scratch (fp32 [pixels][9 R]) and summed, shifted, by a second small kernel (csrc/conv3x3_duo.h).  Same
+ * products, another summation order for those channels (fp32 noise).  scratch == NULL or too small, y_f32 requested, debug switch
+ * "conv_rem" = 0: exactly loftr_conv_bn_act_prepared. */
+size_t loftr_conv_scratch_bytes(int B, int H, int W, int Cout, int KH, int KW, int stride);
+int loftr_conv_bn_act_prepared_scratch(const uint32_t* x_sp, int B, int H, int W, int Cin, const void* prepared,
+                                       size_t prepared_bytes, int Cout, int KH, int KW, int stride, int pad, int act,
+                                       const uint32_t* residual_sp, const uint32_t* low_sp, uint32_t* y_sp, float* y_f32,
+                                       const float* x_inv_scale, void* scratch, size_t scratch_bytes, void* stream);
 /* Stem: nn.Conv2d(1, C0, 7, stride 2, padding 3, bias=False) + eval BatchNorm2d + ReLU (resnet_fpn.py:52-54,101),
  * direct convolution; x [B,1,H,W] fp32 through its element strides (sb, sc, sh, sw), y_sp [B,Ho,Wo,ceil32(C0)]. */
 int loftr_stem_conv_bn_relu(const float* x, const long* x_strides, int B, int H, int W, const float* weight,
@@ -477,6 +490,7 @@ int loftr_rccl_allgather_counts(void* comm, const int32_t* counts_in, int32_t* c
  *   "wgrad_chunk"       0: split-K chunk of the weight-gradient GEMMs chosen by shape; n > 0: forced
  *   "reduce_tall"       1: tall partial-sum reductions use the tall kernel; 0: the generic one
  *   "conv_duo"          1: 3x3 / stride-1 convolutions of 128 k / 192 / 224 output columns run conv3x3_duo_kernel; 0: the generic conv3x3_kernel
+ *   "conv_rem"          1: loftr_conv_bn_act_prepared_scratch takes the remainder form where it applies; 0: never
  *   "conv_patch"        1: 3x3 / stride-1 convolutions run the patch kernels; 0: the implicit-GEMM kernel of the strided / 1x1 layers
  *   "pct_grid"          0: the persistent coarse transformer runs 256 workgroups (one per CU); n > 0: n workgroups
  *   "pct_quota"         0: its workgroups stay until the queue is empty; n > 0: a workgroup leaves after n work items (yielding variant)

@@ -106,6 +106,8 @@ SIGNATURES = {
     "loftr_five_point": (_i, [_p, _p, _i, _p, C.POINTER(_i)]),
     "loftr_conv_prepare": (_i, [_p, C.POINTER(_l), _i, _i, _i, _i, _p, _p, _p, _p, _f, _p, _sz, _p]),
     "loftr_conv_bn_act_prepared": (_i, [_p, _i, _i, _i, _i, _p, _sz, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p]),
+    "loftr_conv_scratch_bytes": (_sz, [_i, _i, _i, _i, _i, _i, _i]),
+    "loftr_conv_bn_act_prepared_scratch": (_i, [_p, _i, _i, _i, _i, _p, _sz, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _sz, _p]),
     "loftr_conv1x1_upsample_add": (_i, [_p, _i, _i, _i, _i, _p, C.POINTER(_l), _i, _p, _p, _p, _sz, _p]),
     "loftr_sp_from_f32": (_i, [_p, _p, _l, _i, _p]),
     "loftr_sp_from_f32_scaled": (_i, [_p, _p, _l, _i, _p, _p]),
@@ -124,7 +126,7 @@ SIGNATURES = {
     "loftr_linear_fwd": (_i, [_p, _p, _p, _i, _i, _i, _p, _sz, _p]),
 }
 
-ABI_VERSION = 22
+ABI_VERSION = 23
 _lib = None
 
 

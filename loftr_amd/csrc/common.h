@@ -59,6 +59,7 @@ enum LoftrDebugKey {
   LOFTR_DBG_PCT_QUOTA,              // 0 (default): persistent workgroups stay until the queue is empty; n > 0: a workgroup leaves after n items (A/B: sharing the GPU with another stream)
   LOFTR_DBG_CONV_DUO,               // 1 (default): 3x3 / stride-1 convolutions with 128 k / 192 / 224 output columns run conv3x3_duo_kernel; 0: the generic conv3x3_kernel (any Cout)
   LOFTR_DBG_CONV_PATCH,             // 1 (default): 3x3 / stride-1 convolutions run the patch kernels; 0: the implicit-GEMM conv_kernel (the strided / 1x1 path)
+  LOFTR_DBG_CONV_REM,               // 1 (default): Cout = 193 .. 199 3x3 / stride-1 layers with a scratch buffer run 192 columns + the tap-decomposed remainder; 0: 224 columns
   LOFTR_DBG_COUNT
 };
 int loftr_debug_value(int key);

@@ -192,6 +192,7 @@ struct Conv3Args {
   int Cout, Coutp, act;
   const sp_t* zeros;
   int tiles_x, tiles_y;
+  float* pbuf;                  // conv3x3_duo.h, Cfg<.., REM>: scratch [pixels][9 R] of the tap-decomposed remainder channels
 };
 
 __global__ __launch_bounds__(512, 2) void conv3x3_kernel(Conv3Args p) {
@@ -689,6 +690,60 @@ static unsigned persistent_grid(unsigned nvirt) {
   return cus > 0 && nvirt > (unsigned)cus ? (unsigned)cus : nvirt;
 }
 
+// Second half of the tap-decomposed remainder channels (conv3x3_duo.h, Cfg<.., REM>): out[y][x][c0 + c] = act(sum over the taps (ky, kx) of
+// P[(y + ky - 1, x + kx - 1)][ky * 3 + kx][c] + bias + residual), zero padding = taps outside the image skipped; writes the whole SP group of the
+// columns c0 .. c0 + 31 (pad channels as zeros).  One thread per pixel: nine R-vectors of P (16-byte loads at R = 4; the neighbours' lines are
+// shared through the caches), the residual's two 16-byte pieces, eight 16-byte stores = the pixel's full 128-byte line; taps in a fixed order.
+template <int RT>     // RT = R when R == 4 (vector loads), 0: any R <= 7
+__global__ __launch_bounds__(256) void conv_rem_gather_kernel(const float* __restrict__ pbuf, long npix, int H, int W, int R, int c0, int Coutp,
+                                                              const float* __restrict__ bias, const sp_t* __restrict__ residual, int act,
+                                                              sp_t* __restrict__ y_sp) {
+  const long pix = (long)blockIdx.x * 256 + threadIdx.x;
+  if (pix >= npix) return;
+  const int x = (int)(pix % W), y = (int)((pix / W) % H);
+  float v[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) v[c] = 0.f;
+  const float* pp = pbuf + pix * (9 * R);
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      const int yy = y + ky - 1, xx = x + kx - 1;
+      if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) {
+        const float* q = pp + ((long)(ky - 1) * W + (kx - 1)) * (9 * R) + (ky * 3 + kx) * R;
+        if (RT == 4) {
+          const f32x4 t = *reinterpret_cast<const f32x4*>(q);
+          v[0] += t[0]; v[1] += t[1]; v[2] += t[2]; v[3] += t[3];
+        } else {
+#pragma unroll
+          for (int c = 0; c < 7; ++c) if (c < R) v[c] += q[c];
+        }
+      }
+    }
+  sp_t* row = y_sp + pix * Coutp + c0;                 // the group: dwords 0 .. 15 = hi halves of the column pairs, 16 .. 31 = lo halves
+  float rv[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) rv[c] = 0.f;
+  if (residual) {
+    const sp_t* rr = residual + pix * Coutp + c0;
+    const u32x4 hi = *reinterpret_cast<const u32x4*>(rr), lo = *reinterpret_cast<const u32x4*>(rr + 16);
+    sp_unpack8(hi, lo, rv);
+  }
+  const float slope = act == 1 ? 0.f : act == 2 ? 0.01f : 1.f;
+  float o[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    const float t = v[c] + ((bias && c < R) ? bias[c0 + c] : 0.f) + rv[c];
+    o[c] = c < R ? fmaxf(t, slope * t) : 0.f;
+  }
+  u32x4 oh, ol;
+  sp_pack8(o, oh, ol);
+  const u32x4 z = {0u, 0u, 0u, 0u};
+  u32x4* dst = reinterpret_cast<u32x4*>(row);
+  dst[0] = oh; dst[1] = z; dst[2] = z; dst[3] = z; dst[4] = ol; dst[5] = z; dst[6] = z; dst[7] = z;
+}
+
 // Folded weights live in a caller-owned buffer laid out [SP weights Cout x K][bias Cout][inverse row scales Cout][zero page 256 B]
 // (loftr_conv_workspace_bytes): conv_prepare fills it, conv_run consumes it.
 struct ConvPrepared { sp_t* wsp; float* bias; float* wscale; sp_t* zeros; };
@@ -720,9 +775,19 @@ static int conv_prepare(const float* weight, const long* weight_strides, int Cin
   return LOFTR_OK;
 }
 
+// Output channels beyond 192 that the remainder form of the 3x3 kernel takes (0: not that shape): 224 padded columns, 1 .. 7 real ones in the
+// last group (9 taps x R <= 64 columns of P)
+static int conv_rem_channels(int Cout, int KH, int KW, int stride) {
+  return (KH == 3 && KW == 3 && stride == 1 && ceil32(Cout) == 224 && Cout - 192 >= 1 && Cout - 192 <= 7) ? Cout - 192 : 0;
+}
+extern "C" size_t loftr_conv_scratch_bytes(int B, int H, int W, int Cout, int KH, int KW, int stride) {
+  const int R = conv_rem_channels(Cout, KH, KW, stride);
+  return (R > 0 && B > 0 && H > 0 && W > 0) ? (size_t)B * H * W * 9 * R * 4 : 0;
+}
+
 static int conv_run(const uint32_t* x_sp, int B, int H, int W, int Cin, const void* prepared, size_t prepared_bytes, int Cout,
                     int KH, int KW, int stride, int pad, int act, const uint32_t* residual_sp, const uint32_t* up_sp,
-                    uint32_t* y_sp, float* y_f32, void* stream, const float* x_inv = nullptr) {
+                    uint32_t* y_sp, float* y_f32, void* stream, const float* x_inv = nullptr, void* scratch = nullptr, size_t scratch_bytes = 0) {
   LOFTR_CHECK_ARG(x_sp && prepared && (y_sp || y_f32) && B >= 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0);
   const bool shared_gpu = (act & LOFTR_CONV_SHARED_GPU) != 0;      // see loftr_hip.h: no persistent workgroups
   act &= ~LOFTR_CONV_SHARED_GPU;
@@ -756,7 +821,7 @@ static int conv_run(const uint32_t* x_sp, int B, int H, int W, int Cin, const vo
     Conv3Args c;
     c.x = x_sp; c.B = B; c.H = H; c.W = W; c.Cp = g.Cp; c.Cin = Cin; c.w = wsp; c.K = K; c.bias = bias; c.wscale = pr.wscale; c.x_inv = x_inv; c.residual = residual_sp;
     c.y_sp = y_sp; c.y_f32 = y_f32; c.Cout = Cout; c.Coutp = ceil32(Cout); c.act = act; c.zeros = zeros;
-    c.tiles_x = ceil_div(W, c3::TX); c.tiles_y = ceil_div(H, c3::TY);
+    c.tiles_x = ceil_div(W, c3::TX); c.tiles_y = ceil_div(H, c3::TY); c.pbuf = nullptr;
     const bool duo = loftr_debug_value(LOFTR_DBG_CONV_DUO) != 0;
     const bool wide = duo && c.Coutp == 32 * 7;
     TimedLaunch tl(wide ? LOFTR_T_CONV3W : LOFTR_T_CONV3, st);
@@ -770,6 +835,21 @@ static int conv_run(const uint32_t* x_sp, int B, int H, int W, int Cin, const vo
       using CF = c3d::Cfg<6, 2, 4, 8, 2>;
       c.tiles_y = ceil_div(H, CF::TY);
       hipLaunchKernelGGL((conv3x3_duo_kernel<CF>), dim3(xcd_grid(B * c.tiles_x * c.tiles_y, 1)), dim3(512), 0, st, c);
+    } else if (wide && conv_rem_channels(Cout, KH, KW, stride) > 0 && !y_f32 && loftr_debug_value(LOFTR_DBG_CONV_REM) &&
+               scratch && scratch_bytes >= (size_t)B * H * W * 9 * conv_rem_channels(Cout, KH, KW, stride) * 4) {
+      // round 6: 192 columns + the channels beyond them as a tap-decomposed product at the centre-tap steps (conv3x3_duo.h), then the gather
+      using CF = c3d::Cfg<6, 2, 4, 8, 2, true>;
+      c.tiles_y = ceil_div(H, CF::TY);
+      c.pbuf = reinterpret_cast<float*>(scratch);
+      hipLaunchKernelGGL((conv3x3_duo_kernel<CF>), dim3(xcd_grid(B * c.tiles_x * c.tiles_y, 1)), dim3(512), 0, st, c);
+      LOFTR_CHECK_LAUNCH();
+      const long npix = (long)B * H * W;
+      if (Cout - 192 == 4)
+        hipLaunchKernelGGL(conv_rem_gather_kernel<4>, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, st, c.pbuf, npix, H, W, 4, 192, c.Coutp,
+                           bias, residual_sp, act, y_sp);
+      else
+        hipLaunchKernelGGL(conv_rem_gather_kernel<0>, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, st, c.pbuf, npix, H, W, Cout - 192, 192, c.Coutp,
+                           bias, residual_sp, act, y_sp);
     } else if (wide) {
       using CF = c3d::Cfg<7, 2, 4, 8, 2>;
       c.tiles_y = ceil_div(H, CF::TY);
@@ -815,6 +895,14 @@ extern "C" int loftr_conv_bn_act_prepared(const uint32_t* x_sp, int B, int H, in
                                           const float* x_inv_scale, void* stream) {
   return conv_run(x_sp, B, H, W, Cin, prepared, prepared_bytes, Cout, KH, KW, stride, pad, act, residual_sp, low_sp, y_sp, y_f32,
                   stream, x_inv_scale);
+}
+
+extern "C" int loftr_conv_bn_act_prepared_scratch(const uint32_t* x_sp, int B, int H, int W, int Cin, const void* prepared,
+                                                  size_t prepared_bytes, int Cout, int KH, int KW, int stride, int pad, int act,
+                                                  const uint32_t* residual_sp, const uint32_t* low_sp, uint32_t* y_sp, float* y_f32,
+                                                  const float* x_inv_scale, void* scratch, size_t scratch_bytes, void* stream) {
+  return conv_run(x_sp, B, H, W, Cin, prepared, prepared_bytes, Cout, KH, KW, stride, pad, act, residual_sp, low_sp, y_sp, y_f32,
+                  stream, x_inv_scale, scratch, scratch_bytes);
 }
 
 extern "C" int loftr_conv_bn_act(const uint32_t* x_sp, int B, int H, int W, int Cin, const float* weight,

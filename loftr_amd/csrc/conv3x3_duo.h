@@ -50,14 +50,23 @@ constexpr int TX = 32, PW = TX + 2;
 //   Cfg<4, 2, 4, 8, 1>  "octo"  512 px x 128 columns, 111 KB, one workgroup per CU: HALF the weight DMA per MFMA
 //   Cfg<7, 2, 4, 8, 2>  "octo"  256 px x 224 columns (a wave: 2 rows x 4 or 3 tiles), 101 KB: half the weight DMA of the duo form,
 //                       whose 15 KB per 21 MFMAs and wave exceed what the global -> LDS path delivers (~14 B / clk / CU)
-template <int NT_, int RW_, int NB_, int WAVES_ = 4, int WN_ = 1>
+//   Cfg<6, 2, 4, 8, 2, true>  "octo + remainder" (round 6): 256 px x 192 columns + the 1 .. 7 output channels beyond 192 (Cout = 196) as a
+//                       TAP-DECOMPOSED product.  The 7th column tile of Cfg<7, ..> spends 32 columns x K = 9 Cin on 4 real channels; but
+//                       conv = sum over the taps of shifted 1x1 convolutions, so P[pixel][tap][c] = sum_cin x[pixel][cin] w[c][tap][cin] on the
+//                       UNSHIFTED pixels is ONE product with N = 9 taps x 4 channels = 36 columns and K = Cin: two column tiles (one per wave
+//                       pair) at the centre-tap steps only, whose A fragments ARE the unshifted pixels -- 56 instead of 63 tile-steps per nine
+//                       taps.  P goes to a scratch buffer (fp32, 36 per pixel); conv_rem_gather_kernel adds the nine shifted P's, bias,
+//                       residual, activation and writes the SP group of the channels 192 .. 223.  Its B rows are a VIEW of the prepared
+//                       filter: row (tap, c) = filter row 192 + c, columns tap * Cp .. (no extra weight preparation).
+template <int NT_, int RW_, int NB_, int WAVES_ = 4, int WN_ = 1, bool REM_ = false>
 struct Cfg {
   static constexpr int NT = NT_, RW = RW_, NB = NB_, LA = NB_ - 1;               // LA: weight stages in flight ahead of the running step
+  static constexpr bool REM = REM_;
   static constexpr int WAVES = WAVES_, WN = WN_, WM = WAVES_ / WN_, NJ = (NT_ + WN_ - 1) / WN_;   // NJ: column tiles per wave (the last split may own NJ - 1)
   static constexpr int TY = WM * RW, PH = TY + 2, PROWS = PW * PH;
   static constexpr int PSLOTS = (PROWS + 15) / 16, PQ = (PSLOTS + WAVES - 1) / WAVES;   // 1 KB DMA slots (16 rows) of a patch half; per wave
   static constexpr int PHALF_BYTES = PSLOTS * 1024;
-  static constexpr int BROWS = NT * 32, BSLOTS = BROWS / 16, BQ = (BSLOTS + WAVES - 1) / WAVES;
+  static constexpr int BROWS = NT * 32 + (REM_ ? 64 : 0), BSLOTS = BROWS / 16, BQ = (BSLOTS + WAVES - 1) / WAVES;   // REM: + 2 column tiles of P rows (centre-tap steps only)
   static constexpr int BSTAGE_BYTES = BSLOTS * 1024;
   static constexpr int LDS_BYTES = 2 * PHALF_BYTES + NB * BSTAGE_BYTES + 1024;    // + 1 KB scratch: destination of the unused DMA slots
   static constexpr int WG_PER_CU = WAVES == 4 ? 2 : 1;
@@ -65,6 +74,7 @@ struct Cfg {
   static_assert(RW <= 2, "patch rows are overwritten in place: row j of the next tap column while rows 2 .. RW+1 are in use");
   static_assert(LA >= 2 && LA <= 3, "vmcnt bookkeeping below");
   static_assert(WN == 1 || NT - (WN - 1) * NJ >= NJ - 1, "the last column split owns NJ or NJ - 1 tiles");
+  static_assert(!REM_ || (WN_ == 2 && NT_ % 2 == 0), "remainder form: two wave splits, one P tile each, equal main shares");
 };
 // Issue order of one step (see C3D_STEP): group J = 3 RW MFMAs with R reads slotted one behind each of its first MFMAs.
 template <int R, int M>
@@ -104,7 +114,9 @@ __global__ __launch_bounds__(CF::WAVES * 64, CF::WG_PER_CU) void conv3x3_duo_ker
   const long long pt0__ = wall_clock64();
 #endif
   int tm, tn;
-  const int tiles_m = p.B * p.tiles_y * p.tiles_x, tiles_n = ceil_div(p.Coutp, NT * 32);
+  constexpr bool REM = CF::REM;
+  constexpr int NJA = NJ + (REM ? 1 : 0);                        // accumulator tiles per wave: its main column tiles + (REM) one tile of P
+  const int tiles_m = p.B * p.tiles_y * p.tiles_x, tiles_n = REM ? 1 : ceil_div(p.Coutp, NT * 32);
   if (!xcd_tile(tiles_m, tiles_n, tm, tn)) return;
   const int b = tm / (p.tiles_y * p.tiles_x), trem = tm - b * (p.tiles_y * p.tiles_x);
   const int y0 = (trem / p.tiles_x) * CF::TY, x0 = (trem % p.tiles_x) * TX, n0 = tn * (NT * 32);
@@ -133,6 +145,11 @@ __global__ __launch_bounds__(CF::WAVES * 64, CF::WG_PER_CU) void conv3x3_duo_ker
     const int r = (q * WAVES + wave) * 16 + drow;
     const int c = dpos ^ ((r >> 2) & 3);
     boff[q] = min(n0 + r, p.Cout - 1) * p.K + (((c & 1) + ((c >> 1) << 2)) << 2);      // rows >= Cout: clamped copies (never stored)
+    if (REM && r >= NT * 32) {
+      // P row pc = (tap, c): filter row NT * 32 + c, columns tap * Cp + (group, half) -- independent of the step's tap; rows beyond 9 R: zero page
+      const int pc = r - NT * 32, R = p.Cout - NT * 32;
+      boff[q] = pc < 9 * R ? (NT * 32 + pc % R) * p.K + (pc / R) * p.Cp + (((c & 1) + ((c >> 1) << 2)) << 2) : -1;
+    }
   }
   const int gpt = p.Cp >> 5;
   // channels >= Cin of the last group are zero padding (activations AND folded weights): when they fill its whole second k-step
@@ -160,9 +177,16 @@ __global__ __launch_bounds__(CF::WAVES * 64, CF::WG_PER_CU) void conv3x3_duo_ker
     const int kx__ = (i_) / 3, ky__ = (i_) - kx__ * 3;                                                      \
     const int ko__ = (ky__ * 3 + kx__) * p.Cp + ((q_) >> 1) * 32 + ((q_) & 1) * 8;                          \
     char* dst__ = bring_base + (stage_) * CF::BSTAGE_BYTES;                                                 \
+    const int kr__ = ((q_) >> 1) * 32 + ((q_) & 1) * 8;          /* P rows: the (group, half) offset only */  \
     _Pragma("unroll") for (int q = 0; q < BQ; ++q) {                                                        \
-      char* d__ = (q * WAVES + wave < CF::BSLOTS) ? dst__ + (q * WAVES + wave) * 1024 : scratch;            \
-      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(wb__ + (boff[q] + ko__)), (lds_ptr_t)d__, 16, 0, 0);     \
+      const bool rem__ = REM && (q * WAVES + wave) * 16 >= NT * 32;        /* wave-uniform */                \
+      if (rem__ && (i_) != 4) {      /* P rows are used at the centre tap only: elsewhere a 4-byte dummy keeps the per-stage DMA count (vmcnt bookkeeping) */ \
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)p.zeros, (lds_ptr_t)scratch, 4, 0, 0);                  \
+      } else {                                                                                              \
+        char* d__ = (q * WAVES + wave < CF::BSLOTS) ? dst__ + (q * WAVES + wave) * 1024 : scratch;          \
+        const sp_t* g__ = rem__ ? (boff[q] >= 0 ? wb__ + (boff[q] + kr__) : p.zeros) : wb__ + (boff[q] + ko__); \
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)g__, (lds_ptr_t)d__, 16, 0, 0);                         \
+      }                                                                                                     \
     }                                                                                                       \
   }
 
@@ -178,7 +202,7 @@ __global__ __launch_bounds__(CF::WAVES * 64, CF::WG_PER_CU) void conv3x3_duo_ker
   const bool full = y0 + CF::TY <= Ho && x0 + TX <= Wo;
   const int nc0 = n0 + jc0 * 32;                                // first column of this wave
   const unsigned lane_sp = (unsigned)(4 * g * p.Coutp + (odd ? 16 : 0) + (tx >> 1));     // this lane's dword inside (pixel x0 + 4 g, group of the wave's column tile 0)
-  f32x16 acc[RW][NJ];
+  f32x16 acc[RW][NJA];
   if (p.residual) {
     if (full) {
 #pragma unroll
@@ -218,11 +242,17 @@ __global__ __launch_bounds__(CF::WAVES * 64, CF::WG_PER_CU) void conv3x3_duo_ker
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   }
 
-  int bbase[NJ];                                               // byte offset of this lane's hi fragment of the wave's column tile j inside a stage
+  int bbase[NJA];                                              // byte offset of this lane's hi fragment of the wave's column tile j inside a stage
 #pragma unroll
-  for (int j = 0; j < NJ; ++j) {
-    const int br = min(jc0 + j, NT - 1) * 32 + tx;
+  for (int j = 0; j < NJA; ++j) {
+    const int br = (REM && j == NJ) ? (NT + wn) * 32 + tx : min(jc0 + j, NT - 1) * 32 + tx;       // (REM: the wave pair's tile of P rows)
     bbase[j] = br * 64 + ((g ^ ((br >> 2) & 3)) << 4);
+  }
+  if (REM) {
+#pragma unroll
+    for (int i = 0; i < RW; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][NJ][r] = 0.f;
   }
   // patch pixel of this lane's output pixel in the wave's patch row jr at tap column kx: (wr * RW + jr) * PW + kx + tx
 #define C3D_LOAD_ROW(jr_, sP_, kx_)                                                                         \
@@ -330,7 +360,7 @@ __global__ __launch_bounds__(CF::WAVES * 64, CF::WG_PER_CU) void conv3x3_duo_ker
     const char* sP = patch_base + (hq & 1) * CF::PHALF_BYTES;                                               \
     const char* sPn = patch_base + ((hq + 1) & 1) * CF::PHALF_BYTES;                                        \
     C3D_STEP(0, 0, NJ_) C3D_STEP(0, 1, NJ_) C3D_STEP(0, 2, NJ_)                                             \
-    C3D_STEP(1, 0, NJ_) C3D_STEP(1, 1, NJ_) C3D_STEP(1, 2, NJ_)                                             \
+    C3D_STEP(1, 0, NJ_) C3D_STEP(1, 1, (NJ_) + (REM ? 1 : 0)) C3D_STEP(1, 2, NJ_)     /* REM: + the P tile at the centre tap */ \
     C3D_STEP(2, 0, NJ_) C3D_STEP(2, 1, NJ_) C3D_STEP(2, 2, NJ_)                                             \
   }
   if (CF::WN == 1 || nj == NJ) { C3D_LOOP(NJ) }
@@ -422,6 +452,24 @@ __global__ __launch_bounds__(CF::WAVES * 64, CF::WG_PER_CU) void conv3x3_duo_ker
             const int x = x0 + (r & 3) + 8 * (r >> 2) + 4 * g;
             if (y < Ho && x < Wo && cpad) p.y_sp[(unsigned)(((b * Ho + y) * Wo + x) * p.Coutp + spc)] = w16[r];
           }
+        }
+      }
+    }
+  }
+  // ---- REM: this wave pair's tile of P = x W_rem (unshifted pixels, columns (tap, c)) -> scratch, times the filter rows' scales; the nine
+  // shifted terms are added by conv_rem_gather_kernel
+  if constexpr (REM) {
+    if (C3D_PROBE_EPI) {
+      const int R = p.Cout - NT * 32, pc = wn * 32 + tx;             // P column of this lane
+      const bool creal = pc < 9 * R;
+      const float wsc = p.wscale[NT * 32 + (creal ? pc % R : 0)] * xinv;
+#pragma unroll
+      for (int i = 0; i < RW; ++i) {
+        const int y = y0 + wr * RW + i;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int x = x0 + (r & 3) + 8 * (r >> 2) + 4 * g;
+          if (creal && y < Ho && x < Wo) p.pbuf[(size_t)((b * Ho + y) * Wo + x) * (9 * R) + pc] = acc[i][NJ][r] * wsc;
         }
       }
     }

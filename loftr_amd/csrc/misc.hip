@@ -56,7 +56,7 @@ extern "C" int loftr_pos_encode_flatten(const loftr_fmap* feat, const float* pe,
 namespace {
 struct DebugSwitch { const char* name; int def; int value; };
 DebugSwitch g_debug[LOFTR_DBG_COUNT] = {{"encoder_schedule", 1, 1}, {"conv_persist_cap", 0, 0}, {"wgrad_chunk", 0, 0}, {"reduce_tall", 1, 1},
-                                        {"pct_grid", 0, 0}, {"pct_skip", 0, 0}, {"pct_quota", 0, 0}, {"conv_duo", 1, 1}, {"conv_patch", 1, 1}};
+                                        {"pct_grid", 0, 0}, {"pct_skip", 0, 0}, {"pct_quota", 0, 0}, {"conv_duo", 1, 1}, {"conv_patch", 1, 1}, {"conv_rem", 1, 1}};
 }  // namespace
 int loftr_debug_value(int key) { return (key >= 0 && key < LOFTR_DBG_COUNT) ? g_debug[key].value : 0; }
 extern "C" int loftr_hip_debug_set(const char* key, int value) {

@@ -572,6 +572,9 @@ CONV_SHARED_GPU = 0x100      # include/loftr_hip.h: LOFTR_CONV_SHARED_GPU
 
 
 @_on_device
+CONV_REM = False      # True: conv_bn_act hands 193 .. 199-channel 3x3 layers a scratch buffer (the tap-decomposed remainder form, see below)
+
+
 def conv_bn_act(x_sp, Cin, conv, bn=None, act=0, residual=None, want_sp=True, want_f32=False, low_sp=None, shared_gpu=False,
                 x_inv_scale=None):
     """nn.Conv2d(bias=False) [+ eval BatchNorm2d] [+ residual] [+ act] on an SP activation.
@@ -590,10 +593,17 @@ def conv_bn_act(x_sp, Cin, conv, bn=None, act=0, residual=None, want_sp=True, wa
     prepared = _prepared_conv(conv, bn)
     y_sp = torch.empty(B, Ho, Wo, ceil32(Cout), dtype=torch.int32, device=dev) if want_sp else None
     y_f32 = torch.empty(B, Ho, Wo, Cout, dtype=torch.float32, device=dev) if want_f32 else None
-    check(_lib.load().loftr_conv_bn_act_prepared(_ptr(x_sp), B, H, W, Cin, _ptr(prepared), prepared.numel(), Cout, KH, KW,
+    lib = _lib.load()
+    # 193 .. 199 output channels (LoFTR's 196): the channels beyond 192 as a tap-decomposed product through a scratch buffer (include/loftr_hip.h);
+    # a fresh tensor per call, not the cached workspace: two streams may run convolutions at the same time
+    # MEASURED AND NOT ADOPTED (CONV_REM = False): the 192-column kernel is no faster than the 224-column one -- a step of these kernels is bound by
+    # its weight stream and barrier, not by its MFMA count (profiles/r06_conv_rem_ab.txt: 2586 + 217 us against 2370 us at 1/2 resolution)
+    nscr = lib.loftr_conv_scratch_bytes(B, H, W, Cout, KH, KW, stride) if (CONV_REM and low_sp is None and not want_f32) else 0
+    scratch = torch.empty(nscr, dtype=torch.uint8, device=dev) if nscr else None
+    check(lib.loftr_conv_bn_act_prepared_scratch(_ptr(x_sp), B, H, W, Cin, _ptr(prepared), prepared.numel(), Cout, KH, KW,
                                                  stride, pad, int(act) | (CONV_SHARED_GPU if shared_gpu else 0), _ptr(residual),
-                                                 _ptr(low_sp), _ptr(y_sp), _ptr(y_f32), _ptr(x_inv_scale),
-                                                 _stream()), "loftr_conv_bn_act_prepared")
+                                                 _ptr(low_sp), _ptr(y_sp), _ptr(y_f32), _ptr(x_inv_scale), _ptr(scratch), nscr,
+                                                 _stream()), "loftr_conv_bn_act_prepared_scratch")
     return y_sp, y_f32
 
 

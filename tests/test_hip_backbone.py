@@ -369,3 +369,50 @@ def test_backbone_chunking_is_bitwise_identical():
     b = data(); model(b)
     for k in ("conf_matrix", "mkpts0_f", "mkpts1_f", "mconf", "b_ids"):
         assert torch.equal(a[k], b[k]), k
+
+
+def test_conv3x3_remainder_channels_tap_decomposed():
+    """Round 6 (round-5 verdict, next #5a): Cout = 196 pads to 224 columns, the 7th column tile does a tile's matrix work for 4 channels.
+    conv3x3_duo_kernel<Cfg<6, 2, 4, 8, 2, REM>> computes 192 columns and the channels beyond them as a tap-decomposed product (all (tap, channel)
+    pairs = the columns of one K = Cin product on the unshifted pixels, at the centre-tap steps) + conv_rem_gather_kernel (the nine shifted
+    terms, bias, residual, activation, SP group).  Against fp64 and against the 224-column kernel (the default: the prototype measured slower), with BatchNorm,
+    residual and every activation, ragged tiles, Cout = 193 .. 199; the pad channels of the SP row must be zero."""
+    from loftr_amd import ops, _lib
+    g = torch.Generator().manual_seed(17)
+    lib = _lib.load()
+    assert lib.loftr_conv_scratch_bytes(2, 30, 40, 196, 3, 3, 1) == 2 * 30 * 40 * 9 * 4 * 4
+    assert lib.loftr_conv_scratch_bytes(2, 30, 40, 192, 3, 3, 1) == 0 and lib.loftr_conv_scratch_bytes(2, 30, 40, 200, 3, 3, 1) == 0
+    assert lib.loftr_conv_scratch_bytes(2, 30, 40, 196, 3, 3, 2) == 0 and lib.loftr_conv_scratch_bytes(2, 30, 40, 196, 1, 1, 1) == 0
+    for cin, cout, (H, W), act, use_res in ((196, 196, (30, 40), 1, True), (256, 196, (17, 33), 2, False), (196, 196, (9, 65), 0, True),
+                                            (128, 193, (16, 32), 1, False), (64, 199, (8, 40), 2, True)):
+        conv = nn.Conv2d(cin, cout, 3, padding=1, bias=False)
+        conv.weight.data = torch.randn(conv.weight.shape, generator=g) * (2.0 / (cin * 9)) ** 0.5
+        bn = nn.BatchNorm2d(cout).eval()
+        bn.weight.data = 1.0 + 0.2 * torch.randn(cout, generator=g); bn.bias.data = 0.1 * torch.randn(cout, generator=g)
+        bn.running_mean.data = 0.1 * torch.randn(cout, generator=g); bn.running_var.data = 0.5 + torch.rand(cout, generator=g)
+        x = torch.randn(3, cin, H, W, generator=g)
+        res = torch.randn(3, cout, H, W, generator=g) if use_res else None
+        ref = bn.double()(F.conv2d(x.double(), conv.weight.double(), padding=1))
+        bn.float()
+        if res is not None:
+            ref = ref + res.double()
+        ref = torch.relu(ref) if act == 1 else (F.leaky_relu(ref, 0.01) if act == 2 else ref)
+        x_sp = ops.sp_from_nhwc(x.permute(0, 2, 3, 1).contiguous().cuda())
+        res_sp = ops.sp_from_nhwc(res.permute(0, 2, 3, 1).contiguous().cuda()) if res is not None else None
+        conv, bn = conv.cuda(), bn.cuda()
+        outs = {}
+        for name, rem in (("rem", True), ("wide", False)):
+            ops.CONV_REM = rem                                         # (off by default: measured slower, profiles/r06_conv_rem_ab.txt)
+            try:
+                y_sp, _ = ops.conv_bn_act(x_sp, cin, conv, bn, act=act, residual=res_sp, want_sp=True, want_f32=False)
+            finally:
+                ops.CONV_REM = False
+            full = ops.sp_to_nhwc(y_sp, 224)                           # all 224 stored columns, pad channels included
+            assert float(full[..., cout:].abs().max()) == 0.0, (name, cin, cout)
+            y = full[..., :cout].permute(0, 3, 1, 2).cpu().double()
+            err = (y - ref).abs().max().item() / ref.abs().max().item()
+            assert err <= 2e-5, (name, cin, cout, err)
+            outs[name] = y
+        scale = ref.abs().max().item()
+        assert torch.equal(outs["rem"][:, :192], outs["wide"][:, :192])              # the 192 main columns: the same arithmetic, bit for bit
+        assert (outs["rem"] - outs["wide"]).abs().max().item() <= 4e-6 * scale        # the remainder channels: another summation order

@@ -85,10 +85,10 @@ def test_hot_kernels_keep_their_register_and_lds_budgets(isa):
     pushes a two-workgroups-per-CU kernel over its LDS / register budget fails here, on the CPU, before it costs GPU time."""
     conv = _kernel_resources(isa["conv.hip"])
     duo = {k: v for k, v in conv.items() if "conv3x3_duo_kernel" in k}
-    assert len(duo) == 3                                     # Cfg<4,2,4> (128 k columns), Cfg<6,2,4,8,2> (192), Cfg<7,2,4,8,2> (224): the A/B variants left in round 6
+    assert len(duo) == 4                                     # Cfg<4,2,4> (128 k columns), Cfg<6,2,4,8,2> (192), Cfg<7,2,4,8,2> (224), Cfg<6,2,4,8,2,REM> (192 + tap-decomposed remainder)
     for k, v in duo.items():
         assert v["scratch"] == 0, (k, v)
-        four_wave = "ELi4ELi1EEE" in k                       # Cfg<.., WAVES = 4, WN = 1>: two workgroups per CU
+        four_wave = "ELi4ELi1ELb0EEE" in k                       # Cfg<.., WAVES = 4, WN = 1>: two workgroups per CU
         assert v["lds"] <= (80 if four_wave else 160) * 1024 and v["vgpr"] <= 256, (k, v)
     enc = _kernel_resources(isa["encoder_fused.hip"])
     for k, v in enc.items():

@@ -1,7 +1,8 @@
 #!/usr/bin/env python
 """Per-layer timing of the backbone's convolutions (ResNetFPN_8_2, 16 images of 480x640 = the bench step) through the C-ABI:
 one line per layer with its launch time, the executed fp16 MFMA rate (3 MFMAs per fp32 product, USEFUL flops only) and the
-fraction of the 2.5 PF dense peak.     python tools/micro/conv_layers.py [B=16] [iters=10] [only=substring]
+fraction of the 2.5 PF dense peak.     python tools/micro/conv_layers.py [B=16] [iters=10] [only=substring] [key=value ...]
+(key=value: debug switches of the library, e.g. conv_rem=0)
 LOFTR_HIP_LIB=<variant .so> selects another build of the library (A/B)."""
 import os
 import sys
@@ -31,7 +32,12 @@ def layers(h=480, w=640):
     ]
 
 
-def main(B=16, iters=10, only=""):
+def main(B=16, iters=10, only="", *switches):
+    for kv in switches:
+        if kv.split("=")[0] == "conv_rem":                    # the remainder form needs the scratch buffer ops.conv_bn_act allocates when asked to
+            ops.CONV_REM = bool(int(kv.split("=")[1]))
+        else:
+            ops.debug_set(kv.split("=")[0], int(kv.split("=")[1]))
     dev = torch.device("cuda", 0)
     torch.manual_seed(0)
     print(f"{'layer':38s} {'us':>9s} {'GFLOP':>8s} {'exec PF':>8s} {'frac':>6s}")
@@ -64,4 +70,4 @@ def main(B=16, iters=10, only=""):
 
 if __name__ == "__main__":
     a = sys.argv[1:]
-    main(int(a[0]) if len(a) > 0 else 16, int(a[1]) if len(a) > 1 else 10, a[2] if len(a) > 2 else "")
+    main(int(a[0]) if len(a) > 0 else 16, int(a[1]) if len(a) > 1 else 10, a[2] if len(a) > 2 else "", *a[3:])
