@@ -571,10 +571,10 @@ def _prepared_conv(conv, bn):
 CONV_SHARED_GPU = 0x100      # include/loftr_hip.h: LOFTR_CONV_SHARED_GPU
 
 
-@_on_device
 CONV_REM = False      # True: conv_bn_act hands 193 .. 199-channel 3x3 layers a scratch buffer (the tap-decomposed remainder form, see below)
 
 
+@_on_device
 def conv_bn_act(x_sp, Cin, conv, bn=None, act=0, residual=None, want_sp=True, want_f32=False, low_sp=None, shared_gpu=False,
                 x_inv_scale=None):
     """nn.Conv2d(bias=False) [+ eval BatchNorm2d] [+ residual] [+ act] on an SP activation.
