@@ -26,6 +26,24 @@
 // reference's fp64 run on e2e_synth where the reference's own fp32 run sits at 2.5e-4 (profiles/r04_parity_margins.txt).
 #include "linear.h"
 
+// timing probes (python -m loftr_amd.build --variant fprobe -DLOFTR_FINE_PROBE [-DFFX_PROBE_READS=0 ...]; tools/micro/fine_probe.py): per-wave
+// phase sums of the 100 MHz wall clock; the 0 settings give WRONG results: fragment reads only in front of a panel / no weight DMA after the
+// prologue / no per-panel barrier
+#ifdef LOFTR_FINE_PROBE
+__device__ long long* g_fine_probe = nullptr;   // set by loftr_fine_probe_buffer: per wave 6 phase sums, start, end
+#define FFX_STAMP(i_) { const long long t__ = wall_clock64(); pacc[i_] += t__ - pt__; pt__ = t__; }
+#else
+#define FFX_STAMP(i_)
+#endif
+#ifndef FFX_PROBE_READS
+#define FFX_PROBE_READS 1
+#endif
+#ifndef FFX_PROBE_DMA
+#define FFX_PROBE_DMA 1
+#endif
+#ifndef FFX_PROBE_BARRIER
+#define FFX_PROBE_BARRIER 1
+#endif
 namespace {
 namespace ffx {
 constexpr int W = 4, STAGE = 16 * 1024, BLK = 4096, NST = 6, DMA_PER_WAVE = 4;
@@ -265,13 +283,14 @@ __global__ __launch_bounds__(W * 64, 1) void fine_pair_kernel(Args a) {
 #define FFX_BEGIN(p_)                                                                                      \
   {                                                                                                        \
     const int rem__ = NPANEL - 1 - (p_);                                                                   \
-    if (rem__ >= 4) LOFTR_WAITCNT_VM(4 * DMA_PER_WAVE);                                                    \
+    if (!FFX_PROBE_DMA) LOFTR_WAITCNT_VM(0);                                                               \
+    else if (rem__ >= 4) LOFTR_WAITCNT_VM(4 * DMA_PER_WAVE);                                                    \
     else if (rem__ == 3) LOFTR_WAITCNT_VM(3 * DMA_PER_WAVE);                                               \
     else if (rem__ == 2) LOFTR_WAITCNT_VM(2 * DMA_PER_WAVE);                                               \
     else if (rem__ == 1) LOFTR_WAITCNT_VM(1 * DMA_PER_WAVE);                                               \
     else LOFTR_WAITCNT_VM(0);                                                                              \
-    __builtin_amdgcn_s_barrier();                                                                          \
-    if ((p_) + NST - 1 < NPANEL) FFX_ISSUE((p_) + NST - 1);                                                \
+    if (FFX_PROBE_BARRIER) __builtin_amdgcn_s_barrier();                                                   \
+    if (FFX_PROBE_DMA && (p_) + NST - 1 < NPANEL) FFX_ISSUE((p_) + NST - 1);                                                \
   }
   const int a_off = lds_chunk_off(li, g);
 #define FFX_RD(st_, blk_, odd_, lo_) (*reinterpret_cast<const h16x8*>((st_) + (blk_) * BLK + (a_off ^ (((odd_) ? 32 : 0) | ((lo_) ? 64 : 0)))))
@@ -289,11 +308,11 @@ __global__ __launch_bounds__(W * 64, 1) void fine_pair_kernel(Args a) {
       h16x8 nah__ = ah__, nal__ = al__, nbh__ = bh__, nbl__ = bl__;                                        \
       M1_;                                                                                                 \
       __builtin_amdgcn_sched_barrier(0);                                                                   \
-      if (u + 1 < 4) { nah__ = FFX_RD(st_, BLK0_(u + 1), ODD0_(u + 1), 0); nal__ = FFX_RD(st_, BLK0_(u + 1), ODD0_(u + 1), 1); } \
+      if (FFX_PROBE_READS && u + 1 < 4) { nah__ = FFX_RD(st_, BLK0_(u + 1), ODD0_(u + 1), 0); nal__ = FFX_RD(st_, BLK0_(u + 1), ODD0_(u + 1), 1); } \
       __builtin_amdgcn_sched_barrier(0);                                                                   \
       M2_;                                                                                                 \
       __builtin_amdgcn_sched_barrier(0);                                                                   \
-      if (u + 1 < 4) { nbh__ = FFX_RD(st_, BLK1_(u + 1), ODD1_(u + 1), 0); nbl__ = FFX_RD(st_, BLK1_(u + 1), ODD1_(u + 1), 1); } \
+      if (FFX_PROBE_READS && u + 1 < 4) { nbh__ = FFX_RD(st_, BLK1_(u + 1), ODD1_(u + 1), 0); nbl__ = FFX_RD(st_, BLK1_(u + 1), ODD1_(u + 1), 1); } \
       __builtin_amdgcn_sched_barrier(0);                                                                   \
       M3_; M4_; M5_; M6_;                                                                                  \
       __builtin_amdgcn_sched_barrier(0);                                                                   \
@@ -330,6 +349,11 @@ __global__ __launch_bounds__(W * 64, 1) void fine_pair_kernel(Args a) {
 #pragma unroll
   for (int p = 0; p < NST - 1; ++p) FFX_ISSUE(p);
 
+#ifdef LOFTR_FINE_PROBE
+  long long pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const long long pstart__ = wall_clock64();
+  long long pt__ = pstart__;
+#endif
   const int fq = 4 * g;
   const float S = (float)T, inv_s = 1.f / (float)T;      // v_length = number of source tokens (linear_attention.py:41-45)
   const h16x8 zero8 = __builtin_bit_cast(h16x8, u32x4{0u, 0u, 0u, 0u});
@@ -363,8 +387,10 @@ __global__ __launch_bounds__(W * 64, 1) void fine_pair_kernel(Args a) {
         kvi[0] = kvi[1]; kvi[1] = kvi[2]; kvi[2] = kvi[3]; kvi[3] = inv__;                                 \
       }                                                                                                    \
     }
+    FFX_STAMP(0)
     if (self) { FFX_KV_LOOP(wah, wal) } else { FFX_KV_LOOP(wbh, wbl) }
 #undef FFX_KV_LOOP
+    FFX_STAMP(1)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                 // the Ksum / KV stores (asm) have left this wave
     // ============ x side: Q_t -> attention of head pair t -> merge, accumulated over t ============================
 #pragma unroll
@@ -424,6 +450,7 @@ __global__ __launch_bounds__(W * 64, 1) void fine_pair_kernel(Args a) {
       FFX_BEGIN(p + 1);
       if (live) FFX_KPANEL(lds + ((p + 1) % NST) * STAGE, mah, mal, big);   // merge: msg += Wm[:, 32 t ..] message_t
     }
+    FFX_STAMP(2)
     // ---- message = LayerNorm1(merge output) -> fragments                                                     transformer.py:51-52
     h16x8 mh[8], ml[8];
     if (live) {
@@ -464,6 +491,7 @@ __global__ __launch_bounds__(W * 64, 1) void fine_pair_kernel(Args a) {
     for (int j = 0; j < 4; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) big[j][r] = 0.f;
+    FFX_STAMP(3)
     // ============ mlp: per 32 hidden features hid = relu(W0[hp] [x, message]) -> out += W2[:, hp] hid ================
 #pragma unroll 1
     for (int hp = 0; hp < 8; ++hp) {
@@ -492,6 +520,7 @@ __global__ __launch_bounds__(W * 64, 1) void fine_pair_kernel(Args a) {
       FFX_BEGIN(p + 2);
       if (live) FFX_KPANEL(lds + ((p + 2) % NST) * STAGE, hh, hl, big);
     }
+    FFX_STAMP(4)
     // ============ x <- x + LayerNorm2(mlp output), in fp32; every call's rows go to HBM ======================     transformer.py:55-58
     if (live) {
       // the window's fp32 rows (the kernel's input in the self layer, the self layer's output in the cross layer): issued here,
@@ -556,7 +585,15 @@ __global__ __launch_bounds__(W * 64, 1) void fine_pair_kernel(Args a) {
       wah[ks] = wbh[ks]; wal[ks] = wbl[ks]; wbh[ks] = th; wbl[ks] = tlo;
     }
     { const float ts = wa_sc, ti = wa_inv; wa_sc = wb_sc; wa_inv = wb_inv; wb_sc = ts; wb_inv = ti; }
+    FFX_STAMP(5)
   }
+#ifdef LOFTR_FINE_PROBE
+  if (g_fine_probe && lane == 0) {
+    long long* o = g_fine_probe + ((long)blockIdx.x * W + wave) * 8;
+    for (int i = 0; i < 6; ++i) o[i] = pacc[i];
+    o[6] = pstart__; o[7] = wall_clock64();
+  }
+#endif
 #undef FFX_ISSUE
 #undef FFX_BEGIN
 #undef FFX_RD
@@ -575,6 +612,13 @@ __global__ __launch_bounds__(W * 64, 1) void fine_pair_kernel(Args a) {
 }
 }  // namespace ffx
 }  // namespace
+
+#ifdef LOFTR_FINE_PROBE
+extern "C" int loftr_fine_probe_buffer(void* buf) {
+  long long* b = (long long*)buf;
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_fine_probe), &b, sizeof(b)) == hipSuccess ? LOFTR_OK : LOFTR_ERR_LAUNCH;
+}
+#endif
 
 int launch_fine_pair(const FinePairArgs& p, hipStream_t st) {
   if (p.C != 128 || p.T < 1 || p.T > 32 || p.M <= 0) return LOFTR_ERR_UNSUPPORTED;
