@@ -779,7 +779,9 @@ namespace {
 // Work decomposition of the Sinkhorn iteration passes (a function of the geometry only) and the iteration loop itself, shared
 // by the forward and by the backward's re-creation of (u_t, v_t).
 // wide rows (up to 12 x 1024 columns): ONE workgroup per CU, one row per round, the next row prefetched.  Measured at 2 x 11025^2
-// (936 MB per pass): iteration 272 us with 512 threads, 321 with 1024; last pass (reads + writes) 786 / 575 us.
+// (936 MB per pass): iteration 272 us with 512 threads, 321 with 1024; last pass (reads + writes) 786 / 575 us.  Round 6: two rows per
+// round (twice the bytes in flight) 370 us with 512 threads, 429 with 1024 -- a round is bound by its two block reductions and the
+// exponentials between them, not by the loads (tools/gpu/r6_ot_wide.sh).
 #ifndef OT_WIDE_NT
 #define OT_WIDE_NT 512
 #endif
