@@ -392,7 +392,8 @@ POOLED_FROM = {
     "score_sweep_kernel<1>": ["sweep::score_sweep_kernel<1, false, false, false>", "sweep::score_sweep_kernel<1, false, false, true>",
                               "sweep::score_sweep_kernel<1, true, false, true>", "(C != 256: score_conf_kernel)"],
     "score_sweep_kernel<2>": ["sweep::score_sweep_kernel<2, false>", "sweep::score_sweep_kernel<2, true>", "(C != 256: score_store_kernel)"],
-    "conv3x3_duo_kernel<Cfg<4,2,4,4,1>>": ["conv3x3_duo_kernel<c3d::Cfg<4, 2, 4, 4, 1> >", "(Cout not a multiple of 128: conv3x3_kernel)"],
+    "conv3x3_duo_kernel<Cfg<4,2,4,4,1>>": ["conv3x3_duo_kernel<c3d::Cfg<4, 2, 4, 4, 1> >", "conv3x3_duo_kernel<c3d::Cfg<6, 2, 4, 8, 2> > (Coutp = 192; not on the LoFTR path)",
+                                           "(Cout not a multiple of 128 / 192 / 224: conv3x3_kernel)"],
     "conv3x3_duo_kernel<Cfg<7,2,4,8,2>>": ["conv3x3_duo_kernel<c3d::Cfg<7, 2, 4, 8, 2> >"],
     "encoder_x_kernel": ["efx::coarse_persistent_kernel", "efx::encoder_x_kernel", "efx::encoder_x2_kernel"],
     "fine_pair_kernel": ["ffx::fine_pair_kernel"],

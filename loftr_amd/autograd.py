@@ -218,7 +218,8 @@ class _Conv2d(torch.autograd.Function):
       dL/dx:    the same kernels on the flipped, transposed filter (stride 2: on dy with zeros interleaved; 1 x 1 stride 2: the
                 low-resolution product scattered to the even pixels);
       dL/dw:    loftr_conv_wgrad (split-K over the output pixels, ordered partial sums).
-    BatchNorm (batch statistics), activations, the residual / FPN adds and the bilinear upsampling stay PyTorch autograd."""
+    BatchNorm (batch statistics), the activations with the residual add and the bilinear upsampling are HIP autograd nodes as well
+    (_BatchNormTrain / _Act / _Upsample2x below, csrc/train_glue.hip); the stem's im2col and the FPN adds stay PyTorch autograd."""
     calls = 0                                                  # forward applications (tests check that the node is the one that ran)
 
     @staticmethod

@@ -42,8 +42,9 @@ enum LoftrTimedKernel {
   LOFTR_T_GATHER = 8,        // fine.hip: gather_windows_kernel
   LOFTR_T_OT_STORE = 9,      // coarse_match.hip: score_store_kernel   (sinkhorn)
   LOFTR_T_CONV = 10,         // conv.hip: conv_kernel               (backbone implicit GEMM: strided / 1x1)
-  LOFTR_T_CONV3 = 11,        // conv.hip: conv3x3_kernel            (3x3 stride-1, input patch in LDS)
-  LOFTR_T_CONV3W = 12,       // conv.hip: conv3x3_wide_kernel       (3x3 stride-1, 7 output column tiles: Cout 193..224)
+  LOFTR_T_CONV3 = 11,        // conv3x3_duo.h: conv3x3_duo_kernel<Cfg<4,2,4,4,1>> (3x3 stride-1, 128-column tiles), also Cfg<6,2,4,8,2> (192 columns,
+                             //   with or without the remainder form) and the generic conv3x3_kernel fallback
+  LOFTR_T_CONV3W = 12,       // conv3x3_duo.h: conv3x3_duo_kernel<Cfg<7,2,4,8,2>> (3x3 stride-1, 7 output column tiles: Cout 193..224)
   LOFTR_T_ENCODER_X = 13,   // encoder_fused.hip: encoder_x_kernel  (q proj -> merge + LN -> mlp.0 -> mlp.2 + LN + residual, one launch)
   LOFTR_T_FINE_PAIR = 14,   // fine_fused.hip: fine_pair_kernel     (the whole fine-level transformer of a match, one launch)
   LOFTR_T_COUNT = 15
