@@ -489,7 +489,7 @@ class LoFTR(nn.Module):
         # persistent form takes 3.13 ms against 3.29 (8 pairs, back to back); inside the bench step the variants of the schedule
         # (persistent / launches, fine branch on a side stream, half batches on two streams) all end within 2 % of each other -- the
         # MFMA-dense kernels run at the part's power limit (profiles/r06_coarse_mode_ab.txt, r06_power.txt).  ops.COARSE_MODE "auto" (the
-        # default) takes the persistent form from 150 token tiles per call on.
+        # default) takes the persistent form from 8 pairs on (profiles/r06_mode_sweep.txt).
         feat_c0, feat_c1 = self.loftr_coarse(feat_c0, feat_c1, mask_c0, mask_c1, inplace=True, mode=self.coarse_mode)   # fresh pos-encoded copies
         # Join the side stream (FPN fine branch) HERE, not after coarse matching (self.fine_join_late restores that): the encoder
         # launches leave partly filled rounds that the convolution workgroups use, the score-volume kernels do not -- sharing the

@@ -237,11 +237,14 @@ def transformer_prepare(layer_structs, Cc, device):
 _COARSE_PLANS = {}
 # "persistent": one dependency-driven launch per coarse transformer call;  "persistent_call_order": the same kernel on the
 # reference's call order (bit-identical results; A/B and tests);  "launches": the per-call launches of loftr_transformer_fwd;
-# "auto" (default): persistent when a call has enough tiles to keep 256 workgroups busy between its dependencies -- a single
-# 640 x 480 pair is a chain of 12 calls of 38 tiles each and finishes sooner as launches (2.06 vs 1.51 ms; 8 pairs: 3.19 vs 3.56 ms,
-# 2 pairs of 840 x 840: 2.36 vs 2.42 ms; tools/micro/pct_check.py, profiles/r06_pct_check.txt)
+# "auto" (default): persistent from 8 pairs on.  The dependencies are per pair, so with few pairs the 256 resident workgroups wait on each
+# other -- and a resident workgroup holds its CU, which the FPN fine branch on the side stream then cannot use.  Alone the persistent form wins
+# from 2 pairs on (8 pairs 3.19 vs 3.56 ms, 2 pairs of 840 x 840 2.36 vs 2.42 ms, a single 640 x 480 pair 2.06 vs 1.51 ms: tools/micro/pct_check.py,
+# profiles/r06_pct_check.txt); INSIDE the forward it loses below 8 pairs (640 x 480: 1 pair 5.1-6.0 vs 4.5 ms, 2 pairs 7.5 vs 6.6, 4 pairs 11.6 vs
+# 10.9, 8 pairs 20.0 vs 20.1-20.2, 16 pairs 39.3 vs 39.3; 840 x 840: 1 / 2 / 4 pairs 8.2 / 13.2 / 24.3 vs 7.3 / 12.6 / 23.9 ms;
+# profiles/r06_mode_sweep.txt)
 COARSE_MODE = os.environ.get("LOFTR_COARSE_MODE", "auto")
-COARSE_AUTO_MIN_TILES = 150
+COARSE_AUTO_MIN_PAIRS = 8
 
 
 def coarse_plan(kinds, N, L, S, device, order=0):
@@ -290,7 +293,7 @@ def transformer(feat0, feat1, layer_structs, layer_names, nhead, mask0=None, mas
     ws = workspace(nbytes, feat0.device)
     mode = mode or COARSE_MODE
     if mode == "auto":
-        mode = "persistent" if N * ((max(L, S) + 127) // 128) >= COARSE_AUTO_MIN_TILES else "launches"
+        mode = "persistent" if N >= COARSE_AUTO_MIN_PAIRS else "launches"
     plan = None
     if mode != "launches" and Cc == 256 and nhead == 8 and N > 0:
         order = 1 if mode == "persistent_call_order" else 0

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """BASELINE configs[3] (outdoor, 840 x 840, MegaDepth-style padding masks + scales): full forward timing, N pairs.
 
-    python tools/micro/outdoor_bench.py [N] [reps] [sinkhorn]"""
+    python tools/micro/outdoor_bench.py [N] [reps] [sinkhorn] [mode=launches|persistent|auto] [overlap=0|1]"""
 import os
 import sys
 
@@ -14,12 +14,17 @@ from loftr_amd.config import get_cfg             # noqa: E402
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
-ot = len(sys.argv) > 3 and sys.argv[3] == "sinkhorn"
+ot = "sinkhorn" in sys.argv[3:]
+kv = dict(a.split("=") for a in sys.argv[3:] if "=" in a)
 torch.manual_seed(0)
 cfg = get_cfg(thr=0.0, border_rm=2)
 if ot:
     cfg["match_coarse"].update(match_type="sinkhorn", skh_prefilter=False, sparse_spvs=True)
 model = LoFTR(cfg).eval().cuda()
+if "mode" in kv:
+    model.coarse_mode = kv["mode"]
+if "overlap" in kv:
+    model.overlap_fine_branch = bool(int(kv["overlap"]))
 g = torch.Generator().manual_seed(1234)
 img0 = torch.rand(N, 1, 840, 840, generator=g)
 img1 = (img0.roll((8, 16), (2, 3)) + 0.02 * torch.rand(N, 1, 840, 840, generator=g)).clamp(0, 1)
@@ -37,4 +42,4 @@ for _ in range(reps):
     dd = dict(d); model(dd)
 e1.record(); torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / reps
-print(f"outdoor 840x840 {'sinkhorn' if ot else 'dual-softmax'}, N={N}: {ms:.2f} ms per forward = {N / ms * 1e3:.1f} pairs/s, M = {dd['mconf'].shape[0]}")
+print(f"outdoor 840x840 {'sinkhorn' if ot else 'dual-softmax'}, N={N}{''.join(' ' + k + '=' + v for k, v in kv.items())}: {ms:.2f} ms per forward = {N / ms * 1e3:.1f} pairs/s, M = {dd['mconf'].shape[0]}")
