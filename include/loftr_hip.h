@@ -49,8 +49,9 @@ typedef enum {
  * 21: training-mode glue of the backbone (loftr_bn_train_fwd / _bwd, loftr_act_fwd / _bwd, loftr_upsample2x_bilinear_fwd / _bwd);
  * 22: the persistent coarse transformer (loftr_coarse_plan_bytes / _build / _signature, loftr_transformer_fwd_planned) and the
  *     debug switches (loftr_hip_debug_set / _get) that replace the library's environment variables;
- * 23: loftr_conv_scratch_bytes / loftr_conv_bn_act_prepared_scratch (the 196-channel layers' remainder channels as a tap-decomposed product) */
-#define LOFTR_HIP_ABI_VERSION 23
+ * 23: loftr_conv_scratch_bytes / loftr_conv_bn_act_prepared_scratch (the 196-channel layers' remainder channels as a tap-decomposed product);
+ * 24: loftr_transformer_fwd_padded (padding masks: 128-token tiles without a valid token are not computed) */
+#define LOFTR_HIP_ABI_VERSION 24
 
 int loftr_hip_abi_version(void);
 const char* loftr_hip_status_string(int status);
@@ -125,6 +126,17 @@ int loftr_transformer_fwd(float* feat0, float* feat1, const uint8_t* mask0, cons
                           const loftr_layer_weights* layers, const int* layer_is_cross,
                           int n_layers, int N, int L, int S, int C, int H, const void* prepared,
                           size_t prepared_bytes, void* ws, size_t ws_bytes, void* stream);
+/* loftr_transformer_fwd for a caller that does not read the features of PADDING tokens (mask byte 0; MegaDepth batches padded to a common
+ * size, dataset.py:107-125).  The reference computes x + LayerNorm2(mlp([x, b1])) for them in every layer, and nothing in LoFTR.forward reads
+ * it: their scores are filled (coarse_matching.py:115-118), as attention sources they are multiplied by zero (linear_attention.py:37-40) and
+ * the fine stage only gathers at matched -- valid -- tokens.  With skip_padded_tiles != 0 and masks given, a 128-token tile (tokens
+ * 128 t .. 128 t + 127 of a sequence) whose mask bytes are all zero keeps its INPUT values in feat0 / feat1; every other token comes out
+ * bit-identical to loftr_transformer_fwd (a fully masked tile's K^T V / Ksum partial is exactly +0 and is written as such in either call).
+ * skip_padded_tiles == 0 or no masks: the same as loftr_transformer_fwd. */
+int loftr_transformer_fwd_padded(float* feat0, float* feat1, const uint8_t* mask0, const uint8_t* mask1,
+                                 const loftr_layer_weights* layers, const int* layer_is_cross,
+                                 int n_layers, int N, int L, int S, int C, int H, const void* prepared,
+                                 size_t prepared_bytes, void* ws, size_t ws_bytes, int skip_padded_tiles, void* stream);
 /* The same forward as ONE persistent launch (csrc/encoder_fused.hip: coarse_persistent_kernel).  The reference's schedule
  * (transformer.py:91-99) synchronises whole calls; its data dependency -- feat1 attends to the UPDATED feat0 -- is per pair, and
  * below that per 128-token tile.  A PLAN is the dependency graph of one forward's work items for a shape (n_layers of the pattern

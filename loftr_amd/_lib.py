@@ -53,6 +53,8 @@ SIGNATURES = {
     "loftr_encoder_layer_bwd": (_i, [_p, _p, _p, _p, C.POINTER(LayerWeights), _p, _p, _p, C.POINTER(LayerWeights), _i, _i, _i, _i, _i, _p, _sz, _p]),
     "loftr_transformer_fwd": (_i, [_p, _p, _p, _p, C.POINTER(LayerWeights), C.POINTER(_i), _i, _i, _i, _i, _i, _i,
                                    _p, _sz, _p, _sz, _p]),
+    "loftr_transformer_fwd_padded": (_i, [_p, _p, _p, _p, C.POINTER(LayerWeights), C.POINTER(_i), _i, _i, _i, _i, _i, _i,
+                                          _p, _sz, _p, _sz, _i, _p]),
     "loftr_coarse_plan_bytes": (_sz, [C.POINTER(_i), _i, _i, _i, _i]),
     "loftr_coarse_plan_build": (_i, [C.POINTER(_i), _i, _i, _i, _i, _i, _p, _sz, _p]),
     "loftr_coarse_plan_signature": (C.c_uint, [_i, _i, _i, _i, _i]),
@@ -126,7 +128,7 @@ SIGNATURES = {
     "loftr_linear_fwd": (_i, [_p, _p, _p, _i, _i, _i, _p, _sz, _p]),
 }
 
-ABI_VERSION = 23
+ABI_VERSION = 24
 _lib = None
 
 

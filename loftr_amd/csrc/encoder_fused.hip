@@ -66,6 +66,7 @@ struct Args {
   float v_length, attn_eps, p_out_scale, ln_eps;
   int nseq, T, groups;                                  // groups of W token blocks per sequence
   int xsplit, gpc;                                      // fewer sequences than XCDs: a sequence's groups are cut into xsplit chunks of gpc groups, one XCD each
+  int skip_padded;                                      // launches only (EncoderXArgs): fully masked 128-token tiles keep their input
 };
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -107,7 +108,9 @@ __device__ __forceinline__ void pack_panel(const float (&v)[16], h16x8 (&fh)[2],
 __device__ __forceinline__ bool job_tile(const Args& a, const int id, int& seq, int& grp) {
   const int xcd = id % NUM_XCD, slot = id / NUM_XCD;
   const int vs = (slot / a.gpc) * NUM_XCD + xcd;        // virtual sequence = (sequence, chunk)
-  seq = vs / a.xsplit; grp = (vs % a.xsplit) * a.gpc + slot % a.gpc;
+  // (a chunk takes every xsplit-th group, not a contiguous range: the padded tail of a masked sequence -- groups that return at once,
+  //  EncoderXArgs.skip_padded -- is then shared out evenly between the sequence's XCDs)
+  seq = vs / a.xsplit; grp = (slot % a.gpc) * a.xsplit + vs % a.xsplit;
   return seq < a.nseq && grp < a.groups;
 }
 
@@ -128,6 +131,17 @@ template <bool FOLD>
 __device__ __forceinline__ void encoder_x_body(const Args& a, const int seq, const int grp, char* const lds, const FoldArgs* fa = nullptr) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 5, li = lane & 31;
   const int T = a.T;
+  // Padding tokens (mask 0) take no part in attention: their scores are filled (coarse_matching.py:115-118), as sources they are multiplied by
+  // zero, the fine stage never selects them -- what the layer computes for them (x + LayerNorm2(mlp([x, b1]))) is read by nobody in LoFTR.forward.
+  // A caller that says so (skip_padded: loftr_transformer_fwd_padded) gets the 128-token tiles without a single valid token back UNCHANGED
+  // instead (in-place calls only); every other token is bit-identical.  Workgroup-uniform.
+  if constexpr (!FOLD) {
+    if (a.skip_padded && a.mask && a.out_f32 == a.x_f32 && a.out_sp == a.x_sp) {
+      const int t = grp * W * PT + (int)threadIdx.x;
+      const bool valid = (int)threadIdx.x < W * PT && t < T && a.mask[(long)seq * T + t] != 0;
+      if (!__syncthreads_or(valid)) return;
+    }
+  }
   const int tok = (grp * W + wave) * PT + li;
   const bool live = (grp * W + wave) * PT < T;          // wave-uniform: a wave beyond the sequence only feeds the ring
   const long row = (long)seq * T + min(tok, T - 1);
@@ -862,6 +876,7 @@ static int make_job(const EncoderXArgs& p, efx::Args& a) {
   a.wq_s = p.wq_s; a.w0_s = p.w0_s; a.w2_s = p.w2_s; a.kv = p.kv; a.mask = p.mask;
   a.g1 = p.g1; a.b1 = p.b1; a.g2 = p.g2; a.b2 = p.b2;
   a.v_length = p.v_length; a.attn_eps = p.attn_eps; a.p_out_scale = p.p_out_scale; a.ln_eps = p.ln_eps;
+  a.skip_padded = p.skip_padded;
   a.nseq = p.nseq; a.T = p.T; a.groups = ceil_div(ceil_div(p.T, efx::PT), efx::W);
   a.xsplit = p.nseq < NUM_XCD ? NUM_XCD / p.nseq : 1;
   if (a.xsplit > a.groups) a.xsplit = a.groups;

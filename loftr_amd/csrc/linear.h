@@ -90,6 +90,7 @@ struct EncoderXArgs {
   const uint8_t* mask;                                // [nseq * T] or null
   const float *g1, *b1, *g2, *b2;
   float v_length, attn_eps, p_out_scale, ln_eps;
+  int skip_padded;                                    // != 0 (in-place calls with a mask only): a 128-token tile whose mask bytes are all zero keeps its input
 };
 int launch_encoder_x(const EncoderXArgs& p, hipStream_t st);
 // Workgroups of the job (0: not a shape the fused kernel takes), and a launch of workgroups [off0, off0 + n0) of job p0 followed by

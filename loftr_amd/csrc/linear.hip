@@ -230,12 +230,26 @@ __global__ __launch_bounds__(Cfg::THREADS, 2) void proj_kv_kernel(ProjKVArgs p) 
   if (!xcd_tile(ceil_div(p.S, Cfg::BM), 2 * p.C / Cfg::BN, tm, tn)) return;
   const int m0 = tm * Cfg::BM, n0 = tn * Cfg::BN;
   const long n = blockIdx.y;
-  f32x16 acc[Cfg::TM][Cfg::TN];
-  gemm_mainloop<Cfg>(asrc_plain(p.a + n * p.S * p.C, p.C), p.w_kv, p.C, p.S, 2 * p.C, p.C, m0, n0, lds, acc);
-  const EpiLane<Cfg> e;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wm = wave % Cfg::WM, wn = wave / Cfg::WM;
   const uint8_t* mask = p.mask ? p.mask + n * p.S : nullptr;
+  // Padding masks (MegaDepth batches, 840 x 840 padded from 840 x 560: a third of the row tiles): every row of a fully masked tile enters
+  // K^T V and Ksum as K = +0 (elu + 1 > 0, times 0), V = +-0 -- its partial is +0 everywhere whatever the descriptors are.  Written as such,
+  // without the projection (bit-identical).  Block-uniform.
+  if (mask) {
+    bool valid = false;
+    for (int r = threadIdx.x; r < Cfg::BM; r += Cfg::THREADS) valid = valid || (m0 + r < p.S && mask[m0 + r] != 0);
+    if (!__syncthreads_or(valid)) {
+      if (wm == 0) {
+        float* out = p.part + (((long)n * 8 + 2 * tn + wn) * p.splits + tm) * (33 * 32);
+        for (int o = lane; o < 33 * 32; o += 64) out[o] = 0.f;
+      }
+      return;
+    }
+  }
+  f32x16 acc[Cfg::TM][Cfg::TN];
+  gemm_mainloop<Cfg>(asrc_plain(p.a + n * p.S * p.C, p.C), p.w_kv, p.C, p.S, 2 * p.C, p.C, m0, n0, lds, acc);
+  const EpiLane<Cfg> e;
   // feature map / masks on the accumulators: tile j = 0 holds K (elu+1), j = 1 holds V (1/S); rows >= S contribute 0
   const float wk = p.wsc ? p.wsc[n0 + e.lcol] : 1.f, wv = p.wsc ? p.wsc[n0 + e.lcol + 32] : 1.f;
   float ksum = 0.f;

@@ -112,9 +112,9 @@ int coarse_kv(const sp_t* src_sp, const uint8_t* src_mask, const LayerSp& w, int
 }
 // everything on the x side of the layer (encoder_fused.hip), in place
 EncoderXArgs coarse_x(float* x_f32, sp_t* x_sp, const uint8_t* x_mask, const LayerSp& w, int nb, int L, int S, int C, const float* kv,
-                      const sp_t* pm) {
+                      const sp_t* pm, int skip_padded = 0) {
   return EncoderXArgs{x_sp, x_f32, x_f32, x_sp, nb, L, C, w.q, pm, (long)C * C, w.mlp0, w.mlp2, w.q_s, w.mlp0_s, w.mlp2_s,
-                      kv, x_mask, w.n1w, w.n1b, w.n2w, w.n2b, (float)S, 1e-6f, 1.f / ATTN_P_SCALE, 1e-5f};
+                      kv, x_mask, w.n1w, w.n1b, w.n2w, w.n2b, (float)S, 1e-6f, 1.f / ATTN_P_SCALE, 1e-5f, skip_padded};
 }
 
 // LocalFeatureTransformer with layers [self, cross] * P at C = 256 (transformer.py:80-101) as a schedule of launches.
@@ -128,7 +128,7 @@ EncoderXArgs coarse_x(float* x_f32, sp_t* x_sp, const uint8_t* x_mask, const Lay
 // call order.  LOFTR_ENCODER_SCHEDULE=0 keeps that order (A/B).  Returns LOFTR_ERR_UNSUPPORTED when the shapes are not the fused kernel's.
 int coarse_transformer_scheduled(float* feat0, float* feat1, sp_t* sp0, sp_t* sp1, const uint8_t* mask0, const uint8_t* mask1,
                                  const LayerSp* lw, int P, bool stacked, int N, int L, int S, int C, int H, const EncoderWs& e,
-                                 hipStream_t st) {
+                                 hipStream_t st, int skip = 0) {
   int rc;
   const float* kvA; const sp_t* pmA; const float* kvB; const sp_t* pmB;
   {
@@ -139,21 +139,21 @@ int coarse_transformer_scheduled(float* feat0, float* feat1, sp_t* sp0, sp_t* sp
   // ---- A_0, B_0
   if (stacked) {
     if ((rc = coarse_kv(sp0, mask0, lw[0], 2 * N, L, C, H, e.attn, e.attn_bytes, &kvA, &pmA, st))) return rc;
-    if ((rc = launch_encoder_x(coarse_x(feat0, sp0, mask0, lw[0], 2 * N, L, L, C, kvA, pmA), st))) return rc;
+    if ((rc = launch_encoder_x(coarse_x(feat0, sp0, mask0, lw[0], 2 * N, L, L, C, kvA, pmA, skip), st))) return rc;
   } else {
     if ((rc = coarse_kv(sp0, mask0, lw[0], N, L, C, H, e.attn, e.attn_bytes, &kvA, &pmA, st))) return rc;
     if ((rc = coarse_kv(sp1, mask1, lw[0], N, S, C, H, e.attn2, e.attn_bytes, &kvB, &pmB, st))) return rc;
-    const EncoderXArgs a = coarse_x(feat0, sp0, mask0, lw[0], N, L, L, C, kvA, pmA), b = coarse_x(feat1, sp1, mask1, lw[0], N, S, S, C, kvB, pmB);
+    const EncoderXArgs a = coarse_x(feat0, sp0, mask0, lw[0], N, L, L, C, kvA, pmA, skip), b = coarse_x(feat1, sp1, mask1, lw[0], N, S, S, C, kvB, pmB, skip);
     if ((rc = launch_encoder_x2(a, 0, encoder_x_workgroups(a), b, 0, encoder_x_workgroups(b), st))) return rc;
   }
   for (int i = 0; i < P; ++i) {
     const LayerSp& wc = lw[2 * i + 1];
     // ---- C_i: feat0 attends to feat1
     if ((rc = coarse_kv(sp1, mask1, wc, N, S, C, H, e.attn, e.attn_bytes, &kvA, &pmA, st))) return rc;
-    if ((rc = launch_encoder_x(coarse_x(feat0, sp0, mask0, wc, N, L, S, C, kvA, pmA), st))) return rc;
+    if ((rc = launch_encoder_x(coarse_x(feat0, sp0, mask0, wc, N, L, S, C, kvA, pmA, skip), st))) return rc;
     // ---- D_i: feat1 attends to the UPDATED feat0 (transformer.py:96-97) ...
     if ((rc = coarse_kv(sp0, mask0, wc, N, L, C, H, e.attn, e.attn_bytes, &kvA, &pmA, st))) return rc;
-    const EncoderXArgs d = coarse_x(feat1, sp1, mask1, wc, N, S, L, C, kvA, pmA);
+    const EncoderXArgs d = coarse_x(feat1, sp1, mask1, wc, N, S, L, C, kvA, pmA, skip);
     const int nd = encoder_x_workgroups(d);
     if (i + 1 == P) {
       if ((rc = launch_encoder_x(d, st))) return rc;
@@ -162,14 +162,14 @@ int coarse_transformer_scheduled(float* feat0, float* feat1, sp_t* sp0, sp_t* sp
     // ---- ... with the head of A_i+1 (self on the same updated feat0) in the slots its last round leaves idle
     const LayerSp& ws = lw[2 * i + 2];
     if ((rc = coarse_kv(sp0, mask0, ws, N, L, C, H, e.attn2, e.attn_bytes, &kvB, &pmB, st))) return rc;
-    const EncoderXArgs a = coarse_x(feat0, sp0, mask0, ws, N, L, L, C, kvB, pmB);
+    const EncoderXArgs a = coarse_x(feat0, sp0, mask0, ws, N, L, L, C, kvB, pmB, skip);
     const int na = encoder_x_workgroups(a);
     int head = (256 - nd % 256) % 256 / 8 * 8;
     if (head > na) head = na;
     if ((rc = launch_encoder_x2(d, 0, nd, a, 0, head, st))) return rc;
     // ---- B_i+1 (self on feat1, which D_i has just finished) + the tail of A_i+1
     if ((rc = coarse_kv(sp1, mask1, ws, N, S, C, H, e.attn, e.attn_bytes, &kvA, &pmA, st))) return rc;
-    const EncoderXArgs b = coarse_x(feat1, sp1, mask1, ws, N, S, S, C, kvA, pmA);
+    const EncoderXArgs b = coarse_x(feat1, sp1, mask1, ws, N, S, S, C, kvA, pmA, skip);
     if ((rc = launch_encoder_x2(b, 0, encoder_x_workgroups(b), a, head, na - head, st))) return rc;
   }
   return LOFTR_OK;
@@ -178,7 +178,7 @@ int coarse_transformer_scheduled(float* feat0, float* feat1, sp_t* sp0, sp_t* sp
 int encoder_layer(const float* x_f32, const sp_t* x_sp, const sp_t* src_sp, bool self,
                   const uint8_t* x_mask, const uint8_t* src_mask, const LayerSp& w,
                   float* out_f32, sp_t* out_sp, int nb, int L, int S, int C, int H,
-                  const EncoderWs& e, hipStream_t st) {
+                  const EncoderWs& e, hipStream_t st, int skip_padded = 0) {
   if (nb <= 0) return LOFTR_OK;
   const int Ml = nb * L, Ms = nb * S;
   const float inv_s = 1.f / (float)S;                 // values / v_length, linear_attention.py:41-42
@@ -197,7 +197,7 @@ int encoder_layer(const float* x_f32, const sp_t* x_sp, const sp_t* src_sp, bool
     // round 3: everything on the x side of the layer in ONE launch, tokens stationary in registers (encoder_fused.hip)
     {
       EncoderXArgs fx{x_sp, x_f32, out_f32, out_sp, nb, L, C, w.q, pm, (long)C * C, w.mlp0, w.mlp2, w.q_s, w.mlp0_s, w.mlp2_s,
-                      kv, x_mask, w.n1w, w.n1b, w.n2w, w.n2b, (float)S, attn_eps, 1.f / ATTN_P_SCALE, 1e-5f};
+                      kv, x_mask, w.n1w, w.n1b, w.n2w, w.n2b, (float)S, attn_eps, 1.f / ATTN_P_SCALE, 1e-5f, skip_padded};
       return launch_encoder_x(fx, st);
     }
   } else {
@@ -314,7 +314,8 @@ static int transformer_fwd(float* feat0, float* feat1, const uint8_t* mask0,
                            const uint8_t* mask1, const loftr_layer_weights* layers,
                            const int* layer_is_cross, int n_layers, int N, int L, int S,
                            int C, int H, const void* prepared, size_t prepared_bytes, void* ws, size_t ws_bytes,
-                           const void* plan, size_t plan_bytes, int plan_order, void* diag, size_t diag_bytes, void* stream) {
+                           const void* plan, size_t plan_bytes, int plan_order, void* diag, size_t diag_bytes, void* stream,
+                           int skip_padded = 0) {
   LOFTR_CHECK_ARG(feat0 && feat1 && layers && layer_is_cross && n_layers >= 0 && N >= 0 && L > 0 && S > 0);
   LOFTR_CHECK_ARG((mask0 == nullptr) == (mask1 == nullptr));
   if (!((C == 256 || C == 128) && H == 8) || n_layers > MAX_LAYERS) return LOFTR_ERR_UNSUPPORTED;
@@ -397,22 +398,22 @@ static int transformer_fwd(float* feat0, float* feat1, const uint8_t* mask0,
     // ... without a plan: the scheduled launches (bit-identical to the call order, fewer rounds of workgroups)
     const bool sched_on = loftr_debug_value(LOFTR_DBG_ENCODER_SCHEDULE) != 0;
     if (sched_on && pattern) {
-      rc = coarse_transformer_scheduled(feat0, feat1, sp0, sp1, mask0, mask1, lw, n_layers / 2, stacked, N, L, S, C, H, e, st);
+      rc = coarse_transformer_scheduled(feat0, feat1, sp0, sp1, mask0, mask1, lw, n_layers / 2, stacked, N, L, S, C, H, e, st, skip_padded);
       if (rc != LOFTR_ERR_UNSUPPORTED) return rc;
     }
   }
   for (int i = 0; i < n_layers; ++i) {
     if (!layer_is_cross[i]) {
       if (stacked) {
-        if ((rc = encoder_layer(feat0, sp0, sp0, true, mask0, mask0, lw[i], feat0, sp0, 2 * N, L, L, C, H, e, st))) return rc;
+        if ((rc = encoder_layer(feat0, sp0, sp0, true, mask0, mask0, lw[i], feat0, sp0, 2 * N, L, L, C, H, e, st, skip_padded))) return rc;
       } else {
-        if ((rc = encoder_layer(feat0, sp0, sp0, true, mask0, mask0, lw[i], feat0, sp0, N, L, L, C, H, e, st))) return rc;
-        if ((rc = encoder_layer(feat1, sp1, sp1, true, mask1, mask1, lw[i], feat1, sp1, N, S, S, C, H, e, st))) return rc;
+        if ((rc = encoder_layer(feat0, sp0, sp0, true, mask0, mask0, lw[i], feat0, sp0, N, L, L, C, H, e, st, skip_padded))) return rc;
+        if ((rc = encoder_layer(feat1, sp1, sp1, true, mask1, mask1, lw[i], feat1, sp1, N, S, S, C, H, e, st, skip_padded))) return rc;
       }
     } else {
       // sequential dependency kept: feat1 attends to the UPDATED feat0 (transformer.py:96-97)
-      if ((rc = encoder_layer(feat0, sp0, sp1, false, mask0, mask1, lw[i], feat0, sp0, N, L, S, C, H, e, st))) return rc;
-      if ((rc = encoder_layer(feat1, sp1, sp0, false, mask1, mask0, lw[i], feat1, sp1, N, S, L, C, H, e, st))) return rc;
+      if ((rc = encoder_layer(feat0, sp0, sp1, false, mask0, mask1, lw[i], feat0, sp0, N, L, S, C, H, e, st, skip_padded))) return rc;
+      if ((rc = encoder_layer(feat1, sp1, sp0, false, mask1, mask0, lw[i], feat1, sp1, N, S, L, C, H, e, st, skip_padded))) return rc;
     }
   }
   return LOFTR_OK;
@@ -425,6 +426,15 @@ extern "C" int loftr_transformer_fwd(float* feat0, float* feat1, const uint8_t* 
                                      void* stream) {
   return transformer_fwd(feat0, feat1, mask0, mask1, layers, layer_is_cross, n_layers, N, L, S, C, H, prepared, prepared_bytes, ws, ws_bytes,
                          nullptr, 0, 0, nullptr, 0, stream);
+}
+
+extern "C" int loftr_transformer_fwd_padded(float* feat0, float* feat1, const uint8_t* mask0,
+                                            const uint8_t* mask1, const loftr_layer_weights* layers,
+                                            const int* layer_is_cross, int n_layers, int N, int L, int S,
+                                            int C, int H, const void* prepared, size_t prepared_bytes, void* ws, size_t ws_bytes,
+                                            int skip_padded_tiles, void* stream) {
+  return transformer_fwd(feat0, feat1, mask0, mask1, layers, layer_is_cross, n_layers, N, L, S, C, H, prepared, prepared_bytes, ws, ws_bytes,
+                         nullptr, 0, 0, nullptr, 0, stream, skip_padded_tiles != 0 && mask0 != nullptr);
 }
 
 extern "C" int loftr_transformer_fwd_planned(float* feat0, float* feat1, const uint8_t* mask0,

@@ -130,10 +130,11 @@ class LocalFeatureTransformer(nn.Module):
                     nn.init.xavier_uniform_(p)
         del first
 
-    def forward(self, feat0, feat1, mask0=None, mask1=None, inplace=False, mode=None):
+    def forward(self, feat0, feat1, mask0=None, mask1=None, inplace=False, mode=None, skip_padded=False):
         """``inplace`` (not in the reference signature): the caller owns feat0 / feat1 and does not need their
         input values any more; when they are the two halves of one buffer the layers then run on it directly.
-        ``mode``: ops.COARSE_MODE for this call ("launches" / "persistent" / "auto"; None = the process default)."""
+        ``mode``: ops.COARSE_MODE for this call ("launches" / "persistent" / "auto"; None = the process default).
+        ``skip_padded``: the caller never reads the features of padding tokens (ops.transformer; inference path only)."""
         assert self.d_model == feat0.size(2), "the feature number of src and transformer must be equal"
         for name in self.layer_names:
             if name not in ("self", "cross"):
@@ -155,7 +156,8 @@ class LocalFeatureTransformer(nn.Module):
             return feat0, feat1
         structs = [layer.weight_struct() for layer in self.layers]
         return ops.transformer(feat0.contiguous(), feat1.contiguous(), structs, self.layer_names, self.nhead,
-                               mask0, mask1, inplace=inplace, prepared=self._prepared(structs, feat0.device), mode=mode)
+                               mask0, mask1, inplace=inplace, prepared=self._prepared(structs, feat0.device), mode=mode,
+                               skip_padded=skip_padded)
 
     def _prepared(self, structs, device):
         """The layers' matrices in the library's GEMM operand format, rebuilt only when a weight tensor is modified in
@@ -377,6 +379,7 @@ class LoFTR(nn.Module):
         # With the HIP backbone the FPN top-down (fine) branch runs on a second HIP stream, concurrently with the
         # coarse transformer + coarse matching it does not feed; joined before FinePreprocess.
         self.overlap_fine_branch = True
+        self.skip_padded_tiles = True                        # with masks: fully padded 128-token tiles of the coarse level are not computed
         self.coarse_mode = None                              # None: ops.COARSE_MODE ("auto"); "launches" / "persistent" / "auto" for this model
         self.fine_join_late = False                          # True: join the side stream after coarse matching instead of after the coarse transformer (A/B)
         self._side_stream = None
@@ -490,7 +493,11 @@ class LoFTR(nn.Module):
         # (persistent / launches, fine branch on a side stream, half batches on two streams) all end within 2 % of each other -- the
         # MFMA-dense kernels run at the part's power limit (profiles/r06_coarse_mode_ab.txt, r06_power.txt).  ops.COARSE_MODE "auto" (the
         # default) takes the persistent form from 8 pairs on (profiles/r06_mode_sweep.txt).
-        feat_c0, feat_c1 = self.loftr_coarse(feat_c0, feat_c1, mask_c0, mask_c1, inplace=True, mode=self.coarse_mode)   # fresh pos-encoded copies
+        # Padding tokens (MegaDepth batches): nothing below reads their features -- coarse matching fills their scores, the fine stage gathers
+        # at matched tokens only -- so the 128-token tiles without a valid token are not computed (self.skip_padded_tiles = False: the
+        # reference's per-token mlp result for them; every other token is bit-identical either way).
+        feat_c0, feat_c1 = self.loftr_coarse(feat_c0, feat_c1, mask_c0, mask_c1, inplace=True, mode=self.coarse_mode,
+                                             skip_padded=self.skip_padded_tiles and mask_c0 is not None)   # fresh pos-encoded copies
         # Join the side stream (FPN fine branch) HERE, not after coarse matching (self.fine_join_late restores that): the encoder
         # launches leave partly filled rounds that the convolution workgroups use, the score-volume kernels do not -- sharing the
         # GPU only doubled their duration (660 vs 340 us for pass B, profiles/r03_overlap_ab.txt) without shortening the step.

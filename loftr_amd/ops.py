@@ -265,11 +265,13 @@ def coarse_plan(kinds, N, L, S, device, order=0):
 
 @_on_device
 def transformer(feat0, feat1, layer_structs, layer_names, nhead, mask0=None, mask1=None, inplace=False, prepared=None, mode=None,
-                diag=None):
+                diag=None, skip_padded=False):
     """LocalFeatureTransformer.forward.  Returns new (feat0, feat1); inputs are not modified unless
     ``inplace`` (then, when feat0 / feat1 are the contiguous halves of one buffer, the layers run on
     that buffer directly instead of on a torch.cat copy of it).  ``mode``: see COARSE_MODE; ``diag``: uint8 tensor for
-    loftr_transformer_fwd_planned's status word / per-item trace."""
+    loftr_transformer_fwd_planned's status word / per-item trace.  ``skip_padded`` (with masks): the caller does not read the
+    features of padding tokens -- 128-token tiles without a valid token keep their input values (loftr_transformer_fwd_padded;
+    per-call launches whatever ``mode`` says: the persistent form computes every tile)."""
     _need(feat0, "feat0"); _need(feat1, "feat1")
     N, L, Cc = feat0.shape
     S = feat1.shape[1]
@@ -292,6 +294,9 @@ def transformer(feat0, feat1, layer_structs, layer_names, nhead, mask0=None, mas
     nbytes = lib.loftr_encoder_workspace_bytes(2 * N, L, S, Cc)
     ws = workspace(nbytes, feat0.device)
     mode = mode or COARSE_MODE
+    skip_padded = bool(skip_padded) and m0 is not None
+    if skip_padded:
+        mode = "launches"
     if mode == "auto":
         mode = "persistent" if N >= COARSE_AUTO_MIN_PAIRS else "launches"
     plan = None
@@ -304,6 +309,10 @@ def transformer(feat0, feat1, layer_structs, layer_names, nhead, mask0=None, mas
                                                 _ptr(ws), ws.numel(), _ptr(plan), plan.numel(), order,
                                                 _ptr(diag), diag.numel() if diag is not None else 0, _stream()),
               "loftr_transformer_fwd_planned")
+    elif skip_padded:
+        check(lib.loftr_transformer_fwd_padded(_ptr(f0), _ptr(f1), _ptr(m0), _ptr(m1), arr, kinds, n_layers, N, L, S, Cc, nhead,
+                                               _ptr(prepared), prepared.numel() if prepared is not None else 0,
+                                               _ptr(ws), ws.numel(), 1, _stream()), "loftr_transformer_fwd_padded")
     else:
         check(lib.loftr_transformer_fwd(_ptr(f0), _ptr(f1), _ptr(m0), _ptr(m1), arr, kinds, n_layers, N, L, S, Cc, nhead,
                                         _ptr(prepared), prepared.numel() if prepared is not None else 0,

@@ -405,6 +405,49 @@ def test_persistent_transformer_order_independent_and_matches_launches(shape):
         assert (b[k] - ref[k]).abs().max().item() <= 2e-6 * scale, (k, (b[k] - ref[k]).abs().max().item(), scale)
 
 
+@pytest.mark.parametrize("shape", [(2, 700, 500), (2, 1200, 1200), (3, 11025, 11025)])
+def test_padded_tiles_are_skipped_without_touching_any_other_token(shape):
+    """ABI 24, loftr_transformer_fwd_padded (MegaDepth padding masks): a 128-token tile without a valid token is not computed -- its rows
+    come back as they went in -- and EVERY other token is bit-identical to loftr_transformer_fwd: the tile's K^T V / Ksum partial is
+    exactly +0 either way (linear_attention.py:37-40).  Masks: a padded tail (bottom padding), a fully padded tile in the middle of
+    sequence 1 of image 1, a pair without padding next to padded ones; unequal grids; the 105 x 105 outdoor grid."""
+    import torch
+    from loftr_amd import ops
+    N, L0, L1 = shape
+    run, tr = _coarse_transformer_case(N, L0, L1, False)
+    structs = [layer.weight_struct() for layer in tr.layers]
+    prepared = tr._prepared(structs, torch.device("cuda", 0))
+    g = torch.Generator(device="cpu").manual_seed(5 * N + L0)
+    f0 = torch.randn(N, L0, 256, generator=g).cuda()
+    f1 = torch.randn(N, L1, 256, generator=g).cuda()
+    m0 = torch.ones(N, L0, dtype=torch.bool); m1 = torch.ones(N, L1, dtype=torch.bool)
+    m0[0, L0 - (2 * L0) // 5:] = False                                   # padded tail: >= one whole tile and a partly padded one
+    m1[0, L1 - L1 // 3:] = False
+    if L1 >= 4 * 128:
+        m1[-1, 128:256] = False                                          # a whole tile in the middle
+        m1[-1, 300:310] = False                                          # and a few tokens of a valid tile
+    m0, m1 = m0.cuda(), m1.cuda()
+    with torch.no_grad():
+        ref = ops.transformer(f0, f1, structs, tr.layer_names, tr.nhead, m0, m1, inplace=False, prepared=prepared, mode="launches")
+        ref = (ref[0].clone(), ref[1].clone())
+        out = ops.transformer(f0, f1, structs, tr.layer_names, tr.nhead, m0, m1, inplace=False, prepared=prepared, mode="persistent", skip_padded=True)
+    torch.cuda.synchronize()
+    skipped = 0
+    for k, (x, m, o, r) in enumerate(((f0, m0, out[0], ref[0]), (f1, m1, out[1], ref[1]))):
+        L = x.shape[1]
+        assert torch.isfinite(o).all()
+        for n in range(N):
+            for t0 in range(0, L, 128):
+                sl = slice(t0, min(t0 + 128, L))
+                if m[n, sl].any():
+                    assert torch.equal(o[n, sl], r[n, sl]), (k, n, t0)
+                else:
+                    skipped += 1
+                    assert torch.equal(o[n, sl], x[n, sl]), (k, n, t0)
+                    assert not torch.equal(r[n, sl], x[n, sl])            # (the reference does compute something there)
+    assert skipped >= 3
+
+
 def test_persistent_transformer_refuses_a_plan_of_another_shape():
     """loftr_transformer_fwd_planned with a plan built for other sizes: nothing is computed, the status word reports 2, and the C-ABI
     call returns an error for a plan buffer that is too small (include/loftr_hip.h)."""

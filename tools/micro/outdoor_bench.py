@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """BASELINE configs[3] (outdoor, 840 x 840, MegaDepth-style padding masks + scales): full forward timing, N pairs.
 
-    python tools/micro/outdoor_bench.py [N] [reps] [sinkhorn] [mode=launches|persistent|auto] [overlap=0|1]"""
+    python tools/micro/outdoor_bench.py [N] [reps] [sinkhorn] [mode=launches|persistent|auto] [overlap=0|1] [skip=0|1]"""
 import os
 import sys
 
@@ -23,6 +23,8 @@ if ot:
 model = LoFTR(cfg).eval().cuda()
 if "mode" in kv:
     model.coarse_mode = kv["mode"]
+if "skip" in kv:
+    model.skip_padded_tiles = bool(int(kv["skip"]))
 if "overlap" in kv:
     model.overlap_fine_branch = bool(int(kv["overlap"]))
 g = torch.Generator().manual_seed(1234)
