@@ -246,12 +246,18 @@ __global__ __launch_bounds__(W * 64, 1) void fine_pair_kernel(Args a) {
   // ---- the weight stream: panel p (16 KB = 4 blocks of 32 rows x 128 B) lives in ring stage p % NST
   //   R panel: block b = k-group b of the panel's 32 rows;  K panel: block b = rows 32 b .. + 31 of the panel's k-group.
   //   wave w issues block w (4 DMA instructions of 8 rows each).
-  int dro[4], dch[4];
+  // DMA addressing: a lane's BYTE offset inside a panel block for the two row pitches that occur (128 / 256 dwords), so that an issue is
+  // `global_load_lds v_offset, s[base]` -- SGPR base + 32-bit VGPR offset, no per-lane 64-bit address arithmetic (round 6: the address
+  // chains were 135 of the ~300 VALU instructions of an mlp iteration)
+  //   pitch 128: off128[oct];  pitch 256: off128[oct] + (lane >> 3) * 512 per lane, + oct * 4096 on the scalar side
+  unsigned off128[4];
 #pragma unroll
   for (int oct = 0; oct < 4; ++oct) {
-    dro[oct] = oct * 8 + (lane >> 3);
-    dch[oct] = ((lane & 7) ^ ((oct * 4 + (lane >> 4)) & 7)) << 2;
+    const unsigned ro = oct * 8 + (lane >> 3), ch = ((lane & 7) ^ ((oct * 4 + (lane >> 4)) & 7)) << 2;
+    off128[oct] = (ro * 128 + ch) * 4;
   }
+  const unsigned rl512 = (unsigned)(lane >> 3) * 512u;
+  const int wave_s = __builtin_amdgcn_readfirstlane(wave);
   // where panel p comes from: decoded once per workgroup into an LDS table (the divisions by 40 and 3 per panel and wave were a
   // few hundred scalar instructions per barrier interval): {address of its first row / k-group (lo, hi), row pitch, K-type}
   for (int p = threadIdx.x; p < NPANEL; p += W * 64) {
@@ -271,11 +277,12 @@ __global__ __launch_bounds__(W * 64, 1) void fine_pair_kernel(Args a) {
     const int4 d__ = reinterpret_cast<const int4*>(lds + OFF_DESC)[p__];                                   \
     const unsigned lo__ = (unsigned)__builtin_amdgcn_readfirstlane(d__.x), hi__ = (unsigned)__builtin_amdgcn_readfirstlane(d__.y); \
     const int pitch__ = __builtin_amdgcn_readfirstlane(d__.z), kt__ = __builtin_amdgcn_readfirstlane(d__.w);        \
-    const sp_t* base__ = reinterpret_cast<const sp_t*>((size_t)(((unsigned long long)hi__ << 32) | lo__)); \
-    char* st__ = lds + (p__ % NST) * STAGE + wave * BLK;                                                   \
-    const sp_t* bb__ = base__ + (kt__ ? (long)wave * 32 * pitch__ : (long)wave * 32);              \
+    const unsigned long long wo__ = (unsigned long long)(kt__ ? wave_s * 32 * pitch__ : wave_s * 32) * 4ull;   /* this wave's block, bytes (uniform) */ \
+    const char* base__ = reinterpret_cast<const char*>((size_t)((((unsigned long long)hi__ << 32) | lo__) + wo__)); \
+    char* st__ = lds + (p__ % NST) * STAGE + wave_s * BLK;                                                 \
+    const unsigned w256__ = pitch__ == 256 ? 1u : 0u;                                                      \
     _Pragma("unroll") for (int oct__ = 0; oct__ < 4; ++oct__)                                              \
-      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(bb__ + dro[oct__] * pitch__ + dch[oct__]),              \
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(base__ + (size_t)(w256__ * (unsigned)(oct__ * 4096)) + (off128[oct__] + w256__ * rl512)), \
                                        (lds_ptr_t)(st__ + oct__ * 1024), 16, 0, 0);                        \
   }
   // panel p has landed once at most the NST - 2 newer panels' DMAs are outstanding; the barrier makes every wave's share
