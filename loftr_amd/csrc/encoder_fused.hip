@@ -102,6 +102,13 @@ __device__ __forceinline__ void pack_panel(const float (&v)[16], h16x8 (&fh)[2],
   }
 }
 
+// a pointer the caller knows to be wave-uniform, as a scalar-register pair (folds away when it already is one)
+__device__ __forceinline__ const sp_t* uniform_ptr(const sp_t* p) {
+  const unsigned long long v = (unsigned long long)(size_t)p;
+  const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
+  return reinterpret_cast<const sp_t*>((size_t)(((unsigned long long)hi << 32) | lo));
+}
+
 // workgroup index inside a job -> (sequence, group of token blocks): a sequence's groups run back to back on one XCD (weights, P in
 // its L2); with fewer sequences than XCDs -- 1 / 2 / 4 at the outdoor configuration's batch sizes -- a sequence is cut into xsplit
 // chunks of groups that take one XCD each (pinned one sequence per XCD, 2 sequences used 64 of the 256 CUs)
@@ -173,22 +180,27 @@ __device__ __forceinline__ void encoder_x_body(const Args& a, const int seq, con
   //   R panel: block b = k-group b of the panel's 32 rows;  K panel: block b = rows 32 b .. + 31 of the panel's k-group.
   //   One DMA instruction = 8 rows x 128 B; wave w issues blocks w and w + 4.
   const sp_t* pm = a.pm + (long)seq * a.pm_seq_stride;
-  int dro[4];                                           // row-octet part of the source offset (rows; dwords of the chunk)
-  int dch[4];
+  // DMA addressing (round 6): SGPR base + a 32-bit per-lane BYTE offset -- `global_load_lds v_off, s[base]` -- instead of a 64-bit address chain
+  // per lane and instruction.  doff[oct]: row octet oct of a block at row pitch 256 dwords; pitch 512 adds (lane >> 3) * 1024 per lane and
+  // oct * 8192 on the scalar side.
+  unsigned doff[4];
 #pragma unroll
-  for (int oct = 0; oct < 4; ++oct) {
-    dro[oct] = oct * 8 + (lane >> 3);
-    dch[oct] = ((lane & 7) ^ ((oct * 4 + (lane >> 4)) & 7)) << 2;
-  }
+  for (int oct = 0; oct < 4; ++oct) doff[oct] = ((unsigned)(oct * 8 + (lane >> 3)) * 256u + ((((unsigned)lane & 7u) ^ ((unsigned)(oct * 4 + (lane >> 4)) & 7u)) << 2)) * 4u;
+  const unsigned drl = (unsigned)(lane >> 3) * 1024u;
+  const int wave_s = __builtin_amdgcn_readfirstlane(wave);
 #define EFX_ISSUE_SRC(p_, base_, pitch_, kt_)                                                              \
   {                                                                                                        \
     char* st__ = lds + ((p_) % NST) * STAGE;                                                               \
+    const unsigned w512__ = (pitch_) == 512 ? 1u : 0u;                                                     \
     _Pragma("unroll") for (int bi__ = 0; bi__ < 2; ++bi__) {                                               \
-      const int b__ = wave + 4 * bi__;                                                                     \
-      const sp_t* bb__ = (kt_) ? (base_) + (long)b__ * 32 * (pitch_) : (base_) + b__ * 32;                 \
-      _Pragma("unroll") for (int oct__ = 0; oct__ < 4; ++oct__)                                            \
-        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(bb__ + dro[oct__] * (pitch_) + dch[oct__]),           \
+      const int b__ = wave_s + 4 * bi__;                                                                   \
+      const char* bb__ = reinterpret_cast<const char*>(uniform_ptr((kt_) ? (base_) + (long)b__ * 32 * (pitch_) : (base_) + b__ * 32)); \
+      _Pragma("unroll") for (int oct__ = 0; oct__ < 4; ++oct__) {                                          \
+        const char* bo__ = bb__ + (size_t)(w512__ * (unsigned)(oct__ * 8192));                             \
+        asm volatile("" : "+s"(bo__));                  /* the scalar part stays a scalar-register pair: saddr form */ \
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(bo__ + (doff[oct__] + w512__ * drl)),                 \
                                          (lds_ptr_t)(st__ + b__ * BLK + oct__ * 1024), 16, 0, 0);          \
+      }                                                                                                    \
     }                                                                                                      \
   }
 #define EFX_ISSUE(p_)                                                                                      \
@@ -594,12 +606,11 @@ __device__ __forceinline__ void kv_tile_main(const KvTile& a, char* const lds, c
   LOFTR_WAITCNT_VM(0);
   __syncthreads();
   for (int f = threadIdx.x; f < 512; f += W * 64) tab[T_W0S + f] = a.wkv_s[f];
-  int dro[4], dch[4];
+  unsigned doff[4];                                     // see encoder_x_body
 #pragma unroll
-  for (int oct = 0; oct < 4; ++oct) {
-    dro[oct] = oct * 8 + (lane >> 3);
-    dch[oct] = ((lane & 7) ^ ((oct * 4 + (lane >> 4)) & 7)) << 2;
-  }
+  for (int oct = 0; oct < 4; ++oct) doff[oct] = ((unsigned)(oct * 8 + (lane >> 3)) * 256u + ((((unsigned)lane & 7u) ^ ((unsigned)(oct * 4 + (lane >> 4)) & 7u)) << 2)) * 4u;
+  [[maybe_unused]] const unsigned drl = 0u;             // (the K / V weights have one pitch)
+  const int wave_s = __builtin_amdgcn_readfirstlane(wave);
   const int a_off = lds_chunk_off(li, g);
   const sp_t* const wkv = a.wkv;
 #define KVX_ISSUE(p_) EFX_ISSUE_SRC((p_), wkv + (long)(p_) * 32 * 256, 256, false)
