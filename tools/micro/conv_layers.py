@@ -18,12 +18,15 @@ def layers(h=480, w=640):
     h2, w2, h4, w4, h8, w8 = h // 2, w // 2, h // 4, w // 4, h // 8, w // 8
     return [
         ("layer1 3x3 128>128 @1/2", 128, 128, 3, 1, h2, w2, True, 1),
+        ("layer1 3x3 128>128 @1/2 (conv1: no residual)", 128, 128, 3, 1, h2, w2, False, 1),
         ("layer2.0 3x3s2 128>196", 128, 196, 3, 2, h2, w2, False, 1),
         ("layer2.0 ds 1x1s2 128>196", 128, 196, 1, 2, h2, w2, False, 0),
         ("layer2 3x3 196>196 @1/4", 196, 196, 3, 1, h4, w4, True, 1),
+        ("layer2 3x3 196>196 @1/4 (conv1: no residual)", 196, 196, 3, 1, h4, w4, False, 1),
         ("layer3.0 3x3s2 196>256", 196, 256, 3, 2, h4, w4, False, 1),
         ("layer3.0 ds 1x1s2 196>256", 196, 256, 1, 2, h4, w4, False, 0),
         ("layer3 3x3 256>256 @1/8", 256, 256, 3, 1, h8, w8, True, 1),
+        ("layer3 3x3 256>256 @1/8 (conv1: no residual)", 256, 256, 3, 1, h8, w8, False, 1),
         ("layer3_outconv 1x1 256>256 @1/8", 256, 256, 1, 1, h8, w8, False, 0),
         ("layer2_outconv2.0 3x3 256>256 @1/4", 256, 256, 3, 1, h4, w4, False, 2),
         ("layer2_outconv2.3 3x3 256>196 @1/4", 256, 196, 3, 1, h4, w4, False, 0),
@@ -40,7 +43,7 @@ def main(B=16, iters=10, only="", *switches):
             ops.debug_set(kv.split("=")[0], int(kv.split("=")[1]))
     dev = torch.device("cuda", 0)
     torch.manual_seed(0)
-    print(f"{'layer':38s} {'us':>9s} {'GFLOP':>8s} {'exec PF':>8s} {'frac':>6s}")
+    print(f"{'layer':48s} {'us':>9s} {'GFLOP':>8s} {'exec PF':>8s} {'frac':>6s}")
     total = 0.0
     for tag, cin, cout, k, s, h, w, res, act in layers():
         if only and only not in tag:
@@ -64,8 +67,8 @@ def main(B=16, iters=10, only="", *switches):
         fl = 2.0 * B * ho * wo * cout * cin * k * k
         pf = 3 * fl / (us * 1e-6) / 1e15
         total += us
-        print(f"{tag:38s} {us:9.1f} {fl / 1e9:8.1f} {pf:8.3f} {pf / 2.5:6.3f}", flush=True)
-    print(f"{'sum (one launch each)':38s} {total:9.1f}")
+        print(f"{tag:48s} {us:9.1f} {fl / 1e9:8.1f} {pf:8.3f} {pf / 2.5:6.3f}", flush=True)
+    print(f"{'sum (one launch each)':48s} {total:9.1f}")
 
 
 if __name__ == "__main__":
