@@ -45,6 +45,12 @@ def main(B=16, iters=10, only="", *switches):
     torch.manual_seed(0)
     print(f"{'layer':48s} {'us':>9s} {'GFLOP':>8s} {'exec PF':>8s} {'frac':>6s}")
     total = 0.0
+    # warm the GPU up first (clocks / power state): without it the FIRST row of the table reads 10-20 % slow (round 6: the residual form
+    # of layer1 is the first row and looked 190 us slower than the same layer without a residual; measured in any other position: +60..90 us)
+    warm = torch.randn(4096, 4096, device=dev)
+    for _ in range(60):
+        warm = (warm @ warm).clamp_(-1, 1)
+    torch.cuda.synchronize()
     for tag, cin, cout, k, s, h, w, res, act in layers():
         if only and only not in tag:
             continue

@@ -15,7 +15,7 @@ from loftr_amd import ops, _lib  # noqa: E402
 from tools.micro.conv_layers import layers  # noqa: E402
 
 
-def main(only="layer1 3x3"):
+def main(only="layer1 3x3", B=16):
     dev = torch.device("cuda", 0)
     lib = _lib.load()
     lib.loftr_conv_probe_buffer.argtypes = [C.c_void_p]
@@ -24,7 +24,6 @@ def main(only="layer1 3x3"):
     for tag, cin, cout, k, s, h, w, res, act in layers():
         if only not in tag or k != 3 or s != 1:
             continue
-        B = 16
         conv = nn.Conv2d(cin, cout, k, s, k // 2, bias=False).to(dev)
         bn = nn.BatchNorm2d(cout).to(dev).eval()
         x = ops.sp_from_nhwc(torch.relu(torch.randn(B, h, w, cin, device=dev)))
@@ -33,7 +32,8 @@ def main(only="layer1 3x3"):
             ops.conv_bn_act(x, cin, conv, bn, act=act, residual=r, want_sp=True)
         buf.zero_()
         torch.cuda.synchronize()
-        ops.conv_bn_act(x, cin, conv, bn, act=act, residual=r, want_sp=True)
+        for _ in range(8):            # back to back: the stamps left in the buffer are the LAST launch's (steady clocks, not a launch after an idle GPU)
+            ops.conv_bn_act(x, cin, conv, bn, act=act, residual=r, want_sp=True)
         torch.cuda.synchronize()
         t = buf.cpu().numpy()
         t = t[t[:, 0] != 0]
@@ -44,6 +44,8 @@ def main(only="layer1 3x3"):
         print(f"{tag}: {len(t)} workgroups, launch span {en.max():.1f} us; distinct CU ids {len(np.unique(cu))}")
         print(f"  per workgroup [us]: prologue {np.mean(lo - st):.2f}  k-loop {np.mean(hi - lo):.2f}  epilogue {np.mean(en - hi):.2f}  "
               f"total {np.mean(en - st):.2f}   (k-loop min {np.min(hi - lo):.2f} max {np.max(hi - lo):.2f}; epilogue min {np.min(en - hi):.2f} max {np.max(en - hi):.2f})")
+        kl = np.sort(hi - lo)
+        print(f"  k-loop percentiles [us]: 5 % {kl[len(kl) // 20]:.2f}  25 % {kl[len(kl) // 4]:.2f}  50 % {kl[len(kl) // 2]:.2f}  75 % {kl[3 * len(kl) // 4]:.2f}  95 % {kl[19 * len(kl) // 20]:.2f}")
         print(f"  wave-slot parity of wave 0: {np.bincount((hw & 1).astype(int))}")
         # phase of the two workgroups that share a CU: for every CU, sort its workgroups by start and look at how much of each
         # epilogue overlaps a k-loop of ANOTHER workgroup on the same CU
@@ -64,4 +66,4 @@ def main(only="layer1 3x3"):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1] if len(sys.argv) > 1 else "layer1 3x3")
+    main(sys.argv[1] if len(sys.argv) > 1 else "layer1 3x3", int(sys.argv[2]) if len(sys.argv) > 2 else 16)

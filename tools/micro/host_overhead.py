@@ -16,7 +16,8 @@ torch.manual_seed(0)
 cfg = get_cfg(thr=0.0)
 cfg["coarse"]["temp_bug_fix"] = True
 model = LoFTR(cfg).eval().cuda()
-i0, i1 = make_images(1234, 8, 480, 640)
+NB = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+i0, i1 = make_images(1234, NB, 480, 640)
 a, b = torch.from_numpy(i0).cuda(), torch.from_numpy(i1).cuda()
 for _ in range(3):
     model({"image0": a, "image1": b})
@@ -30,4 +31,4 @@ for _ in range(10):
     torch.cuda.synchronize()
     t2 = time.perf_counter()
     host.append(t1 - t0); total.append(t2 - t0)
-print(f"forward call returns after {1e3 * sorted(host)[5]:.2f} ms (includes the one device sync on the match count), GPU done after {1e3 * sorted(total)[5]:.2f} ms")
+print(f"batch {NB}: forward call returns after {1e3 * sorted(host)[5]:.2f} ms (includes the one device sync on the match count), GPU done after {1e3 * sorted(total)[5]:.2f} ms")
