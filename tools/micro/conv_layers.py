@@ -45,8 +45,8 @@ def main(B=16, iters=10, only="", *switches):
     torch.manual_seed(0)
     print(f"{'layer':48s} {'us':>9s} {'GFLOP':>8s} {'exec PF':>8s} {'frac':>6s}")
     total = 0.0
-    # warm the GPU up first (clocks / power state): without it the FIRST row of the table reads 10-20 % slow (round 6: the residual form
-    # of layer1 is the first row and looked 190 us slower than the same layer without a residual; measured in any other position: +60..90 us)
+    # warm the GPU up first (clocks / power state).  NOTE (round 6): the rows WITH a residual read ~150 us higher here than the same launch inside
+    # the model or in an interleaved series (tools/micro/conv_residual_exp.py: +90 us for the residual stream, not +190); cause not found
     warm = torch.randn(4096, 4096, device=dev)
     for _ in range(60):
         warm = (warm @ warm).clamp_(-1, 1)
